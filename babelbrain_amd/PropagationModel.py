@@ -1,0 +1,140 @@
+"""Drop-in for `BabelViscoFDTD.PropagationModel.PropagationModel` on AMD MI355X.
+
+The reference instantiates the solver once as a module global and calls two methods on it:
+
+    PModel = PropagationModel()                                       BabelIntegrationBASE.py:43
+    PModel.CalculateMatricesForPropagation(map, MatArray, f, Qcorr, dx, AlphaCFL)   BASE:1799,1801
+    PModel.StaggeredFDTD_3D_with_relaxation(MaterialMap, MaterialList, Frequency, SourceMap,
+                                            PulseSource, SpatialStep, TimeSimulation, SensorMap, **kw)
+                                                                      BASE:2338,2374,2401
+
+This class keeps those names, the positional order, the keyword names and the return shapes, and
+runs the time loop on the hand-written HIP engine (libbabelfdtd_hip.so) through ctypes.
+Errors surface as Python exceptions, which CalculateFieldProcess.py:126-129 turns into its
+`--Babel-Brain-Low-Error` sentinel. There is no CPU fallback.
+"""
+import numpy as np
+
+from . import _engine
+from ._engine import Engine, EngineError, KIND_LAST, KIND_PEAK, KIND_RMS
+
+COMPUTING_BACKEND_HIP = 5   # new code next to 0 CPU, 1 CUDA, 2 OpenCL, 3 Metal, 4 MLX (BabelBrain.py:429-439)
+
+
+def n_steps(TimeSimulation, dt):
+    """Number of time steps of a run of duration TimeSimulation (the caller builds it as nt*dt, BASE:2089)."""
+    return int(np.ceil(TimeSimulation / dt - 1e-6))
+
+
+def sensor_steps(nt, SensorSubSampling, SensorStart):
+    steps = np.arange(nt)
+    return steps[(steps % SensorSubSampling == 0) & (steps // SensorSubSampling >= SensorStart)]
+
+
+def compact_sources(SourceMap, Ox, Oy, Oz, k0=0, nk=None):
+    """SourceMap (uint32, 0 = none, s>=1 -> PulseSource row s-1; Single:326-344) and the per-voxel
+    weights Ox,Oy,Oz (full volume, or size-1 arrays; BASE:2325-2335) -> compact lists for one Z-slab."""
+    N1, N2, N3 = SourceMap.shape
+    nk = N3 - k0 if nk is None else nk
+    sub = SourceMap[:, :, k0:k0 + nk]
+    ii, jj, kk = np.nonzero(sub)
+    lin = (ii.astype(np.int64) + N1 * (jj.astype(np.int64) + N2 * kk.astype(np.int64)))
+    order = np.argsort(lin, kind='stable')
+    ii, jj, kk, lin = ii[order], jj[order], kk[order], lin[order]
+    row = sub[ii, jj, kk].astype(np.int64) - 1
+
+    def w(o):
+        o = np.asarray(o)
+        if o.size == 1:
+            v = float(o.reshape(-1)[0])
+            return None if v == 1.0 else np.full(lin.shape, v, np.float32)
+        if o.shape != SourceMap.shape:
+            raise ValueError('Ox/Oy/Oz must be size-1 or have the shape of the domain')
+        return o[ii, jj, kk + k0].astype(np.float32)
+    return lin.astype(np.uint32), row.astype(np.uint32), w(Ox), w(Oy), w(Oz)
+
+
+def material_slab(MaterialMap, k0, nk):
+    """Slab view plus up to 2 ghost planes each side, as bfd_set_material_map wants it."""
+    N3 = MaterialMap.shape[2]
+    gl = min(2, k0)
+    gh = min(2, N3 - (k0 + nk))
+    return MaterialMap[:, :, k0 - gl:k0 + nk + gh], gl, gh
+
+
+class PropagationModel:
+    def __init__(self, device=0, kernelVariant=0):
+        self._device = device
+        self._kernelVariant = kernelVariant
+        self.last_timing = None
+
+    # ------------------------------------------------------------------------------------------
+    def CalculateMatricesForPropagation(self, MaterialMap, MaterialProperties, Frequency, QfactorCorrection, h,
+                                        AlphaCFL, QCorrection=1.0):
+        """Returns a 10-tuple whose element 0 is the stable time step, like the reference's solver
+        (only element 0 is read: BASE:1799, 1801). Elements 1-7 are this engine's float32
+        per-material tables for that time step, 8 = (c1,k2), 9 = fastest wave speed."""
+        dt = _engine.stable_dt(MaterialProperties, Frequency, QfactorCorrection, h, AlphaCFL, QCorrection)
+        t, c1k2, cmax = _engine.material_tables(MaterialProperties, Frequency, QfactorCorrection, h, dt, QCorrection)
+        return (dt, t[0], t[1], t[2], t[3], t[4], t[5], t[6], c1k2, cmax)
+
+    # ------------------------------------------------------------------------------------------
+    def StaggeredFDTD_3D_with_relaxation(self, MaterialMap, MaterialProperties, Frequency, SourceMap, PulseSource,
+                                         SpatialStep, DurationSimulation, SensorMap,
+                                         Ox=np.array([1]), Oy=np.array([1]), Oz=np.array([1]),
+                                         AlphaCFL=0.99, NDelta=12, ReflectionLimit=1.0000e-05,
+                                         COMPUTING_BACKEND=COMPUTING_BACKEND_HIP, USE_SINGLE=True, DT=None,
+                                         QfactorCorrection=True, QCorrection=1.0, TypeSource=0, SelRMSorPeak=1,
+                                         SelMapsRMSPeakList=('ALLV',), SelMapsSensorsList=('Vx', 'Vy', 'Vz'),
+                                         SensorSubSampling=2, SensorStart=0, DefaultGPUDeviceName='MI355X',
+                                         DefaultGPUDeviceNumber=None, ReflectorMask=None, SILENT=False, **unused):
+        if not USE_SINGLE:
+            raise NotImplementedError('the MI355X engine computes in float32 (USE_SINGLE=True, BASE:2354)')
+        MaterialMap = np.asarray(MaterialMap)
+        if MaterialMap.ndim != 3:
+            raise ValueError('MaterialMap must be a 3-D array')
+        for nm, a in (('SourceMap', SourceMap), ('SensorMap', SensorMap)):
+            if np.asarray(a).shape != MaterialMap.shape:
+                raise ValueError('%s must have the shape of MaterialMap' % nm)
+        N1, N2, N3 = MaterialMap.shape
+        ml = np.ascontiguousarray(MaterialProperties, np.float64).reshape(-1, 5)
+        if DT is None:
+            DT = _engine.stable_dt(ml, Frequency, QfactorCorrection, SpatialStep, AlphaCFL, QCorrection)
+        nt = n_steps(DurationSimulation, DT)
+        device = self._device if DefaultGPUDeviceNumber is None else DefaultGPUDeviceNumber
+        eng = Engine(N1, N2, N3, ml.shape[0], SpatialStep, DT, Frequency, nt, NDelta=NDelta,
+                     reflectionLimit=ReflectionLimit, typeSource=TypeSource, sensorSub=SensorSubSampling,
+                     sensorStart=SensorStart, selRMSorPeak=SelRMSorPeak, selMapsRMS=SelMapsRMSPeakList,
+                     selMapsSensors=SelMapsSensorsList, qfactorCorrection=QfactorCorrection, device=device,
+                     kernelVariant=self._kernelVariant)
+        try:
+            eng.set_materials(ml, QCorrection)
+            eng.set_material_map(MaterialMap, 0, 0)
+            if ReflectorMask is not None:
+                eng.set_reflector(ReflectorMask)
+            lin, row, wx, wy, wz = compact_sources(np.asarray(SourceMap), Ox, Oy, Oz)
+            eng.set_sources(lin, row, wx, wy, wz, PulseSource)
+            eng.set_sensor_map(SensorMap)
+            eng.timing_begin(False)
+            eng.run(nt)
+            self.last_timing = eng.timing_end()
+            self.last_timing['voxel_steps'] = float(N1) * N2 * N3 * nt
+            Sensor = {'time': sensor_steps(nt, SensorSubSampling, SensorStart) * DT}
+            sens = eng.sensors()
+            for q, name in enumerate(eng.selS):
+                Sensor[name] = sens[q]
+            InputParam = {'IndexSensorMap': eng.sensor_index(), 'DT': DT, 'nt': nt,
+                          'device_bytes': eng.device_bytes, 'timing': self.last_timing}
+            LastMap = {name: eng.get_map(KIND_LAST, name) for name in eng.selR}
+            out = [Sensor, LastMap]
+            if SelRMSorPeak & 1:
+                out.append({name: eng.get_map(KIND_RMS, name) for name in eng.selR})
+            if SelRMSorPeak & 2:
+                out.append({name: eng.get_map(KIND_PEAK, name) for name in eng.selR})
+            out.append(InputParam)
+        finally:
+            eng.close()
+        if not SILENT and self.last_timing['total_ms'] > 0:
+            print('HIP FDTD: %d steps, %.1f Mvoxel-steps/s' % (
+                nt, self.last_timing['voxel_steps'] / self.last_timing['total_ms'] / 1e3))
+        return tuple(out)

@@ -1,0 +1,311 @@
+"""ctypes binding of libbabelfdtd_hip.so (include/babelfdtd.h).
+
+This is the thin layer BASELINE.json's north_star asks for: the reference's Python driver
+(TranscranialModeling/BabelIntegrationBASE.py:2338) reaches the HIP engine through it.
+There is no CPU fallback: a missing library or a missing GPU raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libbabelfdtd_hip.so')
+
+MAP_BITS = {'Vx': 0, 'Vy': 1, 'Vz': 2, 'Sigmaxx': 3, 'Sigmayy': 4, 'Sigmazz': 5,
+            'Sigmaxy': 6, 'Sigmaxz': 7, 'Sigmayz': 8, 'Pressure': 9, 'ALLV': 10}
+KIND_RMS, KIND_PEAK, KIND_LAST = 0, 1, 2
+HALO_VELOCITY, HALO_STRESS = 0, 1
+FIELD_NAMES = ['Vx', 'Vy', 'Vz', 'Sxx', 'Syy', 'Szz', 'Sxy', 'Sxz', 'Syz', 'Rxx', 'Ryy', 'Rzz', 'Rxy', 'Rxz', 'Ryz']
+
+# every symbol include/babelfdtd.h declares (tests check that the library exports all of them)
+ABI_SYMBOLS = [
+    'bfd_abi_version', 'bfd_last_error', 'bfd_device_count', 'bfd_device_name', 'bfd_stable_dt',
+    'bfd_material_tables', 'bfd_create', 'bfd_destroy', 'bfd_set_stream', 'bfd_set_materials',
+    'bfd_set_material_map', 'bfd_set_reflector', 'bfd_set_sources', 'bfd_set_sensor_map', 'bfd_run',
+    'bfd_half_step_stress', 'bfd_half_step_velocity', 'bfd_sync', 'bfd_current_step', 'bfd_halo_region',
+    'bfd_timing_begin', 'bfd_timing_end', 'bfd_num_sensors', 'bfd_num_sensor_steps', 'bfd_get_sensor_index',
+    'bfd_get_sensors', 'bfd_get_map', 'bfd_get_field', 'bfd_device_bytes',
+]
+
+
+class Config(C.Structure):
+    _fields_ = [('N1', C.c_int32), ('N2', C.c_int32), ('N3', C.c_int32), ('k0', C.c_int32), ('nk', C.c_int32),
+                ('nMat', C.c_int32), ('NDelta', C.c_int32), ('typeSource', C.c_int32), ('sensorSub', C.c_int32),
+                ('sensorStart', C.c_int32), ('nt', C.c_int32), ('selRMSorPeak', C.c_int32),
+                ('selMapsRMS', C.c_uint32), ('selMapsSensors', C.c_uint32), ('qfactorCorrection', C.c_int32),
+                ('device', C.c_int32), ('kernelVariant', C.c_int32), ('reserved0', C.c_int32),
+                ('h', C.c_double), ('dt', C.c_double), ('freq', C.c_double), ('reflectionLimit', C.c_double)]
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load_library():
+    """Load libbabelfdtd_hip.so; raises if it has not been built (python __graft_entry__.py build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EngineError('HIP engine library missing: %s (build it with `make -C babelbrain_amd/csrc`); '
+                          'there is no CPU fallback' % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    lib.bfd_last_error.restype = C.c_char_p
+    lib.bfd_stable_dt.restype = C.c_double
+    lib.bfd_stable_dt.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_double, C.c_int32, C.c_double, C.c_double]
+    lib.bfd_material_tables.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_double, C.c_int32, C.c_double,
+                                        C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.bfd_create.argtypes = [C.POINTER(Config), C.POINTER(C.c_void_p)]
+    lib.bfd_destroy.argtypes = [C.c_void_p]
+    lib.bfd_destroy.restype = None
+    lib.bfd_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+    lib.bfd_set_materials.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.bfd_set_material_map.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32]
+    lib.bfd_set_reflector.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64]
+    lib.bfd_set_sources.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_int32, C.c_int32]
+    lib.bfd_set_sensor_map.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_int64)]
+    lib.bfd_run.argtypes = [C.c_void_p, C.c_int32]
+    lib.bfd_half_step_stress.argtypes = [C.c_void_p]
+    lib.bfd_half_step_velocity.argtypes = [C.c_void_p]
+    lib.bfd_sync.argtypes = [C.c_void_p]
+    lib.bfd_current_step.argtypes = [C.c_void_p]
+    lib.bfd_halo_region.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p),
+                                    C.POINTER(C.c_size_t)]
+    lib.bfd_timing_begin.argtypes = [C.c_void_p, C.c_int32]
+    lib.bfd_timing_end.argtypes = [C.c_void_p] + [C.POINTER(C.c_double)] * 4 + [C.POINTER(C.c_int64)] * 2
+    lib.bfd_num_sensors.argtypes = [C.c_void_p]
+    lib.bfd_num_sensors.restype = C.c_int64
+    lib.bfd_num_sensor_steps.argtypes = [C.c_void_p]
+    lib.bfd_get_sensor_index.argtypes = [C.c_void_p, C.c_void_p]
+    lib.bfd_get_sensors.argtypes = [C.c_void_p, C.c_void_p]
+    lib.bfd_get_map.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_int64, C.c_int64]
+    lib.bfd_get_field.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_int64, C.c_int64]
+    lib.bfd_device_bytes.argtypes = [C.c_void_p]
+    lib.bfd_device_bytes.restype = C.c_int64
+    lib.bfd_device_name.argtypes = [C.c_int, C.c_char_p, C.c_int]
+    if lib.bfd_abi_version() != 1:
+        raise EngineError('libbabelfdtd_hip.so ABI version mismatch')
+    _lib = lib
+    return lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise EngineError('%s failed (rc=%d): %s' % (what, rc, load_library().bfd_last_error().decode()))
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _estrides(a):
+    return [s // a.itemsize for s in a.strides]
+
+
+def mask_of(names):
+    m = 0
+    for n in names:
+        if n not in MAP_BITS:
+            raise ValueError('unknown map name %r (valid: %s)' % (n, ', '.join(MAP_BITS)))
+        m |= 1 << MAP_BITS[n]
+    return m
+
+
+def ordered(names):
+    return sorted(set(names), key=lambda n: MAP_BITS[n])
+
+
+def list_devices():
+    """[(ordinal, name)] -- counterpart of <backend>.ListDevices (SelFiles/SelFiles.py:245-262)."""
+    lib = load_library()
+    out = []
+    for d in range(lib.bfd_device_count()):
+        buf = C.create_string_buffer(256)
+        _check(lib.bfd_device_name(d, buf, 256), 'bfd_device_name')
+        out.append((d, buf.value.decode()))
+    return out
+
+
+def stable_dt(MaterialList, Frequency, QfactorCorrection, SpatialStep, AlphaCFL, QCorrection=1.0):
+    lib = load_library()
+    ml = np.ascontiguousarray(MaterialList, np.float64).reshape(-1, 5)
+    qc = np.ascontiguousarray(np.broadcast_to(np.asarray(QCorrection, np.float64), (ml.shape[0],)))
+    dt = lib.bfd_stable_dt(ml.shape[0], _ptr(ml), _ptr(qc), float(Frequency), int(bool(QfactorCorrection)),
+                           float(SpatialStep), float(AlphaCFL))
+    if dt <= 0:
+        raise EngineError('bfd_stable_dt failed: ' + lib.bfd_last_error().decode())
+    return dt
+
+
+def material_tables(MaterialList, Frequency, QfactorCorrection, SpatialStep, dt, QCorrection=1.0):
+    lib = load_library()
+    ml = np.ascontiguousarray(MaterialList, np.float64).reshape(-1, 5)
+    qc = np.ascontiguousarray(np.broadcast_to(np.asarray(QCorrection, np.float64), (ml.shape[0],)))
+    t = np.zeros((7, ml.shape[0]), np.float32)
+    c1k2 = np.zeros(2, np.float32)
+    cmax = C.c_double()
+    _check(lib.bfd_material_tables(ml.shape[0], _ptr(ml), _ptr(qc), float(Frequency), int(bool(QfactorCorrection)),
+                                   float(SpatialStep), float(dt), _ptr(t), _ptr(c1k2), C.byref(cmax)),
+           'bfd_material_tables')
+    return t, c1k2, cmax.value
+
+
+class Engine:
+    """One Z-slab of the domain on one GPU."""
+
+    def __init__(self, N1, N2, N3, nMat, h, dt, freq, nt, k0=0, nk=None, NDelta=12, reflectionLimit=1e-5,
+                 typeSource=0, sensorSub=1, sensorStart=0, selRMSorPeak=1, selMapsRMS=('Pressure',),
+                 selMapsSensors=('Pressure',), qfactorCorrection=True, device=0, kernelVariant=0):
+        self.lib = load_library()
+        if self.lib.bfd_device_count() <= 0:
+            raise EngineError('no HIP device visible: the MI355X engine has no CPU fallback')
+        nk = N3 - k0 if nk is None else nk
+        self.selR = ordered(selMapsRMS)
+        self.selS = ordered(selMapsSensors)
+        self.cfg = Config(N1=N1, N2=N2, N3=N3, k0=k0, nk=nk, nMat=nMat, NDelta=NDelta, typeSource=typeSource,
+                          sensorSub=sensorSub, sensorStart=sensorStart, nt=nt, selRMSorPeak=selRMSorPeak,
+                          selMapsRMS=mask_of(self.selR), selMapsSensors=mask_of(self.selS),
+                          qfactorCorrection=int(bool(qfactorCorrection)), device=device, kernelVariant=kernelVariant,
+                          h=h, dt=dt, freq=freq, reflectionLimit=reflectionLimit)
+        self.h = C.c_void_p()
+        _check(self.lib.bfd_create(C.byref(self.cfg), C.byref(self.h)), 'bfd_create')
+        self.shape = (N1, N2, nk)
+
+    def close(self):
+        if getattr(self, 'h', None) is not None and self.h:
+            self.lib.bfd_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- inputs ----
+    def set_stream(self, stream_ptr):
+        _check(self.lib.bfd_set_stream(self.h, C.c_void_p(stream_ptr)), 'bfd_set_stream')
+
+    def set_materials(self, MaterialList, QCorrection=1.0):
+        ml = np.ascontiguousarray(MaterialList, np.float64).reshape(-1, 5)
+        if ml.shape[0] != self.cfg.nMat:
+            raise ValueError('MaterialList rows != nMat')
+        qc = np.ascontiguousarray(np.broadcast_to(np.asarray(QCorrection, np.float64), (ml.shape[0],)))
+        _check(self.lib.bfd_set_materials(self.h, _ptr(ml), _ptr(qc)), 'bfd_set_materials')
+
+    def set_material_map(self, slab_with_ghosts, ghostLow, ghostHigh):
+        """slab_with_ghosts: uint32 (N1,N2,ghostLow+nk+ghostHigh) view/array (any strides >= 0)."""
+        a = np.asarray(slab_with_ghosts)
+        if a.dtype != np.uint32:
+            a = a.astype(np.uint32)
+        assert a.shape == (self.shape[0], self.shape[1], self.shape[2] + ghostLow + ghostHigh), a.shape
+        if any(s < 0 for s in a.strides):
+            a = np.ascontiguousarray(a)
+        s1, s2, s3 = _estrides(a)
+        base = a.ctypes.data + ghostLow * a.strides[2]
+        _check(self.lib.bfd_set_material_map(self.h, C.c_void_p(base), s1, s2, s3, ghostLow, ghostHigh),
+               'bfd_set_material_map')
+
+    def set_reflector(self, mask):
+        if mask is None:
+            _check(self.lib.bfd_set_reflector(self.h, None, 0, 0, 0), 'bfd_set_reflector')
+            return
+        a = self._dense_u32(mask)
+        _check(self.lib.bfd_set_reflector(self.h, _ptr(a), *_estrides(a)), 'bfd_set_reflector')
+
+    def _dense_u32(self, a):
+        a = np.asarray(a)
+        assert a.shape == self.shape, (a.shape, self.shape)
+        if a.dtype != np.uint32 or any(s < 0 for s in a.strides):
+            a = np.ascontiguousarray(a, np.uint32)
+        # the ABI uploads the whole address span of the view: keep it dense
+        if a.size and (sum((n - 1) * s for n, s in zip(a.shape, _estrides(a))) + 1) != a.size:
+            a = np.ascontiguousarray(a)
+        return a
+
+    def set_sources(self, localIndex, row, wx, wy, wz, PulseSource):
+        pulse = np.ascontiguousarray(np.atleast_2d(PulseSource), np.float64)
+        li = np.ascontiguousarray(localIndex, np.uint32)
+        rw = np.ascontiguousarray(row, np.uint32)
+        ws = [None if w is None else np.ascontiguousarray(w, np.float32) for w in (wx, wy, wz)]
+        _check(self.lib.bfd_set_sources(self.h, li.size, _ptr(li), _ptr(rw), _ptr(ws[0]), _ptr(ws[1]), _ptr(ws[2]),
+                                        _ptr(pulse), pulse.shape[0], pulse.shape[1]), 'bfd_set_sources')
+
+    def set_sensor_map(self, sensor_slab):
+        a = self._dense_u32(sensor_slab)
+        n = C.c_int64()
+        _check(self.lib.bfd_set_sensor_map(self.h, _ptr(a), *_estrides(a), C.byref(n)), 'bfd_set_sensor_map')
+        return n.value
+
+    # ---- stepping ----
+    def run(self, nSteps):
+        _check(self.lib.bfd_run(self.h, int(nSteps)), 'bfd_run')
+
+    def half_step_stress(self):
+        _check(self.lib.bfd_half_step_stress(self.h), 'bfd_half_step_stress')
+
+    def half_step_velocity(self):
+        _check(self.lib.bfd_half_step_velocity(self.h), 'bfd_half_step_velocity')
+
+    def sync(self):
+        _check(self.lib.bfd_sync(self.h), 'bfd_sync')
+
+    @property
+    def step(self):
+        return self.lib.bfd_current_step(self.h)
+
+    def halo_region(self, group, f, side, send):
+        p = C.c_void_p()
+        n = C.c_size_t()
+        _check(self.lib.bfd_halo_region(self.h, group, f, side, int(send), C.byref(p), C.byref(n)), 'bfd_halo_region')
+        return p.value, n.value
+
+    def timing_begin(self, perKernel=False):
+        _check(self.lib.bfd_timing_begin(self.h, int(perKernel)), 'bfd_timing_begin')
+
+    def timing_end(self):
+        d = [C.c_double() for _ in range(4)]
+        n = [C.c_int64() for _ in range(2)]
+        _check(self.lib.bfd_timing_end(self.h, *[C.byref(x) for x in d], *[C.byref(x) for x in n]), 'bfd_timing_end')
+        return {'total_ms': d[0].value, 'stress_ms': d[1].value, 'velocity_ms': d[2].value, 'other_ms': d[3].value,
+                'n_stress': n[0].value, 'n_velocity': n[1].value}
+
+    # ---- outputs ----
+    @property
+    def num_sensors(self):
+        return self.lib.bfd_num_sensors(self.h)
+
+    @property
+    def num_sensor_steps(self):
+        return self.lib.bfd_num_sensor_steps(self.h)
+
+    def sensor_index(self):
+        idx = np.zeros(self.num_sensors, np.uint32)
+        _check(self.lib.bfd_get_sensor_index(self.h, _ptr(idx)), 'bfd_get_sensor_index')
+        return idx
+
+    def sensors(self):
+        out = np.zeros((len(self.selS), self.num_sensors, max(self.num_sensor_steps, 0)), np.float32)
+        _check(self.lib.bfd_get_sensors(self.h, _ptr(out)), 'bfd_get_sensors')
+        return out
+
+    def get_map(self, kind, name, out=None):
+        if out is None:
+            out = np.zeros(self.shape, np.float32)
+        _check(self.lib.bfd_get_map(self.h, kind, MAP_BITS[name], _ptr(out), *_estrides(out)), 'bfd_get_map')
+        return out
+
+    def get_field(self, name, out=None):
+        if out is None:
+            out = np.zeros(self.shape, np.float32)
+        _check(self.lib.bfd_get_field(self.h, FIELD_NAMES.index(name), _ptr(out), *_estrides(out)), 'bfd_get_field')
+        return out
+
+    @property
+    def device_bytes(self):
+        return self.lib.bfd_device_bytes(self.h)

@@ -1,0 +1,840 @@
+// C ABI of libbabelfdtd_hip.so (include/babelfdtd.h): host logic, coefficient preparation,
+// layout conversion, sources, sensors, accumulation. gfx950 only.
+//
+// Mirrors what BabelIntegrationBASE.py:2338-2365 hands to the reference's solver
+// (package BabelViscoFDTD==1.2.4, absent from /root/reference).
+#include "bfd_internal.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <hipcub/hipcub.hpp>
+
+static thread_local std::string g_err;
+void bfd_set_error(const std::string &s) { g_err = s; }
+#define BFD_FAIL(code, msg) do { bfd_set_error(msg); return (code); } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// coefficient preparation (float64, rounded once to float32). DESIGN.md "Material model".
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+struct HostTables {
+    std::vector<float> t;   // 7*nMat: AP,BP,AS2,BS2,invMu,tauS,invRho
+    float c1, k2;
+    double cmax;
+};
+
+// one standard-linear-solid mechanism, tau_sigma = 1/omega:  M(omega) = MR[(1+tau/2) + i tau/2]
+void fit_sls(double rho, double c, double alpha, double q, double omega, bool exact, double &MR, double &tau)
+{
+    if (c <= 0.0) { MR = 0.0; tau = 0.0; return; }
+    if (alpha <= 0.0) { MR = rho * c * c; tau = 0.0; return; }
+    const double a = alpha / q;
+    if (exact) {
+        double x = a * c / omega;
+        if (x > 0.4) x = 0.4;
+        const double theta = 2.0 * atan(x);
+        const double tt = tan(theta);
+        const double t = 2.0 * tt / (1.0 - tt);
+        const double re = 1.0 + 0.5 * t, im = 0.5 * t;
+        const double mag = sqrt(re * re + im * im);
+        const double ch = cos(0.5 * theta);
+        tau = t;
+        MR = rho * c * c * ch * ch / mag;
+    } else {
+        double Q = omega / (2.0 * c * a);
+        if (Q < 1.5) Q = 1.5;
+        tau = 2.0 / Q;
+        MR = rho * c * c;
+    }
+}
+
+void make_tables(int nMat, const double *matlist, const double *qcorr, double freq, bool exact,
+                 double h, double dt, HostTables &T)
+{
+    const double omega = 2.0 * M_PI * freq;
+    const double tauSigma = 1.0 / omega;
+    const double dtoh = dt / h;
+    const double half = dt / (2.0 * tauSigma);
+    const double k2 = (dt / tauSigma) / (1.0 + half);
+    T.c1 = (float)((1.0 - half) / (1.0 + half));
+    T.k2 = (float)k2;
+    T.t.assign(7 * (size_t)nMat, 0.0f);
+    float *AP = T.t.data(), *BP = AP + nMat, *AS2 = BP + nMat, *BS2 = AS2 + nMat;
+    float *invMu = BS2 + nMat, *tauS = invMu + nMat, *invRho = tauS + nMat;
+    T.cmax = 0.0;
+    for (int m = 0; m < nMat; m++) {
+        const double *r = matlist + 5 * m;
+        const double q = qcorr ? qcorr[m] : 1.0;
+        double MRp, tauP, MRs, tauSh;
+        fit_sls(r[0], r[1], r[3], q, omega, exact, MRp, tauP);
+        fit_sls(r[0], r[2], r[4], q, omega, exact, MRs, tauSh);
+        AP[m] = (float)(MRp * (1.0 + tauP) * dtoh);
+        BP[m] = (float)(MRp * tauP * dtoh * k2);
+        AS2[m] = (float)(2.0 * MRs * (1.0 + tauSh) * dtoh);
+        BS2[m] = (float)(2.0 * MRs * tauSh * dtoh * k2);
+        invMu[m] = (MRs > 0.0) ? (float)(1.0 / (MRs * dtoh)) : 0.0f;
+        tauS[m] = (float)tauSh;
+        invRho[m] = (float)(dtoh / r[0]);
+        const double cu = sqrt(MRp * (1.0 + tauP) / r[0]);
+        T.cmax = std::max(T.cmax, cu);
+    }
+}
+
+void cpml_one(double depth, double d0, double amax, double dt, float &a, float &b)
+{
+    if (depth <= 0.0) { a = 0.0f; b = 0.0f; return; }
+    if (depth > 1.0) depth = 1.0;
+    const double d = d0 * depth * depth;
+    const double al = amax * (1.0 - depth);
+    const double bb = exp(-(d + al) * dt);
+    b = (float)bb;
+    a = (float)(d / (d + al) * (bb - 1.0));
+}
+
+// aI,bI at integer positions, aH,bH at half positions; see DESIGN.md "Absorbing layer"
+void cpml_axis(int N, int ND, double cmax, double h, double dt, double freq, double R, float *out4N)
+{
+    const double d0 = -3.0 * cmax * log(R) / (2.0 * ND * h);
+    const double amax = M_PI * freq;
+    float *aI = out4N, *bI = aI + N, *aH = bI + N, *bH = aH + N;
+    for (int i = 0; i < N; i++) {
+        const double li = (double)(ND - i) / ND, lh = ((double)(ND - i) - 0.5) / ND;
+        const double ri = (double)(i - (N - 1 - ND)) / ND, rh = ((double)(i - (N - 1 - ND)) + 0.5) / ND;
+        cpml_one(std::max(li, ri), d0, amax, dt, aI[i], bI[i]);
+        cpml_one(std::max(lh, rh), d0, amax, dt, aH[i], bH[i]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// aux kernels
+// ------------------------------------------------------------------------------------------------
+// strided caller layout -> x-fastest device layout. One thread per destination voxel.
+// MODE 0: material ids (value must be < limit, else *flag = 1); MODE 1: boolean (value != 0)
+template <int MODE, typename TO>
+__global__ void gather_to_xfast(const uint32_t *__restrict__ in, long s1, long s2, long s3, TO *__restrict__ out,
+                                int N1, int N2, int nk, int kSrcOffset, int kSrcMin, int kSrcMax, uint32_t limit, int *flag)
+{
+    const long n = (long)N1 * N2 * nk;
+    for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (long)gridDim.x * blockDim.x) {
+        const int i = (int)(v % N1);
+        const int j = (int)((v / N1) % N2);
+        int k = (int)(v / ((long)N1 * N2)) + kSrcOffset;
+        k = min(max(k, kSrcMin), kSrcMax);   // replicate missing ghost planes
+        const uint32_t x = in[i * s1 + j * s2 + k * s3];
+        if (MODE == 0) {
+            if (x >= limit) *flag = 1;
+            out[v] = (TO)x;
+        } else {
+            out[v] = (TO)(x != 0u);
+        }
+    }
+}
+__global__ void or_reflector(const uint32_t *__restrict__ in, long s1, long s2, long s3, uint16_t *__restrict__ mat,
+                             int N1, int N2, int nk, int clear)
+{
+    const long n = (long)N1 * N2 * nk;
+    for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (long)gridDim.x * blockDim.x) {
+        uint16_t m = mat[v] & BFD_MAT_MASK;
+        if (!clear) {
+            const int i = (int)(v % N1), j = (int)((v / N1) % N2), k = (int)(v / ((long)N1 * N2));
+            if (in[i * s1 + j * s2 + k * s3]) m |= BFD_REFLECTOR_BIT;
+        }
+        mat[v] = m;
+    }
+}
+// x-fastest device layout -> strided caller layout (through a dense device staging buffer)
+__global__ void scatter_from_xfast(const float *__restrict__ in, float *__restrict__ out, long s1, long s2, long s3,
+                                   int N1, int N2, int nk)
+{
+    const long n = (long)N1 * N2 * nk;
+    for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (long)gridDim.x * blockDim.x) {
+        const int i = (int)(v % N1), j = (int)((v / N1) % N2), k = (int)(v / ((long)N1 * N2));
+        out[i * s1 + j * s2 + k * s3] = in[v];
+    }
+}
+__global__ void transpose_pulse(const double *__restrict__ in, float *__restrict__ out, int nSrc, int L)
+{   // in [nSrc][L] f64 -> out [L][nSrc] f32
+    const long n = (long)nSrc * L;
+    for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (long)gridDim.x * blockDim.x) {
+        const int s = (int)(v % nSrc);
+        const long t = v / nSrc;
+        out[v] = (float)in[(long)s * L + t];
+    }
+}
+
+__device__ __forceinline__ float map_value(const bfd_dev &d, int sel, long c)
+{
+    switch (sel) {
+    case BFD_MAP_VX: return d.Vx[c];
+    case BFD_MAP_VY: return d.Vy[c];
+    case BFD_MAP_VZ: return d.Vz[c];
+    case BFD_MAP_SIGMAXX: return d.Sxx[c];
+    case BFD_MAP_SIGMAYY: return d.Syy[c];
+    case BFD_MAP_SIGMAZZ: return d.Szz[c];
+    case BFD_MAP_SIGMAXY: return d.Sxy[c];
+    case BFD_MAP_SIGMAXZ: return d.Sxz[c];
+    case BFD_MAP_SIGMAYZ: return d.Syz[c];
+    case BFD_MAP_PRESSURE: {
+        const float s = (d.Sxx[c] + d.Syy[c]) + d.Szz[c];
+        return -s * (1.0f / 3.0f);
+    }
+    default: return 0.0f;
+    }
+}
+__device__ __forceinline__ float map_sq(const bfd_dev &d, int sel, long c)
+{
+    if (sel == BFD_MAP_ALLV) {
+        const float x = d.Vx[c], y = d.Vy[c], z = d.Vz[c];
+        return (x * x + y * y) + z * z;
+    }
+    const float v = map_value(d, sel, c);
+    return v * v;
+}
+
+struct SelList { int n; int sel[BFD_MAP_COUNT]; };
+
+// RMS / peak accumulation outside the absorbing layer (generic path, any map selection)
+__global__ __launch_bounds__(256) void accumulate_maps(bfd_dev d, SelList L, float *__restrict__ acc, float *__restrict__ pk, long nloc)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    const int j = blockIdx.y * 4 + threadIdx.y;
+    const int kl = blockIdx.z;
+    const int k = d.k0 + kl;
+    if (i < d.ND || i >= d.N1 - d.ND || j < d.ND || j >= d.N2 - d.ND || k < d.ND || k >= d.N3 - d.ND) return;
+    const long c = (long)kl * d.plane + (long)j * d.N1 + i;
+    for (int q = 0; q < L.n; q++) {
+        if (acc) acc[q * nloc + c] = acc[q * nloc + c] + map_sq(d, L.sel[q], c);
+        if (pk) {
+            const float v = (L.sel[q] == BFD_MAP_ALLV) ? sqrtf(map_sq(d, BFD_MAP_ALLV, c)) : fabsf(map_value(d, L.sel[q], c));
+            if (v > pk[q * nloc + c]) pk[q * nloc + c] = v;
+        }
+    }
+}
+__global__ void finalize_rms(const float *__restrict__ acc, float *__restrict__ out, long n, float cnt)
+{
+    for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (long)gridDim.x * blockDim.x)
+        out[v] = sqrtf(acc[v] / cnt);
+}
+__global__ void last_map(bfd_dev d, int sel, float *__restrict__ out, long n)
+{
+    for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (long)gridDim.x * blockDim.x)
+        out[v] = (sel == BFD_MAP_ALLV) ? sqrtf(map_sq(d, BFD_MAP_ALLV, v)) : map_value(d, sel, v);
+}
+
+// sensors: out[q][col][s]
+__global__ void record_sensors(bfd_dev d, SelList L, const uint32_t *__restrict__ lin, long nSens, float *__restrict__ out,
+                               int col, int nTs)
+{
+    for (long s = (long)blockIdx.x * blockDim.x + threadIdx.x; s < nSens; s += (long)gridDim.x * blockDim.x) {
+        const long c = lin[s];
+        for (int q = 0; q < L.n; q++) {
+            const float v = (L.sel[q] == BFD_MAP_ALLV) ? sqrtf(map_sq(d, BFD_MAP_ALLV, c)) : map_value(d, L.sel[q], c);
+            out[((long)q * nTs + col) * nSens + s] = v;
+        }
+    }
+}
+// [q][nTs][nSens] -> [q][nSens][nTs]
+__global__ void transpose_sensors(const float *__restrict__ in, float *__restrict__ out, long nSens, int nTs, int nq)
+{
+    const long n = nSens * nTs * nq;
+    for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (long)gridDim.x * blockDim.x) {
+        const int t = (int)(v % nTs);
+        const long s = (v / nTs) % nSens;
+        const long q = v / ((long)nTs * nSens);
+        out[v] = in[(q * nTs + t) * nSens + s];
+    }
+}
+
+// sources. typeSource 0/1: velocity (after the velocity half-step), 2/3: normal stresses (after the stress half-step)
+__global__ void inject_sources(bfd_dev d, int typeSource, const uint32_t *__restrict__ lin, const uint32_t *__restrict__ row,
+                               const float *__restrict__ wx, const float *__restrict__ wy, const float *__restrict__ wz,
+                               const float *__restrict__ pulseAtStep, long nVox)
+{
+    for (long s = (long)blockIdx.x * blockDim.x + threadIdx.x; s < nVox; s += (long)gridDim.x * blockDim.x) {
+        const long c = lin[s];
+        const float val = pulseAtStep[row[s]];
+        const float x = wx ? wx[s] : 1.0f;
+        if (typeSource >= 2) {
+            const float v = val * x;
+            if (typeSource == 2) { d.Sxx[c] = d.Sxx[c] + v; d.Syy[c] = d.Syy[c] + v; d.Szz[c] = d.Szz[c] + v; }
+            else { d.Sxx[c] = v; d.Syy[c] = v; d.Szz[c] = v; }
+        } else {
+            const float y = wy ? wy[s] : 1.0f, z = wz ? wz[s] : 1.0f;
+            if (typeSource == 0) { d.Vx[c] = d.Vx[c] + val * x; d.Vy[c] = d.Vy[c] + val * y; d.Vz[c] = d.Vz[c] + val * z; }
+            else { d.Vx[c] = val * x; d.Vy[c] = val * y; d.Vz[c] = val * z; }
+        }
+    }
+}
+
+inline int grid_for(long n, int block = 256) { return (int)std::min<long>((n + block - 1) / block, 256L * 32); }
+
+template <typename T>
+int dev_alloc(bfd_sim *s, T **p, size_t count, bool zero = true)
+{
+    void *q = nullptr;
+    const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+    BFD_HIP(hipMalloc(&q, bytes));
+    if (zero) BFD_HIP(hipMemsetAsync(q, 0, bytes, s->stream));
+    s->allocs.push_back(q);
+    s->devBytes += (int64_t)bytes;
+    *p = (T *)q;
+    return 0;
+}
+
+inline size_t span_elems(int N1, int N2, int nk, int64_t s1, int64_t s2, int64_t s3)
+{
+    return (size_t)((N1 - 1) * s1 + (N2 - 1) * s2 + (nk - 1) * s3 + 1);
+}
+
+int sel_list(uint32_t mask, int *sel)
+{
+    int n = 0;
+    for (int b = 0; b < BFD_MAP_COUNT; b++) if (mask & (1u << b)) sel[n++] = b;
+    return n;
+}
+
+hipEvent_t get_event(bfd_sim *s)
+{
+    hipEvent_t e;
+    if (!s->evPool.empty()) { e = s->evPool.back(); s->evPool.pop_back(); return e; }
+    hipEventCreate(&e);
+    return e;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+int bfd_abi_version(void) { return BFD_ABI_VERSION; }
+const char *bfd_last_error(void) { return g_err.c_str(); }
+
+int bfd_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+int bfd_device_name(int device, char *buf, int buflen)
+{
+    hipDeviceProp_t p;
+    BFD_HIP(hipGetDeviceProperties(&p, device));
+    snprintf(buf, buflen, "%s (%s)", p.name, p.gcnArchName);
+    return 0;
+}
+
+double bfd_stable_dt(int32_t nMat, const double *matlist, const double *qcorr, double freq,
+                     int32_t qfactorCorrection, double h, double alphaCFL)
+{
+    if (nMat <= 0 || !matlist) { bfd_set_error("bfd_stable_dt: no materials"); return -1.0; }
+    HostTables T;
+    make_tables(nMat, matlist, qcorr, freq, qfactorCorrection != 0, h, 1.0, T);
+    // O(2,4) staggered leapfrog: dt <= (6/7) h / (sqrt(3) cmax)
+    return alphaCFL * (6.0 / 7.0) * h / (sqrt(3.0) * T.cmax);
+}
+
+int bfd_material_tables(int32_t nMat, const double *matlist, const double *qcorr, double freq,
+                        int32_t qfactorCorrection, double h, double dt, float *tables7, float *c1k2, double *cmax)
+{
+    if (nMat <= 0 || !matlist) BFD_FAIL(-1, "bfd_material_tables: no materials");
+    HostTables T;
+    make_tables(nMat, matlist, qcorr, freq, qfactorCorrection != 0, h, dt, T);
+    if (tables7) memcpy(tables7, T.t.data(), T.t.size() * sizeof(float));
+    if (c1k2) { c1k2[0] = T.c1; c1k2[1] = T.k2; }
+    if (cmax) *cmax = T.cmax;
+    return 0;
+}
+
+int bfd_create(const bfd_config *cfg, bfd_sim **out)
+{
+    if (!cfg || !out) BFD_FAIL(-1, "bfd_create: null argument");
+    const int P = cfg->NDelta + 1;
+    if (cfg->N1 < 2 * P + 4 || cfg->N2 < 2 * P + 4 || cfg->N3 < 2 * P + 4)
+        BFD_FAIL(-2, "bfd_create: every dimension must be at least 2*(NDelta+1)+4 voxels");
+    if (cfg->k0 < 0 || cfg->nk < 2 || cfg->k0 + cfg->nk > cfg->N3)
+        BFD_FAIL(-2, "bfd_create: slab [k0,k0+nk) outside the domain or thinner than 2 planes");
+    if (cfg->nMat <= 0 || cfg->nMat > (int)BFD_MAT_MASK) BFD_FAIL(-2, "bfd_create: nMat must be in 1..32767");
+    if (cfg->sensorSub <= 0 || cfg->sensorStart < 0 || cfg->nt < 0) BFD_FAIL(-2, "bfd_create: bad sensor sampling / nt");
+    if (cfg->typeSource < 0 || cfg->typeSource > 3) BFD_FAIL(-2, "bfd_create: TypeSource must be 0..3");
+    if (cfg->selRMSorPeak < 0 || cfg->selRMSorPeak > 3) BFD_FAIL(-2, "bfd_create: SelRMSorPeak must be 0..3");
+    if ((long)cfg->N1 * cfg->N2 * (cfg->nk + 4) >= (1L << 32)) BFD_FAIL(-2, "bfd_create: slab exceeds 2^32 voxels");
+    if (!(cfg->h > 0) || !(cfg->dt > 0) || !(cfg->freq > 0) || !(cfg->reflectionLimit > 0 && cfg->reflectionLimit < 1))
+        BFD_FAIL(-2, "bfd_create: h, dt, freq must be > 0 and 0 < reflectionLimit < 1");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        BFD_FAIL(-3, "bfd_create: no HIP device available (this engine has no CPU fallback)");
+    if (cfg->device < 0 || cfg->device >= ndev) BFD_FAIL(-3, "bfd_create: device ordinal out of range");
+    BFD_HIP(hipSetDevice(cfg->device));
+
+    bfd_sim *s = new bfd_sim();
+    s->cfg = *cfg;
+    s->step = 0; s->devBytes = 0; s->haveMaterials = s->haveMap = false;
+    s->nSrcVox = 0; s->srcLin = s->srcRow = nullptr; s->srcW[0] = s->srcW[1] = s->srcW[2] = nullptr; s->pulseT = nullptr;
+    s->nSources = s->lengthSource = 0;
+    s->nSensors = 0; s->sensLin = nullptr; s->sensOut = nullptr;
+    s->acc = s->pk = nullptr; s->timing = s->perKernel = false;
+    s->tables = nullptr; s->profiles = nullptr; s->cmax = 0;
+    if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) { delete s; BFD_FAIL(-10, "hipStreamCreate failed"); }
+    s->ownStream = true;
+    hipEventCreate(&s->evBegin); hipEventCreate(&s->evEnd);
+
+    bfd_dev &d = s->d;
+    memset(&d, 0, sizeof d);
+    d.N1 = cfg->N1; d.N2 = cfg->N2; d.N3 = cfg->N3; d.k0 = cfg->k0; d.nk = cfg->nk;
+    d.ND = cfg->NDelta; d.P = P; d.plane = cfg->N1 * cfg->N2;
+    s->nloc = (size_t)d.plane * d.nk;
+    s->nalloc = (size_t)d.plane * (d.nk + 4);
+
+    int rc = 0;
+    float **fp[15] = {&d.Vx, &d.Vy, &d.Vz, &d.Sxx, &d.Syy, &d.Szz, &d.Sxy, &d.Sxz, &d.Syz,
+                      &d.Rxx, &d.Ryy, &d.Rzz, &d.Rxy, &d.Rxz, &d.Ryz};
+    for (int a = 0; a < 15 && !rc; a++) {
+        rc = dev_alloc(s, &s->stateBase[a], s->nalloc);
+        if (!rc) *fp[a] = s->stateBase[a] + 2 * (size_t)d.plane;
+    }
+    if (!rc) rc = dev_alloc(s, &s->matBase, s->nalloc);
+    if (!rc) d.mat = s->matBase + 2 * (size_t)d.plane;
+    // CPML memory variables
+    const bool zTouch = (d.k0 < P) || (d.k0 + d.nk > d.N3 - P);
+    static const int dirOf[18] = {0, 1, 2, 1, 0, 2, 0, 2, 1, 0, 1, 2, 0, 1, 2, 0, 1, 2};
+    for (int a = 0; a < 18 && !rc; a++) {
+        size_t n = 0;
+        if (dirOf[a] == 0) n = (size_t)d.nk * d.N2 * 2 * P;
+        else if (dirOf[a] == 1) n = (size_t)d.nk * 2 * P * d.N1;
+        else n = zTouch ? (size_t)2 * P * d.plane : 0;
+        rc = dev_alloc(s, &d.psi[a], n);
+    }
+    if (!rc) rc = dev_alloc(s, &s->tables, 7 * (size_t)cfg->nMat);
+    if (!rc) rc = dev_alloc(s, &s->profiles, 4 * (size_t)(d.N1 + d.N2 + d.N3));
+    s->nSelR = sel_list(cfg->selMapsRMS, s->selR);
+    s->nSelS = sel_list(cfg->selMapsSensors, s->selS);
+    if (!rc && (cfg->selRMSorPeak & 1) && s->nSelR) rc = dev_alloc(s, &s->acc, (size_t)s->nSelR * s->nloc);
+    if (!rc && (cfg->selRMSorPeak & 2) && s->nSelR) rc = dev_alloc(s, &s->pk, (size_t)s->nSelR * s->nloc);
+    s->accStart = cfg->sensorStart * cfg->sensorSub;
+    s->nTs = 0;
+    for (int n = 0; n < cfg->nt; n++) if (n % cfg->sensorSub == 0 && n / cfg->sensorSub >= cfg->sensorStart) s->nTs++;
+    if (rc) { bfd_destroy(s); return rc; }
+    if (hipStreamSynchronize(s->stream) != hipSuccess) { bfd_destroy(s); BFD_FAIL(-10, "bfd_create: sync failed"); }
+    *out = s;
+    return 0;
+}
+
+void bfd_destroy(bfd_sim *s)
+{
+    if (!s) return;
+    hipSetDevice(s->cfg.device);
+    hipDeviceSynchronize();
+    for (void *p : s->allocs) hipFree(p);
+    for (hipEvent_t e : s->evPool) hipEventDestroy(e);
+    for (hipEvent_t e : s->evStress) hipEventDestroy(e);
+    for (hipEvent_t e : s->evVelocity) hipEventDestroy(e);
+    hipEventDestroy(s->evBegin); hipEventDestroy(s->evEnd);
+    if (s->ownStream) hipStreamDestroy(s->stream);
+    delete s;
+}
+
+int bfd_set_stream(bfd_sim *s, void *hipStream)
+{
+    if (!s) BFD_FAIL(-1, "null sim");
+    BFD_HIP(hipSetDevice(s->cfg.device));
+    BFD_HIP(hipStreamSynchronize(s->stream));
+    if (hipStream) {
+        if (s->ownStream) { hipStreamDestroy(s->stream); s->ownStream = false; }
+        s->stream = (hipStream_t)hipStream;
+    } else if (!s->ownStream) {
+        BFD_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+        s->ownStream = true;
+    }
+    return 0;
+}
+
+int bfd_set_materials(bfd_sim *s, const double *matlist, const double *qcorr)
+{
+    if (!s || !matlist) BFD_FAIL(-1, "bfd_set_materials: null argument");
+    BFD_HIP(hipSetDevice(s->cfg.device));
+    const bfd_config &c = s->cfg;
+    for (int m = 0; m < c.nMat; m++) {
+        const double *r = matlist + 5 * m;
+        if (!(r[0] > 0) || !(r[1] > 0) || r[2] < 0 || r[3] < 0 || r[4] < 0)
+            BFD_FAIL(-2, "bfd_set_materials: need rho>0, cL>0, cS>=0, alpha>=0 in every row");
+        if (qcorr && !(qcorr[m] > 0)) BFD_FAIL(-2, "bfd_set_materials: QCorrection must be > 0");
+    }
+    HostTables T;
+    make_tables(c.nMat, matlist, qcorr, c.freq, c.qfactorCorrection != 0, c.h, c.dt, T);
+    const double cfl = T.cmax * c.dt / c.h;
+    if (cfl > (6.0 / 7.0) / sqrt(3.0) * 1.0000001)
+        BFD_FAIL(-4, "bfd_set_materials: DT violates the stability limit dt <= (6/7) h / (sqrt(3) cmax)");
+    s->cmax = T.cmax;
+    BFD_HIP(hipMemcpyAsync(s->tables, T.t.data(), T.t.size() * sizeof(float), hipMemcpyHostToDevice, s->stream));
+    bfd_dev &d = s->d;
+    const int n = c.nMat;
+    d.AP = s->tables; d.BP = d.AP + n; d.AS2 = d.BP + n; d.BS2 = d.AS2 + n;
+    d.invMu = d.BS2 + n; d.tauS = d.invMu + n; d.invRho = d.tauS + n;
+    d.c1 = T.c1; d.k2 = T.k2;
+    std::vector<float> prof(4 * (size_t)(d.N1 + d.N2 + d.N3));
+    float *px = prof.data(), *py = px + 4 * d.N1, *pz = py + 4 * d.N2;
+    cpml_axis(d.N1, d.ND, T.cmax, c.h, c.dt, c.freq, c.reflectionLimit, px);
+    cpml_axis(d.N2, d.ND, T.cmax, c.h, c.dt, c.freq, c.reflectionLimit, py);
+    cpml_axis(d.N3, d.ND, T.cmax, c.h, c.dt, c.freq, c.reflectionLimit, pz);
+    BFD_HIP(hipMemcpyAsync(s->profiles, prof.data(), prof.size() * sizeof(float), hipMemcpyHostToDevice, s->stream));
+    BFD_HIP(hipStreamSynchronize(s->stream));
+    const float *bx = s->profiles, *by = bx + 4 * d.N1, *bz = by + 4 * d.N2;
+    d.axI = bx; d.bxI = bx + d.N1; d.axH = bx + 2 * d.N1; d.bxH = bx + 3 * d.N1;
+    d.ayI = by; d.byI = by + d.N2; d.ayH = by + 2 * d.N2; d.byH = by + 3 * d.N2;
+    d.azI = bz; d.bzI = bz + d.N3; d.azH = bz + 2 * d.N3; d.bzH = bz + 3 * d.N3;
+    s->haveMaterials = true;
+    return 0;
+}
+
+int bfd_set_material_map(bfd_sim *s, const uint32_t *map, int64_t s1, int64_t s2, int64_t s3,
+                         int32_t ghostLow, int32_t ghostHigh)
+{
+    if (!s || !map) BFD_FAIL(-1, "bfd_set_material_map: null argument");
+    if (ghostLow < 0 || ghostLow > 2 || ghostHigh < 0 || ghostHigh > 2) BFD_FAIL(-2, "ghost plane counts must be 0..2");
+    BFD_HIP(hipSetDevice(s->cfg.device));
+    const bfd_dev &d = s->d;
+    // upload the readable span [k=-ghostLow .. nk-1+ghostHigh]
+    const uint32_t *base = map - (int64_t)ghostLow * s3;
+    const int nkSpan = d.nk + ghostLow + ghostHigh;
+    if (s1 < 0 || s2 < 0 || s3 < 0) BFD_FAIL(-2, "negative strides are not supported");
+    const size_t span = span_elems(d.N1, d.N2, nkSpan, s1, s2, s3);
+    uint32_t *tmp = nullptr;
+    BFD_HIP(hipMalloc((void **)&tmp, span * sizeof(uint32_t)));
+    hipError_t e = hipMemcpyAsync(tmp, base, span * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream);
+    int *flag = nullptr; int hflag = 0;
+    if (e == hipSuccess) e = hipMalloc((void **)&flag, sizeof(int));
+    if (e == hipSuccess) e = hipMemsetAsync(flag, 0, sizeof(int), s->stream);
+    if (e == hipSuccess) {
+        // destination covers local planes -2..nk+1; source plane index = local k + ghostLow, clamped to the span
+        hipLaunchKernelGGL((gather_to_xfast<0, uint16_t>), dim3(grid_for((long)s->nalloc)), dim3(256), 0, s->stream,
+                           tmp, (long)s1, (long)s2, (long)s3, s->matBase, d.N1, d.N2, d.nk + 4, ghostLow - 2, 0, nkSpan - 1,
+                           (uint32_t)s->cfg.nMat, flag);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&hflag, flag, sizeof(int), hipMemcpyDeviceToHost, s->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+    hipFree(tmp); if (flag) hipFree(flag);
+    if (e != hipSuccess) BFD_FAIL(-10, std::string("bfd_set_material_map: ") + hipGetErrorString(e));
+    if (hflag) BFD_FAIL(-5, "bfd_set_material_map: MaterialMap holds an id >= number of MaterialList rows");
+    s->haveMap = true;
+    return 0;
+}
+
+int bfd_set_reflector(bfd_sim *s, const uint32_t *mask, int64_t s1, int64_t s2, int64_t s3)
+{
+    if (!s) BFD_FAIL(-1, "null sim");
+    if (!s->haveMap) BFD_FAIL(-6, "bfd_set_reflector: set the material map first");
+    BFD_HIP(hipSetDevice(s->cfg.device));
+    const bfd_dev &d = s->d;
+    uint32_t *tmp = nullptr;
+    if (mask) {
+        const size_t span = span_elems(d.N1, d.N2, d.nk, s1, s2, s3);
+        BFD_HIP(hipMalloc((void **)&tmp, span * sizeof(uint32_t)));
+        BFD_HIP(hipMemcpyAsync(tmp, mask, span * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream));
+    }
+    hipLaunchKernelGGL(or_reflector, dim3(grid_for((long)s->nloc)), dim3(256), 0, s->stream, tmp, (long)s1, (long)s2, (long)s3,
+                       s->matBase + 2 * (size_t)d.plane, d.N1, d.N2, d.nk, mask ? 0 : 1);
+    BFD_HIP(hipStreamSynchronize(s->stream));
+    if (tmp) hipFree(tmp);
+    return 0;
+}
+
+int bfd_set_sources(bfd_sim *s, int64_t nVox, const uint32_t *localIndex, const uint32_t *row,
+                    const float *wx, const float *wy, const float *wz,
+                    const double *pulse, int32_t nSources, int32_t lengthSource)
+{
+    if (!s) BFD_FAIL(-1, "null sim");
+    if (nVox < 0 || (nVox > 0 && (!localIndex || !row || !pulse))) BFD_FAIL(-1, "bfd_set_sources: null argument");
+    if (nSources < 0 || lengthSource < 0) BFD_FAIL(-2, "bfd_set_sources: bad PulseSource shape");
+    BFD_HIP(hipSetDevice(s->cfg.device));
+    for (int64_t v = 0; v < nVox; v++) {
+        if (localIndex[v] >= s->nloc) BFD_FAIL(-2, "bfd_set_sources: voxel index outside the slab");
+        if ((int)row[v] >= nSources) BFD_FAIL(-2, "bfd_set_sources: SourceMap id exceeds PulseSource rows");
+    }
+    s->nSrcVox = nVox; s->nSources = nSources; s->lengthSource = lengthSource;
+    if (nVox == 0) return 0;
+    int rc = 0;
+    if ((rc = dev_alloc(s, &s->srcLin, nVox, false))) return rc;
+    if ((rc = dev_alloc(s, &s->srcRow, nVox, false))) return rc;
+    BFD_HIP(hipMemcpyAsync(s->srcLin, localIndex, nVox * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream));
+    BFD_HIP(hipMemcpyAsync(s->srcRow, row, nVox * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream));
+    const float *w[3] = {wx, wy, wz};
+    for (int a = 0; a < 3; a++) {
+        s->srcW[a] = nullptr;
+        if (w[a]) {
+            if ((rc = dev_alloc(s, &s->srcW[a], nVox, false))) return rc;
+            BFD_HIP(hipMemcpyAsync(s->srcW[a], w[a], nVox * sizeof(float), hipMemcpyHostToDevice, s->stream));
+        }
+    }
+    const size_t np = (size_t)nSources * lengthSource;
+    if ((rc = dev_alloc(s, &s->pulseT, np, false))) return rc;
+    double *tmp = nullptr;
+    BFD_HIP(hipMalloc((void **)&tmp, std::max<size_t>(np, 1) * sizeof(double)));
+    BFD_HIP(hipMemcpyAsync(tmp, pulse, np * sizeof(double), hipMemcpyHostToDevice, s->stream));
+    hipLaunchKernelGGL(transpose_pulse, dim3(grid_for((long)np)), dim3(256), 0, s->stream, tmp, s->pulseT, nSources, lengthSource);
+    BFD_HIP(hipStreamSynchronize(s->stream));
+    hipFree(tmp);
+    return 0;
+}
+
+int bfd_set_sensor_map(bfd_sim *s, const uint32_t *map, int64_t s1, int64_t s2, int64_t s3, int64_t *nSensors)
+{
+    if (!s || !map) BFD_FAIL(-1, "bfd_set_sensor_map: null argument");
+    BFD_HIP(hipSetDevice(s->cfg.device));
+    const bfd_dev &d = s->d;
+    const size_t span = span_elems(d.N1, d.N2, d.nk, s1, s2, s3);
+    uint32_t *tmp = nullptr; uint8_t *flags = nullptr; uint32_t *sel = nullptr; int *dcount = nullptr; void *work = nullptr;
+    hipError_t e = hipMalloc((void **)&tmp, span * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&flags, s->nloc);
+    if (e == hipSuccess) e = hipMalloc((void **)&sel, s->nloc * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&dcount, sizeof(int));
+    if (e == hipSuccess) e = hipMemcpyAsync(tmp, map, span * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream);
+    int count = 0;
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL((gather_to_xfast<1, uint8_t>), dim3(grid_for((long)s->nloc)), dim3(256), 0, s->stream,
+                           tmp, (long)s1, (long)s2, (long)s3, flags, d.N1, d.N2, d.nk, 0, 0, d.nk - 1, 0u, (int *)nullptr);
+        size_t wbytes = 0;
+        hipcub::CountingInputIterator<uint32_t> ids(0);
+        e = hipcub::DeviceSelect::Flagged(nullptr, wbytes, ids, flags, sel, dcount, (int)s->nloc, s->stream);
+        if (e == hipSuccess) e = hipMalloc(&work, std::max<size_t>(wbytes, 1));
+        if (e == hipSuccess) e = hipcub::DeviceSelect::Flagged(work, wbytes, ids, flags, sel, dcount, (int)s->nloc, s->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(&count, dcount, sizeof(int), hipMemcpyDeviceToHost, s->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+    }
+    int rc = 0;
+    if (e == hipSuccess) {
+        s->nSensors = count;
+        rc = dev_alloc(s, &s->sensLin, (size_t)count, false);
+        if (!rc && count) e = hipMemcpyAsync(s->sensLin, sel, (size_t)count * sizeof(uint32_t), hipMemcpyDeviceToDevice, s->stream);
+        if (!rc && s->nSelS && s->nTs > 0) rc = dev_alloc(s, &s->sensOut, (size_t)s->nSelS * s->nTs * (size_t)count);
+        if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+    }
+    hipFree(tmp); hipFree(flags); hipFree(sel); hipFree(dcount); if (work) hipFree(work);
+    if (e != hipSuccess) BFD_FAIL(-10, std::string("bfd_set_sensor_map: ") + hipGetErrorString(e));
+    if (rc) return rc;
+    if (nSensors) *nSensors = s->nSensors;
+    return 0;
+}
+
+static int check_ready(bfd_sim *s)
+{
+    if (!s) BFD_FAIL(-1, "null sim");
+    if (!s->haveMaterials || !s->haveMap) BFD_FAIL(-6, "materials and material map must be set before stepping");
+    return 0;
+}
+
+int bfd_half_step_stress(bfd_sim *s)
+{
+    int rc = check_ready(s); if (rc) return rc;
+    BFD_HIP(hipSetDevice(s->cfg.device));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (s->timing && s->perKernel) { e0 = get_event(s); e1 = get_event(s); hipEventRecord(e0, s->stream); }
+    if (s->cfg.kernelVariant == 1) bfd_launch_stress_v1(s->d, s->stream);
+    else bfd_launch_stress_v2(s->d, s->stream);
+    if (e0) { hipEventRecord(e1, s->stream); s->evStress.push_back(e0); s->evStress.push_back(e1); }
+    if (s->nSrcVox && s->cfg.typeSource >= 2 && s->step < s->lengthSource)
+        hipLaunchKernelGGL(inject_sources, dim3(grid_for(s->nSrcVox)), dim3(256), 0, s->stream, s->d, s->cfg.typeSource,
+                           s->srcLin, s->srcRow, s->srcW[0], s->srcW[1], s->srcW[2],
+                           s->pulseT + (size_t)s->step * s->nSources, (long)s->nSrcVox);
+    BFD_HIP(hipGetLastError());
+    return 0;
+}
+
+int bfd_half_step_velocity(bfd_sim *s)
+{
+    int rc = check_ready(s); if (rc) return rc;
+    BFD_HIP(hipSetDevice(s->cfg.device));
+    const bfd_dev &d = s->d;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (s->timing && s->perKernel) { e0 = get_event(s); e1 = get_event(s); hipEventRecord(e0, s->stream); }
+    if (s->cfg.kernelVariant == 1) bfd_launch_velocity_v1(d, s->stream);
+    else bfd_launch_velocity_v2(d, s->stream);
+    if (e0) { hipEventRecord(e1, s->stream); s->evVelocity.push_back(e0); s->evVelocity.push_back(e1); }
+    if (s->nSrcVox && s->cfg.typeSource < 2 && s->step < s->lengthSource)
+        hipLaunchKernelGGL(inject_sources, dim3(grid_for(s->nSrcVox)), dim3(256), 0, s->stream, d, s->cfg.typeSource,
+                           s->srcLin, s->srcRow, s->srcW[0], s->srcW[1], s->srcW[2],
+                           s->pulseT + (size_t)s->step * s->nSources, (long)s->nSrcVox);
+    const int n = s->step;
+    if ((s->acc || s->pk) && n >= s->accStart) {
+        SelList L; L.n = s->nSelR; memcpy(L.sel, s->selR, sizeof L.sel);
+        dim3 block(64, 4, 1), grid((d.N1 + 63) / 64, (d.N2 + 3) / 4, d.nk);
+        hipLaunchKernelGGL(accumulate_maps, grid, block, 0, s->stream, d, L, s->acc, s->pk, (long)s->nloc);
+    }
+    if (s->nSensors && s->sensOut && n % s->cfg.sensorSub == 0 && n / s->cfg.sensorSub >= s->cfg.sensorStart) {
+        const int col = n / s->cfg.sensorSub - s->cfg.sensorStart;
+        if (col < s->nTs) {
+            SelList L; L.n = s->nSelS; memcpy(L.sel, s->selS, sizeof L.sel);
+            hipLaunchKernelGGL(record_sensors, dim3(grid_for(s->nSensors)), dim3(256), 0, s->stream, d, L, s->sensLin,
+                               (long)s->nSensors, s->sensOut, col, s->nTs);
+        }
+    }
+    BFD_HIP(hipGetLastError());
+    s->step++;
+    return 0;
+}
+
+int bfd_run(bfd_sim *s, int32_t nSteps)
+{
+    for (int n = 0; n < nSteps; n++) {
+        int rc = bfd_half_step_stress(s); if (rc) return rc;
+        rc = bfd_half_step_velocity(s); if (rc) return rc;
+    }
+    return 0;
+}
+
+int bfd_sync(bfd_sim *s)
+{
+    if (!s) BFD_FAIL(-1, "null sim");
+    BFD_HIP(hipSetDevice(s->cfg.device));
+    BFD_HIP(hipStreamSynchronize(s->stream));
+    return 0;
+}
+int bfd_current_step(bfd_sim *s) { return s ? s->step : -1; }
+
+int bfd_halo_region(bfd_sim *s, int32_t group, int32_t f, int32_t side, int32_t send, void **devPtr, size_t *bytes)
+{
+    if (!s || !devPtr || !bytes) BFD_FAIL(-1, "bfd_halo_region: null argument");
+    if (group < 0 || group > 1 || f < 0 || f > 2 || side < 0 || side > 1) BFD_FAIL(-2, "bfd_halo_region: bad selector");
+    const bfd_dev &d = s->d;
+    float *arr[2][3] = {{d.Vx, d.Vy, d.Vz}, {d.Sxz, d.Syz, d.Szz}};
+    float *a = arr[group][f];
+    long kl;
+    if (side == 0) kl = send ? 0 : -2; else kl = send ? d.nk - 2 : d.nk;
+    *devPtr = a + kl * (long)d.plane;
+    *bytes = 2 * (size_t)d.plane * sizeof(float);
+    return 0;
+}
+
+int bfd_timing_begin(bfd_sim *s, int32_t perKernel)
+{
+    if (!s) BFD_FAIL(-1, "null sim");
+    BFD_HIP(hipSetDevice(s->cfg.device));
+    for (hipEvent_t e : s->evStress) s->evPool.push_back(e);
+    for (hipEvent_t e : s->evVelocity) s->evPool.push_back(e);
+    s->evStress.clear(); s->evVelocity.clear();
+    s->timing = true; s->perKernel = perKernel != 0;
+    BFD_HIP(hipEventRecord(s->evBegin, s->stream));
+    return 0;
+}
+
+int bfd_timing_end(bfd_sim *s, double *totalMs, double *stressMs, double *velocityMs, double *otherMs,
+                   int64_t *nStress, int64_t *nVelocity)
+{
+    if (!s) BFD_FAIL(-1, "null sim");
+    if (!s->timing) BFD_FAIL(-6, "bfd_timing_end without bfd_timing_begin");
+    BFD_HIP(hipSetDevice(s->cfg.device));
+    BFD_HIP(hipEventRecord(s->evEnd, s->stream));
+    BFD_HIP(hipEventSynchronize(s->evEnd));
+    float ms = 0;
+    BFD_HIP(hipEventElapsedTime(&ms, s->evBegin, s->evEnd));
+    double st = 0, ve = 0;
+    for (size_t a = 0; a + 1 < s->evStress.size(); a += 2) { float t; BFD_HIP(hipEventElapsedTime(&t, s->evStress[a], s->evStress[a + 1])); st += t; }
+    for (size_t a = 0; a + 1 < s->evVelocity.size(); a += 2) { float t; BFD_HIP(hipEventElapsedTime(&t, s->evVelocity[a], s->evVelocity[a + 1])); ve += t; }
+    if (totalMs) *totalMs = ms;
+    if (stressMs) *stressMs = st;
+    if (velocityMs) *velocityMs = ve;
+    if (otherMs) *otherMs = ms - st - ve;
+    if (nStress) *nStress = (int64_t)s->evStress.size() / 2;
+    if (nVelocity) *nVelocity = (int64_t)s->evVelocity.size() / 2;
+    s->timing = false;
+    return 0;
+}
+
+int64_t bfd_num_sensors(bfd_sim *s) { return s ? s->nSensors : -1; }
+int32_t bfd_num_sensor_steps(bfd_sim *s) { return s ? s->nTs : -1; }
+
+int bfd_get_sensor_index(bfd_sim *s, uint32_t *index)
+{
+    if (!s || (!index && s->nSensors)) BFD_FAIL(-1, "bfd_get_sensor_index: null argument");
+    if ((long)s->d.N1 * s->d.N2 * s->d.N3 >= (1L << 32) - 1) BFD_FAIL(-2, "domain too large for 32-bit sensor indices");
+    if (!s->nSensors) return 0;
+    BFD_HIP(hipSetDevice(s->cfg.device));
+    BFD_HIP(hipMemcpy(index, s->sensLin, (size_t)s->nSensors * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    const uint32_t off = (uint32_t)((size_t)s->d.k0 * s->d.plane + 1);
+    for (int64_t v = 0; v < s->nSensors; v++) index[v] += off;
+    return 0;
+}
+
+int bfd_get_sensors(bfd_sim *s, float *out)
+{
+    if (!s) BFD_FAIL(-1, "null sim");
+    const size_t n = (size_t)s->nSelS * s->nTs * (size_t)s->nSensors;
+    if (!n) return 0;
+    if (!out || !s->sensOut) BFD_FAIL(-1, "bfd_get_sensors: null argument");
+    BFD_HIP(hipSetDevice(s->cfg.device));
+    float *tmp = nullptr;
+    BFD_HIP(hipMalloc((void **)&tmp, n * sizeof(float)));
+    hipLaunchKernelGGL(transpose_sensors, dim3(grid_for((long)n)), dim3(256), 0, s->stream, s->sensOut, tmp, (long)s->nSensors, s->nTs, s->nSelS);
+    hipError_t e = hipMemcpyAsync(out, tmp, n * sizeof(float), hipMemcpyDeviceToHost, s->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+    hipFree(tmp);
+    if (e != hipSuccess) BFD_FAIL(-10, std::string("bfd_get_sensors: ") + hipGetErrorString(e));
+    return 0;
+}
+
+static int download_volume(bfd_sim *s, const float *devXfast, float *out, int64_t s1, int64_t s2, int64_t s3)
+{
+    const bfd_dev &d = s->d;
+    if (s1 < 0 || s2 < 0 || s3 < 0) BFD_FAIL(-2, "negative strides are not supported");
+    const size_t span = span_elems(d.N1, d.N2, d.nk, s1, s2, s3);
+    float *tmp = nullptr;
+    BFD_HIP(hipMalloc((void **)&tmp, span * sizeof(float)));
+    hipError_t e = hipSuccess;
+    if (span != s->nloc) {   // non-dense view: keep what the caller has in the gaps
+        e = hipMemcpyAsync(tmp, out, span * sizeof(float), hipMemcpyHostToDevice, s->stream);
+    }
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(scatter_from_xfast, dim3(grid_for((long)s->nloc)), dim3(256), 0, s->stream, devXfast, tmp,
+                           (long)s1, (long)s2, (long)s3, d.N1, d.N2, d.nk);
+        e = hipMemcpyAsync(out, tmp, span * sizeof(float), hipMemcpyDeviceToHost, s->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+    hipFree(tmp);
+    if (e != hipSuccess) BFD_FAIL(-10, std::string("download: ") + hipGetErrorString(e));
+    return 0;
+}
+
+int bfd_get_map(bfd_sim *s, int32_t kind, int32_t map, float *out, int64_t s1, int64_t s2, int64_t s3)
+{
+    if (!s || !out) BFD_FAIL(-1, "bfd_get_map: null argument");
+    BFD_HIP(hipSetDevice(s->cfg.device));
+    int q = -1;
+    for (int a = 0; a < s->nSelR; a++) if (s->selR[a] == map) q = a;
+    if (kind != BFD_KIND_LAST && q < 0) BFD_FAIL(-2, "bfd_get_map: map was not selected in selMapsRMS");
+    float *tmp = nullptr;
+    BFD_HIP(hipMalloc((void **)&tmp, s->nloc * sizeof(float)));
+    int rc = 0;
+    if (kind == BFD_KIND_RMS) {
+        if (!s->acc) { hipFree(tmp); BFD_FAIL(-2, "bfd_get_map: RMS was not selected (SelRMSorPeak)"); }
+        const int nAcc = s->step - s->accStart;
+        hipLaunchKernelGGL(finalize_rms, dim3(grid_for((long)s->nloc)), dim3(256), 0, s->stream, s->acc + (size_t)q * s->nloc, tmp,
+                           (long)s->nloc, (float)(nAcc > 0 ? nAcc : 1));
+        rc = download_volume(s, tmp, out, s1, s2, s3);
+    } else if (kind == BFD_KIND_PEAK) {
+        if (!s->pk) { hipFree(tmp); BFD_FAIL(-2, "bfd_get_map: peak was not selected (SelRMSorPeak)"); }
+        rc = download_volume(s, s->pk + (size_t)q * s->nloc, out, s1, s2, s3);
+    } else if (kind == BFD_KIND_LAST) {
+        if (map < 0 || map >= BFD_MAP_COUNT) { hipFree(tmp); BFD_FAIL(-2, "bfd_get_map: bad map id"); }
+        hipLaunchKernelGGL(last_map, dim3(grid_for((long)s->nloc)), dim3(256), 0, s->stream, s->d, map, tmp, (long)s->nloc);
+        rc = download_volume(s, tmp, out, s1, s2, s3);
+    } else {
+        rc = -2; bfd_set_error("bfd_get_map: bad kind");
+    }
+    hipFree(tmp);
+    return rc;
+}
+
+int bfd_get_field(bfd_sim *s, int32_t a, float *out, int64_t s1, int64_t s2, int64_t s3)
+{
+    if (!s || !out || a < 0 || a > 14) BFD_FAIL(-1, "bfd_get_field: bad argument");
+    BFD_HIP(hipSetDevice(s->cfg.device));
+    return download_volume(s, s->stateBase[a] + 2 * (size_t)s->d.plane, out, s1, s2, s3);
+}
+
+int64_t bfd_device_bytes(bfd_sim *s) { return s ? s->devBytes : -1; }
+
+}  // extern "C"

@@ -1,0 +1,80 @@
+// Internal structures of libbabelfdtd_hip.so (gfx950 only). Not part of the ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "../../include/babelfdtd.h"
+
+#define BFD_REFLECTOR_BIT 0x8000u   // bit 15 of the device material id marks a reflector voxel
+#define BFD_MAT_MASK 0x7FFFu
+
+// CA, CB of the O(4) staggered first derivative
+#define BFD_CA 1.125f
+#define BFD_CB (1.0f / 24.0f)
+
+// device-side view of one slab; passed by value to kernels
+struct bfd_dev {
+    int N1, N2, N3;        // global dims
+    int k0, nk;            // slab
+    int ND, P;             // layer thickness, zone width P = ND+1
+    int plane;             // N1*N2
+    // state, each (nk+4) planes; pointer addresses local plane 0 (ghost planes at -2,-1,nk,nk+1)
+    float *Vx, *Vy, *Vz, *Sxx, *Syy, *Szz, *Sxy, *Sxz, *Syz, *Rxx, *Ryy, *Rzz, *Rxy, *Rxz, *Ryz;
+    const uint16_t *mat;   // same ghosting; bit 15 = reflector
+    // per-material tables
+    const float *AP, *BP, *AS2, *BS2, *invMu, *tauS, *invRho;
+    float c1, k2;
+    // CPML profiles: [axis][aI,bI,aH,bH]
+    const float *axI, *bxI, *axH, *bxH, *ayI, *byI, *ayH, *byH, *azI, *bzI, *azH, *bzH;
+    // CPML memory variables (compact zone storage)
+    //   x zones: [nk][N2][2P]      y zones: [nk][2P][N1]      z zones: [2P][N2][N1] (global z zone index)
+    // stress half-step: 0 dxVx 1 dyVy 2 dzVz 3 dyVx 4 dxVy 5 dzVx 6 dxVz 7 dzVy 8 dyVz
+    // velocity half-step: 9 dxSxx 10 dySxy 11 dzSxz 12 dxSxy 13 dySyy 14 dzSyz 15 dxSxz 16 dySyz 17 dzSzz
+    float *psi[18];
+};
+
+struct bfd_sim {
+    bfd_config cfg;
+    bfd_dev d;
+    hipStream_t stream;
+    bool ownStream;
+    int step;
+    size_t nloc, nalloc;            // owned voxels, allocated voxels per state array
+    float *stateBase[15];           // allocation bases
+    uint16_t *matBase;
+    float *tables;                  // 7*nMat
+    float *profiles;                // 4*(N1+N2+N3)
+    std::vector<void *> allocs;     // everything to free
+    int64_t devBytes;
+    bool haveMaterials, haveMap;
+    double cmax;
+    // sources
+    int64_t nSrcVox; uint32_t *srcLin, *srcRow; float *srcW[3]; float *pulseT; int nSources, lengthSource;
+    // sensors
+    int64_t nSensors; uint32_t *sensLin; float *sensOut; int nTs; int nSelS; int selS[BFD_MAP_COUNT];
+    // accumulators
+    int nSelR; int selR[BFD_MAP_COUNT]; float *acc, *pk;
+    int accStart;
+    // timing
+    bool timing, perKernel;
+    hipEvent_t evBegin, evEnd;
+    std::vector<hipEvent_t> evStress, evVelocity;  // pairs
+    std::vector<hipEvent_t> evPool;
+};
+
+void bfd_set_error(const std::string &s);
+#define BFD_HIP(call)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            bfd_set_error(std::string(#call) + ": " + hipGetErrorString(e_));                      \
+            return -10;                                                                            \
+        }                                                                                          \
+    } while (0)
+
+// kernel launchers (bfd_kernels_*.hip)
+void bfd_launch_stress_v1(const bfd_dev &d, hipStream_t s);
+void bfd_launch_velocity_v1(const bfd_dev &d, hipStream_t s);
+void bfd_launch_stress_v2(const bfd_dev &d, hipStream_t s);
+void bfd_launch_velocity_v2(const bfd_dev &d, hipStream_t s);

@@ -1,0 +1,199 @@
+"""Z-slab domain decomposition: one process per GPU, neighbour halo exchange through
+torch.distributed (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in CPU tests).
+
+The reference has no multi-device path (every backend of its solver is single-device,
+SURVEY.md 2.2); this is the new capability BASELINE.json asks for. In the solver's own linear
+order i is fastest and k slowest (BabelIntegrationBASE.py:2508-2511), so a Z-slab is one
+contiguous block and every halo plane is one contiguous N1*N2 run.
+
+Per time step and interface:
+    exchange Vx,Vy,Vz boundary planes (2 per side)  -> stress half-step
+    exchange Sxz,Syz,Szz boundary planes            -> velocity half-step
+i.e. 2 x 6 fields x 2 planes x N1*N2 x 4 B = 96*N1*N2 bytes per interface per step, point to
+point between neighbours only (open chain: rank r talks to r-1 and r+1, no collective).
+"""
+import numpy as np
+
+from . import _engine
+from ._engine import HALO_STRESS, HALO_VELOCITY, KIND_LAST, KIND_PEAK, KIND_RMS
+from .PropagationModel import compact_sources, material_slab, n_steps, sensor_steps
+
+MIN_PLANES = 4   # a slab must own at least the 2+2 planes its neighbours read
+
+
+def partition(N3, world):
+    """Balanced contiguous split of the N3 planes: [(k0, nk)] per rank."""
+    if world < 1 or N3 < MIN_PLANES * world:
+        raise ValueError('cannot split %d planes over %d ranks (>= %d planes per rank)' % (N3, world, MIN_PLANES))
+    base, rem = divmod(N3, world)
+    out, k0 = [], 0
+    for r in range(world):
+        nk = base + (1 if r < rem else 0)
+        out.append((k0, nk))
+        k0 += nk
+    return out
+
+
+class _DevBuf:
+    """Exposes a raw device pointer through __cuda_array_interface__ so torch can alias it."""
+    def __init__(self, ptr, nfloats):
+        self.__cuda_array_interface__ = {'shape': (nfloats,), 'typestr': '<f4', 'data': (ptr, False), 'version': 2}
+
+
+class HipSlab:
+    """One slab on one MI355X; halo tensors alias the engine's own device memory (zero copy)."""
+
+    def __init__(self, engine, device):
+        import torch
+        self.eng = engine
+        self.torch = torch
+        self.device = device
+        torch.cuda.set_device(device)
+        # run the engine on torch's current stream so RCCL work orders against the kernels
+        engine.set_stream(torch.cuda.current_stream(device).cuda_stream)
+        self._t = {}
+        for g in (HALO_VELOCITY, HALO_STRESS):
+            for f in range(3):
+                for side in (0, 1):
+                    for send in (0, 1):
+                        ptr, nbytes = engine.halo_region(g, f, side, send)
+                        self._t[(g, f, side, send)] = torch.as_tensor(_DevBuf(ptr, nbytes // 4), device='cuda:%d' % device)
+
+    def halo(self, group, f, side, send):
+        return self._t[(group, f, side, int(send))]
+
+    def before_send(self, group):
+        pass
+
+    def after_recv(self, group, sides):
+        pass
+
+    def half_step_stress(self):
+        self.eng.half_step_stress()
+
+    def half_step_velocity(self):
+        self.eng.half_step_velocity()
+
+    def sync(self):
+        self.torch.cuda.synchronize(self.device)
+
+
+class SlabRunner:
+    """Advances one slab in lock-step with its Z-neighbours."""
+
+    def __init__(self, slab, rank, world, dist=None, group=None):
+        self.slab, self.rank, self.world, self.group = slab, rank, world, group
+        if world > 1 and dist is None:
+            import torch.distributed as dist
+        self.dist = dist
+        self.low = rank - 1 if rank > 0 else None
+        self.high = rank + 1 if rank < world - 1 else None
+        self.bytes_sent = 0
+
+    def exchange(self, halo_group):
+        if self.world == 1:
+            return
+        dist = self.dist
+        s = self.slab
+        s.before_send(halo_group)
+        ops = []
+        sides = []
+        # the low neighbour's high ghost planes are my low boundary planes, and vice versa
+        for side, peer in ((0, self.low), (1, self.high)):
+            if peer is None:
+                continue
+            sides.append(side)
+            for f in range(3):
+                ops.append(dist.P2POp(dist.isend, s.halo(halo_group, f, side, True), peer, self.group))
+                ops.append(dist.P2POp(dist.irecv, s.halo(halo_group, f, side, False), peer, self.group))
+                self.bytes_sent += s.halo(halo_group, f, side, True).numel() * 4
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+        s.after_recv(halo_group, sides)
+
+    def step(self):
+        self.exchange(HALO_VELOCITY)
+        self.slab.half_step_stress()
+        self.exchange(HALO_STRESS)
+        self.slab.half_step_velocity()
+
+    def run(self, nSteps):
+        for _ in range(nSteps):
+            self.step()
+
+
+def create_hip_slab(args, kwargs, rank, world, device, kernelVariant=0, local=None):
+    """Build the engine for this rank's slab from the same arguments the reference passes to
+    StaggeredFDTD_3D_with_relaxation (BASE:2338-2365). Returns (HipSlab, info).
+    local=(N3, k0, nk, gl, gh): the volumes in `args` are already this rank's slab (MaterialMap with
+    gl/gh ghost planes, Ox/Oy/Oz size-1) -- every rank built only its own share."""
+    MaterialMap, MaterialList, Frequency, SourceMap, PulseSource, SpatialStep, Duration, SensorMap = args
+    N1, N2 = MaterialMap.shape[:2]
+    if local is None:
+        N3 = MaterialMap.shape[2]
+        k0, nk = partition(N3, world)[rank]
+    else:
+        N3, k0, nk, gl, gh = local
+        if partition(N3, world)[rank] != (k0, nk):
+            raise ValueError('local slab does not match the partition of N3 over the ranks')
+    ml = np.ascontiguousarray(MaterialList, np.float64).reshape(-1, 5)
+    DT = kwargs['DT']
+    nt = n_steps(Duration, DT)
+    one = np.array([1])
+    eng = _engine.Engine(N1, N2, N3, ml.shape[0], SpatialStep, DT, Frequency, nt, k0=k0, nk=nk,
+                         NDelta=kwargs.get('NDelta', 12), reflectionLimit=kwargs.get('ReflectionLimit', 1e-5),
+                         typeSource=kwargs.get('TypeSource', 0), sensorSub=kwargs.get('SensorSubSampling', 1),
+                         sensorStart=kwargs.get('SensorStart', 0), selRMSorPeak=kwargs.get('SelRMSorPeak', 1),
+                         selMapsRMS=kwargs.get('SelMapsRMSPeakList', ('Pressure',)),
+                         selMapsSensors=kwargs.get('SelMapsSensorsList', ('Pressure',)),
+                         qfactorCorrection=kwargs.get('QfactorCorrection', True), device=device,
+                         kernelVariant=kernelVariant)
+    eng.set_materials(ml, kwargs.get('QCorrection', 1.0))
+    if local is None:
+        view, gl, gh = material_slab(np.asarray(MaterialMap), k0, nk)
+        ks = slice(k0, k0 + nk)
+        lin, row, wx, wy, wz = compact_sources(np.asarray(SourceMap), kwargs.get('Ox', one), kwargs.get('Oy', one),
+                                               kwargs.get('Oz', one), k0, nk)
+    else:
+        view = np.asarray(MaterialMap)
+        ks = slice(0, nk)
+        lin, row, wx, wy, wz = compact_sources(np.asarray(SourceMap), kwargs.get('Ox', one), kwargs.get('Oy', one),
+                                               kwargs.get('Oz', one), 0, nk)
+    eng.set_material_map(np.ascontiguousarray(view), gl, gh)
+    if kwargs.get('ReflectorMask') is not None:
+        eng.set_reflector(np.ascontiguousarray(kwargs['ReflectorMask'][:, :, ks]))
+    eng.set_sources(lin, row, wx, wy, wz, PulseSource)
+    eng.set_sensor_map(np.ascontiguousarray(np.asarray(SensorMap)[:, :, ks]))
+    info = dict(k0=k0, nk=nk, nt=nt, DT=DT, N=(N1, N2, N3))
+    return HipSlab(eng, device), info
+
+
+def collect_slab_outputs(eng, kwargs, info):
+    """This rank's share of the solver's return values (slab-local volumes, global sensor indices)."""
+    sub, start = kwargs.get('SensorSubSampling', 1), kwargs.get('SensorStart', 0)
+    Sensor = {'time': sensor_steps(info['nt'], sub, start) * info['DT']}
+    sens = eng.sensors()
+    for q, name in enumerate(eng.selS):
+        Sensor[name] = sens[q]
+    out = {'Sensor': Sensor, 'IndexSensorMap': eng.sensor_index(),
+           'LastMap': {n: eng.get_map(KIND_LAST, n) for n in eng.selR}}
+    mode = kwargs.get('SelRMSorPeak', 1)
+    if mode & 1:
+        out['RMS'] = {n: eng.get_map(KIND_RMS, n) for n in eng.selR}
+    if mode & 2:
+        out['Peak'] = {n: eng.get_map(KIND_PEAK, n) for n in eng.selR}
+    return out
+
+
+def merge_slab_outputs(parts):
+    """Concatenate per-rank outputs (rank order) into whole-domain results: volumes along k,
+    sensors along the sensor axis -- ascending global index, since slabs are ordered in k."""
+    merged = {'Sensor': {'time': parts[0]['Sensor']['time']}}
+    for key in parts[0]['Sensor']:
+        if key != 'time':
+            merged['Sensor'][key] = np.concatenate([p['Sensor'][key] for p in parts], axis=0)
+    merged['IndexSensorMap'] = np.concatenate([p['IndexSensorMap'] for p in parts])
+    for grp in ('LastMap', 'RMS', 'Peak'):
+        if grp in parts[0]:
+            merged[grp] = {n: np.concatenate([p[grp][n] for p in parts], axis=2) for n in parts[0][grp]}
+    return merged

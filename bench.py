@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""Benchmark of the Step-2 FDTD hot path on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one full time step (stress half-step + velocity half-step + RMS accumulation
++ sensor capture when due) over the whole domain. Workload at N=1: BASELINE.json configs[2]
+("512^3 CT-derived heterogeneous skull, CTX500 transducer, PML on"), the configuration the metric
+is quoted on. At N>1 every rank owns a 512x512x512 Z-slab of a 512x512x(512 N) domain (weak
+scaling), with neighbour halo exchange over RCCL.
+
+Prints ONE JSON line on rank 0. `value` = voxel-steps of all ranks / max-over-ranks wall time of
+the K timed steps (inputs resident in HBM), in Mvoxel-steps/s.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+BYTES_STRESS = 112.0           # algorithmic bytes per voxel, stress half-step   
+BYTES_VELOCITY = 52.0          # velocity half-step
+BYTES_RMS = 8.0                # Pressure RMS accumulate
+BYTES_STEP = BYTES_STRESS + BYTES_VELOCITY + BYTES_RMS   # 172
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=60)
+    ap.add_argument('--warmup', type=int, default=6)
+    ap.add_argument('--config', default='C3')
+    ap.add_argument('--size', type=int, nargs=3, default=None, help='override per-GPU grid N1 N2 N3')
+    ap.add_argument('--variant', type=int, default=0, help='kernel variant (0 default, 1 simple, 2 LDS-tiled)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-sample', type=int, nargs=4, default=[192, 192, 128, 16], help='N1 N2 N3 steps of the oracle sample')
+    return ap.parse_args()
+
+
+def cpu_baseline(args, dt_fn):
+    """The oracle (build's own CPU restatement, kind 'port') timed on this host on a bounded
+    sample of the same workload: a smaller grid of the same medium/source/sensor construction."""
+    from babelbrain_amd import harness as H
+    from oracle import oracle as O
+    n1, n2, n3, steps = args.cpu_sample
+    a, k, info = H.make_problem(args.config, N=(n1, n2, n3), steps=steps, stable_dt_fn=dt_fn, accumulate_all_steps=True)
+    out = O.StaggeredFDTD_3D_with_relaxation(*a, **k)
+    secs = out[-1]['stepLoopSeconds']
+    try:
+        import multiprocessing
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        cores = os.cpu_count()
+    threads = int(os.environ.get('OMP_NUM_THREADS', cores))
+    model = ''
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                model = line.split(':', 1)[1].strip()
+                break
+    except Exception:
+        pass
+    return {'value': n1 * n2 * n3 * steps / secs / 1e6, 'unit': 'Mvoxel-steps/s', 'cores': threads, 'kind': 'port',
+            'sample': '%s medium/source on a %dx%dx%d grid, %d steps, OpenMP float32 oracle (oracle/fdtd_oracle.c)' % (args.config, n1, n2, n3, steps),
+            'cpu_model': model, 'host_cores': cores}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('launch with torch.distributed.run --nproc-per-node %d for --gpus %d' % (args.gpus, args.gpus))
+        args.gpus = world
+    import torch
+    from babelbrain_amd import _engine, harness as H, slab
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU (the HIP engine has no CPU fallback)')
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+
+    def dt_fn(ml, f, h, acfl):
+        return _engine.stable_dt(ml, f, True, h, acfl)
+
+    cfg = H.CONFIGS[args.config]
+    n1, n2, n3 = args.size if args.size else cfg['N']
+    N = (n1, n2, n3 * world)                       # weak scaling: one full grid per GPU
+    nt = args.steps + args.warmup
+    t0 = time.time()
+    if world == 1:
+        a, k, info = H.make_problem(args.config, N=N, steps=nt, stable_dt_fn=dt_fn)
+        local = None
+    else:   # every rank builds only its own Z-slab of the domain
+        k0, nk = slab.partition(N[2], world)[rank]
+        a, k, info = H.make_problem(args.config, N=N, steps=nt, stable_dt_fn=dt_fn, zslab=(k0, nk))
+        local = (N[2], k0, nk) + tuple(info['ghost'])
+    t_build = time.time() - t0
+    s, sinfo = slab.create_hip_slab(a, k, rank, world, local_rank, kernelVariant=args.variant, local=local)
+    eng = s.eng
+    runner = slab.SlabRunner(s, rank, world, dist)
+    del a
+    nvox_rank = float(n1) * n2 * sinfo['nk']
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    runner.run(args.warmup)
+    barrier()
+    eng.timing_begin(True)
+    t0 = time.perf_counter()
+    runner.run(args.steps)
+    torch.cuda.synchronize()
+    barrier()
+    wall = time.perf_counter() - t0
+    tm = eng.timing_end()
+    if world > 1:
+        w = torch.tensor([wall], dtype=torch.float64, device='cuda')
+        dist.all_reduce(w, op=dist.ReduceOp.MAX)
+        wall = float(w.item())
+    total_vox = float(n1) * n2 * n3 * world
+    value = total_vox * args.steps / wall / 1e6
+
+    if rank == 0:
+        st = tm['stress_ms'] / max(tm['n_stress'], 1) * 1e-3
+        ve = tm['velocity_ms'] / max(tm['n_velocity'], 1) * 1e-3
+        step_dev = tm['total_ms'] / args.steps * 1e-3
+        ach_stress = BYTES_STRESS * nvox_rank / st / 1e9
+        ach_vel = BYTES_VELOCITY * nvox_rank / ve / 1e9
+        ach_step = BYTES_STEP * nvox_rank / step_dev / 1e9
+        line = {
+            'metric': 'Mvoxel-steps/sec, 512^3 skull FDTD (achieved HBM GB/s in roofline)',
+            'value': value, 'unit': 'Mvoxel-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': wall / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': '%s: %dx%dx%d per GPU (%dx%dx%d total), %s medium, %s source, PML 12, %d materials, '
+                                   'Pressure RMS + sensors on' % (args.config, n1, n2, n3, N[0], N[1], N[2], info['medium'], info['tx'], info['n_mat']),
+                       'parallelism': 'z-slab x%d' % world, 'kernel_variant': args.variant, 'dt': info['dt'], 'ppp': info['ppp'],
+                       'n_sources': info['n_sources'], 'n_sensors_rank0': int(eng.num_sensors)},
+            'roofline': {'bound': 'hbm', 'kernel': 'stress half-step', 'achieved': ach_stress, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': ach_stress / HBM_PEAK_GBS, 'traffic': None,
+                         'algorithmic_bytes_per_voxel': BYTES_STRESS, 'avg_launch_ms': st * 1e3},
+            'roofline_velocity': {'achieved': ach_vel, 'frac': ach_vel / HBM_PEAK_GBS, 'algorithmic_bytes_per_voxel': BYTES_VELOCITY,
+                                  'avg_launch_ms': ve * 1e3},
+            'roofline_step': {'achieved': ach_step, 'frac': ach_step / HBM_PEAK_GBS, 'algorithmic_bytes_per_voxel_step': BYTES_STEP,
+                              'device_ms_per_step': step_dev * 1e3, 'other_ms_per_step': tm['other_ms'] / args.steps},
+            'device_bytes': int(eng.device_bytes), 'host_build_s': t_build,
+        }
+        if not args.no_cpu_baseline:
+            try:
+                line['cpu_baseline'] = cpu_baseline(args, dt_fn)
+            except Exception as e:   # the baseline is a reported extra; never lose the GPU line over it
+                line['cpu_baseline'] = {'value': None, 'unit': 'Mvoxel-steps/s', 'cores': 0, 'kind': 'port', 'sample': 'failed: %r' % (e,)}
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,158 @@
+/*
+ * babelfdtd.h -- C ABI of the MI355X-native viscoelastic FDTD engine (libbabelfdtd_hip.so).
+ *
+ * This is the drop-in boundary for BabelBrain's Step-2 hot path. The reference reaches its
+ * solver through two Python methods of a module-global object
+ *     PModel = PropagationModel()                                   BabelIntegrationBASE.py:43
+ *     PModel.CalculateMatricesForPropagation(...)                   BabelIntegrationBASE.py:1799,1801
+ *     PModel.StaggeredFDTD_3D_with_relaxation(...)                  BabelIntegrationBASE.py:2338,2374,2401
+ * whose implementation (package BabelViscoFDTD==1.2.4, environment_linux.yml:44) binds a
+ * per-backend native module selected by the integer COMPUTING_BACKEND (BabelBrain.py:429-439,
+ * SelFiles/SelFiles.py:245-262). The functions below are what such a backend module binds:
+ * plain pointers and sizes, int return codes (0 = ok, <0 = error, text via bfd_last_error()),
+ * no exceptions, no torch types. babelbrain_amd/PropagationModel.py is the ctypes binding.
+ *
+ * Conventions
+ *  - Volumes handed in by the caller are described by a base pointer and three ELEMENT strides
+ *    (s1,s2,s3) for the axes (i,j,k) of an (N1,N2,nk) view, so a C-order numpy array is passed
+ *    without a host transpose: element (i,j,k) is base[i*s1 + j*s2 + k*s3]. The byte span
+ *    base[0 .. (N1-1)*s1+(N2-1)*s2+(nk-1)*s3] must be readable/writable. Inputs are never modified.
+ *  - On the device every volume is "x-fastest": linear index i + N1*(j + N2*k), the order the
+ *    reference decodes IndexSensorMap with (BabelIntegrationBASE.py:2508-2511).
+ *  - One bfd_sim owns the Z-slab [k0, k0+nk) of the global N1 x N2 x N3 domain (single GPU:
+ *    k0=0, nk=N3). Slabs are advanced half-step by half-step; the two ghost planes on each side
+ *    are exchanged by the caller between half-steps (bfd_halo_region gives device pointers), or
+ *    are zero at the ends of the domain.
+ *  - Selectable maps are a bitmask of BFD_MAP_* (names follow the reference's SelMapsRMSPeakList /
+ *    SelMapsSensorsList strings, BabelIntegrationBASE.py:1413-1417, 2355-2356).
+ */
+#ifndef BABELFDTD_H
+#define BABELFDTD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BFD_ABI_VERSION 1
+
+enum {
+    BFD_MAP_VX = 0, BFD_MAP_VY = 1, BFD_MAP_VZ = 2,
+    BFD_MAP_SIGMAXX = 3, BFD_MAP_SIGMAYY = 4, BFD_MAP_SIGMAZZ = 5,
+    BFD_MAP_SIGMAXY = 6, BFD_MAP_SIGMAXZ = 7, BFD_MAP_SIGMAYZ = 8,
+    BFD_MAP_PRESSURE = 9, BFD_MAP_ALLV = 10, BFD_MAP_COUNT = 11
+};
+
+/* which accumulated volume bfd_get_map returns */
+enum { BFD_KIND_RMS = 0, BFD_KIND_PEAK = 1, BFD_KIND_LAST = 2 };
+
+/* halo groups exchanged between Z-neighbours */
+enum { BFD_HALO_VELOCITY = 0 /* Vx,Vy,Vz: before the stress half-step   */,
+       BFD_HALO_STRESS = 1   /* Sxz,Syz,Szz: before the velocity half-step */ };
+
+typedef struct bfd_sim bfd_sim;
+
+typedef struct bfd_config {
+    int32_t N1, N2, N3;        /* global domain, voxels, absorbing layer included (BASE:1876-1878) */
+    int32_t k0, nk;            /* this slab owns global planes [k0, k0+nk)                        */
+    int32_t nMat;              /* rows of MaterialList                                            */
+    int32_t NDelta;            /* absorbing-layer thickness in cells (NDelta=12, BASE:2350)       */
+    int32_t typeSource;        /* TypeSource: 0 add velocity, 1 set velocity, 2 add stress, 3 set stress (BASE:2327,2332,2393) */
+    int32_t sensorSub;         /* SensorSubSampling (BASE:2363)                                   */
+    int32_t sensorStart;       /* SensorStart, in sub-sampled steps (BASE:2109,2364)              */
+    int32_t nt;                /* total number of time steps of the run (sizes the sensor block)  */
+    int32_t selRMSorPeak;      /* SelRMSorPeak: 1 RMS, 2 peak, 3 both (BASE:2357)                 */
+    uint32_t selMapsRMS;       /* SelMapsRMSPeakList as BFD_MAP_* bits (BASE:2355)                */
+    uint32_t selMapsSensors;   /* SelMapsSensorsList as BFD_MAP_* bits (BASE:2356)                */
+    int32_t qfactorCorrection; /* QfactorCorrection (BASE:2361)                                   */
+    int32_t device;            /* HIP device ordinal                                              */
+    int32_t kernelVariant;     /* 0 = default (fastest), 1 = simple reference kernels, 2 = LDS-tiled */
+    int32_t reserved0;
+    double h;                  /* SpatialStep, m (BASE:2344)                                      */
+    double dt;                 /* DT, s (BASE:2351)                                               */
+    double freq;               /* Frequency, Hz (BASE:2341)                                       */
+    double reflectionLimit;    /* ReflectionLimit (BASE:2352)                                     */
+} bfd_config;
+
+/* ---- library / device ---- */
+int bfd_abi_version(void);
+const char *bfd_last_error(void);
+int bfd_device_count(void);                                   /* replaces <backend>.ListDevices, SelFiles.py:245-262 */
+int bfd_device_name(int device, char *buf, int buflen);
+
+/* ---- CalculateMatricesForPropagation (BASE:1799,1801): stable dt and per-material tables ----
+ * matlist: nMat x 5 float64 rows [rho, cL, cS, alphaL, alphaS] (BASE:1712-1729); qcorr: nMat
+ * float64 QCorrection factors or NULL (BASE:1290). tables7 (may be NULL) receives 7*nMat
+ * float32: AP,BP,AS2,BS2,invMu,tauS,invRho for the given dt. */
+double bfd_stable_dt(int32_t nMat, const double *matlist, const double *qcorr, double freq,
+                     int32_t qfactorCorrection, double h, double alphaCFL);
+int bfd_material_tables(int32_t nMat, const double *matlist, const double *qcorr, double freq,
+                        int32_t qfactorCorrection, double h, double dt, float *tables7,
+                        float *c1k2, double *cmax);
+
+/* ---- StaggeredFDTD_3D_with_relaxation (BASE:2338-2365), decomposed ---- */
+int bfd_create(const bfd_config *cfg, bfd_sim **out);
+void bfd_destroy(bfd_sim *sim);
+
+/* launch every kernel of this sim on an existing HIP stream (hipStream_t as void*), e.g. torch's
+ * current stream, so the caller's halo exchange orders against it; NULL = the sim's own stream */
+int bfd_set_stream(bfd_sim *sim, void *hipStream);
+
+/* MaterialList + QCorrection (BASE:2340,2362) */
+int bfd_set_materials(bfd_sim *sim, const double *matlist, const double *qcorr);
+/* MaterialMap slab (BASE:2339). ghostLow/ghostHigh (0..2): planes readable below k=0 / above
+ * k=nk-1 of the view (neighbour slab's cells); missing ghost planes replicate the edge plane. */
+int bfd_set_material_map(bfd_sim *sim, const uint32_t *map, int64_t s1, int64_t s2, int64_t s3,
+                         int32_t ghostLow, int32_t ghostHigh);
+/* ReflectorMask slab (BASE:2365); NULL clears it */
+int bfd_set_reflector(bfd_sim *sim, const uint32_t *mask, int64_t s1, int64_t s2, int64_t s3);
+/* SourceMap/PulseSource/Ox,Oy,Oz (BASE:2342-2349) in compact form: nVox source voxels of this
+ * slab, local x-fastest linear index, 0-based PulseSource row, per-voxel weights (NULL = 1),
+ * pulse = [nSources][lengthSource] float64 exactly as the caller built it (Single:335-346). */
+int bfd_set_sources(bfd_sim *sim, int64_t nVox, const uint32_t *localIndex, const uint32_t *row,
+                    const float *wx, const float *wy, const float *wz,
+                    const double *pulse, int32_t nSources, int32_t lengthSource);
+/* SensorMap slab (BASE:2346); returns the number of sensors of this slab in *nSensors */
+int bfd_set_sensor_map(bfd_sim *sim, const uint32_t *map, int64_t s1, int64_t s2, int64_t s3,
+                       int64_t *nSensors);
+
+/* time stepping. bfd_run = nSteps x (stress half-step, velocity half-step, accumulate, sensors)
+ * for a slab without neighbours. With neighbours the caller alternates:
+ *   exchange VELOCITY halos -> bfd_half_step_stress -> exchange STRESS halos -> bfd_half_step_velocity */
+int bfd_run(bfd_sim *sim, int32_t nSteps);
+int bfd_half_step_stress(bfd_sim *sim);
+int bfd_half_step_velocity(bfd_sim *sim);   /* also accumulates, records sensors, advances the step counter */
+int bfd_sync(bfd_sim *sim);
+int bfd_current_step(bfd_sim *sim);
+
+/* device pointer/bytes of a halo region: field f (0..2 within the group), side 0 = low-k face,
+ * 1 = high-k face; send = 1: the 2 owned boundary planes, send = 0: the 2 ghost planes.
+ * Each region is 2*N1*N2 contiguous float32. */
+int bfd_halo_region(bfd_sim *sim, int32_t group, int32_t f, int32_t side, int32_t send,
+                    void **devPtr, size_t *bytes);
+
+/* timing of the step loop, device time from HIP events on the sim's stream */
+int bfd_timing_begin(bfd_sim *sim, int32_t perKernel);
+int bfd_timing_end(bfd_sim *sim, double *totalMs, double *stressMs, double *velocityMs,
+                   double *otherMs, int64_t *nStressLaunches, int64_t *nVelocityLaunches);
+
+/* results */
+int64_t bfd_num_sensors(bfd_sim *sim);
+int32_t bfd_num_sensor_steps(bfd_sim *sim);
+/* 1-based GLOBAL x-fastest linear index of every sensor of this slab, ascending (BASE:2369,2503) */
+int bfd_get_sensor_index(bfd_sim *sim, uint32_t *index);
+/* out[nSelSensors][nSensors][nTs] float32, maps in ascending BFD_MAP_* order (BASE:2507: FFT along axis 1) */
+int bfd_get_sensors(bfd_sim *sim, float *out);
+/* one accumulated volume of this slab into a strided (N1,N2,nk) float32 view */
+int bfd_get_map(bfd_sim *sim, int32_t kind, int32_t map, float *out, int64_t s1, int64_t s2, int64_t s3);
+/* raw state array a (0..14: Vx Vy Vz Sxx Syy Szz Sxy Sxz Syz Rxx Ryy Rzz Rxy Rxz Ryz), for tests */
+int bfd_get_field(bfd_sim *sim, int32_t a, float *out, int64_t s1, int64_t s2, int64_t s3);
+/* device memory this sim holds, bytes */
+int64_t bfd_device_bytes(bfd_sim *sim);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BABELFDTD_H */

@@ -1,0 +1,139 @@
+"""Parity of the HIP engine (through the C ABI / ctypes shim) against the CPU oracle.
+
+Tolerance: BASELINE.json north_star -- pressure fields within 1e-5 relative L2 on identical
+inputs. (Both sides follow the same canonical float32 arithmetic, so the observed error is 0 or
+a few ulp; the assertion keeps the stated 1e-5.)
+"""
+import numpy as np
+import pytest
+
+from babelbrain_amd import harness as H
+from oracle import oracle as O
+from tests.util import ALL_MAPS, compare_runs, oracle_dt, rel_l2
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def hip_model(variant=0):
+    from babelbrain_amd import PropagationModel
+    return PropagationModel(kernelVariant=variant)
+
+
+def run_both(args, kwargs, variant=0):
+    out_h = hip_model(variant).StaggeredFDTD_3D_with_relaxation(*args, SILENT=True, **kwargs)
+    out_r = O.StaggeredFDTD_3D_with_relaxation(*args, **kwargs)
+    return out_h, out_r
+
+
+@pytest.mark.parametrize('variant', [1, 2])
+def test_water_c1_small(variant):
+    a, k, info = H.make_problem('C1', N=(48, 52, 64), steps=160, stable_dt_fn=oracle_dt)
+    k['SelMapsRMSPeakList'] = ALL_MAPS
+    oh, orf = run_both(a, k, variant)
+    w = compare_runs(oh, orf, TOL)
+    assert orf[2]['Pressure'].max() > 0
+    print('worst rel L2', w)
+
+
+@pytest.mark.parametrize('variant', [1, 2])
+def test_skull3_c2_small(variant):
+    a, k, info = H.make_problem('C2', N=(64, 60, 72), steps=220, stable_dt_fn=oracle_dt)
+    k['SelMapsRMSPeakList'] = ALL_MAPS
+    k['SelMapsSensorsList'] = ['Pressure', 'Vz', 'Sigmaxy']
+    k['SelRMSorPeak'] = 3
+    oh, orf = run_both(a, k, variant)
+    w = compare_runs(oh, orf, TOL, both=True)
+    assert np.abs(orf[1]['Sigmaxy']).max() > 0, 'shear never excited: test is not covering the solid path'
+    print('worst rel L2', w)
+
+
+@pytest.mark.parametrize('variant', [1, 2])
+def test_ct_bins_qcorr_reflector(variant):
+    a, k, info = H.make_problem('C3', N=(56, 56, 70), steps=200, stable_dt_fn=oracle_dt)
+    mm = a[0]
+    refl = np.zeros(mm.shape, np.uint32)
+    refl[20:26, 30:34, 40:44] = 1            # an "air" pocket (BASE:2182-2190)
+    k['ReflectorMask'] = refl
+    k['SelMapsRMSPeakList'] = ['Pressure', 'Vx', 'Sigmazz', 'ALLV']
+    oh, orf = run_both(a, k, variant)
+    compare_runs(oh, orf, TOL)
+    assert np.all(oh[1]['Pressure'][refl > 0] == 0)
+
+
+@pytest.mark.parametrize('variant', [1, 2])
+def test_stress_point_source_backprop(variant):
+    """Second solver call of the reference (BASE:2374-2398): point stress source, plane sensor,
+    Ox/Oy/Oz left at their size-1 defaults."""
+    a, k, info = H.make_problem('C2', N=(50, 45, 61), steps=150, stable_dt_fn=oracle_dt)
+    mm, ml, f, smap, pulse, h, T, sensor = a
+    N1, N2, N3 = mm.shape
+    smap = np.zeros_like(smap)
+    smap[N1 // 2, N2 // 2, N3 // 2] = 1
+    pulse = H.punctual_source(f, k['DT'], T, ramp_length=1)
+    _, back = H.sensor_maps(N1, N2, N3, info['zsrc'])
+    for key in ('Ox', 'Oy', 'Oz'):
+        k.pop(key)
+    k['TypeSource'] = 2
+    oh, orf = run_both((mm, ml, f, smap, pulse, h, T, back), k, variant)
+    compare_runs(oh, orf, TOL)
+    i, j, kk = H.decode_sensor_index(oh[-1]['IndexSensorMap'], N1, N2)
+    assert np.all(kk == H.PML_THICKNESS)       # asserted by the caller too, BASE:2537
+    assert np.abs(oh[0]['Pressure']).max() > 0
+
+
+def test_hard_sources_and_no_sensors():
+    a, k, info = H.make_problem('C1', N=(40, 40, 44), steps=60, stable_dt_fn=oracle_dt)
+    a = list(a)
+    a[7] = np.zeros_like(a[7])                 # empty SensorMap
+    k['TypeSource'] = 1
+    oh, orf = run_both(tuple(a), k)
+    compare_runs(oh, orf, TOL)
+    assert oh[0]['Pressure'].shape == (0, orf[0]['Pressure'].shape[1])
+
+
+def test_no_sources_stays_zero():
+    a, k, info = H.make_problem('C1', N=(40, 40, 44), steps=20, stable_dt_fn=oracle_dt)
+    a = list(a)
+    a[3] = np.zeros_like(a[3])
+    out = hip_model().StaggeredFDTD_3D_with_relaxation(*a, SILENT=True, **k)
+    assert out[2]['Pressure'].max() == 0 and np.all(out[0]['Pressure'] == 0)
+
+
+def test_stable_dt_and_tables_match_oracle():
+    from babelbrain_amd import _engine
+    ml = H.ct_material_rows(500e3, 64)
+    h = H.spatial_step(500e3, 6)
+    q = np.ones(len(ml)); q[2:] = 3
+    for corr in (True, False):
+        dt_h = _engine.stable_dt(ml, 500e3, corr, h, 0.5, q)
+        dt_o = O.stable_dt(ml, 500e3, corr, h, 0.5, q)
+        assert dt_h == dt_o
+        th, ch, cmh = _engine.material_tables(ml, 500e3, corr, h, dt_h, q)
+        to, co, cmo = O.tables(ml, 500e3, h, dt_o, corr, q)
+        assert np.array_equal(th, to) and np.array_equal(ch, co) and cmh == cmo
+
+
+def test_calculate_matrices_tuple():
+    pm = hip_model()
+    ml = np.array([H.MATERIALS[500e3][n] for n in ('Water', 'Cortical', 'Brain')])
+    dummy = np.zeros((10, 10, 3), np.uint32)
+    out = pm.CalculateMatricesForPropagation(dummy, ml, 500e3, True, 3.675e-4, 0.5)
+    assert len(out) == 10 and out[0] > 0          # unpacked as 10 values at BASE:1799
+    out1 = pm.CalculateMatricesForPropagation(dummy * 0, ml[0, :].reshape((1, 5)), 500e3, True, 3.675e-4, 1.0)
+    assert out1[0] > out[0]
+
+
+def test_error_paths_raise():
+    from babelbrain_amd._engine import EngineError
+    a, k, info = H.make_problem('C1', N=(40, 40, 44), steps=10, stable_dt_fn=oracle_dt)
+    pm = hip_model()
+    bad = list(a); bad[0] = a[0] + 5                  # material id beyond MaterialList
+    with pytest.raises(EngineError):
+        pm.StaggeredFDTD_3D_with_relaxation(*bad, SILENT=True, **k)
+    k2 = dict(k); k2['DT'] = k['DT'] * 20             # unstable time step
+    with pytest.raises(EngineError):
+        pm.StaggeredFDTD_3D_with_relaxation(*a, SILENT=True, **k2)
+    with pytest.raises(EngineError):
+        pm.StaggeredFDTD_3D_with_relaxation(a[0][:20, :20, :20], *a[1:3], a[3][:20, :20, :20], *a[4:7], a[7][:20, :20, :20],
+                                            SILENT=True, **{kk: v for kk, v in k.items() if kk not in ('Ox', 'Oy', 'Oz')})
