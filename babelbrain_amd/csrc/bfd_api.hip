@@ -195,7 +195,7 @@ __device__ __forceinline__ float map_sq(const bfd_dev &d, int sel, long c)
     return v * v;
 }
 
-struct SelList { int n; int sel[BFD_MAP_COUNT]; };
+struct SelList { int n; int sel[BFD_MAP_COUNT]; int skip[BFD_MAP_COUNT]; };
 
 // RMS / peak accumulation outside the absorbing layer (generic path, any map selection)
 __global__ __launch_bounds__(256) void accumulate_maps(bfd_dev d, SelList L, float *__restrict__ acc, float *__restrict__ pk, long nloc)
@@ -207,6 +207,7 @@ __global__ __launch_bounds__(256) void accumulate_maps(bfd_dev d, SelList L, flo
     if (i < d.ND || i >= d.N1 - d.ND || j < d.ND || j >= d.N2 - d.ND || k < d.ND || k >= d.N3 - d.ND) return;
     const long c = (long)kl * d.plane + (long)j * d.N1 + i;
     for (int q = 0; q < L.n; q++) {
+        if (L.skip[q]) continue;    // accumulated inside the velocity kernel
         if (acc) acc[q * nloc + c] = acc[q * nloc + c] + map_sq(d, L.sel[q], c);
         if (pk) {
             const float v = (L.sel[q] == BFD_MAP_ALLV) ? sqrtf(map_sq(d, BFD_MAP_ALLV, c)) : fabsf(map_value(d, L.sel[q], c));
@@ -651,23 +652,29 @@ int bfd_half_step_velocity(bfd_sim *s)
     const bfd_dev &d = s->d;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (s->timing && s->perKernel) { e0 = get_event(s); e1 = get_event(s); hipEventRecord(e0, s->stream); }
+    const int n = s->step;
+    const bool accNow = (s->acc || s->pk) && n >= s->accStart;
+    int qP = -1;   // Pressure is accumulated inside the variant-2 velocity kernel
+    if (accNow && s->cfg.kernelVariant != 1)
+        for (int q = 0; q < s->nSelR; q++) if (s->selR[q] == BFD_MAP_PRESSURE) qP = q;
     if (s->cfg.kernelVariant == 1) bfd_launch_velocity_v1(d, s->stream);
-    else bfd_launch_velocity_v2(d, s->stream);
+    else bfd_launch_velocity_v2(d, s->stream, (qP >= 0 && s->acc) ? s->acc + (size_t)qP * s->nloc : nullptr,
+                                (qP >= 0 && s->pk) ? s->pk + (size_t)qP * s->nloc : nullptr);
     if (e0) { hipEventRecord(e1, s->stream); s->evVelocity.push_back(e0); s->evVelocity.push_back(e1); }
     if (s->nSrcVox && s->cfg.typeSource < 2 && s->step < s->lengthSource)
         hipLaunchKernelGGL(inject_sources, dim3(grid_for(s->nSrcVox)), dim3(256), 0, s->stream, d, s->cfg.typeSource,
                            s->srcLin, s->srcRow, s->srcW[0], s->srcW[1], s->srcW[2],
                            s->pulseT + (size_t)s->step * s->nSources, (long)s->nSrcVox);
-    const int n = s->step;
-    if ((s->acc || s->pk) && n >= s->accStart) {
+    if (accNow && !(qP >= 0 && s->nSelR == 1)) {
         SelList L; L.n = s->nSelR; memcpy(L.sel, s->selR, sizeof L.sel);
+        for (int q = 0; q < BFD_MAP_COUNT; q++) L.skip[q] = (q == qP);
         dim3 block(64, 4, 1), grid((d.N1 + 63) / 64, (d.N2 + 3) / 4, d.nk);
         hipLaunchKernelGGL(accumulate_maps, grid, block, 0, s->stream, d, L, s->acc, s->pk, (long)s->nloc);
     }
     if (s->nSensors && s->sensOut && n % s->cfg.sensorSub == 0 && n / s->cfg.sensorSub >= s->cfg.sensorStart) {
         const int col = n / s->cfg.sensorSub - s->cfg.sensorStart;
         if (col < s->nTs) {
-            SelList L; L.n = s->nSelS; memcpy(L.sel, s->selS, sizeof L.sel);
+            SelList L; L.n = s->nSelS; memcpy(L.sel, s->selS, sizeof L.sel); memset(L.skip, 0, sizeof L.skip);
             hipLaunchKernelGGL(record_sensors, dim3(grid_for(s->nSensors)), dim3(256), 0, s->stream, d, L, s->sensLin,
                                (long)s->nSensors, s->sensOut, col, s->nTs);
         }

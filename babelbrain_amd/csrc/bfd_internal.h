@@ -77,4 +77,5 @@ void bfd_set_error(const std::string &s);
 void bfd_launch_stress_v1(const bfd_dev &d, hipStream_t s);
 void bfd_launch_velocity_v1(const bfd_dev &d, hipStream_t s);
 void bfd_launch_stress_v2(const bfd_dev &d, hipStream_t s);
-void bfd_launch_velocity_v2(const bfd_dev &d, hipStream_t s);
+// accP / pkP: Pressure RMS / peak accumulators of this step (slab-local, x-fastest) or nullptr
+void bfd_launch_velocity_v2(const bfd_dev &d, hipStream_t s, float *accP, float *pkP);

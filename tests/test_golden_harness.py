@@ -1,0 +1,100 @@
+"""Caller-side contract pinned to vectors generated from the reference itself
+(tests/golden/make_golden.py imports /root/reference/TranscranialModeling and runs its code).
+These pin what is fed to / read from the solver; the solver's own numerics have no reference
+fixture (parity unpinned)."""
+import inspect
+
+import numpy as np
+
+from babelbrain_amd import harness as H
+from babelbrain_amd.PropagationModel import PropagationModel, compact_sources, n_steps, sensor_steps
+
+
+def test_material_rows(golden):
+    g, meta = golden
+    for f in (500e3, 700e3, 1000e3):
+        rows = np.array([H.MATERIALS[f][n] for n in meta['material_names']])
+        np.testing.assert_allclose(rows, g['matfreq_%d' % int(f)], rtol=1e-15, atol=0)
+        assert H.smallest_sos(f, True) == g['smallest_sos_%d' % int(f)][0]
+        assert H.smallest_sos(f, False) == g['smallest_sos_%d' % int(f)][1]
+
+
+def test_ppp_rule(golden):
+    g, _ = golden
+    for f, dt_ideal, ppp, dt in g['ppp_rule']:
+        p, d = H.ppp_rule(dt_ideal, f)
+        assert p == ppp and d == dt, (f, dt_ideal)
+
+
+def test_time_plan(golden):
+    g, _ = golden
+    for N1, N2, N3, f, ppp, sub, h, dt, T, nt, sub_out, start in g['time_plan']:
+        T2, nt2, sub2, start2 = H.time_plan(int(N1), int(N2), int(N3), h, dt, int(ppp), 1500.0, sensor_sub=int(sub))
+        assert (nt2, sub2, start2) == (nt, sub_out, start)
+        assert T2 == T
+        assert n_steps(T2, dt) == nt          # the engine derives nt back from TimeSimulation and DT
+        assert len(sensor_steps(nt2, sub2, start2)) == 2 * ppp / sub2
+
+
+def test_sensor_maps(golden):
+    g, _ = golden
+    N1, N2, N3, pml, zsrc = g['sensormap_args']
+    s, b = H.sensor_maps(N1, N2, N3, zsrc, pml)
+    assert np.array_equal(s, g['sensormap']) and np.array_equal(b, g['sensormap_back'])
+    assert s.dtype == g['sensormap'].dtype
+
+
+def test_pulse_sources(golden):
+    g, _ = golden
+    f, dt, T, N3, zsrc = g['sources_args']
+    smap, pulse = H.pulse_sources(g['sources_plane'], f, dt, T, int(N3), int(zsrc))
+    assert np.array_equal(smap, g['sources_map'])
+    assert pulse.shape == g['sources_pulse'].shape and pulse.dtype == np.float64
+    np.testing.assert_allclose(pulse, g['sources_pulse'], rtol=1e-13, atol=1e-13)
+
+
+def test_compact_sources_follow_source_map(golden):
+    g, _ = golden
+    smap = g['sources_map']
+    N1, N2, N3 = smap.shape
+    Oz = np.random.default_rng(0).normal(size=smap.shape)
+    lin, row, wx, wy, wz = compact_sources(smap, np.zeros(smap.shape), np.array([1]), Oz)
+    i, j, k = lin % N1, (lin // N1) % N2, lin // (N1 * N2)
+    assert np.array_equal(smap[i, j, k] - 1, row)
+    assert wy is None and np.all(wx == 0) and np.array_equal(wz, Oz[i, j, k].astype(np.float32))
+    assert len(lin) == np.count_nonzero(smap) and np.all(np.diff(lin.astype(np.int64)) > 0)
+
+
+def test_run_simulation_call_is_accepted(golden):
+    """Every keyword RUN_SIMULATION passes (BASE:2338-2365) binds to the drop-in's signature, with
+    8 positional arguments in the reference's order."""
+    _, meta = golden
+    sig = inspect.signature(PropagationModel.StaggeredFDTD_3D_with_relaxation)
+    kw = {k: None for k in meta['run_simulation_kwargs']}
+    ba = sig.bind(None, *range(meta['run_simulation_positional']), **kw)
+    names = list(sig.parameters)[1:9]
+    assert names == ['MaterialMap', 'MaterialProperties', 'Frequency', 'SourceMap', 'PulseSource', 'SpatialStep',
+                     'DurationSimulation', 'SensorMap']
+    assert 'unused' not in ba.arguments     # nothing the caller passes is silently swallowed
+    v = meta['run_simulation_kwvalues']
+    assert v['NDelta'] == H.PML_THICKNESS and v['ReflectionLimit'] == H.REFLECTION_LIMIT
+    assert v['SelMapsSensorsList'] == ['Pressure'] and v['TypeSource'] == 0 and v['USE_SINGLE'] is True
+
+
+def test_dispersion_correction_scaling(golden):
+    g, _ = golden
+    dt, dtw, peak_scaled, sensor_scaled = g['run_scaling']
+    c = H.dispersion_correction(dt, dtw)
+    np.testing.assert_allclose(c * np.sqrt(2), peak_scaled, rtol=1e-6)     # maps: Correction*sqrt(2), BASE:2440
+    np.testing.assert_allclose(c, sensor_scaled, rtol=1e-6)                  # sensors: Correction, BASE:2444
+    oz, ox = g['run_oz_value']
+    assert ox == 0 and oz == 1 / 1.5e6                                       # Oz = 1/(rho0 c0), BASE:2335
+
+
+def test_sensor_index_decode(golden):
+    g, _ = golden
+    N1, N2, N3 = (int(v) for v in g['phase_args'][:3])
+    i, j, k = H.decode_sensor_index(g['phase_index'], N1, N2)
+    sm = np.zeros((N1, N2, N3), np.uint32)
+    sm[i, j, k] = 1
+    assert sm.sum() == len(i) and np.all(sm[12:-12, 12:-12, 15:-12] == 1)
