@@ -25,7 +25,7 @@ ABI_SYMBOLS = [
     'bfd_set_material_map', 'bfd_set_reflector', 'bfd_set_sources', 'bfd_set_sensor_map', 'bfd_run',
     'bfd_half_step_stress', 'bfd_half_step_velocity', 'bfd_sync', 'bfd_current_step', 'bfd_halo_region',
     'bfd_timing_begin', 'bfd_timing_end', 'bfd_num_sensors', 'bfd_num_sensor_steps', 'bfd_get_sensor_index',
-    'bfd_get_sensors', 'bfd_get_map', 'bfd_get_field', 'bfd_device_bytes',
+    'bfd_get_sensors', 'bfd_get_map', 'bfd_get_field', 'bfd_tile_counts', 'bfd_device_bytes',
 ]
 
 
@@ -86,6 +86,7 @@ def load_library():
     lib.bfd_get_map.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_int64, C.c_int64]
     lib.bfd_get_field.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_int64, C.c_int64]
     lib.bfd_device_bytes.argtypes = [C.c_void_p]
+    lib.bfd_tile_counts.argtypes = [C.c_void_p] + [C.POINTER(C.c_int32)] * 3
     lib.bfd_device_bytes.restype = C.c_int64
     lib.bfd_device_name.argtypes = [C.c_int, C.c_char_p, C.c_int]
     if lib.bfd_abi_version() != 1:
@@ -305,6 +306,11 @@ class Engine:
             out = np.zeros(self.shape, np.float32)
         _check(self.lib.bfd_get_field(self.h, FIELD_NAMES.index(name), _ptr(out), *_estrides(out)), 'bfd_get_field')
         return out
+
+    def tile_counts(self):
+        n = [C.c_int32() for _ in range(3)]
+        _check(self.lib.bfd_tile_counts(self.h, *[C.byref(x) for x in n]), 'bfd_tile_counts')
+        return {'lossless_fluid': n[0].value, 'lossy_fluid': n[1].value, 'solid': n[2].value}
 
     @property
     def device_bytes(self):

@@ -373,7 +373,7 @@ int bfd_create(const bfd_config *cfg, bfd_sim **out)
 
     bfd_sim *s = new bfd_sim();
     s->cfg = *cfg;
-    s->step = 0; s->devBytes = 0; s->haveMaterials = s->haveMap = false;
+    s->step = 0; s->devBytes = 0; s->haveMaterials = s->haveMap = false; s->tilesReady = false;
     s->nSrcVox = 0; s->srcLin = s->srcRow = nullptr; s->srcW[0] = s->srcW[1] = s->srcW[2] = nullptr; s->pulseT = nullptr;
     s->nSources = s->lengthSource = 0;
     s->nSensors = 0; s->sensLin = nullptr; s->sensOut = nullptr;
@@ -487,7 +487,7 @@ int bfd_set_materials(bfd_sim *s, const double *matlist, const double *qcorr)
     d.axI = bx; d.bxI = bx + d.N1; d.axH = bx + 2 * d.N1; d.bxH = bx + 3 * d.N1;
     d.ayI = by; d.byI = by + d.N2; d.ayH = by + 2 * d.N2; d.byH = by + 3 * d.N2;
     d.azI = bz; d.bzI = bz + d.N3; d.azH = bz + 2 * d.N3; d.bzH = bz + 3 * d.N3;
-    s->haveMaterials = true;
+    s->haveMaterials = true; s->tilesReady = false;
     return 0;
 }
 
@@ -521,7 +521,7 @@ int bfd_set_material_map(bfd_sim *s, const uint32_t *map, int64_t s1, int64_t s2
     hipFree(tmp); if (flag) hipFree(flag);
     if (e != hipSuccess) BFD_FAIL(-10, std::string("bfd_set_material_map: ") + hipGetErrorString(e));
     if (hflag) BFD_FAIL(-5, "bfd_set_material_map: MaterialMap holds an id >= number of MaterialList rows");
-    s->haveMap = true;
+    s->haveMap = true; s->tilesReady = false;
     return 0;
 }
 
@@ -621,10 +621,40 @@ int bfd_set_sensor_map(bfd_sim *s, const uint32_t *map, int64_t s1, int64_t s2, 
     return 0;
 }
 
+// variant 0/3: split the tiles into lossless-fluid / lossy-fluid / solid lists (bfd_kernels_v2.hip)
+static int build_tile_lists(bfd_sim *s)
+{
+    int tx, ty, tz; bfd_tile_grid(s->d, &tx, &ty, &tz);
+    const int n = tx * ty * tz;
+    int *flagsDev = nullptr;
+    BFD_HIP(hipMalloc((void **)&flagsDev, n * sizeof(int)));
+    bfd_launch_classify(s->d, s->stream, flagsDev);
+    std::vector<int> flags(n), list;
+    hipError_t e = hipMemcpyAsync(flags.data(), flagsDev, n * sizeof(int), hipMemcpyDeviceToHost, s->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+    hipFree(flagsDev);
+    if (e != hipSuccess) BFD_FAIL(-10, std::string("classify tiles: ") + hipGetErrorString(e));
+    list.reserve(n);
+    int nA = 0, nB = 0, nC = 0;
+    for (int t = 0; t < n; t++) if (flags[t] == 0) { list.push_back(t); nA++; }
+    for (int t = 0; t < n; t++) if (flags[t] == 2) { list.push_back(t); nB++; }
+    for (int t = 0; t < n; t++) if (flags[t] & 1) { list.push_back(t); nC++; }
+    int rc = dev_alloc(s, &s->tiles.list, (size_t)n, false);
+    if (rc) return rc;
+    BFD_HIP(hipMemcpy(s->tiles.list, list.data(), n * sizeof(int), hipMemcpyHostToDevice));
+    s->tiles.nLossless = nA; s->tiles.nLossy = nB; s->tiles.nSolid = nC;
+    s->tilesReady = true;
+    return 0;
+}
+
 static int check_ready(bfd_sim *s)
 {
     if (!s) BFD_FAIL(-1, "null sim");
     if (!s->haveMaterials || !s->haveMap) BFD_FAIL(-6, "materials and material map must be set before stepping");
+    if (!s->tilesReady && (s->cfg.kernelVariant == 0 || s->cfg.kernelVariant == 3)) {
+        BFD_HIP(hipSetDevice(s->cfg.device));
+        return build_tile_lists(s);
+    }
     return 0;
 }
 
@@ -635,7 +665,7 @@ int bfd_half_step_stress(bfd_sim *s)
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (s->timing && s->perKernel) { e0 = get_event(s); e1 = get_event(s); hipEventRecord(e0, s->stream); }
     if (s->cfg.kernelVariant == 1) bfd_launch_stress_v1(s->d, s->stream);
-    else bfd_launch_stress_v2(s->d, s->stream);
+    else bfd_launch_stress_v2(s->d, s->stream, s->tilesReady ? &s->tiles : nullptr);
     if (e0) { hipEventRecord(e1, s->stream); s->evStress.push_back(e0); s->evStress.push_back(e1); }
     if (s->nSrcVox && s->cfg.typeSource >= 2 && s->step < s->lengthSource)
         hipLaunchKernelGGL(inject_sources, dim3(grid_for(s->nSrcVox)), dim3(256), 0, s->stream, s->d, s->cfg.typeSource,
@@ -659,7 +689,7 @@ int bfd_half_step_velocity(bfd_sim *s)
         for (int q = 0; q < s->nSelR; q++) if (s->selR[q] == BFD_MAP_PRESSURE) qP = q;
     if (s->cfg.kernelVariant == 1) bfd_launch_velocity_v1(d, s->stream);
     else bfd_launch_velocity_v2(d, s->stream, (qP >= 0 && s->acc) ? s->acc + (size_t)qP * s->nloc : nullptr,
-                                (qP >= 0 && s->pk) ? s->pk + (size_t)qP * s->nloc : nullptr);
+                                (qP >= 0 && s->pk) ? s->pk + (size_t)qP * s->nloc : nullptr, s->tilesReady ? &s->tiles : nullptr);
     if (e0) { hipEventRecord(e1, s->stream); s->evVelocity.push_back(e0); s->evVelocity.push_back(e1); }
     if (s->nSrcVox && s->cfg.typeSource < 2 && s->step < s->lengthSource)
         hipLaunchKernelGGL(inject_sources, dim3(grid_for(s->nSrcVox)), dim3(256), 0, s->stream, d, s->cfg.typeSource,
@@ -840,6 +870,15 @@ int bfd_get_field(bfd_sim *s, int32_t a, float *out, int64_t s1, int64_t s2, int
     if (!s || !out || a < 0 || a > 14) BFD_FAIL(-1, "bfd_get_field: bad argument");
     BFD_HIP(hipSetDevice(s->cfg.device));
     return download_volume(s, s->stateBase[a] + 2 * (size_t)s->d.plane, out, s1, s2, s3);
+}
+
+int bfd_tile_counts(bfd_sim *s, int32_t *nLossless, int32_t *nLossy, int32_t *nSolid)
+{
+    int rc = check_ready(s); if (rc) return rc;
+    if (nLossless) *nLossless = s->tilesReady ? s->tiles.nLossless : 0;
+    if (nLossy) *nLossy = s->tilesReady ? s->tiles.nLossy : 0;
+    if (nSolid) *nSolid = s->tilesReady ? s->tiles.nSolid : 0;
+    return 0;
 }
 
 int64_t bfd_device_bytes(bfd_sim *s) { return s ? s->devBytes : -1; }

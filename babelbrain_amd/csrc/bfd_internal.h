@@ -34,6 +34,9 @@ struct bfd_dev {
     float *psi[18];
 };
 
+// tile lists of the class-specialised path (variant 3): device array [lossless fluid | lossy fluid | solid]
+struct bfd_tiles { int *list; int nLossless, nLossy, nSolid; };
+
 struct bfd_sim {
     bfd_config cfg;
     bfd_dev d;
@@ -48,6 +51,7 @@ struct bfd_sim {
     std::vector<void *> allocs;     // everything to free
     int64_t devBytes;
     bool haveMaterials, haveMap;
+    bfd_tiles tiles; bool tilesReady;   // variant 3
     double cmax;
     // sources
     int64_t nSrcVox; uint32_t *srcLin, *srcRow; float *srcW[3]; float *pulseT; int nSources, lengthSource;
@@ -76,6 +80,9 @@ void bfd_set_error(const std::string &s);
 // kernel launchers (bfd_kernels_*.hip)
 void bfd_launch_stress_v1(const bfd_dev &d, hipStream_t s);
 void bfd_launch_velocity_v1(const bfd_dev &d, hipStream_t s);
-void bfd_launch_stress_v2(const bfd_dev &d, hipStream_t s);
+void bfd_tile_grid(const bfd_dev &d, int *tilesX, int *tilesY, int *tilesZ);
+void bfd_launch_classify(const bfd_dev &d, hipStream_t s, int *flagsDev);
+// t == nullptr: dense kernels on every tile (variant 2)
+void bfd_launch_stress_v2(const bfd_dev &d, hipStream_t s, const bfd_tiles *t);
 // accP / pkP: Pressure RMS / peak accumulators of this step (slab-local, x-fastest) or nullptr
-void bfd_launch_velocity_v2(const bfd_dev &d, hipStream_t s, float *accP, float *pkP);
+void bfd_launch_velocity_v2(const bfd_dev &d, hipStream_t s, float *accP, float *pkP, const bfd_tiles *t);

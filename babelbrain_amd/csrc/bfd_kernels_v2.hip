@@ -26,6 +26,12 @@ constexpr int LH = TY + 4;          // LDS rows
 constexpr int NTHREADS = TX * TY;   // 512
 constexpr int YT = 4 * TX;          // y-halo tasks per array (4 rows x 64)
 constexpr int XT = 4 * TY;          // x-halo tasks per array (4 cols x TY)
+#ifndef STRESS_WAVES_PER_SIMD
+#define STRESS_WAVES_PER_SIMD 4     // 2 workgroups of 8 waves per CU (<= 128 VGPRs); 6 or 8 spill and run 1.4-2.4x slower (measured)
+#endif
+#ifndef VELOCITY_WAVES_PER_SIMD
+#define VELOCITY_WAVES_PER_SIMD 4
+#endif
 
 __device__ __forceinline__ float dminus4(float fm2, float fm1, float f0, float fp1)
 {
@@ -85,11 +91,13 @@ __device__ __forceinline__ void xtask(int u, int arr, int i0, int j0, int N1, in
 // stress half-step
 // ------------------------------------------------------------------------------------------------
 template <int ZC>
-__global__ __launch_bounds__(NTHREADS) void stress_v2(bfd_dev d, int tilesX, int tilesY, int nblocks)
+__global__ __launch_bounds__(NTHREADS, STRESS_WAVES_PER_SIMD) void stress_v2(bfd_dev d, int tilesX, int tilesY, int nblocks,
+                                                                             const int *__restrict__ list)
 {
     __shared__ float sV[2][3][LH * LW];
     const int N1 = d.N1, N2 = d.N2;
-    const int tile = remap_block(blockIdx.x, nblocks);
+    const int pos = remap_block(blockIdx.x, nblocks);
+    const int tile = list ? list[pos] : pos;
     const int bx = tile % tilesX, by = (tile / tilesX) % tilesY, bz = tile / (tilesX * tilesY);
     const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * TX + tx;
     const int i0 = bx * TX, j0 = by * TY;
@@ -99,7 +107,7 @@ __global__ __launch_bounds__(NTHREADS) void stress_v2(bfd_dev d, int tilesX, int
     const int kbeg = bz * ZC, kend = min(kbeg + ZC, d.nk);
     const int P = d.P;
     const int own = (ty + 2) * LW + tx + 2;
-    const long cij = valid ? (long)j * N1 + i : 0;
+    const unsigned cij = valid ? (unsigned)(j * N1 + i) : 0u;    // in-plane offset shared by every array
 
     // halo tasks: [Vx-y, Vy-y, Vz-y] 3*256, then [Vx-x, Vy-x, Vz-x] 3*32
     HaloTask ta, tb;
@@ -110,55 +118,56 @@ __global__ __launch_bounds__(NTHREADS) void stress_v2(bfd_dev d, int tilesX, int
         else if (t2 < 3 * YT + 3 * XT) { const int u = t2 - 3 * YT; xtask(u % XT, u / XT, i0, j0, N1, N2, tb); }
         else { tb.lofs = -1; tb.ok = false; tb.arr = 0; tb.gofs = 0; }
     }
-    const float *Varr[3] = {d.Vx, d.Vy, d.Vz};
-    const float *pa = ta.arr == 0 ? d.Vx : (ta.arr == 1 ? d.Vy : d.Vz);
-    const float *pb = tb.arr == 0 ? d.Vx : (tb.arr == 1 ? d.Vy : d.Vz);
-    (void)Varr;
+    const float *pa = (ta.arr == 0 ? d.Vx : (ta.arr == 1 ? d.Vy : d.Vz)) + (ta.ok ? ta.gofs : 0);
+    const float *pb = (tb.arr == 0 ? d.Vx : (tb.arr == 1 ? d.Vy : d.Vz)) + (tb.ok ? tb.gofs : 0);
+    float *la = &sV[0][ta.arr][ta.lofs];
+    float *lb = &sV[0][tb.arr][tb.lofs < 0 ? 0 : tb.lofs];
+    const bool hasB = tb.lofs >= 0;
 
-    // per-thread constants of the absorbing layer in x and y
     const bool zi = valid && (i < P || i >= N1 - P);
     const bool zj = valid && (j < P || j >= N2 - P);
-    float axI = 0, bxI = 0, axH = 0, bxH = 0, ayI = 0, byI = 0, ayH = 0, byH = 0;
-    int xi = 0, yj = 0;
-    if (zi) { axI = d.axI[i]; bxI = d.bxI[i]; axH = d.axH[i]; bxH = d.bxH[i]; xi = i < P ? i : i - (N1 - 2 * P); }
-    if (zj) { ayI = d.ayI[j]; byI = d.byI[j]; ayH = d.ayH[j]; byH = d.byH[j]; yj = j < P ? j : j - (N2 - 2 * P); }
     const float c1 = d.c1, k2 = d.k2;
 
     // z register queues, primed for plane kbeg (ghost planes make kbeg-2 .. always addressable)
     float vxm1 = 0, vx0 = 0, vxp1 = 0, vxp2 = 0, vym1 = 0, vy0 = 0, vyp1 = 0, vyp2 = 0, vzm2 = 0, vzm1 = 0, vz0 = 0, vzp1 = 0;
-    if (valid) {
-        const long c = (long)kbeg * pl + cij;
-        vxm1 = d.Vx[c - pl]; vx0 = d.Vx[c]; vxp1 = d.Vx[c + pl]; vxp2 = d.Vx[c + 2 * pl];
-        vym1 = d.Vy[c - pl]; vy0 = d.Vy[c]; vyp1 = d.Vy[c + pl]; vyp2 = d.Vy[c + 2 * pl];
-        vzm2 = d.Vz[c - 2 * pl]; vzm1 = d.Vz[c - pl]; vz0 = d.Vz[c]; vzp1 = d.Vz[c + pl];
+    {
+        const float *bVx = d.Vx + kbeg * pl, *bVy = d.Vy + kbeg * pl, *bVz = d.Vz + kbeg * pl;
+        if (valid) {
+            vxm1 = (bVx - pl)[cij]; vx0 = bVx[cij]; vxp1 = (bVx + pl)[cij]; vxp2 = (bVx + 2 * pl)[cij];
+            vym1 = (bVy - pl)[cij]; vy0 = bVy[cij]; vyp1 = (bVy + pl)[cij]; vyp2 = (bVy + 2 * pl)[cij];
+            vzm2 = (bVz - 2 * pl)[cij]; vzm1 = (bVz - pl)[cij]; vz0 = bVz[cij]; vzp1 = (bVz + pl)[cij];
+        }
     }
-    float ha = ta.ok ? pa[(long)kbeg * pl + ta.gofs] : 0.0f;
-    float hb = tb.ok ? pb[(long)kbeg * pl + tb.gofs] : 0.0f;
+    float ha = ta.ok ? pa[kbeg * pl] : 0.0f;
+    float hb = tb.ok ? pb[kbeg * pl] : 0.0f;
 
     for (int kl = kbeg; kl < kend; kl++) {
         const int b = kl & 1;
-        const long ko = (long)kl * pl;
-        const long c = ko + cij;
+        const long ko = (long)kl * pl;          // uniform: plane bases stay in SGPRs
         const int k = d.k0 + kl;
+        const int bo = b * (3 * LH * LW);
         // stage plane kl in LDS
         sV[b][0][own] = vx0; sV[b][1][own] = vy0; sV[b][2][own] = vz0;
-        sV[b][ta.arr][ta.lofs] = ha;
-        if (tb.lofs >= 0) sV[b][tb.arr][tb.lofs] = hb;
+        la[bo] = ha;
+        if (hasB) lb[bo] = hb;
         __syncthreads();
 
         // this plane's state first (needed soonest), then the prefetches for plane kl+1
-        uint16_t mraw = 0;
+        float *pSxx = d.Sxx + ko, *pSyy = d.Syy + ko, *pSzz = d.Szz + ko;
+        float *pRxx = d.Rxx + ko, *pRyy = d.Ryy + ko, *pRzz = d.Rzz + ko;
+        const uint16_t *pM = d.mat + ko;
+        unsigned mraw = 0;
         float sxx = 0, syy = 0, szz = 0, rxx = 0, ryy = 0, rzz = 0;
         if (valid) {
-            mraw = d.mat[c];
-            sxx = d.Sxx[c]; syy = d.Syy[c]; szz = d.Szz[c];
-            rxx = d.Rxx[c]; ryy = d.Ryy[c]; rzz = d.Rzz[c];
+            mraw = pM[cij];
+            sxx = pSxx[cij]; syy = pSyy[cij]; szz = pSzz[cij];
+            rxx = pRxx[cij]; ryy = pRyy[cij]; rzz = pRzz[cij];
         }
         float nvx = 0, nvy = 0, nvz = 0, nha = 0, nhb = 0;
         if (kl + 1 < kend) {
-            if (valid) { nvx = d.Vx[c + 3 * pl]; nvy = d.Vy[c + 3 * pl]; nvz = d.Vz[c + 2 * pl]; }
-            if (ta.ok) nha = pa[ko + pl + ta.gofs];
-            if (tb.ok) nhb = pb[ko + pl + tb.gofs];
+            if (valid) { nvx = (d.Vx + ko + 3 * pl)[cij]; nvy = (d.Vy + ko + 3 * pl)[cij]; nvz = (d.Vz + ko + 2 * pl)[cij]; }
+            if (ta.ok) nha = pa[ko + pl];
+            if (tb.ok) nhb = pb[ko + pl];
         }
 
         if (valid) {
@@ -174,21 +183,23 @@ __global__ __launch_bounds__(NTHREADS) void stress_v2(bfd_dev d, int tilesX, int
             float dyVz = dplus4(sz[-LW], vz0, sz[LW], sz[2 * LW]);
 
             if (mraw & BFD_REFLECTOR_BIT) {
-                d.Sxx[c] = 0.f; d.Syy[c] = 0.f; d.Szz[c] = 0.f; d.Sxy[c] = 0.f; d.Sxz[c] = 0.f; d.Syz[c] = 0.f;
-                d.Rxx[c] = 0.f; d.Ryy[c] = 0.f; d.Rzz[c] = 0.f; d.Rxy[c] = 0.f; d.Rxz[c] = 0.f; d.Ryz[c] = 0.f;
+                pSxx[cij] = 0.f; pSyy[cij] = 0.f; pSzz[cij] = 0.f; (d.Sxy + ko)[cij] = 0.f; (d.Sxz + ko)[cij] = 0.f; (d.Syz + ko)[cij] = 0.f;
+                pRxx[cij] = 0.f; pRyy[cij] = 0.f; pRzz[cij] = 0.f; (d.Rxy + ko)[cij] = 0.f; (d.Rxz + ko)[cij] = 0.f; (d.Ryz + ko)[cij] = 0.f;
             } else {
                 const int m = mraw & BFD_MAT_MASK;
                 if (zi) {
+                    const int xi = i < P ? i : i - (N1 - 2 * P);
                     const long q = ((long)kl * N2 + j) * (2 * P) + xi;
-                    dxVx = cpml(d.psi[0], q, axI, bxI, dxVx);
-                    dxVy = cpml(d.psi[4], q, axH, bxH, dxVy);
-                    dxVz = cpml(d.psi[6], q, axH, bxH, dxVz);
+                    dxVx = cpml(d.psi[0], q, d.axI[i], d.bxI[i], dxVx);
+                    dxVy = cpml(d.psi[4], q, d.axH[i], d.bxH[i], dxVy);
+                    dxVz = cpml(d.psi[6], q, d.axH[i], d.bxH[i], dxVz);
                 }
                 if (zj) {
+                    const int yj = j < P ? j : j - (N2 - 2 * P);
                     const long q = ((long)kl * (2 * P) + yj) * N1 + i;
-                    dyVy = cpml(d.psi[1], q, ayI, byI, dyVy);
-                    dyVx = cpml(d.psi[3], q, ayH, byH, dyVx);
-                    dyVz = cpml(d.psi[8], q, ayH, byH, dyVz);
+                    dyVy = cpml(d.psi[1], q, d.ayI[j], d.byI[j], dyVy);
+                    dyVx = cpml(d.psi[3], q, d.ayH[j], d.byH[j], dyVx);
+                    dyVz = cpml(d.psi[8], q, d.ayH[j], d.byH[j], dyVz);
                 }
                 if (k < P || k >= d.N3 - P) {
                     const int zk = k < P ? k : k - (d.N3 - 2 * P);
@@ -204,52 +215,56 @@ __global__ __launch_bounds__(NTHREADS) void stress_v2(bfd_dev d, int tilesX, int
                     const float sYZ = dyVy + dzVz, sXZ = dxVx + dzVz;
                     float rn;
                     rn = c1 * rxx - (BP * div - BS2 * sYZ);
-                    d.Sxx[c] = sxx + ((AP * div - AS2 * sYZ) + 0.5f * (rxx + rn)); d.Rxx[c] = rn;
+                    pSxx[cij] = sxx + ((AP * div - AS2 * sYZ) + 0.5f * (rxx + rn)); pRxx[cij] = rn;
                     rn = c1 * ryy - (BP * div - BS2 * sXZ);
-                    d.Syy[c] = syy + ((AP * div - AS2 * sXZ) + 0.5f * (ryy + rn)); d.Ryy[c] = rn;
+                    pSyy[cij] = syy + ((AP * div - AS2 * sXZ) + 0.5f * (ryy + rn)); pRyy[cij] = rn;
                     rn = c1 * rzz - (BP * div - BS2 * sXY);
-                    d.Szz[c] = szz + ((AP * div - AS2 * sXY) + 0.5f * (rzz + rn)); d.Rzz[c] = rn;
+                    pSzz[cij] = szz + ((AP * div - AS2 * sXY) + 0.5f * (rzz + rn)); pRzz[cij] = rn;
                 }
                 const float iv0 = d.invMu[m];
                 if (iv0 > 0.f) {    // shear only where the centre cell is solid
                     const float t0 = d.tauS[m];
                     const int i1 = min(i + 1, N1 - 1), j1 = min(j + 1, N2 - 1);
-                    const long r0 = ko + (long)j * N1, r1 = ko + (long)j1 * N1;
-                    const int mx = d.mat[r0 + i1] & BFD_MAT_MASK, my = d.mat[r1 + i] & BFD_MAT_MASK;
-                    const int mz = d.mat[r0 + pl + i] & BFD_MAT_MASK, mxy = d.mat[r1 + i1] & BFD_MAT_MASK;
-                    const int mxz = d.mat[r0 + pl + i1] & BFD_MAT_MASK, myz = d.mat[r1 + pl + i] & BFD_MAT_MASK;
+                    const unsigned r0 = (unsigned)(j * N1), r1 = (unsigned)(j1 * N1);
+                    const uint16_t *pM1 = pM + pl;
+                    const int mx = pM[r0 + i1] & BFD_MAT_MASK, my = pM[r1 + i] & BFD_MAT_MASK;
+                    const int mz = pM1[r0 + i] & BFD_MAT_MASK, mxy = pM[r1 + i1] & BFD_MAT_MASK;
+                    const int mxz = pM1[r0 + i1] & BFD_MAT_MASK, myz = pM1[r1 + i] & BFD_MAT_MASK;
                     const float ivx = d.invMu[mx], ivy = d.invMu[my], ivz = d.invMu[mz];
                     {
                         const float e4 = d.invMu[mxy];
                         if (ivx > 0.f && ivy > 0.f && e4 > 0.f) {
+                            float *pS = d.Sxy + ko, *pR = d.Rxy + ko;
                             const float muH = 4.0f / ((iv0 + ivx) + (ivy + e4));
                             const float tau = 0.25f * ((t0 + d.tauS[mx]) + (d.tauS[my] + d.tauS[mxy]));
                             const float A = muH * (1.0f + tau), B = (muH * tau) * k2;
                             const float e = dyVx + dxVy;
-                            const float r = d.Rxy[c], rn = c1 * r - B * e;
-                            d.Sxy[c] = d.Sxy[c] + (A * e + 0.5f * (r + rn)); d.Rxy[c] = rn;
+                            const float r = pR[cij], rn = c1 * r - B * e;
+                            pS[cij] = pS[cij] + (A * e + 0.5f * (r + rn)); pR[cij] = rn;
                         }
                     }
                     {
                         const float e4 = d.invMu[mxz];
                         if (ivx > 0.f && ivz > 0.f && e4 > 0.f) {
+                            float *pS = d.Sxz + ko, *pR = d.Rxz + ko;
                             const float muH = 4.0f / ((iv0 + ivx) + (ivz + e4));
                             const float tau = 0.25f * ((t0 + d.tauS[mx]) + (d.tauS[mz] + d.tauS[mxz]));
                             const float A = muH * (1.0f + tau), B = (muH * tau) * k2;
                             const float e = dzVx + dxVz;
-                            const float r = d.Rxz[c], rn = c1 * r - B * e;
-                            d.Sxz[c] = d.Sxz[c] + (A * e + 0.5f * (r + rn)); d.Rxz[c] = rn;
+                            const float r = pR[cij], rn = c1 * r - B * e;
+                            pS[cij] = pS[cij] + (A * e + 0.5f * (r + rn)); pR[cij] = rn;
                         }
                     }
                     {
                         const float e4 = d.invMu[myz];
                         if (ivy > 0.f && ivz > 0.f && e4 > 0.f) {
+                            float *pS = d.Syz + ko, *pR = d.Ryz + ko;
                             const float muH = 4.0f / ((iv0 + ivy) + (ivz + e4));
                             const float tau = 0.25f * ((t0 + d.tauS[my]) + (d.tauS[mz] + d.tauS[myz]));
                             const float A = muH * (1.0f + tau), B = (muH * tau) * k2;
                             const float e = dzVy + dyVz;
-                            const float r = d.Ryz[c], rn = c1 * r - B * e;
-                            d.Syz[c] = d.Syz[c] + (A * e + 0.5f * (r + rn)); d.Ryz[c] = rn;
+                            const float r = pR[cij], rn = c1 * r - B * e;
+                            pS[cij] = pS[cij] + (A * e + 0.5f * (r + rn)); pR[cij] = rn;
                         }
                     }
                 }
@@ -268,12 +283,14 @@ __global__ __launch_bounds__(NTHREADS) void stress_v2(bfd_dev d, int tilesX, int
 // ------------------------------------------------------------------------------------------------
 // LDS set: 0 Sxx (x halo), 1 Syy (y halo), 2 Sxy (x and y halo), 3 Sxz (x halo), 4 Syz (y halo)
 template <int ZC, bool ACC>
-__global__ __launch_bounds__(NTHREADS) void velocity_v2(bfd_dev d, int tilesX, int tilesY, int nblocks,
-                                                        float *__restrict__ accP, float *__restrict__ pkP)
+__global__ __launch_bounds__(NTHREADS, VELOCITY_WAVES_PER_SIMD) void velocity_v2(bfd_dev d, int tilesX, int tilesY, int nblocks,
+                                                        float *__restrict__ accP, float *__restrict__ pkP,
+                                                        const int *__restrict__ list)
 {
     __shared__ float sS[2][5][LH * LW];
     const int N1 = d.N1, N2 = d.N2;
-    const int tile = remap_block(blockIdx.x, nblocks);
+    const int pos = remap_block(blockIdx.x, nblocks);
+    const int tile = list ? list[pos] : pos;
     const int bx = tile % tilesX, by = (tile / tilesX) % tilesY, bz = tile / (tilesX * tilesY);
     const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * TX + tx;
     const int i0 = bx * TX, j0 = by * TY;
@@ -283,7 +300,7 @@ __global__ __launch_bounds__(NTHREADS) void velocity_v2(bfd_dev d, int tilesX, i
     const int kbeg = bz * ZC, kend = min(kbeg + ZC, d.nk);
     const int P = d.P;
     const int own = (ty + 2) * LW + tx + 2;
-    const long cij = valid ? (long)j * N1 + i : 0;
+    const unsigned cij = valid ? (unsigned)(j * N1 + i) : 0u;
 
     // halo tasks: [Syy-y, Sxy-y] 2*256 (task A: every thread), then [Syz-y] 256, [Sxx-x, Sxy-x, Sxz-x] 3*32
     HaloTask ta, tb;
@@ -297,51 +314,52 @@ __global__ __launch_bounds__(NTHREADS) void velocity_v2(bfd_dev d, int tilesX, i
             xtask(u % XT, a == 0 ? 0 : (a == 1 ? 2 : 3), i0, j0, N1, N2, tb);
         } else { tb.lofs = -1; tb.ok = false; tb.arr = 0; tb.gofs = 0; }
     }
-    const float *pa = ta.arr == 1 ? d.Syy : d.Sxy;
-    const float *pb = tb.arr == 4 ? d.Syz : (tb.arr == 0 ? d.Sxx : (tb.arr == 2 ? d.Sxy : d.Sxz));
+    const float *pa = (ta.arr == 1 ? d.Syy : d.Sxy) + (ta.ok ? ta.gofs : 0);
+    const float *pb = (tb.arr == 4 ? d.Syz : (tb.arr == 0 ? d.Sxx : (tb.arr == 2 ? d.Sxy : d.Sxz))) + (tb.ok ? tb.gofs : 0);
+    float *la = &sS[0][ta.arr][ta.lofs];
+    float *lb = &sS[0][tb.arr][tb.lofs < 0 ? 0 : tb.lofs];
+    const bool hasB = tb.lofs >= 0;
 
     const bool zi = valid && (i < P || i >= N1 - P);
     const bool zj = valid && (j < P || j >= N2 - P);
-    float axI = 0, bxI = 0, axH = 0, bxH = 0, ayI = 0, byI = 0, ayH = 0, byH = 0;
-    int xi = 0, yj = 0;
-    if (zi) { axI = d.axI[i]; bxI = d.bxI[i]; axH = d.axH[i]; bxH = d.bxH[i]; xi = i < P ? i : i - (N1 - 2 * P); }
-    if (zj) { ayI = d.ayI[j]; byI = d.byI[j]; ayH = d.ayH[j]; byH = d.byH[j]; yj = j < P ? j : j - (N2 - 2 * P); }
     const bool inner = valid && i >= d.ND && i < N1 - d.ND && j >= d.ND && j < N2 - d.ND;
 
     // z queues: Szz k-1..k+2 ; Sxz, Syz k-2..k+1 ; in-plane arrays one plane ahead
     float zzm1 = 0, zz0 = 0, zzp1 = 0, zzp2 = 0, xzm2 = 0, xzm1 = 0, xz0 = 0, xzp1 = 0, yzm2 = 0, yzm1 = 0, yz0 = 0, yzp1 = 0;
     float sxx = 0, syy = 0, sxy = 0;
     if (valid) {
-        const long c = (long)kbeg * pl + cij;
-        zzm1 = d.Szz[c - pl]; zz0 = d.Szz[c]; zzp1 = d.Szz[c + pl]; zzp2 = d.Szz[c + 2 * pl];
-        xzm2 = d.Sxz[c - 2 * pl]; xzm1 = d.Sxz[c - pl]; xz0 = d.Sxz[c]; xzp1 = d.Sxz[c + pl];
-        yzm2 = d.Syz[c - 2 * pl]; yzm1 = d.Syz[c - pl]; yz0 = d.Syz[c]; yzp1 = d.Syz[c + pl];
-        sxx = d.Sxx[c]; syy = d.Syy[c]; sxy = d.Sxy[c];
+        const float *bzz = d.Szz + kbeg * pl, *bxz = d.Sxz + kbeg * pl, *byz = d.Syz + kbeg * pl;
+        zzm1 = (bzz - pl)[cij]; zz0 = bzz[cij]; zzp1 = (bzz + pl)[cij]; zzp2 = (bzz + 2 * pl)[cij];
+        xzm2 = (bxz - 2 * pl)[cij]; xzm1 = (bxz - pl)[cij]; xz0 = bxz[cij]; xzp1 = (bxz + pl)[cij];
+        yzm2 = (byz - 2 * pl)[cij]; yzm1 = (byz - pl)[cij]; yz0 = byz[cij]; yzp1 = (byz + pl)[cij];
+        sxx = (d.Sxx + kbeg * pl)[cij]; syy = (d.Syy + kbeg * pl)[cij]; sxy = (d.Sxy + kbeg * pl)[cij];
     }
-    float ha = ta.ok ? pa[(long)kbeg * pl + ta.gofs] : 0.0f;
-    float hb = tb.ok ? pb[(long)kbeg * pl + tb.gofs] : 0.0f;
+    float ha = ta.ok ? pa[kbeg * pl] : 0.0f;
+    float hb = tb.ok ? pb[kbeg * pl] : 0.0f;
 
     for (int kl = kbeg; kl < kend; kl++) {
         const int b = kl & 1;
         const long ko = (long)kl * pl;
-        const long c = ko + cij;
         const int k = d.k0 + kl;
+        const int bo = b * (5 * LH * LW);
         sS[b][0][own] = sxx; sS[b][1][own] = syy; sS[b][2][own] = sxy; sS[b][3][own] = xz0; sS[b][4][own] = yz0;
-        sS[b][ta.arr][ta.lofs] = ha;
-        if (tb.lofs >= 0) sS[b][tb.arr][tb.lofs] = hb;
+        la[bo] = ha;
+        if (hasB) lb[bo] = hb;
         __syncthreads();
 
-        uint16_t mraw = 0;
+        float *pVx = d.Vx + ko, *pVy = d.Vy + ko, *pVz = d.Vz + ko;
+        const uint16_t *pM = d.mat + ko;
+        unsigned mraw = 0;
         float vx = 0, vy = 0, vz = 0;
-        if (valid) { mraw = d.mat[c]; vx = d.Vx[c]; vy = d.Vy[c]; vz = d.Vz[c]; }
+        if (valid) { mraw = pM[cij]; vx = pVx[cij]; vy = pVy[cij]; vz = pVz[cij]; }
         float nzz = 0, nxz = 0, nyz = 0, nxx = 0, nyy = 0, nxy = 0, nha = 0, nhb = 0;
         if (kl + 1 < kend) {
             if (valid) {
-                nzz = d.Szz[c + 3 * pl]; nxz = d.Sxz[c + 2 * pl]; nyz = d.Syz[c + 2 * pl];
-                nxx = d.Sxx[c + pl]; nyy = d.Syy[c + pl]; nxy = d.Sxy[c + pl];
+                nzz = (d.Szz + ko + 3 * pl)[cij]; nxz = (d.Sxz + ko + 2 * pl)[cij]; nyz = (d.Syz + ko + 2 * pl)[cij];
+                nxx = (d.Sxx + ko + pl)[cij]; nyy = (d.Syy + ko + pl)[cij]; nxy = (d.Sxy + ko + pl)[cij];
             }
-            if (ta.ok) nha = pa[ko + pl + ta.gofs];
-            if (tb.ok) nhb = pb[ko + pl + tb.gofs];
+            if (ta.ok) nha = pa[ko + pl];
+            if (tb.ok) nhb = pb[ko + pl];
         }
 
         if (valid) {
@@ -351,12 +369,12 @@ __global__ __launch_bounds__(NTHREADS) void velocity_v2(bfd_dev d, int tilesX, i
                 if (inner && k >= d.ND && k < d.N3 - d.ND) {
                     const float s = (sxx + syy) + zz0;
                     const float p = -s * (1.0f / 3.0f);
-                    if (accP) accP[c] = accP[c] + p * p;
-                    if (pkP) { const float ap = fabsf(p); if (ap > pkP[c]) pkP[c] = ap; }
+                    if (accP) (accP + ko)[cij] = (accP + ko)[cij] + p * p;
+                    if (pkP) { const float ap = fabsf(p); if (ap > (pkP + ko)[cij]) (pkP + ko)[cij] = ap; }
                 }
             }
             if (mraw & BFD_REFLECTOR_BIT) {
-                d.Vx[c] = 0.f; d.Vy[c] = 0.f; d.Vz[c] = 0.f;
+                pVx[cij] = 0.f; pVy[cij] = 0.f; pVz[cij] = 0.f;
             } else {
                 const float *pxx = &sS[b][0][own], *pyy = &sS[b][1][own], *pxy = &sS[b][2][own];
                 const float *pxz = &sS[b][3][own], *pyz = &sS[b][4][own];
@@ -370,16 +388,18 @@ __global__ __launch_bounds__(NTHREADS) void velocity_v2(bfd_dev d, int tilesX, i
                 float dySyz = dminus4(pyz[-2 * LW], pyz[-LW], yz0, pyz[LW]);
                 float dzSzz = dplus4(zzm1, zz0, zzp1, zzp2);
                 if (zi) {
+                    const int xi = i < P ? i : i - (N1 - 2 * P);
                     const long q = ((long)kl * N2 + j) * (2 * P) + xi;
-                    dxSxx = cpml(d.psi[9], q, axH, bxH, dxSxx);
-                    dxSxy = cpml(d.psi[12], q, axI, bxI, dxSxy);
-                    dxSxz = cpml(d.psi[15], q, axI, bxI, dxSxz);
+                    dxSxx = cpml(d.psi[9], q, d.axH[i], d.bxH[i], dxSxx);
+                    dxSxy = cpml(d.psi[12], q, d.axI[i], d.bxI[i], dxSxy);
+                    dxSxz = cpml(d.psi[15], q, d.axI[i], d.bxI[i], dxSxz);
                 }
                 if (zj) {
+                    const int yj = j < P ? j : j - (N2 - 2 * P);
                     const long q = ((long)kl * (2 * P) + yj) * N1 + i;
-                    dySxy = cpml(d.psi[10], q, ayI, byI, dySxy);
-                    dySyy = cpml(d.psi[13], q, ayH, byH, dySyy);
-                    dySyz = cpml(d.psi[16], q, ayI, byI, dySyz);
+                    dySxy = cpml(d.psi[10], q, d.ayI[j], d.byI[j], dySxy);
+                    dySyy = cpml(d.psi[13], q, d.ayH[j], d.byH[j], dySyy);
+                    dySyz = cpml(d.psi[16], q, d.ayI[j], d.byI[j], dySyz);
                 }
                 if (k < P || k >= d.N3 - P) {
                     const int zk = k < P ? k : k - (d.N3 - 2 * P);
@@ -391,12 +411,12 @@ __global__ __launch_bounds__(NTHREADS) void velocity_v2(bfd_dev d, int tilesX, i
                 const int m = mraw & BFD_MAT_MASK;
                 const int i1 = min(i + 1, N1 - 1), j1 = min(j + 1, N2 - 1);
                 const float r0 = d.invRho[m];
-                const float bxv = 0.5f * (r0 + d.invRho[d.mat[ko + (long)j * N1 + i1] & BFD_MAT_MASK]);
-                const float byv = 0.5f * (r0 + d.invRho[d.mat[ko + (long)j1 * N1 + i] & BFD_MAT_MASK]);
-                const float bzv = 0.5f * (r0 + d.invRho[d.mat[c + pl] & BFD_MAT_MASK]);
-                d.Vx[c] = vx + bxv * ((dxSxx + dySxy) + dzSxz);
-                d.Vy[c] = vy + byv * ((dxSxy + dySyy) + dzSyz);
-                d.Vz[c] = vz + bzv * ((dxSxz + dySyz) + dzSzz);
+                const float bxv = 0.5f * (r0 + d.invRho[pM[(unsigned)(j * N1 + i1)] & BFD_MAT_MASK]);
+                const float byv = 0.5f * (r0 + d.invRho[pM[(unsigned)(j1 * N1 + i)] & BFD_MAT_MASK]);
+                const float bzv = 0.5f * (r0 + d.invRho[(pM + pl)[cij] & BFD_MAT_MASK]);
+                pVx[cij] = vx + bxv * ((dxSxx + dySxy) + dzSxz);
+                pVy[cij] = vy + byv * ((dxSxy + dySyy) + dzSyz);
+                pVz[cij] = vz + bzv * ((dxSxz + dySyz) + dzSzz);
             }
         }
         zzm1 = zz0; zz0 = zzp1; zzp1 = zzp2; zzp2 = nzz;
@@ -409,21 +429,277 @@ __global__ __launch_bounds__(NTHREADS) void velocity_v2(bfd_dev d, int tilesX, i
 
 constexpr int ZCHUNK = 32;
 
-}  // namespace
-
-void bfd_launch_stress_v2(const bfd_dev &d, hipStream_t s)
+// ------------------------------------------------------------------------------------------------
+// FLUID tiles: no solid cell within the tile grown by 2 cells in every direction. There
+//   * shear stresses and their memory variables are never updated (a shear update needs the 4
+//     cells around an edge to be solid), so they stay exactly 0 and need not be read;
+//   * the three normal stresses (and their memory variables) receive the same update
+//     (AS2 = BS2 = 0 in a fluid cell), so Sxx == Syy == Szz bit for bit: one is read, the
+//     identical result is written to all three (the arrays stay fully valid for neighbours).
+// Values equal the canonical sequence (only the sign of an exact zero can differ).
+// ------------------------------------------------------------------------------------------------
+template <int ZC, bool LOSSY>
+__global__ __launch_bounds__(NTHREADS, 8) void stress_fluid(bfd_dev d, int tilesX, int tilesY, int nblocks,
+                                                            const int *__restrict__ list)
 {
-    const int tilesX = (d.N1 + TX - 1) / TX, tilesY = (d.N2 + TY - 1) / TY, tilesZ = (d.nk + ZCHUNK - 1) / ZCHUNK;
-    const int nblocks = tilesX * tilesY * tilesZ;
-    hipLaunchKernelGGL((stress_v2<ZCHUNK>), dim3(nblocks), dim3(TX, TY, 1), 0, s, d, tilesX, tilesY, nblocks);
+    __shared__ float sV[2][2][LH * LW];
+    const int N1 = d.N1, N2 = d.N2;
+    const int tile = list[remap_block(blockIdx.x, nblocks)];
+    const int bx = tile % tilesX, by = (tile / tilesX) % tilesY, bz = tile / (tilesX * tilesY);
+    const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * TX + tx;
+    const int i0 = bx * TX, j0 = by * TY;
+    const int i = i0 + tx, j = j0 + ty;
+    const bool valid = (i < N1) && (j < N2);
+    const long pl = d.plane;
+    const int kbeg = bz * ZC, kend = min(kbeg + ZC, d.nk);
+    const int P = d.P;
+    const int own = (ty + 2) * LW + tx + 2;
+    const unsigned cij = valid ? (unsigned)(j * N1 + i) : 0u;
+
+    // halo tasks: Vy rows above/below (256), Vx columns left/right (32)
+    HaloTask t; t.lofs = -1; t.ok = false; t.arr = 0; t.gofs = 0;
+    if (tid < YT) ytask(tid, 1, i0, j0, N1, N2, t);
+    else if (tid < YT + XT) xtask(tid - YT, 0, i0, j0, N1, N2, t);
+    const bool has = t.lofs >= 0;
+    const float *ph = (t.arr == 0 ? d.Vx : d.Vy) + (t.ok ? t.gofs : 0);
+    float *lh = &sV[0][t.arr][has ? t.lofs : 0];
+
+    const bool zi = valid && (i < P || i >= N1 - P);
+    const bool zj = valid && (j < P || j >= N2 - P);
+    const float c1 = d.c1;
+
+    float vx0 = 0, vy0 = 0, vzm2 = 0, vzm1 = 0, vz0 = 0, vzp1 = 0;
+    if (valid) {
+        const float *bVz = d.Vz + kbeg * pl;
+        vx0 = (d.Vx + kbeg * pl)[cij]; vy0 = (d.Vy + kbeg * pl)[cij];
+        vzm2 = (bVz - 2 * pl)[cij]; vzm1 = (bVz - pl)[cij]; vz0 = bVz[cij]; vzp1 = (bVz + pl)[cij];
+    }
+    float hv = t.ok ? ph[kbeg * pl] : 0.0f;
+
+    for (int kl = kbeg; kl < kend; kl++) {
+        const int b = kl & 1;
+        const long ko = (long)kl * pl;
+        const int k = d.k0 + kl;
+        sV[b][0][own] = vx0; sV[b][1][own] = vy0;
+        if (has) lh[b * (2 * LH * LW)] = hv;
+        __syncthreads();
+
+        unsigned mraw = 0;
+        float sxx = 0, rxx = 0;
+        if (valid) {
+            mraw = (d.mat + ko)[cij];
+            sxx = (d.Sxx + ko)[cij];
+            if (LOSSY) rxx = (d.Rxx + ko)[cij];
+        }
+        float nvx = 0, nvy = 0, nvz = 0, nh = 0;
+        if (kl + 1 < kend) {
+            if (valid) { nvx = (d.Vx + ko + pl)[cij]; nvy = (d.Vy + ko + pl)[cij]; nvz = (d.Vz + ko + 2 * pl)[cij]; }
+            if (t.ok) nh = ph[ko + pl];
+        }
+        if (valid) {
+            const float *sx = &sV[b][0][own], *sy = &sV[b][1][own];
+            float dxVx = dminus4(sx[-2], sx[-1], vx0, sx[1]);
+            float dyVy = dminus4(sy[-2 * LW], sy[-LW], vy0, sy[LW]);
+            float dzVz = dminus4(vzm2, vzm1, vz0, vzp1);
+            float val = 0.f, rn = 0.f;
+            const bool refl = (mraw & BFD_REFLECTOR_BIT) != 0;
+            if (!refl) {
+                const int m = mraw & BFD_MAT_MASK;
+                if (zi) {
+                    const int xi = i < P ? i : i - (N1 - 2 * P);
+                    dxVx = cpml(d.psi[0], ((long)kl * N2 + j) * (2 * P) + xi, d.axI[i], d.bxI[i], dxVx);
+                }
+                if (zj) {
+                    const int yj = j < P ? j : j - (N2 - 2 * P);
+                    dyVy = cpml(d.psi[1], ((long)kl * (2 * P) + yj) * N1 + i, d.ayI[j], d.byI[j], dyVy);
+                }
+                if (k < P || k >= d.N3 - P) {
+                    const int zk = k < P ? k : k - (d.N3 - 2 * P);
+                    dzVz = cpml(d.psi[2], (long)zk * pl + cij, d.azI[k], d.bzI[k], dzVz);
+                }
+                const float div = (dxVx + dyVy) + dzVz;
+                const float AP = d.AP[m];
+                if (LOSSY) {
+                    rn = c1 * rxx - d.BP[m] * div;
+                    val = sxx + (AP * div + 0.5f * (rxx + rn));
+                } else {
+                    val = sxx + AP * div;
+                }
+            }
+            (d.Sxx + ko)[cij] = val; (d.Syy + ko)[cij] = val; (d.Szz + ko)[cij] = val;
+            if (LOSSY) { (d.Rxx + ko)[cij] = rn; (d.Ryy + ko)[cij] = rn; (d.Rzz + ko)[cij] = rn; }
+        }
+        vx0 = nvx; vy0 = nvy;
+        vzm2 = vzm1; vzm1 = vz0; vz0 = vzp1; vzp1 = nvz;
+        hv = nh;
+    }
 }
 
-void bfd_launch_velocity_v2(const bfd_dev &d, hipStream_t s, float *accP, float *pkP)
+template <int ZC, bool ACC>
+__global__ __launch_bounds__(NTHREADS, 8) void velocity_fluid(bfd_dev d, int tilesX, int tilesY, int nblocks,
+                                                              const int *__restrict__ list,
+                                                              float *__restrict__ accP, float *__restrict__ pkP)
 {
-    const int tilesX = (d.N1 + TX - 1) / TX, tilesY = (d.N2 + TY - 1) / TY, tilesZ = (d.nk + ZCHUNK - 1) / ZCHUNK;
-    const int nblocks = tilesX * tilesY * tilesZ;
-    if (accP || pkP)
-        hipLaunchKernelGGL((velocity_v2<ZCHUNK, true>), dim3(nblocks), dim3(TX, TY, 1), 0, s, d, tilesX, tilesY, nblocks, accP, pkP);
-    else
-        hipLaunchKernelGGL((velocity_v2<ZCHUNK, false>), dim3(nblocks), dim3(TX, TY, 1), 0, s, d, tilesX, tilesY, nblocks, accP, pkP);
+    __shared__ float sS[2][LH * LW];
+    const int N1 = d.N1, N2 = d.N2;
+    const int tile = list[remap_block(blockIdx.x, nblocks)];
+    const int bx = tile % tilesX, by = (tile / tilesX) % tilesY, bz = tile / (tilesX * tilesY);
+    const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * TX + tx;
+    const int i0 = bx * TX, j0 = by * TY;
+    const int i = i0 + tx, j = j0 + ty;
+    const bool valid = (i < N1) && (j < N2);
+    const long pl = d.plane;
+    const int kbeg = bz * ZC, kend = min(kbeg + ZC, d.nk);
+    const int P = d.P;
+    const int own = (ty + 2) * LW + tx + 2;
+    const unsigned cij = valid ? (unsigned)(j * N1 + i) : 0u;
+
+    // halo ring of Sxx (== Syy == Szz here): rows (256) and columns (32)
+    HaloTask t; t.lofs = -1; t.ok = false; t.arr = 0; t.gofs = 0;
+    if (tid < YT) ytask(tid, 0, i0, j0, N1, N2, t);
+    else if (tid < YT + XT) xtask(tid - YT, 0, i0, j0, N1, N2, t);
+    const bool has = t.lofs >= 0;
+    const float *ph = d.Sxx + (t.ok ? t.gofs : 0);
+    float *lh = &sS[0][has ? t.lofs : 0];
+
+    const bool zi = valid && (i < P || i >= N1 - P);
+    const bool zj = valid && (j < P || j >= N2 - P);
+    const bool inner = valid && i >= d.ND && i < N1 - d.ND && j >= d.ND && j < N2 - d.ND;
+
+    float sm1 = 0, s0 = 0, sp1 = 0, sp2 = 0;
+    if (valid) {
+        const float *bS = d.Sxx + kbeg * pl;
+        sm1 = (bS - pl)[cij]; s0 = bS[cij]; sp1 = (bS + pl)[cij]; sp2 = (bS + 2 * pl)[cij];
+    }
+    float hv = t.ok ? ph[kbeg * pl] : 0.0f;
+
+    for (int kl = kbeg; kl < kend; kl++) {
+        const int b = kl & 1;
+        const long ko = (long)kl * pl;
+        const int k = d.k0 + kl;
+        sS[b][own] = s0;
+        if (has) lh[b * (LH * LW)] = hv;
+        __syncthreads();
+
+        const uint16_t *pM = d.mat + ko;
+        unsigned mraw = 0;
+        float vx = 0, vy = 0, vz = 0;
+        if (valid) { mraw = pM[cij]; vx = (d.Vx + ko)[cij]; vy = (d.Vy + ko)[cij]; vz = (d.Vz + ko)[cij]; }
+        float ns = 0, nh = 0;
+        if (kl + 1 < kend) {
+            if (valid) ns = (d.Sxx + ko + 3 * pl)[cij];
+            if (t.ok) nh = ph[ko + pl];
+        }
+        if (valid) {
+            if (ACC) {
+                if (inner && k >= d.ND && k < d.N3 - d.ND) {
+                    const float s = (s0 + s0) + s0;
+                    const float p = -s * (1.0f / 3.0f);
+                    if (accP) (accP + ko)[cij] = (accP + ko)[cij] + p * p;
+                    if (pkP) { const float ap = fabsf(p); if (ap > (pkP + ko)[cij]) (pkP + ko)[cij] = ap; }
+                }
+            }
+            if (mraw & BFD_REFLECTOR_BIT) {
+                (d.Vx + ko)[cij] = 0.f; (d.Vy + ko)[cij] = 0.f; (d.Vz + ko)[cij] = 0.f;
+            } else {
+                const float *p = &sS[b][own];
+                float dx = dplus4(p[-1], s0, p[1], p[2]);
+                float dy = dplus4(p[-LW], s0, p[LW], p[2 * LW]);
+                float dz = dplus4(sm1, s0, sp1, sp2);
+                if (zi) {
+                    const int xi = i < P ? i : i - (N1 - 2 * P);
+                    dx = cpml(d.psi[9], ((long)kl * N2 + j) * (2 * P) + xi, d.axH[i], d.bxH[i], dx);
+                }
+                if (zj) {
+                    const int yj = j < P ? j : j - (N2 - 2 * P);
+                    dy = cpml(d.psi[13], ((long)kl * (2 * P) + yj) * N1 + i, d.ayH[j], d.byH[j], dy);
+                }
+                if (k < P || k >= d.N3 - P) {
+                    const int zk = k < P ? k : k - (d.N3 - 2 * P);
+                    dz = cpml(d.psi[17], (long)zk * pl + cij, d.azH[k], d.bzH[k], dz);
+                }
+                const int m = mraw & BFD_MAT_MASK;
+                const int i1 = min(i + 1, N1 - 1), j1 = min(j + 1, N2 - 1);
+                const float r0 = d.invRho[m];
+                const float bxv = 0.5f * (r0 + d.invRho[pM[(unsigned)(j * N1 + i1)] & BFD_MAT_MASK]);
+                const float byv = 0.5f * (r0 + d.invRho[pM[(unsigned)(j1 * N1 + i)] & BFD_MAT_MASK]);
+                const float bzv = 0.5f * (r0 + d.invRho[(pM + pl)[cij] & BFD_MAT_MASK]);
+                (d.Vx + ko)[cij] = vx + bxv * dx;
+                (d.Vy + ko)[cij] = vy + byv * dy;
+                (d.Vz + ko)[cij] = vz + bzv * dz;
+            }
+        }
+        sm1 = s0; s0 = sp1; sp1 = sp2; sp2 = ns;
+        hv = nh;
+    }
+}
+
+// one workgroup per tile: flags bit0 = a solid cell within the tile grown by 2 cells,
+// bit1 = a cell of the tile itself has a relaxing P modulus (BP != 0)
+template <int ZC>
+__global__ void classify_tiles(bfd_dev d, int tilesX, int tilesY, int *__restrict__ flags)
+{
+    const int tile = blockIdx.x;
+    const int bx = tile % tilesX, by = (tile / tilesX) % tilesY, bz = tile / (tilesX * tilesY);
+    const int i0 = bx * TX - 2, j0 = by * TY - 2, k0 = bz * ZC - 2;
+    const int nx = TX + 4, ny = TY + 4, nz = min(ZC, d.nk - bz * ZC) + 4;
+    int solid = 0, lossy = 0;
+    for (int v = threadIdx.x; v < nx * ny * nz; v += blockDim.x) {
+        const int li = v % nx, lj = (v / nx) % ny, lk = v / (nx * ny);
+        const int i = i0 + li, j = j0 + lj, kl = k0 + lk;       // kl in [-2, nk+2): ghost planes exist
+        if (i < 0 || i >= d.N1 || j < 0 || j >= d.N2) continue;
+        const int m = d.mat[(long)kl * d.plane + (long)j * d.N1 + i] & BFD_MAT_MASK;
+        if (d.invMu[m] > 0.f) solid = 1;
+        if (li >= 2 && li < nx - 2 && lj >= 2 && lj < ny - 2 && lk >= 2 && lk < nz - 2 && d.BP[m] != 0.f) lossy = 1;
+    }
+    solid = __syncthreads_or(solid);
+    lossy = __syncthreads_or(lossy);
+    if (threadIdx.x == 0) flags[tile] = solid | (lossy << 1);
+}
+
+}  // namespace
+
+void bfd_tile_grid(const bfd_dev &d, int *tilesX, int *tilesY, int *tilesZ)
+{
+    *tilesX = (d.N1 + TX - 1) / TX; *tilesY = (d.N2 + TY - 1) / TY; *tilesZ = (d.nk + ZCHUNK - 1) / ZCHUNK;
+}
+
+void bfd_launch_classify(const bfd_dev &d, hipStream_t s, int *flagsDev)
+{
+    int tx, ty, tz; bfd_tile_grid(d, &tx, &ty, &tz);
+    hipLaunchKernelGGL((classify_tiles<ZCHUNK>), dim3(tx * ty * tz), dim3(256), 0, s, d, tx, ty, flagsDev);
+}
+
+void bfd_launch_stress_v2(const bfd_dev &d, hipStream_t s, const bfd_tiles *t)
+{
+    int tilesX, tilesY, tilesZ; bfd_tile_grid(d, &tilesX, &tilesY, &tilesZ);
+    if (!t) {
+        const int nblocks = tilesX * tilesY * tilesZ;
+        hipLaunchKernelGGL((stress_v2<ZCHUNK>), dim3(nblocks), dim3(TX, TY, 1), 0, s, d, tilesX, tilesY, nblocks, (const int *)nullptr);
+        return;
+    }
+    if (t->nLossless)
+        hipLaunchKernelGGL((stress_fluid<ZCHUNK, false>), dim3(t->nLossless), dim3(TX, TY, 1), 0, s, d, tilesX, tilesY, t->nLossless, t->list);
+    if (t->nLossy)
+        hipLaunchKernelGGL((stress_fluid<ZCHUNK, true>), dim3(t->nLossy), dim3(TX, TY, 1), 0, s, d, tilesX, tilesY, t->nLossy, t->list + t->nLossless);
+    if (t->nSolid)
+        hipLaunchKernelGGL((stress_v2<ZCHUNK>), dim3(t->nSolid), dim3(TX, TY, 1), 0, s, d, tilesX, tilesY, t->nSolid,
+                           t->list + t->nLossless + t->nLossy);
+}
+
+void bfd_launch_velocity_v2(const bfd_dev &d, hipStream_t s, float *accP, float *pkP, const bfd_tiles *t)
+{
+    int tilesX, tilesY, tilesZ; bfd_tile_grid(d, &tilesX, &tilesY, &tilesZ);
+    const bool acc = accP || pkP;
+    const int nFluid = t ? t->nLossless + t->nLossy : 0;
+    const int nDense = t ? t->nSolid : tilesX * tilesY * tilesZ;
+    const int *denseList = t ? t->list + nFluid : nullptr;
+    if (nFluid) {
+        if (acc) hipLaunchKernelGGL((velocity_fluid<ZCHUNK, true>), dim3(nFluid), dim3(TX, TY, 1), 0, s, d, tilesX, tilesY, nFluid, t->list, accP, pkP);
+        else hipLaunchKernelGGL((velocity_fluid<ZCHUNK, false>), dim3(nFluid), dim3(TX, TY, 1), 0, s, d, tilesX, tilesY, nFluid, t->list, accP, pkP);
+    }
+    if (nDense) {
+        if (acc) hipLaunchKernelGGL((velocity_v2<ZCHUNK, true>), dim3(nDense), dim3(TX, TY, 1), 0, s, d, tilesX, tilesY, nDense, accP, pkP, denseList);
+        else hipLaunchKernelGGL((velocity_v2<ZCHUNK, false>), dim3(nDense), dim3(TX, TY, 1), 0, s, d, tilesX, tilesY, nDense, accP, pkP, denseList);
+    }
 }

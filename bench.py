@@ -151,7 +151,7 @@ def main():
             'config': {'workload': '%s: %dx%dx%d per GPU (%dx%dx%d total), %s medium, %s source, PML 12, %d materials, '
                                    'Pressure RMS + sensors on' % (args.config, n1, n2, n3, N[0], N[1], N[2], info['medium'], info['tx'], info['n_mat']),
                        'parallelism': 'z-slab x%d' % world, 'kernel_variant': args.variant, 'dt': info['dt'], 'ppp': info['ppp'],
-                       'n_sources': info['n_sources'], 'n_sensors_rank0': int(eng.num_sensors)},
+                       'n_sources': info['n_sources'], 'n_sensors_rank0': int(eng.num_sensors), 'tiles_rank0': eng.tile_counts()},
             'roofline': {'bound': 'hbm', 'kernel': 'stress half-step', 'achieved': ach_stress, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': ach_stress / HBM_PEAK_GBS, 'traffic': None,
                          'algorithmic_bytes_per_voxel': BYTES_STRESS, 'avg_launch_ms': st * 1e3},

@@ -68,7 +68,7 @@ typedef struct bfd_config {
     uint32_t selMapsSensors;   /* SelMapsSensorsList as BFD_MAP_* bits (BASE:2356)                */
     int32_t qfactorCorrection; /* QfactorCorrection (BASE:2361)                                   */
     int32_t device;            /* HIP device ordinal                                              */
-    int32_t kernelVariant;     /* 0 = default (fastest), 1 = simple reference kernels, 2 = LDS-tiled */
+    int32_t kernelVariant;     /* 0 = default (= 3), 1 = simple one-thread-per-voxel kernels, 2 = LDS-tiled dense, 3 = LDS-tiled with fluid/solid tile classes */
     int32_t reserved0;
     double h;                  /* SpatialStep, m (BASE:2344)                                      */
     double dt;                 /* DT, s (BASE:2351)                                               */
@@ -149,6 +149,9 @@ int bfd_get_sensors(bfd_sim *sim, float *out);
 int bfd_get_map(bfd_sim *sim, int32_t kind, int32_t map, float *out, int64_t s1, int64_t s2, int64_t s3);
 /* raw state array a (0..14: Vx Vy Vz Sxx Syy Szz Sxy Sxz Syz Rxx Ryy Rzz Rxy Rxz Ryz), for tests */
 int bfd_get_field(bfd_sim *sim, int32_t a, float *out, int64_t s1, int64_t s2, int64_t s3);
+/* number of 64x8x32-voxel tiles per class of the class-specialised kernels (variant 0/3):
+ * lossless fluid, lossy fluid, solid (DESIGN.md "Tile classes"); zeros for variants 1 and 2 */
+int bfd_tile_counts(bfd_sim *sim, int32_t *nLossless, int32_t *nLossy, int32_t *nSolid);
 /* device memory this sim holds, bytes */
 int64_t bfd_device_bytes(bfd_sim *sim);
 

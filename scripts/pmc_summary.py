@@ -1,0 +1,25 @@
+"""Collates rocprofv3 --pmc CSVs (one directory per pass) into per-kernel averages."""
+import collections
+import csv
+import glob
+import sys
+
+root = sys.argv[1]
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(root + '/p*/**/*counter_collection.csv', recursive=True):
+    for r in csv.DictReader(open(f)):
+        name = r['Kernel_Name']
+        if 'stress' in name or 'velocity' in name or 'accumulate' in name or 'record_sensors' in name:
+            short = name.split('(')[1].split(')')[-1] if False else name.replace('(anonymous namespace)::', '').split('(')[0]
+            agg[short][r['Counter_Name']].append(float(r['Counter_Value']))
+            agg[short]['VGPR'].append(float(r['VGPR_Count'])); agg[short]['SGPR'].append(float(r['SGPR_Count']))
+            agg[short]['LDS'].append(float(r['LDS_Block_Size']))
+            agg[short]['dur_us'].append((float(r['End_Timestamp']) - float(r['Start_Timestamp'])) / 1e3)
+for k, d in sorted(agg.items()):
+    print('==', k)
+    for c, v in sorted(d.items()):
+        print('   %-28s n=%3d avg=%.6g' % (c, len(v), sum(v) / len(v)))
+    if 'FETCH_SIZE' in d and 'WRITE_SIZE' in d:
+        f = sum(d['FETCH_SIZE']) / len(d['FETCH_SIZE']); w = sum(d['WRITE_SIZE']) / len(d['WRITE_SIZE'])
+        print('   HBM bytes/launch (gfx950: FETCH_SIZE x2 KB + WRITE_SIZE KB): read %.3f GB write %.3f GB total %.3f GB'
+              % (2 * f * 1024 / 1e9, w * 1024 / 1e9, (2 * f + w) * 1024 / 1e9))

@@ -26,7 +26,7 @@ def run_both(args, kwargs, variant=0):
     return out_h, out_r
 
 
-@pytest.mark.parametrize('variant', [1, 2])
+@pytest.mark.parametrize('variant', [1, 2, 3])
 def test_water_c1_small(variant):
     a, k, info = H.make_problem('C1', N=(48, 52, 64), steps=160, stable_dt_fn=oracle_dt)
     k['SelMapsRMSPeakList'] = ALL_MAPS
@@ -36,7 +36,7 @@ def test_water_c1_small(variant):
     print('worst rel L2', w)
 
 
-@pytest.mark.parametrize('variant', [1, 2])
+@pytest.mark.parametrize('variant', [1, 2, 3])
 def test_skull3_c2_small(variant):
     a, k, info = H.make_problem('C2', N=(64, 60, 72), steps=220, stable_dt_fn=oracle_dt)
     k['SelMapsRMSPeakList'] = ALL_MAPS
@@ -48,7 +48,7 @@ def test_skull3_c2_small(variant):
     print('worst rel L2', w)
 
 
-@pytest.mark.parametrize('variant', [1, 2])
+@pytest.mark.parametrize('variant', [1, 2, 3])
 def test_ct_bins_qcorr_reflector(variant):
     a, k, info = H.make_problem('C3', N=(56, 56, 70), steps=200, stable_dt_fn=oracle_dt)
     mm = a[0]
@@ -61,7 +61,7 @@ def test_ct_bins_qcorr_reflector(variant):
     assert np.all(oh[1]['Pressure'][refl > 0] == 0)
 
 
-@pytest.mark.parametrize('variant', [1, 2])
+@pytest.mark.parametrize('variant', [1, 2, 3])
 def test_stress_point_source_backprop(variant):
     """Second solver call of the reference (BASE:2374-2398): point stress source, plane sensor,
     Ox/Oy/Oz left at their size-1 defaults."""
