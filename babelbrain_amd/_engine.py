@@ -21,7 +21,7 @@ FIELD_NAMES = ['Vx', 'Vy', 'Vz', 'Sxx', 'Syy', 'Szz', 'Sxy', 'Sxz', 'Syz', 'Rxx'
 # every symbol include/babelfdtd.h declares (tests check that the library exports all of them)
 ABI_SYMBOLS = [
     'bfd_abi_version', 'bfd_last_error', 'bfd_device_count', 'bfd_device_name', 'bfd_stable_dt',
-    'bfd_material_tables', 'bfd_create', 'bfd_destroy', 'bfd_set_stream', 'bfd_set_materials',
+    'bfd_material_tables', 'bfd_create', 'bfd_destroy', 'bfd_set_stream', 'bfd_use_private_stream', 'bfd_set_materials',
     'bfd_set_material_map', 'bfd_set_reflector', 'bfd_set_sources', 'bfd_set_sensor_map', 'bfd_run',
     'bfd_half_step_stress', 'bfd_half_step_velocity', 'bfd_sync', 'bfd_current_step', 'bfd_halo_region',
     'bfd_timing_begin', 'bfd_timing_end', 'bfd_num_sensors', 'bfd_num_sensor_steps', 'bfd_get_sensor_index',
@@ -63,6 +63,7 @@ def load_library():
     lib.bfd_destroy.argtypes = [C.c_void_p]
     lib.bfd_destroy.restype = None
     lib.bfd_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+    lib.bfd_use_private_stream.argtypes = [C.c_void_p]
     lib.bfd_set_materials.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.bfd_set_material_map.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32]
     lib.bfd_set_reflector.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64]

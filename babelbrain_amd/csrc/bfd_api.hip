@@ -443,13 +443,19 @@ int bfd_set_stream(bfd_sim *s, void *hipStream)
     if (!s) BFD_FAIL(-1, "null sim");
     BFD_HIP(hipSetDevice(s->cfg.device));
     BFD_HIP(hipStreamSynchronize(s->stream));
-    if (hipStream) {
-        if (s->ownStream) { hipStreamDestroy(s->stream); s->ownStream = false; }
-        s->stream = (hipStream_t)hipStream;
-    } else if (!s->ownStream) {
-        BFD_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
-        s->ownStream = true;
-    }
+    if (s->ownStream) { hipStreamDestroy(s->stream); s->ownStream = false; }
+    s->stream = (hipStream_t)hipStream;      // NULL = the device's default (null) stream, which is torch's default too
+    return 0;
+}
+
+int bfd_use_private_stream(bfd_sim *s)
+{
+    if (!s) BFD_FAIL(-1, "null sim");
+    BFD_HIP(hipSetDevice(s->cfg.device));
+    if (s->ownStream) return 0;
+    BFD_HIP(hipStreamSynchronize(s->stream));
+    BFD_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    s->ownStream = true;
     return 0;
 }
 

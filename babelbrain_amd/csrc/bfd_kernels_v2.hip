@@ -29,6 +29,9 @@ constexpr int XT = 4 * TY;          // x-halo tasks per array (4 cols x TY)
 #ifndef STRESS_WAVES_PER_SIMD
 #define STRESS_WAVES_PER_SIMD 4     // 2 workgroups of 8 waves per CU (<= 128 VGPRs); 6 or 8 spill and run 1.4-2.4x slower (measured)
 #endif
+#ifndef FLUID_WAVES_PER_SIMD
+#define FLUID_WAVES_PER_SIMD 6      // measured at 512^3: 6 -> 61 Gvoxel-steps/s, 8 (spills) -> 47, 5 -> 57, 4 -> 58
+#endif
 #ifndef VELOCITY_WAVES_PER_SIMD
 #define VELOCITY_WAVES_PER_SIMD 4
 #endif
@@ -439,9 +442,11 @@ constexpr int ZCHUNK = 32;
 // Values equal the canonical sequence (only the sign of an exact zero can differ).
 // ------------------------------------------------------------------------------------------------
 template <int ZC, bool LOSSY>
-__global__ __launch_bounds__(NTHREADS, 8) void stress_fluid(bfd_dev d, int tilesX, int tilesY, int nblocks,
-                                                            const int *__restrict__ list)
+__global__ __launch_bounds__(NTHREADS, FLUID_WAVES_PER_SIMD) void stress_fluid(bfd_dev d, int tilesX, int tilesY, int nblocks,
+                                                                               const int *__restrict__ list)
 {
+    // The three normal stresses are identical in a FLUID tile; Szz is the one that is read (it is
+    // also the one whose ghost planes the Z-neighbour exchange carries), all three are written.
     __shared__ float sV[2][2][LH * LW];
     const int N1 = d.N1, N2 = d.N2;
     const int tile = list[remap_block(blockIdx.x, nblocks)];
@@ -468,11 +473,17 @@ __global__ __launch_bounds__(NTHREADS, 8) void stress_fluid(bfd_dev d, int tiles
     const bool zj = valid && (j < P || j >= N2 - P);
     const float c1 = d.c1;
 
-    float vx0 = 0, vy0 = 0, vzm2 = 0, vzm1 = 0, vz0 = 0, vzp1 = 0;
+    // software pipeline: everything plane kl needs is in registers when its iteration starts; the
+    // iteration issues the loads of plane kl+1 (material id: kl+1, its table rows: at the top of kl+1)
+    float vx0 = 0, vy0 = 0, vzm2 = 0, vzm1 = 0, vz0 = 0, vzp1 = 0, szz = 0, rzz = 0;
+    unsigned mraw = 0;
     if (valid) {
         const float *bVz = d.Vz + kbeg * pl;
         vx0 = (d.Vx + kbeg * pl)[cij]; vy0 = (d.Vy + kbeg * pl)[cij];
         vzm2 = (bVz - 2 * pl)[cij]; vzm1 = (bVz - pl)[cij]; vz0 = bVz[cij]; vzp1 = (bVz + pl)[cij];
+        szz = (d.Szz + kbeg * pl)[cij];
+        if (LOSSY) rzz = (d.Rzz + kbeg * pl)[cij];
+        mraw = (d.mat + kbeg * pl)[cij];
     }
     float hv = t.ok ? ph[kbeg * pl] : 0.0f;
 
@@ -482,18 +493,21 @@ __global__ __launch_bounds__(NTHREADS, 8) void stress_fluid(bfd_dev d, int tiles
         const int k = d.k0 + kl;
         sV[b][0][own] = vx0; sV[b][1][own] = vy0;
         if (has) lh[b * (2 * LH * LW)] = hv;
+        // table rows of this plane (cache-resident; short latency, overlaps the barrier)
+        const int m = mraw & BFD_MAT_MASK;
+        float AP = 0.f, BP = 0.f;
+        if (valid) { AP = d.AP[m]; if (LOSSY) BP = d.BP[m]; }
         __syncthreads();
 
-        unsigned mraw = 0;
-        float sxx = 0, rxx = 0;
-        if (valid) {
-            mraw = (d.mat + ko)[cij];
-            sxx = (d.Sxx + ko)[cij];
-            if (LOSSY) rxx = (d.Rxx + ko)[cij];
-        }
-        float nvx = 0, nvy = 0, nvz = 0, nh = 0;
+        float nvx = 0, nvy = 0, nvz = 0, nh = 0, nszz = 0, nrzz = 0;
+        unsigned nmraw = 0;
         if (kl + 1 < kend) {
-            if (valid) { nvx = (d.Vx + ko + pl)[cij]; nvy = (d.Vy + ko + pl)[cij]; nvz = (d.Vz + ko + 2 * pl)[cij]; }
+            if (valid) {
+                nvx = (d.Vx + ko + pl)[cij]; nvy = (d.Vy + ko + pl)[cij]; nvz = (d.Vz + ko + 2 * pl)[cij];
+                nszz = (d.Szz + ko + pl)[cij];
+                if (LOSSY) nrzz = (d.Rzz + ko + pl)[cij];
+                nmraw = (d.mat + ko + pl)[cij];
+            }
             if (t.ok) nh = ph[ko + pl];
         }
         if (valid) {
@@ -502,9 +516,7 @@ __global__ __launch_bounds__(NTHREADS, 8) void stress_fluid(bfd_dev d, int tiles
             float dyVy = dminus4(sy[-2 * LW], sy[-LW], vy0, sy[LW]);
             float dzVz = dminus4(vzm2, vzm1, vz0, vzp1);
             float val = 0.f, rn = 0.f;
-            const bool refl = (mraw & BFD_REFLECTOR_BIT) != 0;
-            if (!refl) {
-                const int m = mraw & BFD_MAT_MASK;
+            if (!(mraw & BFD_REFLECTOR_BIT)) {
                 if (zi) {
                     const int xi = i < P ? i : i - (N1 - 2 * P);
                     dxVx = cpml(d.psi[0], ((long)kl * N2 + j) * (2 * P) + xi, d.axI[i], d.bxI[i], dxVx);
@@ -518,12 +530,11 @@ __global__ __launch_bounds__(NTHREADS, 8) void stress_fluid(bfd_dev d, int tiles
                     dzVz = cpml(d.psi[2], (long)zk * pl + cij, d.azI[k], d.bzI[k], dzVz);
                 }
                 const float div = (dxVx + dyVy) + dzVz;
-                const float AP = d.AP[m];
                 if (LOSSY) {
-                    rn = c1 * rxx - d.BP[m] * div;
-                    val = sxx + (AP * div + 0.5f * (rxx + rn));
+                    rn = c1 * rzz - BP * div;
+                    val = szz + (AP * div + 0.5f * (rzz + rn));
                 } else {
-                    val = sxx + AP * div;
+                    val = szz + AP * div;
                 }
             }
             (d.Sxx + ko)[cij] = val; (d.Syy + ko)[cij] = val; (d.Szz + ko)[cij] = val;
@@ -531,14 +542,14 @@ __global__ __launch_bounds__(NTHREADS, 8) void stress_fluid(bfd_dev d, int tiles
         }
         vx0 = nvx; vy0 = nvy;
         vzm2 = vzm1; vzm1 = vz0; vz0 = vzp1; vzp1 = nvz;
-        hv = nh;
+        hv = nh; szz = nszz; rzz = nrzz; mraw = nmraw;
     }
 }
 
 template <int ZC, bool ACC>
-__global__ __launch_bounds__(NTHREADS, 8) void velocity_fluid(bfd_dev d, int tilesX, int tilesY, int nblocks,
-                                                              const int *__restrict__ list,
-                                                              float *__restrict__ accP, float *__restrict__ pkP)
+__global__ __launch_bounds__(NTHREADS, FLUID_WAVES_PER_SIMD) void velocity_fluid(bfd_dev d, int tilesX, int tilesY, int nblocks,
+                                                                                 const int *__restrict__ list,
+                                                                                 float *__restrict__ accP, float *__restrict__ pkP)
 {
     __shared__ float sS[2][LH * LW];
     const int N1 = d.N1, N2 = d.N2;
@@ -553,23 +564,35 @@ __global__ __launch_bounds__(NTHREADS, 8) void velocity_fluid(bfd_dev d, int til
     const int P = d.P;
     const int own = (ty + 2) * LW + tx + 2;
     const unsigned cij = valid ? (unsigned)(j * N1 + i) : 0u;
+    const unsigned cx = valid ? (unsigned)(j * N1 + min(i + 1, N1 - 1)) : 0u;      // (i+1, j)
+    const unsigned cy = valid ? (unsigned)(min(j + 1, N2 - 1) * N1 + i) : 0u;      // (i, j+1)
 
-    // halo ring of Sxx (== Syy == Szz here): rows (256) and columns (32)
+    // halo ring of Szz (== Sxx == Syy here): rows (256) and columns (32)
     HaloTask t; t.lofs = -1; t.ok = false; t.arr = 0; t.gofs = 0;
     if (tid < YT) ytask(tid, 0, i0, j0, N1, N2, t);
     else if (tid < YT + XT) xtask(tid - YT, 0, i0, j0, N1, N2, t);
     const bool has = t.lofs >= 0;
-    const float *ph = d.Sxx + (t.ok ? t.gofs : 0);
+    const float *ph = d.Szz + (t.ok ? t.gofs : 0);
     float *lh = &sS[0][has ? t.lofs : 0];
 
     const bool zi = valid && (i < P || i >= N1 - P);
     const bool zj = valid && (j < P || j >= N2 - P);
     const bool inner = valid && i >= d.ND && i < N1 - d.ND && j >= d.ND && j < N2 - d.ND;
+    const bool accA = ACC && accP != nullptr, accK = ACC && pkP != nullptr;
 
-    float sm1 = 0, s0 = 0, sp1 = 0, sp2 = 0;
+    // software pipeline (see stress_fluid): own material id runs two planes ahead because the z
+    // face needs 1/rho of plane kl+1; neighbour ids one plane ahead; table rows at the top of the iteration
+    float sm1 = 0, s0 = 0, sp1 = 0, sp2 = 0, vx = 0, vy = 0, vz = 0, av = 0, pv = 0, r0 = 0;
+    unsigned mraw = 0, mraw1 = 0, mx = 0, my = 0;
     if (valid) {
-        const float *bS = d.Sxx + kbeg * pl;
+        const float *bS = d.Szz + kbeg * pl;
+        const uint16_t *bM = d.mat + kbeg * pl;
         sm1 = (bS - pl)[cij]; s0 = bS[cij]; sp1 = (bS + pl)[cij]; sp2 = (bS + 2 * pl)[cij];
+        vx = (d.Vx + kbeg * pl)[cij]; vy = (d.Vy + kbeg * pl)[cij]; vz = (d.Vz + kbeg * pl)[cij];
+        mraw = bM[cij]; mraw1 = (bM + pl)[cij]; mx = bM[cx]; my = bM[cy];
+        if (accA) av = (accP + kbeg * pl)[cij];
+        if (accK) pv = (pkP + kbeg * pl)[cij];
+        r0 = d.invRho[mraw & BFD_MAT_MASK];
     }
     float hv = t.ok ? ph[kbeg * pl] : 0.0f;
 
@@ -579,15 +602,25 @@ __global__ __launch_bounds__(NTHREADS, 8) void velocity_fluid(bfd_dev d, int til
         const int k = d.k0 + kl;
         sS[b][own] = s0;
         if (has) lh[b * (LH * LW)] = hv;
+        float r1 = 0, rx = 0, ry = 0;
+        if (valid) {
+            r1 = d.invRho[mraw1 & BFD_MAT_MASK];       // plane kl+1, becomes r0 of the next iteration
+            rx = d.invRho[mx & BFD_MAT_MASK];
+            ry = d.invRho[my & BFD_MAT_MASK];
+        }
         __syncthreads();
 
-        const uint16_t *pM = d.mat + ko;
-        unsigned mraw = 0;
-        float vx = 0, vy = 0, vz = 0;
-        if (valid) { mraw = pM[cij]; vx = (d.Vx + ko)[cij]; vy = (d.Vy + ko)[cij]; vz = (d.Vz + ko)[cij]; }
-        float ns = 0, nh = 0;
+        float ns = 0, nh = 0, nvx = 0, nvy = 0, nvz = 0, nav = 0, npv = 0;
+        unsigned nm2 = 0, nmx = 0, nmy = 0;
+        if (valid) nm2 = (d.mat + ko + 2 * pl)[cij];              // ghost planes make kl+2 addressable
         if (kl + 1 < kend) {
-            if (valid) ns = (d.Sxx + ko + 3 * pl)[cij];
+            if (valid) {
+                ns = (d.Szz + ko + 3 * pl)[cij];
+                nvx = (d.Vx + ko + pl)[cij]; nvy = (d.Vy + ko + pl)[cij]; nvz = (d.Vz + ko + pl)[cij];
+                nmx = (d.mat + ko + pl)[cx]; nmy = (d.mat + ko + pl)[cy];
+                if (accA) nav = (accP + ko + pl)[cij];
+                if (accK) npv = (pkP + ko + pl)[cij];
+            }
             if (t.ok) nh = ph[ko + pl];
         }
         if (valid) {
@@ -595,8 +628,8 @@ __global__ __launch_bounds__(NTHREADS, 8) void velocity_fluid(bfd_dev d, int til
                 if (inner && k >= d.ND && k < d.N3 - d.ND) {
                     const float s = (s0 + s0) + s0;
                     const float p = -s * (1.0f / 3.0f);
-                    if (accP) (accP + ko)[cij] = (accP + ko)[cij] + p * p;
-                    if (pkP) { const float ap = fabsf(p); if (ap > (pkP + ko)[cij]) (pkP + ko)[cij] = ap; }
+                    if (accA) (accP + ko)[cij] = av + p * p;
+                    if (accK) { const float ap = fabsf(p); if (ap > pv) (pkP + ko)[cij] = ap; }
                 }
             }
             if (mraw & BFD_REFLECTOR_BIT) {
@@ -618,19 +651,14 @@ __global__ __launch_bounds__(NTHREADS, 8) void velocity_fluid(bfd_dev d, int til
                     const int zk = k < P ? k : k - (d.N3 - 2 * P);
                     dz = cpml(d.psi[17], (long)zk * pl + cij, d.azH[k], d.bzH[k], dz);
                 }
-                const int m = mraw & BFD_MAT_MASK;
-                const int i1 = min(i + 1, N1 - 1), j1 = min(j + 1, N2 - 1);
-                const float r0 = d.invRho[m];
-                const float bxv = 0.5f * (r0 + d.invRho[pM[(unsigned)(j * N1 + i1)] & BFD_MAT_MASK]);
-                const float byv = 0.5f * (r0 + d.invRho[pM[(unsigned)(j1 * N1 + i)] & BFD_MAT_MASK]);
-                const float bzv = 0.5f * (r0 + d.invRho[(pM + pl)[cij] & BFD_MAT_MASK]);
-                (d.Vx + ko)[cij] = vx + bxv * dx;
-                (d.Vy + ko)[cij] = vy + byv * dy;
-                (d.Vz + ko)[cij] = vz + bzv * dz;
+                (d.Vx + ko)[cij] = vx + (0.5f * (r0 + rx)) * dx;
+                (d.Vy + ko)[cij] = vy + (0.5f * (r0 + ry)) * dy;
+                (d.Vz + ko)[cij] = vz + (0.5f * (r0 + r1)) * dz;
             }
         }
         sm1 = s0; s0 = sp1; sp1 = sp2; sp2 = ns;
-        hv = nh;
+        hv = nh; vx = nvx; vy = nvy; vz = nvz; av = nav; pv = npv;
+        r0 = r1; mraw = mraw1; mraw1 = nm2; mx = nmx; my = nmy;
     }
 }
 

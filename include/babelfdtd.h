@@ -97,8 +97,10 @@ int bfd_create(const bfd_config *cfg, bfd_sim **out);
 void bfd_destroy(bfd_sim *sim);
 
 /* launch every kernel of this sim on an existing HIP stream (hipStream_t as void*), e.g. torch's
- * current stream, so the caller's halo exchange orders against it; NULL = the sim's own stream */
+ * current stream, so the caller's halo exchange orders against it; NULL = the device's default
+ * (null) stream. A new sim runs on a private non-blocking stream; bfd_use_private_stream returns to one. */
 int bfd_set_stream(bfd_sim *sim, void *hipStream);
+int bfd_use_private_stream(bfd_sim *sim);
 
 /* MaterialList + QCorrection (BASE:2340,2362) */
 int bfd_set_materials(bfd_sim *sim, const double *matlist, const double *qcorr);
