@@ -179,10 +179,19 @@ __device__ __forceinline__ float map_value(const bfd_dev &d, int sel, long c)
     case BFD_MAP_SIGMAXZ: return d.Sxz[c];
     case BFD_MAP_SIGMAYZ: return d.Syz[c];
     case BFD_MAP_PRESSURE: {
-        const float s = (d.Sxx[c] + d.Syy[c]) + d.Szz[c];
+        const float zz = d.Szz[c];
+        const float s = d.collapsed ? (zz + zz) + zz : (d.Sxx[c] + d.Syy[c]) + zz;
         return -s * (1.0f / 3.0f);
     }
     default: return 0.0f;
+    }
+}
+// collapsed slabs keep only Szz/Rzz of the identical normal stresses: restore the other copies
+__global__ void expand_normal(bfd_dev d, long n)
+{
+    for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (long)gridDim.x * blockDim.x) {
+        const float s = d.Szz[v], r = d.Rzz[v];
+        d.Sxx[v] = s; d.Syy[v] = s; d.Rxx[v] = r; d.Ryy[v] = r;
     }
 }
 __device__ __forceinline__ float map_sq(const bfd_dev &d, int sel, long c)
@@ -649,6 +658,9 @@ static int build_tile_lists(bfd_sim *s)
     if (rc) return rc;
     BFD_HIP(hipMemcpy(s->tiles.list, list.data(), n * sizeof(int), hipMemcpyHostToDevice));
     s->tiles.nLossless = nA; s->tiles.nLossy = nB; s->tiles.nSolid = nC;
+    // per-component normal stresses are needed only by solid tiles or by a Sigma** output selection
+    const uint32_t sig = (1u << BFD_MAP_SIGMAXX) | (1u << BFD_MAP_SIGMAYY) | (1u << BFD_MAP_SIGMAZZ);
+    s->d.collapsed = (nC == 0 && ((s->cfg.selMapsRMS | s->cfg.selMapsSensors) & sig) == 0) ? 1 : 0;
     s->tilesReady = true;
     return 0;
 }
@@ -841,6 +853,8 @@ static int download_volume(bfd_sim *s, const float *devXfast, float *out, int64_
     return 0;
 }
 
+static void expand_if_collapsed(bfd_sim *s);
+
 int bfd_get_map(bfd_sim *s, int32_t kind, int32_t map, float *out, int64_t s1, int64_t s2, int64_t s3)
 {
     if (!s || !out) BFD_FAIL(-1, "bfd_get_map: null argument");
@@ -862,6 +876,7 @@ int bfd_get_map(bfd_sim *s, int32_t kind, int32_t map, float *out, int64_t s1, i
         rc = download_volume(s, s->pk + (size_t)q * s->nloc, out, s1, s2, s3);
     } else if (kind == BFD_KIND_LAST) {
         if (map < 0 || map >= BFD_MAP_COUNT) { hipFree(tmp); BFD_FAIL(-2, "bfd_get_map: bad map id"); }
+        if (map >= BFD_MAP_SIGMAXX && map <= BFD_MAP_SIGMAZZ) expand_if_collapsed(s);
         hipLaunchKernelGGL(last_map, dim3(grid_for((long)s->nloc)), dim3(256), 0, s->stream, s->d, map, tmp, (long)s->nloc);
         rc = download_volume(s, tmp, out, s1, s2, s3);
     } else {
@@ -871,10 +886,17 @@ int bfd_get_map(bfd_sim *s, int32_t kind, int32_t map, float *out, int64_t s1, i
     return rc;
 }
 
+static void expand_if_collapsed(bfd_sim *s)
+{
+    if (s->d.collapsed)
+        hipLaunchKernelGGL(expand_normal, dim3(grid_for((long)s->nloc)), dim3(256), 0, s->stream, s->d, (long)s->nloc);
+}
+
 int bfd_get_field(bfd_sim *s, int32_t a, float *out, int64_t s1, int64_t s2, int64_t s3)
 {
     if (!s || !out || a < 0 || a > 14) BFD_FAIL(-1, "bfd_get_field: bad argument");
     BFD_HIP(hipSetDevice(s->cfg.device));
+    expand_if_collapsed(s);
     return download_volume(s, s->stateBase[a] + 2 * (size_t)s->d.plane, out, s1, s2, s3);
 }
 

@@ -32,6 +32,8 @@ struct bfd_dev {
     // stress half-step: 0 dxVx 1 dyVy 2 dzVz 3 dyVx 4 dxVy 5 dzVx 6 dxVz 7 dzVy 8 dyVz
     // velocity half-step: 9 dxSxx 10 dySxy 11 dzSxz 12 dxSxy 13 dySyy 14 dzSyz 15 dxSxz 16 dySyz 17 dzSzz
     float *psi[18];
+    // 1: every tile of the slab is FLUID and only Szz/Rzz of the (identical) normal stresses are kept
+    int collapsed;
 };
 
 // tile lists of the class-specialised path (variant 3): device array [lossless fluid | lossy fluid | solid]

@@ -441,7 +441,7 @@ constexpr int ZCHUNK = 32;
 //     identical result is written to all three (the arrays stay fully valid for neighbours).
 // Values equal the canonical sequence (only the sign of an exact zero can differ).
 // ------------------------------------------------------------------------------------------------
-template <int ZC, bool LOSSY>
+template <int ZC, bool LOSSY, bool COLLAPSED>
 __global__ __launch_bounds__(NTHREADS, FLUID_WAVES_PER_SIMD) void stress_fluid(bfd_dev d, int tilesX, int tilesY, int nblocks,
                                                                                const int *__restrict__ list)
 {
@@ -537,8 +537,14 @@ __global__ __launch_bounds__(NTHREADS, FLUID_WAVES_PER_SIMD) void stress_fluid(b
                     val = szz + AP * div;
                 }
             }
-            (d.Sxx + ko)[cij] = val; (d.Syy + ko)[cij] = val; (d.Szz + ko)[cij] = val;
-            if (LOSSY) { (d.Rxx + ko)[cij] = rn; (d.Ryy + ko)[cij] = rn; (d.Rzz + ko)[cij] = rn; }
+            // COLLAPSED (no solid tile in the slab, no per-component stress output selected): nobody
+            // reads Sxx/Syy/Rxx/Ryy, so only the Szz/Rzz copy is kept (expanded on demand, bfd_api.hip)
+            (d.Szz + ko)[cij] = val;
+            if (!COLLAPSED) { (d.Sxx + ko)[cij] = val; (d.Syy + ko)[cij] = val; }
+            if (LOSSY) {
+                (d.Rzz + ko)[cij] = rn;
+                if (!COLLAPSED) { (d.Rxx + ko)[cij] = rn; (d.Ryy + ko)[cij] = rn; }
+            }
         }
         vx0 = nvx; vy0 = nvy;
         vzm2 = vzm1; vzm1 = vz0; vz0 = vzp1; vzp1 = nvz;
@@ -706,10 +712,14 @@ void bfd_launch_stress_v2(const bfd_dev &d, hipStream_t s, const bfd_tiles *t)
         hipLaunchKernelGGL((stress_v2<ZCHUNK>), dim3(nblocks), dim3(TX, TY, 1), 0, s, d, tilesX, tilesY, nblocks, (const int *)nullptr);
         return;
     }
-    if (t->nLossless)
-        hipLaunchKernelGGL((stress_fluid<ZCHUNK, false>), dim3(t->nLossless), dim3(TX, TY, 1), 0, s, d, tilesX, tilesY, t->nLossless, t->list);
-    if (t->nLossy)
-        hipLaunchKernelGGL((stress_fluid<ZCHUNK, true>), dim3(t->nLossy), dim3(TX, TY, 1), 0, s, d, tilesX, tilesY, t->nLossy, t->list + t->nLossless);
+    if (t->nLossless) {
+        if (d.collapsed) hipLaunchKernelGGL((stress_fluid<ZCHUNK, false, true>), dim3(t->nLossless), dim3(TX, TY, 1), 0, s, d, tilesX, tilesY, t->nLossless, t->list);
+        else hipLaunchKernelGGL((stress_fluid<ZCHUNK, false, false>), dim3(t->nLossless), dim3(TX, TY, 1), 0, s, d, tilesX, tilesY, t->nLossless, t->list);
+    }
+    if (t->nLossy) {
+        if (d.collapsed) hipLaunchKernelGGL((stress_fluid<ZCHUNK, true, true>), dim3(t->nLossy), dim3(TX, TY, 1), 0, s, d, tilesX, tilesY, t->nLossy, t->list + t->nLossless);
+        else hipLaunchKernelGGL((stress_fluid<ZCHUNK, true, false>), dim3(t->nLossy), dim3(TX, TY, 1), 0, s, d, tilesX, tilesY, t->nLossy, t->list + t->nLossless);
+    }
     if (t->nSolid)
         hipLaunchKernelGGL((stress_v2<ZCHUNK>), dim3(t->nSolid), dim3(TX, TY, 1), 0, s, d, tilesX, tilesY, t->nSolid,
                            t->list + t->nLossless + t->nLossy);

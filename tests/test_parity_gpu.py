@@ -137,3 +137,35 @@ def test_error_paths_raise():
     with pytest.raises(EngineError):
         pm.StaggeredFDTD_3D_with_relaxation(a[0][:20, :20, :20], *a[1:3], a[3][:20, :20, :20], *a[4:7], a[7][:20, :20, :20],
                                             SILENT=True, **{kk: v for kk, v in k.items() if kk not in ('Ox', 'Oy', 'Oz')})
+
+
+def test_collapsed_fluid_slab_and_expansion():
+    """All-fluid slab with no per-component stress output: the engine keeps only Szz/Rzz of the three
+    identical normal stresses (DESIGN.md 'Tile classes'); outputs and the expanded fields must still
+    match the oracle."""
+    from babelbrain_amd import _engine
+    from babelbrain_amd.PropagationModel import compact_sources
+    a, k, info = H.make_problem('C3', N=(64, 48, 70), steps=150, stable_dt_fn=oracle_dt)
+    k['SelMapsRMSPeakList'] = ['Pressure', 'Vx']
+    k['SelRMSorPeak'] = 3
+    oh, orf = run_both(a, k, 3)
+    compare_runs(oh, orf, TOL, both=True)
+    # engine level: the collapsed flag is on, and get_field expands Sxx/Syy from Szz
+    mm, ml, f, smap, pulse, h, T, sensor = a
+    N1, N2, N3 = mm.shape
+    eng = _engine.Engine(N1, N2, N3, len(ml), h, k['DT'], f, info['nt'], sensorSub=k['SensorSubSampling'],
+                         sensorStart=k['SensorStart'], selMapsRMS=['Pressure'], selMapsSensors=['Pressure'], kernelVariant=3)
+    eng.set_materials(ml, k['QCorrection'])
+    eng.set_material_map(mm, 0, 0)
+    eng.set_sources(*compact_sources(smap, k['Ox'], k['Oy'], k['Oz']), pulse)
+    eng.set_sensor_map(sensor)
+    assert eng.tile_counts()['solid'] == 0
+    eng.run(info['nt'])
+    szz = eng.get_field('Szz')
+    assert np.abs(szz).max() > 0
+    assert np.array_equal(eng.get_field('Sxx'), szz) and np.array_equal(eng.get_field('Syy'), szz)
+    assert np.array_equal(eng.get_field('Rxx'), eng.get_field('Rzz'))
+    k2 = dict(k); k2['SelMapsRMSPeakList'] = ['Sigmaxx', 'Sigmazz']; k2['SelRMSorPeak'] = 1
+    ref = O.StaggeredFDTD_3D_with_relaxation(*a, **k2)
+    assert rel_l2(szz, ref[1]['Sigmazz']) <= TOL and rel_l2(eng.get_field('Sxx'), ref[1]['Sigmaxx']) <= TOL
+    eng.close()
