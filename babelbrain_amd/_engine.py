@@ -87,7 +87,7 @@ def load_library():
     lib.bfd_get_map.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_int64, C.c_int64]
     lib.bfd_get_field.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_int64, C.c_int64]
     lib.bfd_device_bytes.argtypes = [C.c_void_p]
-    lib.bfd_tile_counts.argtypes = [C.c_void_p] + [C.POINTER(C.c_int32)] * 3
+    lib.bfd_tile_counts.argtypes = [C.c_void_p] + [C.POINTER(C.c_int32)] * 5
     lib.bfd_device_bytes.restype = C.c_int64
     lib.bfd_device_name.argtypes = [C.c_int, C.c_char_p, C.c_int]
     if lib.bfd_abi_version() != 1:
@@ -309,9 +309,10 @@ class Engine:
         return out
 
     def tile_counts(self):
-        n = [C.c_int32() for _ in range(3)]
+        n = [C.c_int32() for _ in range(5)]
         _check(self.lib.bfd_tile_counts(self.h, *[C.byref(x) for x in n]), 'bfd_tile_counts')
-        return {'lossless_fluid': n[0].value, 'lossy_fluid': n[1].value, 'solid': n[2].value}
+        return {'lossless_fluid': n[0].value, 'lossy_fluid': n[1].value, 'solid': n[2].value,
+                'uniform_fluid': n[3].value, 'pml_fluid': n[4].value}
 
     @property
     def device_bytes(self):

@@ -641,23 +641,28 @@ static int build_tile_lists(bfd_sim *s)
 {
     int tx, ty, tz; bfd_tile_grid(s->d, &tx, &ty, &tz);
     const int n = tx * ty * tz;
-    int *flagsDev = nullptr;
-    BFD_HIP(hipMalloc((void **)&flagsDev, n * sizeof(int)));
-    bfd_launch_classify(s->d, s->stream, flagsDev);
+    int rc = dev_alloc(s, &s->tiles.tileMat, (size_t)n, false);
+    if (!rc) rc = dev_alloc(s, &s->tiles.tileFlags, (size_t)n, false);
+    if (rc) return rc;
+    bfd_launch_classify(s->d, s->stream, s->tiles.tileFlags, s->tiles.tileMat);
     std::vector<int> flags(n), list;
-    hipError_t e = hipMemcpyAsync(flags.data(), flagsDev, n * sizeof(int), hipMemcpyDeviceToHost, s->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
-    hipFree(flagsDev);
-    if (e != hipSuccess) BFD_FAIL(-10, std::string("classify tiles: ") + hipGetErrorString(e));
+    BFD_HIP(hipMemcpyAsync(flags.data(), s->tiles.tileFlags, n * sizeof(int), hipMemcpyDeviceToHost, s->stream));
+    BFD_HIP(hipStreamSynchronize(s->stream));
     list.reserve(n);
-    int nA = 0, nB = 0, nC = 0;
-    for (int t = 0; t < n; t++) if (flags[t] == 0) { list.push_back(t); nA++; }
-    for (int t = 0; t < n; t++) if (flags[t] == 2) { list.push_back(t); nB++; }
-    for (int t = 0; t < n; t++) if (flags[t] & 1) { list.push_back(t); nC++; }
-    int rc = dev_alloc(s, &s->tiles.list, (size_t)n, false);
+    // flags: bit0 solid, bit1 lossy, bit2 UNI, bit3 PML
+    bfd_tiles &T = s->tiles;
+    T.nFluid = T.nSolid = T.nLossless = T.nLossy = T.nUni = T.nPml = 0;
+    for (int t = 0; t < n; t++) if (!(flags[t] & 1)) {
+        list.push_back(t); T.nFluid++;
+        if (flags[t] & 2) T.nLossy++; else T.nLossless++;
+        if (flags[t] & 4) T.nUni++;
+        if (flags[t] & 8) T.nPml++;
+    }
+    for (int t = 0; t < n; t++) if (flags[t] & 1) { list.push_back(t); T.nSolid++; }
+    rc = dev_alloc(s, &s->tiles.list, (size_t)n, false);
     if (rc) return rc;
     BFD_HIP(hipMemcpy(s->tiles.list, list.data(), n * sizeof(int), hipMemcpyHostToDevice));
-    s->tiles.nLossless = nA; s->tiles.nLossy = nB; s->tiles.nSolid = nC;
+    const int nC = T.nSolid;
     // per-component normal stresses are needed only by solid tiles or by a Sigma** output selection
     const uint32_t sig = (1u << BFD_MAP_SIGMAXX) | (1u << BFD_MAP_SIGMAYY) | (1u << BFD_MAP_SIGMAZZ);
     s->d.collapsed = (nC == 0 && ((s->cfg.selMapsRMS | s->cfg.selMapsSensors) & sig) == 0) ? 1 : 0;
@@ -900,12 +905,14 @@ int bfd_get_field(bfd_sim *s, int32_t a, float *out, int64_t s1, int64_t s2, int
     return download_volume(s, s->stateBase[a] + 2 * (size_t)s->d.plane, out, s1, s2, s3);
 }
 
-int bfd_tile_counts(bfd_sim *s, int32_t *nLossless, int32_t *nLossy, int32_t *nSolid)
+int bfd_tile_counts(bfd_sim *s, int32_t *nLossless, int32_t *nLossy, int32_t *nSolid, int32_t *nUni, int32_t *nPml)
 {
     int rc = check_ready(s); if (rc) return rc;
     if (nLossless) *nLossless = s->tilesReady ? s->tiles.nLossless : 0;
     if (nLossy) *nLossy = s->tilesReady ? s->tiles.nLossy : 0;
     if (nSolid) *nSolid = s->tilesReady ? s->tiles.nSolid : 0;
+    if (nUni) *nUni = s->tilesReady ? s->tiles.nUni : 0;
+    if (nPml) *nPml = s->tilesReady ? s->tiles.nPml : 0;
     return 0;
 }
 

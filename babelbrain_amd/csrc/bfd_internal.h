@@ -36,8 +36,10 @@ struct bfd_dev {
     int collapsed;
 };
 
-// tile lists of the class-specialised path (variant 3): device array [lossless fluid | lossy fluid | solid]
-struct bfd_tiles { int *list; int nLossless, nLossy, nSolid; };
+// tile lists of the class-specialised path (variant 3): device array
+// [fluid tiles | solid tiles], each in natural order; per tile: flags (bit0 solid, bit1 lossy, bit2 UNI,
+// bit3 PML) and the material id of UNI tiles
+struct bfd_tiles { int *list; int *tileMat; int *tileFlags; int nFluid, nSolid, nLossless, nLossy, nUni, nPml; };
 
 struct bfd_sim {
     bfd_config cfg;
@@ -83,7 +85,7 @@ void bfd_set_error(const std::string &s);
 void bfd_launch_stress_v1(const bfd_dev &d, hipStream_t s);
 void bfd_launch_velocity_v1(const bfd_dev &d, hipStream_t s);
 void bfd_tile_grid(const bfd_dev &d, int *tilesX, int *tilesY, int *tilesZ);
-void bfd_launch_classify(const bfd_dev &d, hipStream_t s, int *flagsDev);
+void bfd_launch_classify(const bfd_dev &d, hipStream_t s, int *flagsDev, int *tileMatDev);
 // t == nullptr: dense kernels on every tile (variant 2)
 void bfd_launch_stress_v2(const bfd_dev &d, hipStream_t s, const bfd_tiles *t);
 // accP / pkP: Pressure RMS / peak accumulators of this step (slab-local, x-fastest) or nullptr

@@ -441,15 +441,21 @@ constexpr int ZCHUNK = 32;
 //     identical result is written to all three (the arrays stay fully valid for neighbours).
 // Values equal the canonical sequence (only the sign of an exact zero can differ).
 // ------------------------------------------------------------------------------------------------
-template <int ZC, bool LOSSY, bool COLLAPSED>
-__global__ __launch_bounds__(NTHREADS, FLUID_WAVES_PER_SIMD) void stress_fluid(bfd_dev d, int tilesX, int tilesY, int nblocks,
-                                                                               const int *__restrict__ list)
+// Fluid-tile bodies are specialised per tile on two more properties found at setup (classify_tiles):
+//   UNI : the tile grown by 2 cells holds ONE material and no reflector -> coefficients are per-tile
+//         scalars; no id loads, table lookups or reflector tests;
+//   PML : some cell of the tile lies in an absorbing-layer zone (otherwise no CPML code at all).
+// One launch covers all fluid tiles of a half-step in their natural (XCD-remapped) order; the workgroup
+// switches on its tile's flags (block-uniform) into the matching instantiation.
+// All bodies are software pipelined: every value plane kl needs is in registers when its iteration starts
+// and the iteration issues the loads for plane kl+1 (CPML memory variables included).
+template <int ZC, bool LOSSY, bool COLLAPSED, bool UNI, bool PML>
+__device__ __forceinline__ void stress_fluid_body(const bfd_dev &d, int tilesX, int tilesY, int tile, int tm,
+                                                  float (*sV)[2][LH * LW])
 {
     // The three normal stresses are identical in a FLUID tile; Szz is the one that is read (it is
     // also the one whose ghost planes the Z-neighbour exchange carries), all three are written.
-    __shared__ float sV[2][2][LH * LW];
     const int N1 = d.N1, N2 = d.N2;
-    const int tile = list[remap_block(blockIdx.x, nblocks)];
     const int bx = tile % tilesX, by = (tile / tilesX) % tilesY, bz = tile / (tilesX * tilesY);
     const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * TX + tx;
     const int i0 = bx * TX, j0 = by * TY;
@@ -469,12 +475,23 @@ __global__ __launch_bounds__(NTHREADS, FLUID_WAVES_PER_SIMD) void stress_fluid(b
     const float *ph = (t.arr == 0 ? d.Vx : d.Vy) + (t.ok ? t.gofs : 0);
     float *lh = &sV[0][t.arr][has ? t.lofs : 0];
 
-    const bool zi = valid && (i < P || i >= N1 - P);
-    const bool zj = valid && (j < P || j >= N2 - P);
     const float c1 = d.c1;
+    float APu = 0.f, BPu = 0.f;
+    if (UNI) { APu = d.AP[tm]; BPu = d.BP[tm]; }
 
-    // software pipeline: everything plane kl needs is in registers when its iteration starts; the
-    // iteration issues the loads of plane kl+1 (material id: kl+1, its table rows: at the top of kl+1)
+    // absorbing layer (PML flavours only): per-thread x/y coefficients and running zone offsets
+    const bool zi = PML && valid && (i < P || i >= N1 - P);
+    const bool zj = PML && valid && (j < P || j >= N2 - P);
+    float ax = 0, bxc = 0, ay = 0, byc = 0, px = 0, py = 0, pz = 0;
+    unsigned qx = 0, qy = 0;
+    const unsigned dqx = (unsigned)(N2 * 2 * P), dqy = (unsigned)(2 * P * N1);
+    if (PML) {
+        if (zi) { ax = d.axI[i]; bxc = d.bxI[i]; qx = (unsigned)((kbeg * N2 + j) * (2 * P) + (i < P ? i : i - (N1 - 2 * P))); px = d.psi[0][qx]; }
+        if (zj) { ay = d.ayI[j]; byc = d.byI[j]; qy = (unsigned)((kbeg * (2 * P) + (j < P ? j : j - (N2 - 2 * P))) * N1 + i); py = d.psi[1][qy]; }
+        const int kg = d.k0 + kbeg;
+        if (valid && (kg < P || kg >= d.N3 - P)) pz = d.psi[2][(long)(kg < P ? kg : kg - (d.N3 - 2 * P)) * pl + cij];
+    }
+
     float vx0 = 0, vy0 = 0, vzm2 = 0, vzm1 = 0, vz0 = 0, vzp1 = 0, szz = 0, rzz = 0;
     unsigned mraw = 0;
     if (valid) {
@@ -483,7 +500,7 @@ __global__ __launch_bounds__(NTHREADS, FLUID_WAVES_PER_SIMD) void stress_fluid(b
         vzm2 = (bVz - 2 * pl)[cij]; vzm1 = (bVz - pl)[cij]; vz0 = bVz[cij]; vzp1 = (bVz + pl)[cij];
         szz = (d.Szz + kbeg * pl)[cij];
         if (LOSSY) rzz = (d.Rzz + kbeg * pl)[cij];
-        mraw = (d.mat + kbeg * pl)[cij];
+        if (!UNI) mraw = (d.mat + kbeg * pl)[cij];
     }
     float hv = t.ok ? ph[kbeg * pl] : 0.0f;
 
@@ -494,21 +511,26 @@ __global__ __launch_bounds__(NTHREADS, FLUID_WAVES_PER_SIMD) void stress_fluid(b
         sV[b][0][own] = vx0; sV[b][1][own] = vy0;
         if (has) lh[b * (2 * LH * LW)] = hv;
         // table rows of this plane (cache-resident; short latency, overlaps the barrier)
-        const int m = mraw & BFD_MAT_MASK;
-        float AP = 0.f, BP = 0.f;
-        if (valid) { AP = d.AP[m]; if (LOSSY) BP = d.BP[m]; }
+        float AP = APu, BP = BPu;
+        if (!UNI && valid) { const int m = mraw & BFD_MAT_MASK; AP = d.AP[m]; if (LOSSY) BP = d.BP[m]; }
         __syncthreads();
 
-        float nvx = 0, nvy = 0, nvz = 0, nh = 0, nszz = 0, nrzz = 0;
+        float nvx = 0, nvy = 0, nvz = 0, nh = 0, nszz = 0, nrzz = 0, npx = 0, npy = 0, npz = 0;
         unsigned nmraw = 0;
         if (kl + 1 < kend) {
             if (valid) {
                 nvx = (d.Vx + ko + pl)[cij]; nvy = (d.Vy + ko + pl)[cij]; nvz = (d.Vz + ko + 2 * pl)[cij];
                 nszz = (d.Szz + ko + pl)[cij];
                 if (LOSSY) nrzz = (d.Rzz + ko + pl)[cij];
-                nmraw = (d.mat + ko + pl)[cij];
+                if (!UNI) nmraw = (d.mat + ko + pl)[cij];
             }
             if (t.ok) nh = ph[ko + pl];
+            if (PML) {
+                if (zi) npx = d.psi[0][qx + dqx];
+                if (zj) npy = d.psi[1][qy + dqy];
+                const int kn = k + 1;
+                if (valid && (kn < P || kn >= d.N3 - P)) npz = d.psi[2][(long)(kn < P ? kn : kn - (d.N3 - 2 * P)) * pl + cij];
+            }
         }
         if (valid) {
             const float *sx = &sV[b][0][own], *sy = &sV[b][1][own];
@@ -516,18 +538,15 @@ __global__ __launch_bounds__(NTHREADS, FLUID_WAVES_PER_SIMD) void stress_fluid(b
             float dyVy = dminus4(sy[-2 * LW], sy[-LW], vy0, sy[LW]);
             float dzVz = dminus4(vzm2, vzm1, vz0, vzp1);
             float val = 0.f, rn = 0.f;
-            if (!(mraw & BFD_REFLECTOR_BIT)) {
-                if (zi) {
-                    const int xi = i < P ? i : i - (N1 - 2 * P);
-                    dxVx = cpml(d.psi[0], ((long)kl * N2 + j) * (2 * P) + xi, d.axI[i], d.bxI[i], dxVx);
-                }
-                if (zj) {
-                    const int yj = j < P ? j : j - (N2 - 2 * P);
-                    dyVy = cpml(d.psi[1], ((long)kl * (2 * P) + yj) * N1 + i, d.ayI[j], d.byI[j], dyVy);
-                }
-                if (k < P || k >= d.N3 - P) {
-                    const int zk = k < P ? k : k - (d.N3 - 2 * P);
-                    dzVz = cpml(d.psi[2], (long)zk * pl + cij, d.azI[k], d.bzI[k], dzVz);
+            if (UNI || !(mraw & BFD_REFLECTOR_BIT)) {
+                if (PML) {
+                    if (zi) { const float pn = bxc * px + ax * dxVx; d.psi[0][qx] = pn; dxVx = dxVx + pn; }
+                    if (zj) { const float pn = byc * py + ay * dyVy; d.psi[1][qy] = pn; dyVy = dyVy + pn; }
+                    if (k < P || k >= d.N3 - P) {
+                        const float pn = d.bzI[k] * pz + d.azI[k] * dzVz;
+                        d.psi[2][(long)(k < P ? k : k - (d.N3 - 2 * P)) * pl + cij] = pn;
+                        dzVz = dzVz + pn;
+                    }
                 }
                 const float div = (dxVx + dyVy) + dzVz;
                 if (LOSSY) {
@@ -549,17 +568,15 @@ __global__ __launch_bounds__(NTHREADS, FLUID_WAVES_PER_SIMD) void stress_fluid(b
         vx0 = nvx; vy0 = nvy;
         vzm2 = vzm1; vzm1 = vz0; vz0 = vzp1; vzp1 = nvz;
         hv = nh; szz = nszz; rzz = nrzz; mraw = nmraw;
+        px = npx; py = npy; pz = npz; qx += dqx; qy += dqy;
     }
 }
 
-template <int ZC, bool ACC>
-__global__ __launch_bounds__(NTHREADS, FLUID_WAVES_PER_SIMD) void velocity_fluid(bfd_dev d, int tilesX, int tilesY, int nblocks,
-                                                                                 const int *__restrict__ list,
-                                                                                 float *__restrict__ accP, float *__restrict__ pkP)
+template <int ZC, bool ACC, bool UNI, bool PML>
+__device__ __forceinline__ void velocity_fluid_body(const bfd_dev &d, int tilesX, int tilesY, int tile, int tm,
+                                                    float (*sS)[LH * LW], float *__restrict__ accP, float *__restrict__ pkP)
 {
-    __shared__ float sS[2][LH * LW];
     const int N1 = d.N1, N2 = d.N2;
-    const int tile = list[remap_block(blockIdx.x, nblocks)];
     const int bx = tile % tilesX, by = (tile / tilesX) % tilesY, bz = tile / (tilesX * tilesY);
     const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * TX + tx;
     const int i0 = bx * TX, j0 = by * TY;
@@ -581,24 +598,38 @@ __global__ __launch_bounds__(NTHREADS, FLUID_WAVES_PER_SIMD) void velocity_fluid
     const float *ph = d.Szz + (t.ok ? t.gofs : 0);
     float *lh = &sS[0][has ? t.lofs : 0];
 
-    const bool zi = valid && (i < P || i >= N1 - P);
-    const bool zj = valid && (j < P || j >= N2 - P);
     const bool inner = valid && i >= d.ND && i < N1 - d.ND && j >= d.ND && j < N2 - d.ND;
     const bool accA = ACC && accP != nullptr, accK = ACC && pkP != nullptr;
+    float ru = 0.f;
+    if (UNI) ru = d.invRho[tm];                       // 0.5*(r+r) == r exactly: every face of a UNI tile sees one 1/rho
 
-    // software pipeline (see stress_fluid): own material id runs two planes ahead because the z
-    // face needs 1/rho of plane kl+1; neighbour ids one plane ahead; table rows at the top of the iteration
-    float sm1 = 0, s0 = 0, sp1 = 0, sp2 = 0, vx = 0, vy = 0, vz = 0, av = 0, pv = 0, r0 = 0;
+    const bool zi = PML && valid && (i < P || i >= N1 - P);
+    const bool zj = PML && valid && (j < P || j >= N2 - P);
+    float ax = 0, bxc = 0, ay = 0, byc = 0, px = 0, py = 0, pz = 0;
+    unsigned qx = 0, qy = 0;
+    const unsigned dqx = (unsigned)(N2 * 2 * P), dqy = (unsigned)(2 * P * N1);
+    if (PML) {
+        if (zi) { ax = d.axH[i]; bxc = d.bxH[i]; qx = (unsigned)((kbeg * N2 + j) * (2 * P) + (i < P ? i : i - (N1 - 2 * P))); px = d.psi[9][qx]; }
+        if (zj) { ay = d.ayH[j]; byc = d.byH[j]; qy = (unsigned)((kbeg * (2 * P) + (j < P ? j : j - (N2 - 2 * P))) * N1 + i); py = d.psi[13][qy]; }
+        const int kg = d.k0 + kbeg;
+        if (valid && (kg < P || kg >= d.N3 - P)) pz = d.psi[17][(long)(kg < P ? kg : kg - (d.N3 - 2 * P)) * pl + cij];
+    }
+
+    // own material id runs two planes ahead because the z face needs 1/rho of plane kl+1; neighbour ids
+    // one plane ahead; table rows at the top of the iteration
+    float sm1 = 0, s0 = 0, sp1 = 0, sp2 = 0, vx = 0, vy = 0, vz = 0, av = 0, pv = 0, r0 = ru;
     unsigned mraw = 0, mraw1 = 0, mx = 0, my = 0;
     if (valid) {
         const float *bS = d.Szz + kbeg * pl;
-        const uint16_t *bM = d.mat + kbeg * pl;
         sm1 = (bS - pl)[cij]; s0 = bS[cij]; sp1 = (bS + pl)[cij]; sp2 = (bS + 2 * pl)[cij];
         vx = (d.Vx + kbeg * pl)[cij]; vy = (d.Vy + kbeg * pl)[cij]; vz = (d.Vz + kbeg * pl)[cij];
-        mraw = bM[cij]; mraw1 = (bM + pl)[cij]; mx = bM[cx]; my = bM[cy];
         if (accA) av = (accP + kbeg * pl)[cij];
         if (accK) pv = (pkP + kbeg * pl)[cij];
-        r0 = d.invRho[mraw & BFD_MAT_MASK];
+        if (!UNI) {
+            const uint16_t *bM = d.mat + kbeg * pl;
+            mraw = bM[cij]; mraw1 = (bM + pl)[cij]; mx = bM[cx]; my = bM[cy];
+            r0 = d.invRho[mraw & BFD_MAT_MASK];
+        }
     }
     float hv = t.ok ? ph[kbeg * pl] : 0.0f;
 
@@ -608,26 +639,32 @@ __global__ __launch_bounds__(NTHREADS, FLUID_WAVES_PER_SIMD) void velocity_fluid
         const int k = d.k0 + kl;
         sS[b][own] = s0;
         if (has) lh[b * (LH * LW)] = hv;
-        float r1 = 0, rx = 0, ry = 0;
-        if (valid) {
+        float r1 = ru, rx = ru, ry = ru;
+        if (!UNI && valid) {
             r1 = d.invRho[mraw1 & BFD_MAT_MASK];       // plane kl+1, becomes r0 of the next iteration
             rx = d.invRho[mx & BFD_MAT_MASK];
             ry = d.invRho[my & BFD_MAT_MASK];
         }
         __syncthreads();
 
-        float ns = 0, nh = 0, nvx = 0, nvy = 0, nvz = 0, nav = 0, npv = 0;
+        float ns = 0, nh = 0, nvx = 0, nvy = 0, nvz = 0, nav = 0, npv = 0, npx = 0, npy = 0, npz = 0;
         unsigned nm2 = 0, nmx = 0, nmy = 0;
-        if (valid) nm2 = (d.mat + ko + 2 * pl)[cij];              // ghost planes make kl+2 addressable
+        if (!UNI && valid) nm2 = (d.mat + ko + 2 * pl)[cij];     // ghost planes make kl+2 addressable
         if (kl + 1 < kend) {
             if (valid) {
                 ns = (d.Szz + ko + 3 * pl)[cij];
                 nvx = (d.Vx + ko + pl)[cij]; nvy = (d.Vy + ko + pl)[cij]; nvz = (d.Vz + ko + pl)[cij];
-                nmx = (d.mat + ko + pl)[cx]; nmy = (d.mat + ko + pl)[cy];
+                if (!UNI) { nmx = (d.mat + ko + pl)[cx]; nmy = (d.mat + ko + pl)[cy]; }
                 if (accA) nav = (accP + ko + pl)[cij];
                 if (accK) npv = (pkP + ko + pl)[cij];
             }
             if (t.ok) nh = ph[ko + pl];
+            if (PML) {
+                if (zi) npx = d.psi[9][qx + dqx];
+                if (zj) npy = d.psi[13][qy + dqy];
+                const int kn = k + 1;
+                if (valid && (kn < P || kn >= d.N3 - P)) npz = d.psi[17][(long)(kn < P ? kn : kn - (d.N3 - 2 * P)) * pl + cij];
+            }
         }
         if (valid) {
             if (ACC) {
@@ -638,24 +675,21 @@ __global__ __launch_bounds__(NTHREADS, FLUID_WAVES_PER_SIMD) void velocity_fluid
                     if (accK) { const float ap = fabsf(p); if (ap > pv) (pkP + ko)[cij] = ap; }
                 }
             }
-            if (mraw & BFD_REFLECTOR_BIT) {
+            if (!UNI && (mraw & BFD_REFLECTOR_BIT)) {
                 (d.Vx + ko)[cij] = 0.f; (d.Vy + ko)[cij] = 0.f; (d.Vz + ko)[cij] = 0.f;
             } else {
                 const float *p = &sS[b][own];
                 float dx = dplus4(p[-1], s0, p[1], p[2]);
                 float dy = dplus4(p[-LW], s0, p[LW], p[2 * LW]);
                 float dz = dplus4(sm1, s0, sp1, sp2);
-                if (zi) {
-                    const int xi = i < P ? i : i - (N1 - 2 * P);
-                    dx = cpml(d.psi[9], ((long)kl * N2 + j) * (2 * P) + xi, d.axH[i], d.bxH[i], dx);
-                }
-                if (zj) {
-                    const int yj = j < P ? j : j - (N2 - 2 * P);
-                    dy = cpml(d.psi[13], ((long)kl * (2 * P) + yj) * N1 + i, d.ayH[j], d.byH[j], dy);
-                }
-                if (k < P || k >= d.N3 - P) {
-                    const int zk = k < P ? k : k - (d.N3 - 2 * P);
-                    dz = cpml(d.psi[17], (long)zk * pl + cij, d.azH[k], d.bzH[k], dz);
+                if (PML) {
+                    if (zi) { const float pn = bxc * px + ax * dx; d.psi[9][qx] = pn; dx = dx + pn; }
+                    if (zj) { const float pn = byc * py + ay * dy; d.psi[13][qy] = pn; dy = dy + pn; }
+                    if (k < P || k >= d.N3 - P) {
+                        const float pn = d.bzH[k] * pz + d.azH[k] * dz;
+                        d.psi[17][(long)(k < P ? k : k - (d.N3 - 2 * P)) * pl + cij] = pn;
+                        dz = dz + pn;
+                    }
                 }
                 (d.Vx + ko)[cij] = vx + (0.5f * (r0 + rx)) * dx;
                 (d.Vy + ko)[cij] = vy + (0.5f * (r0 + ry)) * dy;
@@ -665,30 +699,87 @@ __global__ __launch_bounds__(NTHREADS, FLUID_WAVES_PER_SIMD) void velocity_fluid
         sm1 = s0; s0 = sp1; sp1 = sp2; sp2 = ns;
         hv = nh; vx = nvx; vy = nvy; vz = nvz; av = nav; pv = npv;
         r0 = r1; mraw = mraw1; mraw1 = nm2; mx = nmx; my = nmy;
+        px = npx; py = npy; pz = npz; qx += dqx; qy += dqy;
     }
 }
 
-// one workgroup per tile: flags bit0 = a solid cell within the tile grown by 2 cells,
-// bit1 = a cell of the tile itself has a relaxing P modulus (BP != 0)
+// ---- dispatchers: one launch for all fluid tiles; block-uniform switch on the tile's flags ----
+// tile flags: bit0 solid, bit1 lossy, bit2 UNI, bit3 PML
+template <int ZC, bool COLLAPSED>
+__global__ __launch_bounds__(NTHREADS, FLUID_WAVES_PER_SIMD) void stress_fluid(bfd_dev d, int tilesX, int tilesY, int nblocks,
+                                                                               const int *__restrict__ list,
+                                                                               const int *__restrict__ tileFlags,
+                                                                               const int *__restrict__ tileMat)
+{
+    __shared__ float sV[2][2][LH * LW];
+    const int tile = list[remap_block(blockIdx.x, nblocks)];
+    const int f = __builtin_amdgcn_readfirstlane(tileFlags[tile]);
+    const int tm = __builtin_amdgcn_readfirstlane(tileMat[tile]);
+    switch ((f >> 1) & 7) {
+    case 0: stress_fluid_body<ZC, false, COLLAPSED, false, false>(d, tilesX, tilesY, tile, tm, sV); break;
+    case 1: stress_fluid_body<ZC, true, COLLAPSED, false, false>(d, tilesX, tilesY, tile, tm, sV); break;
+    case 2: stress_fluid_body<ZC, false, COLLAPSED, true, false>(d, tilesX, tilesY, tile, tm, sV); break;
+    case 3: stress_fluid_body<ZC, true, COLLAPSED, true, false>(d, tilesX, tilesY, tile, tm, sV); break;
+    case 4: stress_fluid_body<ZC, false, COLLAPSED, false, true>(d, tilesX, tilesY, tile, tm, sV); break;
+    case 5: stress_fluid_body<ZC, true, COLLAPSED, false, true>(d, tilesX, tilesY, tile, tm, sV); break;
+    case 6: stress_fluid_body<ZC, false, COLLAPSED, true, true>(d, tilesX, tilesY, tile, tm, sV); break;
+    default: stress_fluid_body<ZC, true, COLLAPSED, true, true>(d, tilesX, tilesY, tile, tm, sV); break;
+    }
+}
+
+template <int ZC, bool ACC>
+__global__ __launch_bounds__(NTHREADS, FLUID_WAVES_PER_SIMD) void velocity_fluid(bfd_dev d, int tilesX, int tilesY, int nblocks,
+                                                                                 const int *__restrict__ list,
+                                                                                 const int *__restrict__ tileFlags,
+                                                                                 const int *__restrict__ tileMat,
+                                                                                 float *__restrict__ accP, float *__restrict__ pkP)
+{
+    __shared__ float sS[2][LH * LW];
+    const int tile = list[remap_block(blockIdx.x, nblocks)];
+    const int f = __builtin_amdgcn_readfirstlane(tileFlags[tile]);
+    const int tm = __builtin_amdgcn_readfirstlane(tileMat[tile]);
+    switch ((f >> 2) & 3) {
+    case 0: velocity_fluid_body<ZC, ACC, false, false>(d, tilesX, tilesY, tile, tm, sS, accP, pkP); break;
+    case 1: velocity_fluid_body<ZC, ACC, true, false>(d, tilesX, tilesY, tile, tm, sS, accP, pkP); break;
+    case 2: velocity_fluid_body<ZC, ACC, false, true>(d, tilesX, tilesY, tile, tm, sS, accP, pkP); break;
+    default: velocity_fluid_body<ZC, ACC, true, true>(d, tilesX, tilesY, tile, tm, sS, accP, pkP); break;
+    }
+}
+
+// one workgroup per tile. flags: bit0 = a solid cell within the tile grown by 2 cells; bit1 = a cell of the
+// tile relaxes (BP != 0); bit2 = UNI: one material and no reflector in the grown region; bit3 = PML: a cell
+// of the tile lies inside an absorbing-layer zone. tileMat[tile] = the id at the tile's first cell.
 template <int ZC>
-__global__ void classify_tiles(bfd_dev d, int tilesX, int tilesY, int *__restrict__ flags)
+__global__ void classify_tiles(bfd_dev d, int tilesX, int tilesY, int *__restrict__ flags, int *__restrict__ tileMat)
 {
     const int tile = blockIdx.x;
     const int bx = tile % tilesX, by = (tile / tilesX) % tilesY, bz = tile / (tilesX * tilesY);
     const int i0 = bx * TX - 2, j0 = by * TY - 2, k0 = bz * ZC - 2;
-    const int nx = TX + 4, ny = TY + 4, nz = min(ZC, d.nk - bz * ZC) + 4;
-    int solid = 0, lossy = 0;
+    const int nzOwn = min(ZC, d.nk - bz * ZC);
+    const int nx = TX + 4, ny = TY + 4, nz = nzOwn + 4;
+    const unsigned first = d.mat[(long)(bz * ZC) * d.plane + (long)min(by * TY, d.N2 - 1) * d.N1 + min(bx * TX, d.N1 - 1)];
+    int solid = 0, lossy = 0, mixed = (first & BFD_REFLECTOR_BIT) ? 1 : 0;
     for (int v = threadIdx.x; v < nx * ny * nz; v += blockDim.x) {
         const int li = v % nx, lj = (v / nx) % ny, lk = v / (nx * ny);
         const int i = i0 + li, j = j0 + lj, kl = k0 + lk;       // kl in [-2, nk+2): ghost planes exist
         if (i < 0 || i >= d.N1 || j < 0 || j >= d.N2) continue;
-        const int m = d.mat[(long)kl * d.plane + (long)j * d.N1 + i] & BFD_MAT_MASK;
+        const unsigned raw = d.mat[(long)kl * d.plane + (long)j * d.N1 + i];
+        const int m = raw & BFD_MAT_MASK;
+        if (raw != first) mixed = 1;
         if (d.invMu[m] > 0.f) solid = 1;
         if (li >= 2 && li < nx - 2 && lj >= 2 && lj < ny - 2 && lk >= 2 && lk < nz - 2 && d.BP[m] != 0.f) lossy = 1;
     }
     solid = __syncthreads_or(solid);
     lossy = __syncthreads_or(lossy);
-    if (threadIdx.x == 0) flags[tile] = solid | (lossy << 1);
+    mixed = __syncthreads_or(mixed);
+    if (threadIdx.x == 0) {
+        const int P = d.P;
+        const int xa = bx * TX, xb = min(xa + TX, d.N1), ya = by * TY, yb = min(ya + TY, d.N2);
+        const int za = d.k0 + bz * ZC, zb = za + nzOwn;
+        const bool pml = xa < P || xb > d.N1 - P || ya < P || yb > d.N2 - P || za < P || zb > d.N3 - P;
+        flags[tile] = solid | (lossy << 1) | (mixed ? 0 : 4) | (pml ? 8 : 0);
+        tileMat[tile] = (int)(first & BFD_MAT_MASK);
+    }
 }
 
 }  // namespace
@@ -698,46 +789,43 @@ void bfd_tile_grid(const bfd_dev &d, int *tilesX, int *tilesY, int *tilesZ)
     *tilesX = (d.N1 + TX - 1) / TX; *tilesY = (d.N2 + TY - 1) / TY; *tilesZ = (d.nk + ZCHUNK - 1) / ZCHUNK;
 }
 
-void bfd_launch_classify(const bfd_dev &d, hipStream_t s, int *flagsDev)
+void bfd_launch_classify(const bfd_dev &d, hipStream_t s, int *flagsDev, int *tileMatDev)
 {
     int tx, ty, tz; bfd_tile_grid(d, &tx, &ty, &tz);
-    hipLaunchKernelGGL((classify_tiles<ZCHUNK>), dim3(tx * ty * tz), dim3(256), 0, s, d, tx, ty, flagsDev);
+    hipLaunchKernelGGL((classify_tiles<ZCHUNK>), dim3(tx * ty * tz), dim3(256), 0, s, d, tx, ty, flagsDev, tileMatDev);
 }
 
+#define BFD_LAUNCH(K, n, ...) hipLaunchKernelGGL(K, dim3(n), dim3(TX, TY, 1), 0, s, d, tilesX, tilesY, n, __VA_ARGS__)
+
+// tile list layout: [fluid tiles in natural order | solid tiles in natural order]
 void bfd_launch_stress_v2(const bfd_dev &d, hipStream_t s, const bfd_tiles *t)
 {
     int tilesX, tilesY, tilesZ; bfd_tile_grid(d, &tilesX, &tilesY, &tilesZ);
     if (!t) {
         const int nblocks = tilesX * tilesY * tilesZ;
-        hipLaunchKernelGGL((stress_v2<ZCHUNK>), dim3(nblocks), dim3(TX, TY, 1), 0, s, d, tilesX, tilesY, nblocks, (const int *)nullptr);
+        BFD_LAUNCH((stress_v2<ZCHUNK>), nblocks, (const int *)nullptr);
         return;
     }
-    if (t->nLossless) {
-        if (d.collapsed) hipLaunchKernelGGL((stress_fluid<ZCHUNK, false, true>), dim3(t->nLossless), dim3(TX, TY, 1), 0, s, d, tilesX, tilesY, t->nLossless, t->list);
-        else hipLaunchKernelGGL((stress_fluid<ZCHUNK, false, false>), dim3(t->nLossless), dim3(TX, TY, 1), 0, s, d, tilesX, tilesY, t->nLossless, t->list);
+    if (t->nFluid) {
+        if (d.collapsed) BFD_LAUNCH((stress_fluid<ZCHUNK, true>), t->nFluid, t->list, t->tileFlags, t->tileMat);
+        else BFD_LAUNCH((stress_fluid<ZCHUNK, false>), t->nFluid, t->list, t->tileFlags, t->tileMat);
     }
-    if (t->nLossy) {
-        if (d.collapsed) hipLaunchKernelGGL((stress_fluid<ZCHUNK, true, true>), dim3(t->nLossy), dim3(TX, TY, 1), 0, s, d, tilesX, tilesY, t->nLossy, t->list + t->nLossless);
-        else hipLaunchKernelGGL((stress_fluid<ZCHUNK, true, false>), dim3(t->nLossy), dim3(TX, TY, 1), 0, s, d, tilesX, tilesY, t->nLossy, t->list + t->nLossless);
-    }
-    if (t->nSolid)
-        hipLaunchKernelGGL((stress_v2<ZCHUNK>), dim3(t->nSolid), dim3(TX, TY, 1), 0, s, d, tilesX, tilesY, t->nSolid,
-                           t->list + t->nLossless + t->nLossy);
+    if (t->nSolid) BFD_LAUNCH((stress_v2<ZCHUNK>), t->nSolid, t->list + t->nFluid);
 }
 
 void bfd_launch_velocity_v2(const bfd_dev &d, hipStream_t s, float *accP, float *pkP, const bfd_tiles *t)
 {
     int tilesX, tilesY, tilesZ; bfd_tile_grid(d, &tilesX, &tilesY, &tilesZ);
     const bool acc = accP || pkP;
-    const int nFluid = t ? t->nLossless + t->nLossy : 0;
+    const int nFluid = t ? t->nFluid : 0;
     const int nDense = t ? t->nSolid : tilesX * tilesY * tilesZ;
-    const int *denseList = t ? t->list + nFluid : nullptr;
     if (nFluid) {
-        if (acc) hipLaunchKernelGGL((velocity_fluid<ZCHUNK, true>), dim3(nFluid), dim3(TX, TY, 1), 0, s, d, tilesX, tilesY, nFluid, t->list, accP, pkP);
-        else hipLaunchKernelGGL((velocity_fluid<ZCHUNK, false>), dim3(nFluid), dim3(TX, TY, 1), 0, s, d, tilesX, tilesY, nFluid, t->list, accP, pkP);
+        if (acc) BFD_LAUNCH((velocity_fluid<ZCHUNK, true>), nFluid, t->list, t->tileFlags, t->tileMat, accP, pkP);
+        else BFD_LAUNCH((velocity_fluid<ZCHUNK, false>), nFluid, t->list, t->tileFlags, t->tileMat, accP, pkP);
     }
     if (nDense) {
-        if (acc) hipLaunchKernelGGL((velocity_v2<ZCHUNK, true>), dim3(nDense), dim3(TX, TY, 1), 0, s, d, tilesX, tilesY, nDense, accP, pkP, denseList);
-        else hipLaunchKernelGGL((velocity_v2<ZCHUNK, false>), dim3(nDense), dim3(TX, TY, 1), 0, s, d, tilesX, tilesY, nDense, accP, pkP, denseList);
+        const int *denseList = t ? t->list + nFluid : nullptr;
+        if (acc) BFD_LAUNCH((velocity_v2<ZCHUNK, true>), nDense, accP, pkP, denseList);
+        else BFD_LAUNCH((velocity_v2<ZCHUNK, false>), nDense, accP, pkP, denseList);
     }
 }
