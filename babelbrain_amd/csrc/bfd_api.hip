@@ -572,18 +572,28 @@ int bfd_set_sources(bfd_sim *s, int64_t nVox, const uint32_t *localIndex, const 
         if ((int)row[v] >= nSources) BFD_FAIL(-2, "bfd_set_sources: SourceMap id exceeds PulseSource rows");
     }
     s->nSrcVox = nVox; s->nSources = nSources; s->lengthSource = lengthSource;
+    s->srcLowEnd = 0; s->srcHighBeg = nVox; s->tilesReady = false;
     if (nVox == 0) return 0;
+    // keep the source voxels sorted by voxel index: the boundary/interior split of a half-step injects
+    // the sources of the first and last z-chunk separately (build_tile_lists)
+    std::vector<int64_t> order((size_t)nVox);
+    for (int64_t v = 0; v < nVox; v++) order[v] = v;
+    std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return localIndex[a] < localIndex[b]; });
+    std::vector<uint32_t> hl((size_t)nVox), hr((size_t)nVox);
+    for (int64_t v = 0; v < nVox; v++) { hl[v] = localIndex[order[v]]; hr[v] = row[order[v]]; }
     int rc = 0;
     if ((rc = dev_alloc(s, &s->srcLin, nVox, false))) return rc;
     if ((rc = dev_alloc(s, &s->srcRow, nVox, false))) return rc;
-    BFD_HIP(hipMemcpyAsync(s->srcLin, localIndex, nVox * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream));
-    BFD_HIP(hipMemcpyAsync(s->srcRow, row, nVox * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream));
+    BFD_HIP(hipMemcpy(s->srcLin, hl.data(), nVox * sizeof(uint32_t), hipMemcpyHostToDevice));
+    BFD_HIP(hipMemcpy(s->srcRow, hr.data(), nVox * sizeof(uint32_t), hipMemcpyHostToDevice));
     const float *w[3] = {wx, wy, wz};
+    std::vector<float> hw((size_t)nVox);
     for (int a = 0; a < 3; a++) {
         s->srcW[a] = nullptr;
         if (w[a]) {
             if ((rc = dev_alloc(s, &s->srcW[a], nVox, false))) return rc;
-            BFD_HIP(hipMemcpyAsync(s->srcW[a], w[a], nVox * sizeof(float), hipMemcpyHostToDevice, s->stream));
+            for (int64_t v = 0; v < nVox; v++) hw[v] = w[a][order[v]];
+            BFD_HIP(hipMemcpy(s->srcW[a], hw.data(), nVox * sizeof(float), hipMemcpyHostToDevice));
         }
     }
     const size_t np = (size_t)nSources * lengthSource;
@@ -644,21 +654,34 @@ static int build_tile_lists(bfd_sim *s)
     int rc = dev_alloc(s, &s->tiles.tileMat, (size_t)n, false);
     if (!rc) rc = dev_alloc(s, &s->tiles.tileFlags, (size_t)n, false);
     if (rc) return rc;
-    bfd_launch_classify(s->d, s->stream, s->tiles.tileFlags, s->tiles.tileMat);
     std::vector<int> flags(n), list;
-    BFD_HIP(hipMemcpyAsync(flags.data(), s->tiles.tileFlags, n * sizeof(int), hipMemcpyDeviceToHost, s->stream));
+    if (s->cfg.kernelVariant == 2) {
+        flags.assign(n, 1);        // dense kernels everywhere: every tile goes to the "solid" list
+        BFD_HIP(hipMemcpyAsync(s->tiles.tileFlags, flags.data(), n * sizeof(int), hipMemcpyHostToDevice, s->stream));
+        BFD_HIP(hipMemsetAsync(s->tiles.tileMat, 0, n * sizeof(int), s->stream));
+    } else {
+        bfd_launch_classify(s->d, s->stream, s->tiles.tileFlags, s->tiles.tileMat);
+        BFD_HIP(hipMemcpyAsync(flags.data(), s->tiles.tileFlags, n * sizeof(int), hipMemcpyDeviceToHost, s->stream));
+    }
     BFD_HIP(hipStreamSynchronize(s->stream));
     list.reserve(n);
     // flags: bit0 solid, bit1 lossy, bit2 UNI, bit3 PML
     bfd_tiles &T = s->tiles;
-    T.nFluid = T.nSolid = T.nLossless = T.nLossy = T.nUni = T.nPml = 0;
-    for (int t = 0; t < n; t++) if (!(flags[t] & 1)) {
-        list.push_back(t); T.nFluid++;
-        if (flags[t] & 2) T.nLossy++; else T.nLossless++;
-        if (flags[t] & 4) T.nUni++;
-        if (flags[t] & 8) T.nPml++;
-    }
-    for (int t = 0; t < n; t++) if (flags[t] & 1) { list.push_back(t); T.nSolid++; }
+    T.nFluid = T.nFluidB = T.nSolid = T.nSolidB = T.nLossless = T.nLossy = T.nUni = T.nPml = 0;
+    auto boundary = [&](int t) { const int bz = t / (tx * ty); return bz == 0 || bz == tz - 1; };
+    for (int pass = 0; pass < 2; pass++)
+        for (int t = 0; t < n; t++) if (!(flags[t] & 1) && boundary(t) == (pass == 0)) {
+            list.push_back(t); T.nFluid++;
+            if (pass == 0) T.nFluidB++;
+            if (flags[t] & 2) T.nLossy++; else T.nLossless++;
+            if (flags[t] & 4) T.nUni++;
+            if (flags[t] & 8) T.nPml++;
+        }
+    for (int pass = 0; pass < 2; pass++)
+        for (int t = 0; t < n; t++) if ((flags[t] & 1) && boundary(t) == (pass == 0)) {
+            list.push_back(t); T.nSolid++;
+            if (pass == 0) T.nSolidB++;
+        }
     rc = dev_alloc(s, &s->tiles.list, (size_t)n, false);
     if (rc) return rc;
     BFD_HIP(hipMemcpy(s->tiles.list, list.data(), n * sizeof(int), hipMemcpyHostToDevice));
@@ -666,6 +689,13 @@ static int build_tile_lists(bfd_sim *s)
     // per-component normal stresses are needed only by solid tiles or by a Sigma** output selection
     const uint32_t sig = (1u << BFD_MAP_SIGMAXX) | (1u << BFD_MAP_SIGMAYY) | (1u << BFD_MAP_SIGMAZZ);
     s->d.collapsed = (nC == 0 && ((s->cfg.selMapsRMS | s->cfg.selMapsSensors) & sig) == 0) ? 1 : 0;
+    {   // sources of the first / last z-chunk (bfd_set_sources sorted them by voxel)
+        const uint32_t zc = (uint32_t)bfd_tile_zchunk() * (uint32_t)s->d.plane;
+        std::vector<uint32_t> lin((size_t)s->nSrcVox);
+        if (s->nSrcVox) BFD_HIP(hipMemcpy(lin.data(), s->srcLin, lin.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        s->srcLowEnd = std::lower_bound(lin.begin(), lin.end(), zc) - lin.begin();
+        s->srcHighBeg = tz > 1 ? std::lower_bound(lin.begin(), lin.end(), zc * (uint32_t)(tz - 1)) - lin.begin() : s->nSrcVox;
+    }
     s->tilesReady = true;
     return 0;
 }
@@ -674,50 +704,68 @@ static int check_ready(bfd_sim *s)
 {
     if (!s) BFD_FAIL(-1, "null sim");
     if (!s->haveMaterials || !s->haveMap) BFD_FAIL(-6, "materials and material map must be set before stepping");
-    if (!s->tilesReady && (s->cfg.kernelVariant == 0 || s->cfg.kernelVariant == 3)) {
+    if (!s->tilesReady && s->cfg.kernelVariant != 1) {
         BFD_HIP(hipSetDevice(s->cfg.device));
         return build_tile_lists(s);
     }
     return 0;
 }
 
-int bfd_half_step_stress(bfd_sim *s)
+// sources of one part of a half-step: part 0 all, 1 = first+last z-chunk, 2 = the chunks between
+static void inject_part(bfd_sim *s, int part)
+{
+    const int64_t n = s->nSrcVox;
+    int64_t beg[2] = {0, 0}, end[2] = {0, 0};
+    if (part == 0 || s->cfg.kernelVariant == 1) { if (part == 1) return; end[0] = n; }
+    else if (part == 1) { end[0] = s->srcLowEnd; beg[1] = s->srcHighBeg; end[1] = n; }
+    else { beg[0] = s->srcLowEnd; end[0] = s->srcHighBeg; }
+    const float *pulse = s->pulseT + (size_t)s->step * s->nSources;
+    for (int r = 0; r < 2; r++) {
+        const int64_t c = end[r] - beg[r];
+        if (c <= 0) continue;
+        hipLaunchKernelGGL(inject_sources, dim3(grid_for(c)), dim3(256), 0, s->stream, s->d, s->cfg.typeSource,
+                           s->srcLin + beg[r], s->srcRow + beg[r], s->srcW[0] ? s->srcW[0] + beg[r] : nullptr,
+                           s->srcW[1] ? s->srcW[1] + beg[r] : nullptr, s->srcW[2] ? s->srcW[2] + beg[r] : nullptr, pulse, (long)c);
+    }
+}
+
+// part 0 = whole half-step; 1 = boundary tiles (first/last z-chunk: what a Z-neighbour reads) with their
+// sources; 2 = interior tiles with theirs. Variant 1 has no tiles: part 1 is empty, part 2 is everything.
+static int stress_part(bfd_sim *s, int part)
 {
     int rc = check_ready(s); if (rc) return rc;
+    if (part < 0 || part > 2) BFD_FAIL(-2, "half-step part must be 0, 1 or 2");
     BFD_HIP(hipSetDevice(s->cfg.device));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (s->timing && s->perKernel) { e0 = get_event(s); e1 = get_event(s); hipEventRecord(e0, s->stream); }
-    if (s->cfg.kernelVariant == 1) bfd_launch_stress_v1(s->d, s->stream);
-    else bfd_launch_stress_v2(s->d, s->stream, s->tilesReady ? &s->tiles : nullptr);
+    if (s->cfg.kernelVariant == 1) { if (part != 1) bfd_launch_stress_v1(s->d, s->stream); }
+    else bfd_launch_stress_v2(s->d, s->stream, &s->tiles, part);
     if (e0) { hipEventRecord(e1, s->stream); s->evStress.push_back(e0); s->evStress.push_back(e1); }
-    if (s->nSrcVox && s->cfg.typeSource >= 2 && s->step < s->lengthSource)
-        hipLaunchKernelGGL(inject_sources, dim3(grid_for(s->nSrcVox)), dim3(256), 0, s->stream, s->d, s->cfg.typeSource,
-                           s->srcLin, s->srcRow, s->srcW[0], s->srcW[1], s->srcW[2],
-                           s->pulseT + (size_t)s->step * s->nSources, (long)s->nSrcVox);
+    if (s->nSrcVox && s->cfg.typeSource >= 2 && s->step < s->lengthSource) inject_part(s, part);
     BFD_HIP(hipGetLastError());
     return 0;
 }
 
-int bfd_half_step_velocity(bfd_sim *s)
+static int velocity_part(bfd_sim *s, int part)
 {
     int rc = check_ready(s); if (rc) return rc;
+    if (part < 0 || part > 2) BFD_FAIL(-2, "half-step part must be 0, 1 or 2");
     BFD_HIP(hipSetDevice(s->cfg.device));
     const bfd_dev &d = s->d;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (s->timing && s->perKernel) { e0 = get_event(s); e1 = get_event(s); hipEventRecord(e0, s->stream); }
     const int n = s->step;
     const bool accNow = (s->acc || s->pk) && n >= s->accStart;
-    int qP = -1;   // Pressure is accumulated inside the variant-2 velocity kernel
+    int qP = -1;   // Pressure is accumulated inside the tiled velocity kernels
     if (accNow && s->cfg.kernelVariant != 1)
         for (int q = 0; q < s->nSelR; q++) if (s->selR[q] == BFD_MAP_PRESSURE) qP = q;
-    if (s->cfg.kernelVariant == 1) bfd_launch_velocity_v1(d, s->stream);
+    if (s->cfg.kernelVariant == 1) { if (part != 1) bfd_launch_velocity_v1(d, s->stream); }
     else bfd_launch_velocity_v2(d, s->stream, (qP >= 0 && s->acc) ? s->acc + (size_t)qP * s->nloc : nullptr,
-                                (qP >= 0 && s->pk) ? s->pk + (size_t)qP * s->nloc : nullptr, s->tilesReady ? &s->tiles : nullptr);
+                                (qP >= 0 && s->pk) ? s->pk + (size_t)qP * s->nloc : nullptr, &s->tiles, part);
     if (e0) { hipEventRecord(e1, s->stream); s->evVelocity.push_back(e0); s->evVelocity.push_back(e1); }
-    if (s->nSrcVox && s->cfg.typeSource < 2 && s->step < s->lengthSource)
-        hipLaunchKernelGGL(inject_sources, dim3(grid_for(s->nSrcVox)), dim3(256), 0, s->stream, d, s->cfg.typeSource,
-                           s->srcLin, s->srcRow, s->srcW[0], s->srcW[1], s->srcW[2],
-                           s->pulseT + (size_t)s->step * s->nSources, (long)s->nSrcVox);
+    if (s->nSrcVox && s->cfg.typeSource < 2 && s->step < s->lengthSource) inject_part(s, part);
+    if (part == 1) { BFD_HIP(hipGetLastError()); return 0; }
+    // end of the time step: remaining accumulators, sensors
     if (accNow && !(qP >= 0 && s->nSelR == 1)) {
         SelList L; L.n = s->nSelR; memcpy(L.sel, s->selR, sizeof L.sel);
         for (int q = 0; q < BFD_MAP_COUNT; q++) L.skip[q] = (q == qP);
@@ -736,6 +784,11 @@ int bfd_half_step_velocity(bfd_sim *s)
     s->step++;
     return 0;
 }
+
+int bfd_half_step_stress(bfd_sim *s) { return stress_part(s, 0); }
+int bfd_half_step_velocity(bfd_sim *s) { return velocity_part(s, 0); }
+int bfd_half_step_stress_part(bfd_sim *s, int32_t part) { return stress_part(s, part); }
+int bfd_half_step_velocity_part(bfd_sim *s, int32_t part) { return velocity_part(s, part); }
 
 int bfd_run(bfd_sim *s, int32_t nSteps)
 {

@@ -37,9 +37,9 @@ struct bfd_dev {
 };
 
 // tile lists of the class-specialised path (variant 3): device array
-// [fluid tiles | solid tiles], each in natural order; per tile: flags (bit0 solid, bit1 lossy, bit2 UNI,
-// bit3 PML) and the material id of UNI tiles
-struct bfd_tiles { int *list; int *tileMat; int *tileFlags; int nFluid, nSolid, nLossless, nLossy, nUni, nPml; };
+// [fluid boundary | fluid interior | solid boundary | solid interior] (boundary = first/last z-chunk);
+// per tile: flags (bit0 solid, bit1 lossy, bit2 UNI, bit3 PML) and the material id of UNI tiles
+struct bfd_tiles { int *list; int *tileMat; int *tileFlags; int nFluid, nFluidB, nSolid, nSolidB, nLossless, nLossy, nUni, nPml; };
 
 struct bfd_sim {
     bfd_config cfg;
@@ -58,7 +58,8 @@ struct bfd_sim {
     bfd_tiles tiles; bool tilesReady;   // variant 3
     double cmax;
     // sources
-    int64_t nSrcVox; uint32_t *srcLin, *srcRow; float *srcW[3]; float *pulseT; int nSources, lengthSource;
+    int64_t nSrcVox, srcLowEnd, srcHighBeg;   // sources sorted by voxel: [0,lowEnd) first z-chunk, [highBeg,n) last z-chunk
+    uint32_t *srcLin, *srcRow; float *srcW[3]; float *pulseT; int nSources, lengthSource;
     // sensors
     int64_t nSensors; uint32_t *sensLin; float *sensOut; int nTs; int nSelS; int selS[BFD_MAP_COUNT];
     // accumulators
@@ -86,7 +87,8 @@ void bfd_launch_stress_v1(const bfd_dev &d, hipStream_t s);
 void bfd_launch_velocity_v1(const bfd_dev &d, hipStream_t s);
 void bfd_tile_grid(const bfd_dev &d, int *tilesX, int *tilesY, int *tilesZ);
 void bfd_launch_classify(const bfd_dev &d, hipStream_t s, int *flagsDev, int *tileMatDev);
-// t == nullptr: dense kernels on every tile (variant 2)
-void bfd_launch_stress_v2(const bfd_dev &d, hipStream_t s, const bfd_tiles *t);
+int bfd_tile_zchunk(void);
+// part: 0 = every tile, 1 = boundary tiles, 2 = interior tiles (variant 2 lists every tile as solid)
+void bfd_launch_stress_v2(const bfd_dev &d, hipStream_t s, const bfd_tiles *t, int part);
 // accP / pkP: Pressure RMS / peak accumulators of this step (slab-local, x-fastest) or nullptr
-void bfd_launch_velocity_v2(const bfd_dev &d, hipStream_t s, float *accP, float *pkP, const bfd_tiles *t);
+void bfd_launch_velocity_v2(const bfd_dev &d, hipStream_t s, float *accP, float *pkP, const bfd_tiles *t, int part);

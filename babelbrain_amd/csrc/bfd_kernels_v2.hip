@@ -797,35 +797,45 @@ void bfd_launch_classify(const bfd_dev &d, hipStream_t s, int *flagsDev, int *ti
 
 #define BFD_LAUNCH(K, n, ...) hipLaunchKernelGGL(K, dim3(n), dim3(TX, TY, 1), 0, s, d, tilesX, tilesY, n, __VA_ARGS__)
 
-// tile list layout: [fluid tiles in natural order | solid tiles in natural order]
-void bfd_launch_stress_v2(const bfd_dev &d, hipStream_t s, const bfd_tiles *t)
+int bfd_tile_zchunk(void) { return ZCHUNK; }
+
+// tile list layout: [fluid boundary | fluid interior | solid boundary | solid interior]; "boundary" = the
+// first and the last z-chunk of the slab (the tiles whose planes a Z-neighbour reads).
+// part: 0 = every tile, 1 = boundary tiles, 2 = interior tiles
+static inline void part_range(int n, int nB, int part, int *off, int *cnt)
 {
-    int tilesX, tilesY, tilesZ; bfd_tile_grid(d, &tilesX, &tilesY, &tilesZ);
-    if (!t) {
-        const int nblocks = tilesX * tilesY * tilesZ;
-        BFD_LAUNCH((stress_v2<ZCHUNK>), nblocks, (const int *)nullptr);
-        return;
-    }
-    if (t->nFluid) {
-        if (d.collapsed) BFD_LAUNCH((stress_fluid<ZCHUNK, true>), t->nFluid, t->list, t->tileFlags, t->tileMat);
-        else BFD_LAUNCH((stress_fluid<ZCHUNK, false>), t->nFluid, t->list, t->tileFlags, t->tileMat);
-    }
-    if (t->nSolid) BFD_LAUNCH((stress_v2<ZCHUNK>), t->nSolid, t->list + t->nFluid);
+    if (part == 1) { *off = 0; *cnt = nB; }
+    else if (part == 2) { *off = nB; *cnt = n - nB; }
+    else { *off = 0; *cnt = n; }
 }
 
-void bfd_launch_velocity_v2(const bfd_dev &d, hipStream_t s, float *accP, float *pkP, const bfd_tiles *t)
+void bfd_launch_stress_v2(const bfd_dev &d, hipStream_t s, const bfd_tiles *t, int part)
+{
+    int tilesX, tilesY, tilesZ; bfd_tile_grid(d, &tilesX, &tilesY, &tilesZ);
+    int off, n;
+    part_range(t->nFluid, t->nFluidB, part, &off, &n);
+    if (n) {
+        if (d.collapsed) BFD_LAUNCH((stress_fluid<ZCHUNK, true>), n, t->list + off, t->tileFlags, t->tileMat);
+        else BFD_LAUNCH((stress_fluid<ZCHUNK, false>), n, t->list + off, t->tileFlags, t->tileMat);
+    }
+    part_range(t->nSolid, t->nSolidB, part, &off, &n);
+    if (n) BFD_LAUNCH((stress_v2<ZCHUNK>), n, t->list + t->nFluid + off);
+}
+
+void bfd_launch_velocity_v2(const bfd_dev &d, hipStream_t s, float *accP, float *pkP, const bfd_tiles *t, int part)
 {
     int tilesX, tilesY, tilesZ; bfd_tile_grid(d, &tilesX, &tilesY, &tilesZ);
     const bool acc = accP || pkP;
-    const int nFluid = t ? t->nFluid : 0;
-    const int nDense = t ? t->nSolid : tilesX * tilesY * tilesZ;
-    if (nFluid) {
-        if (acc) BFD_LAUNCH((velocity_fluid<ZCHUNK, true>), nFluid, t->list, t->tileFlags, t->tileMat, accP, pkP);
-        else BFD_LAUNCH((velocity_fluid<ZCHUNK, false>), nFluid, t->list, t->tileFlags, t->tileMat, accP, pkP);
+    int off, n;
+    part_range(t->nFluid, t->nFluidB, part, &off, &n);
+    if (n) {
+        if (acc) BFD_LAUNCH((velocity_fluid<ZCHUNK, true>), n, t->list + off, t->tileFlags, t->tileMat, accP, pkP);
+        else BFD_LAUNCH((velocity_fluid<ZCHUNK, false>), n, t->list + off, t->tileFlags, t->tileMat, accP, pkP);
     }
-    if (nDense) {
-        const int *denseList = t ? t->list + nFluid : nullptr;
-        if (acc) BFD_LAUNCH((velocity_v2<ZCHUNK, true>), nDense, accP, pkP, denseList);
-        else BFD_LAUNCH((velocity_v2<ZCHUNK, false>), nDense, accP, pkP, denseList);
+    part_range(t->nSolid, t->nSolidB, part, &off, &n);
+    if (n) {
+        const int *denseList = t->list + t->nFluid + off;
+        if (acc) BFD_LAUNCH((velocity_v2<ZCHUNK, true>), n, accP, pkP, denseList);
+        else BFD_LAUNCH((velocity_v2<ZCHUNK, false>), n, accP, pkP, denseList);
     }
 }

@@ -42,6 +42,7 @@ class _DevBuf:
 
 class HipSlab:
     """One slab on one MI355X; halo tensors alias the engine's own device memory (zero copy)."""
+    supports_parts = True     # half-steps can run boundary tiles first, so the exchange overlaps the interior
 
     def __init__(self, engine, device):
         import torch
@@ -62,26 +63,37 @@ class HipSlab:
     def halo(self, group, f, side, send):
         return self._t[(group, f, side, int(send))]
 
+    def halo_fields(self):
+        return self.eng.halo_fields()
+
     def before_send(self, group):
         pass
 
     def after_recv(self, group, sides):
         pass
 
-    def half_step_stress(self):
-        self.eng.half_step_stress()
+    def half_step_stress(self, part=0):
+        self.eng.half_step_stress(part)
 
-    def half_step_velocity(self):
-        self.eng.half_step_velocity()
+    def half_step_velocity(self, part=0):
+        self.eng.half_step_velocity(part)
 
     def sync(self):
         self.torch.cuda.synchronize(self.device)
 
 
-class SlabRunner:
-    """Advances one slab in lock-step with its Z-neighbours."""
+ALL_FIELDS = {HALO_VELOCITY: [0, 1, 2], HALO_STRESS: [0, 1, 2]}
 
-    def __init__(self, slab, rank, world, dist=None, group=None):
+
+class SlabRunner:
+    """Advances one slab in lock-step with its Z-neighbours.
+
+    Every rank announces once which halo fields it reads (an all-fluid slab needs only Vz and Szz);
+    across an interface each side sends exactly what the other side reads. If the slab engine can split
+    a half-step (HipSlab), the boundary tiles run first, the exchange is started, and the interior tiles
+    run while the planes travel."""
+
+    def __init__(self, slab, rank, world, dist=None, group=None, overlap=None):
         self.slab, self.rank, self.world, self.group = slab, rank, world, group
         if world > 1 and dist is None:
             import torch.distributed as dist
@@ -89,33 +101,59 @@ class SlabRunner:
         self.low = rank - 1 if rank > 0 else None
         self.high = rank + 1 if rank < world - 1 else None
         self.bytes_sent = 0
+        self.overlap = (getattr(slab, 'supports_parts', False) if overlap is None else overlap) and world > 1
+        mine = slab.halo_fields() if hasattr(slab, 'halo_fields') else ALL_FIELDS
+        self.needs = [mine]
+        if world > 1:
+            self.needs = [None] * world
+            dist.all_gather_object(self.needs, mine, group=group)
 
-    def exchange(self, halo_group):
+    def exchange_start(self, halo_group):
         if self.world == 1:
-            return
+            return []
         dist = self.dist
         s = self.slab
         s.before_send(halo_group)
         ops = []
-        sides = []
-        # the low neighbour's high ghost planes are my low boundary planes, and vice versa
+        # side 0 = my low face <-> peer's high ghosts, side 1 = my high face <-> peer's low ghosts
         for side, peer in ((0, self.low), (1, self.high)):
             if peer is None:
                 continue
-            sides.append(side)
-            for f in range(3):
-                ops.append(dist.P2POp(dist.isend, s.halo(halo_group, f, side, True), peer, self.group))
+            for f in self.needs[peer][halo_group]:          # what the peer reads from me
+                t = s.halo(halo_group, f, side, True)
+                ops.append(dist.P2POp(dist.isend, t, peer, self.group))
+                self.bytes_sent += t.numel() * 4
+            for f in self.needs[self.rank][halo_group]:     # what I read from the peer
                 ops.append(dist.P2POp(dist.irecv, s.halo(halo_group, f, side, False), peer, self.group))
-                self.bytes_sent += s.halo(halo_group, f, side, True).numel() * 4
-        for req in dist.batch_isend_irecv(ops):
+        return dist.batch_isend_irecv(ops) if ops else []
+
+    def exchange_finish(self, reqs, halo_group):
+        if self.world == 1:
+            return
+        for req in reqs:
             req.wait()
-        s.after_recv(halo_group, sides)
+        self.slab.after_recv(halo_group, [sd for sd, p in ((0, self.low), (1, self.high)) if p is not None])
+
+    def exchange(self, halo_group):
+        self.exchange_finish(self.exchange_start(halo_group), halo_group)
 
     def step(self):
-        self.exchange(HALO_VELOCITY)
-        self.slab.half_step_stress()
-        self.exchange(HALO_STRESS)
-        self.slab.half_step_velocity()
+        s = self.slab
+        if self.overlap:
+            # ghosts of V are current on entry (zero before the first step, exchanged at the end of every step)
+            s.half_step_stress(1)
+            w = self.exchange_start(HALO_STRESS)
+            s.half_step_stress(2)
+            self.exchange_finish(w, HALO_STRESS)
+            s.half_step_velocity(1)
+            w = self.exchange_start(HALO_VELOCITY)
+            s.half_step_velocity(2)
+            self.exchange_finish(w, HALO_VELOCITY)
+        else:
+            self.exchange(HALO_VELOCITY)
+            s.half_step_stress()
+            self.exchange(HALO_STRESS)
+            s.half_step_velocity()
 
     def run(self, nSteps):
         for _ in range(nSteps):
