@@ -42,7 +42,7 @@ def parse():
     ap.add_argument('--size', type=int, nargs=3, default=None, help='override per-GPU grid N1 N2 N3')
     ap.add_argument('--variant', type=int, default=0, help='kernel variant (0 default, 1 simple, 2 LDS-tiled)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-sample', type=int, nargs=4, default=[192, 192, 128, 16], help='N1 N2 N3 steps of the oracle sample')
+    ap.add_argument('--cpu-sample', type=int, nargs=4, default=[256, 256, 192, 24], help='N1 N2 N3 steps of the oracle sample')
     return ap.parse_args()
 
 
@@ -72,6 +72,17 @@ def cpu_baseline(args, dt_fn):
     return {'value': n1 * n2 * n3 * steps / secs / 1e6, 'unit': 'Mvoxel-steps/s', 'cores': threads, 'kind': 'port',
             'sample': '%s medium/source on a %dx%dx%d grid, %d steps, OpenMP float32 oracle (oracle/fdtd_oracle.c)' % (args.config, n1, n2, n3, steps),
             'cpu_model': model, 'host_cores': cores}
+
+
+def measured_traffic(args, n1, n2, n3):
+    """HBM bytes per half-step from the committed rocprofv3 PMC profile of this workload, if one exists
+    (profiles/traffic.json, written from the PMC passes of scripts/pmc_passes.sh)."""
+    try:
+        t = json.load(open(os.path.join(ROOT, 'profiles', 'traffic.json')))
+        key = '%s_%dx%dx%d_variant%d' % (args.config, n1, n2, n3, args.variant)
+        return t.get(key, {})
+    except Exception:
+        return {}
 
 
 def main():
@@ -137,12 +148,21 @@ def main():
     value = total_vox * args.steps / wall / 1e6
 
     if rank == 0:
-        st = tm['stress_ms'] / max(tm['n_stress'], 1) * 1e-3
-        ve = tm['velocity_ms'] / max(tm['n_velocity'], 1) * 1e-3
+        st = tm['stress_ms'] / args.steps * 1e-3          # all launches of one stress half-step
+        ve = tm['velocity_ms'] / args.steps * 1e-3        # all launches of one velocity half-step (+ fused Pressure RMS)
         step_dev = tm['total_ms'] / args.steps * 1e-3
         ach_stress = BYTES_STRESS * nvox_rank / st / 1e9
-        ach_vel = BYTES_VELOCITY * nvox_rank / ve / 1e9
+        ach_vel = (BYTES_VELOCITY + BYTES_RMS) * nvox_rank / ve / 1e9
         ach_step = BYTES_STEP * nvox_rank / step_dev / 1e9
+        traffic = measured_traffic(args, n1, n2, n3)
+        # `roofline` describes the half-step that takes longer; the other one is in `roofline_other`
+        halves = {'stress half-step': dict(achieved=ach_stress, frac=ach_stress / HBM_PEAK_GBS, algorithmic_bytes_per_voxel=BYTES_STRESS,
+                                           avg_launch_ms=st * 1e3, traffic=traffic.get('stress')),
+                  'velocity half-step (+ fused Pressure RMS)': dict(achieved=ach_vel, frac=ach_vel / HBM_PEAK_GBS,
+                                                                    algorithmic_bytes_per_voxel=BYTES_VELOCITY + BYTES_RMS,
+                                                                    avg_launch_ms=ve * 1e3, traffic=traffic.get('velocity'))}
+        dom = max(halves, key=lambda n: halves[n]['avg_launch_ms'])
+        oth = [n for n in halves if n != dom][0]
         line = {
             'metric': 'Mvoxel-steps/sec, 512^3 skull FDTD (achieved HBM GB/s in roofline)',
             'value': value, 'unit': 'Mvoxel-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -151,12 +171,14 @@ def main():
             'config': {'workload': '%s: %dx%dx%d per GPU (%dx%dx%d total), %s medium, %s source, PML 12, %d materials, '
                                    'Pressure RMS + sensors on' % (args.config, n1, n2, n3, N[0], N[1], N[2], info['medium'], info['tx'], info['n_mat']),
                        'parallelism': 'z-slab x%d' % world, 'kernel_variant': args.variant, 'dt': info['dt'], 'ppp': info['ppp'],
-                       'n_sources': info['n_sources'], 'n_sensors_rank0': int(eng.num_sensors), 'tiles_rank0': eng.tile_counts()},
-            'roofline': {'bound': 'hbm', 'kernel': 'stress half-step', 'achieved': ach_stress, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': ach_stress / HBM_PEAK_GBS, 'traffic': None,
-                         'algorithmic_bytes_per_voxel': BYTES_STRESS, 'avg_launch_ms': st * 1e3},
-            'roofline_velocity': {'achieved': ach_vel, 'frac': ach_vel / HBM_PEAK_GBS, 'algorithmic_bytes_per_voxel': BYTES_VELOCITY,
-                                  'avg_launch_ms': ve * 1e3},
+                       'n_sources': info['n_sources'], 'n_sensors_rank0': int(eng.num_sensors), 'tiles_rank0': eng.tile_counts(),
+                       'halo_exchange': 'overlapped' if runner.overlap else ('none' if world == 1 else 'blocking')},
+            'roofline': dict(bound='hbm', kernel=dom, peak=HBM_PEAK_GBS, unit='GB/s',
+                             note='achieved = algorithmic bytes (SURVEY 8d) / measured time; the tiled kernels move fewer bytes than '
+                                  'the algorithmic count (exact fluid-tile shortcuts), so frac can exceed 1; traffic = HBM bytes per '
+                                  'launch from rocprofv3 PMC (profiles/), null if no profile matches this grid',
+                             **halves[dom]),
+            'roofline_other': dict(kernel=oth, **halves[oth]),
             'roofline_step': {'achieved': ach_step, 'frac': ach_step / HBM_PEAK_GBS, 'algorithmic_bytes_per_voxel_step': BYTES_STEP,
                               'device_ms_per_step': step_dev * 1e3, 'other_ms_per_step': tm['other_ms'] / args.steps},
             'device_bytes': int(eng.device_bytes), 'host_build_s': t_build,

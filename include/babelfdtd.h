@@ -164,6 +164,15 @@ int bfd_tile_counts(bfd_sim *sim, int32_t *nLossless, int32_t *nLossy, int32_t *
 /* device memory this sim holds, bytes */
 int64_t bfd_device_bytes(bfd_sim *sim);
 
+/* ---- Rayleigh-Sommerfeld integral: replaces BabelViscoFDTD.tools.RayleighAndBHTE.ForwardSimple ----
+ * (call sites BabelIntegrationSingle.py:295, BabelIntegrationANNULAR_ARRAY.py:383,411,
+ * BabelIntegrationCONCAVE_PHASEDARRAY.py:307,328,425,446).
+ *   out[n] = (i k / 2pi) sum_m u0[m] ds[m] exp(-i k R_nm) / R_nm,  k = kReal + i kImag
+ * center: nSrc x 3 float32 (m), ds: nSrc float32 (m^2), u0: nSrc x 2 float32 (re,im),
+ * rf: nPts x 3 float32 (m), out: nPts x 2 float32 (re,im). kernelMs (may be NULL): device time. */
+int bfd_rayleigh_forward(int32_t device, int64_t nSrc, const float *center, const float *ds, const float *u0,
+                         double kReal, double kImag, int64_t nPts, const float *rf, float *out, double *kernelMs);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,21 @@
+"""CPU ORACLE (test infrastructure) for the Rayleigh-Sommerfeld sum that the reference obtains from
+`BabelViscoFDTD.tools.RayleighAndBHTE.ForwardSimple` (package absent from /root/reference; call site
+TranscranialModeling/BabelIntegrationSingle.py:295). PARITY UNPINNED against that package: the formula
+below is the published Rayleigh integral for a baffled velocity source,
+    u2(r) = (i k / 2 pi) sum_m u0_m dS_m exp(-i k R_m) / R_m ,
+evaluated in float64 with numpy. The FDTD-vs-Rayleigh known-answer test (tests/test_oracle_physics.py,
+K5) shows it reproduces the reference's own acceptance study together with the FDTD oracle.
+Only tests/ may import this."""
+import numpy as np
+
+
+def ForwardSimple(cwvnb, center, ds, u0, rf, chunk=2048):
+    k = complex(np.asarray(cwvnb).reshape(-1)[0])
+    cen = np.asarray(center, np.float64).reshape(-1, 3)
+    w = np.asarray(u0).reshape(-1).astype(np.complex128) * np.asarray(ds, np.float64).reshape(-1)
+    pts = np.asarray(rf, np.float64).reshape(-1, 3)
+    out = np.zeros(len(pts), np.complex128)
+    for a in range(0, len(pts), chunk):
+        R = np.sqrt(((pts[a:a + chunk, None, :] - cen[None, :, :]) ** 2).sum(axis=2))
+        out[a:a + chunk] = (np.exp(-1j * k * R) / R) @ w
+    return 1j * k / (2 * np.pi) * out

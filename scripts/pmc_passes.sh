@@ -8,5 +8,5 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_BUS
   i=$((i+1))
   timeout 300 rocprofv3 --pmc $grp --output-format csv -d gpurun_out/pmc_$tag/p$i -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline "$@" > gpurun_out/pmc_$tag/p$i.log 2>&1
 done
-python3 scripts/pmc_summary.py gpurun_out/pmc_$tag > gpurun_out/pmc_$tag/summary.txt
+python3 scripts/pmc_summary.py gpurun_out/pmc_$tag ${TRAFFIC_KEY:-C3_512x512x512_variant0} > gpurun_out/pmc_$tag/summary.txt
 cat gpurun_out/pmc_$tag/summary.txt

@@ -15,6 +15,14 @@ for f in glob.glob(root + '/p*/**/*counter_collection.csv', recursive=True):
             agg[short]['VGPR'].append(float(r['VGPR_Count'])); agg[short]['SGPR'].append(float(r['SGPR_Count']))
             agg[short]['LDS'].append(float(r['LDS_Block_Size']))
             agg[short]['dur_us'].append((float(r['End_Timestamp']) - float(r['Start_Timestamp'])) / 1e3)
+import json
+traffic = {'stress': 0.0, 'velocity': 0.0}
+for k, d in agg.items():
+    if 'FETCH_SIZE' in d and 'WRITE_SIZE' in d and ('stress' in k or 'velocity' in k):
+        f = sum(d['FETCH_SIZE']) / len(d['FETCH_SIZE']); w = sum(d['WRITE_SIZE']) / len(d['WRITE_SIZE'])
+        traffic['stress' if 'stress' in k else 'velocity'] += (2 * f + w) * 1024     # gfx950: FETCH_SIZE counts half the read bytes
+if len(sys.argv) > 2:
+    json.dump({sys.argv[2]: traffic}, open(root + '/traffic.json', 'w'))
 for k, d in sorted(agg.items()):
     print('==', k)
     for c, v in sorted(d.items()):
