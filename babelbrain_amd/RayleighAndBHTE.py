@@ -38,7 +38,7 @@ InitCuda = InitOpenCL = InitMetal = InitHIP = _init
 
 def ForwardSimple(cwvnb, center, ds, u0, rf, deviceMetal=None, MacOsPlatform=None, u0step=0):
     """u2[n] = (i k / 2 pi) sum_m u0[m] ds[m] exp(-i k |rf[n]-center[m]|) / |rf[n]-center[m]|.
-    cwvnb: complex wavenumber (imag >= 0 attenuates); center (M,3) f32; ds (M,) or (M,1) f32;
+    cwvnb: complex wavenumber (Im k < 0 attenuates: the sum uses exp(-i k R) as written); center (M,3) f32; ds (M,) or (M,1) f32;
     u0 (M,) or (M,1) complex64; rf (N,3) f32. Returns complex64 (N,)."""
     global last_kernel_ms
     lib = _engine.load_library()

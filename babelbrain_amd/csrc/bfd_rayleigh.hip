@@ -7,7 +7,7 @@
 //                                   TranscranialModeling/BabelIntegrationSingle.py:295
 //     (also BabelIntegrationANNULAR_ARRAY.py:383,411; BabelIntegrationCONCAVE_PHASEDARRAY.py:307,328,425,446)
 //
-//     u2(r_n) = (i k / 2 pi) * sum_m u0_m dS_m exp(-i k R_nm) / R_nm ,   k = k_r + i k_i  (k_i >= 0 attenuates)
+//     u2(r_n) = (i k / 2 pi) * sum_m u0_m dS_m exp(-i k R_nm) / R_nm ,   k = k_r + i k_i  (k_i < 0 attenuates)
 //
 // Bound: vector ALU (not HBM, not MFMA: one sqrt + one sincos per source/point pair, no matrix shape).
 // One thread per field point; sources are staged through LDS in blocks and read as broadcasts.
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(RB) void rayleigh_forward(const float *__restrict__
                 float sn, cs;
                 sincosf(fr * 6.283185307179586f, &sn, &cs);
                 float amp = (float)inv;
-                if (ki != 0.0) amp *= expf((float)(-ki * R));
+                if (ki != 0.0) amp *= expf((float)(ki * R));     // exp(-i k R) with complex k: Im k < 0 attenuates
                 // exp(-i k R) = amp * (cos - i sin)
                 const float er = amp * cs, ei = -amp * sn;
                 accr += (double)(sre[q] * er - sim[q] * ei);

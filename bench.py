@@ -95,7 +95,7 @@ def main():
             raise SystemExit('launch with torch.distributed.run --nproc-per-node %d for --gpus %d' % (args.gpus, args.gpus))
         args.gpus = world
     import torch
-    from babelbrain_amd import _engine, harness as H, slab
+    from babelbrain_amd import _engine, harness as H, slab, RayleighAndBHTE
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (the HIP engine has no CPU fallback)')
     torch.cuda.set_device(local_rank)
@@ -113,11 +113,12 @@ def main():
     nt = args.steps + args.warmup
     t0 = time.time()
     if world == 1:
-        a, k, info = H.make_problem(args.config, N=N, steps=nt, stable_dt_fn=dt_fn)
+        a, k, info = H.make_problem(args.config, N=N, steps=nt, stable_dt_fn=dt_fn, forward=RayleighAndBHTE.ForwardSimple)
         local = None
     else:   # every rank builds only its own Z-slab of the domain
         k0, nk = slab.partition(N[2], world)[rank]
-        a, k, info = H.make_problem(args.config, N=N, steps=nt, stable_dt_fn=dt_fn, zslab=(k0, nk))
+        RayleighAndBHTE._device = local_rank
+        a, k, info = H.make_problem(args.config, N=N, steps=nt, stable_dt_fn=dt_fn, zslab=(k0, nk), forward=RayleighAndBHTE.ForwardSimple)
         local = (N[2], k0, nk) + tuple(info['ghost'])
     t_build = time.time() - t0
     s, sinfo = slab.create_hip_slab(a, k, rank, world, local_rank, kernelVariant=args.variant, local=local)
@@ -183,7 +184,7 @@ def main():
                               'device_ms_per_step': step_dev * 1e3, 'other_ms_per_step': tm['other_ms'] / args.steps},
             'device_bytes': int(eng.device_bytes), 'host_build_s': t_build,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             try:
                 line['cpu_baseline'] = cpu_baseline(args, dt_fn)
             except Exception as e:   # the baseline is a reported extra; never lose the GPU line over it
