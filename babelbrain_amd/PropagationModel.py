@@ -87,7 +87,8 @@ class PropagationModel:
                                          QfactorCorrection=True, QCorrection=1.0, TypeSource=0, SelRMSorPeak=1,
                                          SelMapsRMSPeakList=('ALLV',), SelMapsSensorsList=('Vx', 'Vy', 'Vz'),
                                          SensorSubSampling=2, SensorStart=0, DefaultGPUDeviceName='MI355X',
-                                         DefaultGPUDeviceNumber=None, ReflectorMask=None, SILENT=False, **unused):
+                                         DefaultGPUDeviceNumber=None, ReflectorMask=None, SILENT=False,
+                                         ReturnSensorDFT=False, **unused):
         if not USE_SINGLE:
             raise NotImplementedError('the MI355X engine computes in float32 (USE_SINGLE=True, BASE:2354)')
         MaterialMap = np.asarray(MaterialMap)
@@ -125,6 +126,12 @@ class PropagationModel:
                 Sensor[name] = sens[q]
             InputParam = {'IndexSensorMap': eng.sensor_index(), 'DT': DT, 'nt': nt,
                           'device_bytes': eng.device_bytes, 'timing': self.last_timing}
+            if ReturnSensorDFT:
+                # extension: what CalculatePhaseData extracts from the sensor block
+                # (BASE:2498-2520), computed on the device
+                F, pk = eng.sensor_dft(Frequency)
+                InputParam['SensorDFT'] = {name: F[q] for q, name in enumerate(eng.selS)}
+                InputParam['SensorPeak'] = {name: pk[q] for q, name in enumerate(eng.selS)}
             LastMap = {name: eng.get_map(KIND_LAST, name) for name in eng.selR}
             out = [Sensor, LastMap]
             if SelRMSorPeak & 1:

@@ -25,7 +25,7 @@ ABI_SYMBOLS = [
     'bfd_set_material_map', 'bfd_set_reflector', 'bfd_set_sources', 'bfd_set_sensor_map', 'bfd_run',
     'bfd_half_step_stress', 'bfd_half_step_velocity', 'bfd_half_step_stress_part', 'bfd_half_step_velocity_part', 'bfd_sync', 'bfd_current_step', 'bfd_halo_region',
     'bfd_timing_begin', 'bfd_timing_end', 'bfd_num_sensors', 'bfd_num_sensor_steps', 'bfd_get_sensor_index',
-    'bfd_get_sensors', 'bfd_get_map', 'bfd_get_field', 'bfd_tile_counts', 'bfd_device_bytes', 'bfd_rayleigh_forward',
+    'bfd_get_sensors', 'bfd_get_map', 'bfd_get_field', 'bfd_tile_counts', 'bfd_device_bytes', 'bfd_rayleigh_forward', 'bfd_get_sensor_dft', 'bfd_dft_series',
 ]
 
 
@@ -92,6 +92,8 @@ def load_library():
     lib.bfd_tile_counts.argtypes = [C.c_void_p] + [C.POINTER(C.c_int32)] * 5
     lib.bfd_device_bytes.restype = C.c_int64
     lib.bfd_device_name.argtypes = [C.c_int, C.c_char_p, C.c_int]
+    lib.bfd_get_sensor_dft.argtypes = [C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]
+    lib.bfd_dft_series.argtypes = [C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_double, C.c_double, C.c_void_p, C.c_void_p]
     lib.bfd_rayleigh_forward.argtypes = [C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double,
                                          C.c_int64, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
     if lib.bfd_abi_version() != 1:
@@ -159,6 +161,17 @@ def material_tables(MaterialList, Frequency, QfactorCorrection, SpatialStep, dt,
                                    float(SpatialStep), float(dt), _ptr(t), _ptr(c1k2), C.byref(cmax)),
            'bfd_material_tables')
     return t, c1k2, cmax.value
+
+
+def dft_series(series, dt_sensor, freq, device=0):
+    """Device single-bin DFT (+ peak) of a host (nSensor, nTs) float32 series: bfd_dft_series."""
+    lib = load_library()
+    x = np.ascontiguousarray(series, np.float32)
+    F = np.zeros(x.shape[0], np.complex64)
+    pk = np.zeros(x.shape[0], np.float32)
+    _check(lib.bfd_dft_series(device, x.shape[0], x.shape[1], _ptr(x), float(dt_sensor), float(freq), _ptr(F.view(np.float32)), _ptr(pk)),
+           'bfd_dft_series')
+    return F, pk
 
 
 class Engine:
@@ -306,6 +319,13 @@ class Engine:
         out = np.zeros((len(self.selS), self.num_sensors, max(self.num_sensor_steps, 0)), np.float32)
         _check(self.lib.bfd_get_sensors(self.h, _ptr(out)), 'bfd_get_sensors')
         return out
+
+    def sensor_dft(self, freq):
+        """(F, peak): complex64 and float32 arrays [nSelSensors][nSensors] (bfd_get_sensor_dft)."""
+        F = np.zeros((len(self.selS), self.num_sensors), np.complex64)
+        pk = np.zeros((len(self.selS), self.num_sensors), np.float32)
+        _check(self.lib.bfd_get_sensor_dft(self.h, float(freq), _ptr(F.view(np.float32)), _ptr(pk)), 'bfd_get_sensor_dft')
+        return F, pk
 
     def get_map(self, kind, name, out=None):
         if out is None:

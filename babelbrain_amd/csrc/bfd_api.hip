@@ -259,6 +259,27 @@ __global__ void transpose_sensors(const float *__restrict__ in, float *__restric
     }
 }
 
+// single-bin DFT + peak of sensor series. x(s,n) = in[s*sS + n*sN]; out[s] = (2/nTs) sum_n x exp(-2 pi i bin n/nTs)
+__global__ void dft_series(const float *__restrict__ in, long sS, long sN, long nSens, int nTs, int bin,
+                           float *__restrict__ outReIm, float *__restrict__ outPeak)
+{
+    for (long s = (long)blockIdx.x * blockDim.x + threadIdx.x; s < nSens; s += (long)gridDim.x * blockDim.x) {
+        double re = 0.0, im = 0.0;
+        float pk = -INFINITY;
+        for (int n = 0; n < nTs; n++) {
+            const float x = in[s * sS + n * sN];
+            const int r = (int)(((long)bin * n) % nTs);                 // exact phase index
+            double sn, cs;
+            sincospi(2.0 * (double)r / (double)nTs, &sn, &cs);
+            re += (double)x * cs; im -= (double)x * sn;
+            pk = fmaxf(pk, x);
+        }
+        const double sc = 2.0 / (double)nTs;
+        outReIm[2 * s] = (float)(re * sc); outReIm[2 * s + 1] = (float)(im * sc);
+        if (outPeak) outPeak[s] = pk;
+    }
+}
+
 // sources. typeSource 0/1: velocity (after the velocity half-step), 2/3: normal stresses (after the stress half-step)
 __global__ void inject_sources(bfd_dev d, int typeSource, const uint32_t *__restrict__ lin, const uint32_t *__restrict__ row,
                                const float *__restrict__ wx, const float *__restrict__ wy, const float *__restrict__ wz,
@@ -956,6 +977,70 @@ int bfd_get_field(bfd_sim *s, int32_t a, float *out, int64_t s1, int64_t s2, int
     BFD_HIP(hipSetDevice(s->cfg.device));
     expand_if_collapsed(s);
     return download_volume(s, s->stateBase[a] + 2 * (size_t)s->d.plane, out, s1, s2, s3);
+}
+
+// numpy.fft.fftfreq(n, d) bin closest to freq (first minimum, like np.argmin; BASE:2498-2499)
+static int dft_bin(int n, double d, double freq)
+{
+    int best = 0; double bd = INFINITY;
+    for (int k = 0; k < n; k++) {
+        const int kk = (k < (n + 1) / 2) ? k : k - n;
+        const double f = (double)kk / ((double)n * d);
+        const double e = fabs(f - freq);
+        if (e < bd) { bd = e; best = k; }
+    }
+    return best;
+}
+
+int bfd_get_sensor_dft(bfd_sim *s, double freq, float *outReIm, float *outPeak)
+{
+    if (!s) BFD_FAIL(-1, "null sim");
+    const size_t n = (size_t)s->nSelS * (size_t)s->nSensors;
+    if (!n || s->nTs <= 0) return 0;
+    if (!outReIm || !s->sensOut) BFD_FAIL(-1, "bfd_get_sensor_dft: null argument");
+    BFD_HIP(hipSetDevice(s->cfg.device));
+    const int bin = dft_bin(s->nTs, s->cfg.dt * s->cfg.sensorSub, freq);
+    float *dre = nullptr, *dpk = nullptr;
+    BFD_HIP(hipMalloc((void **)&dre, 2 * n * sizeof(float)));
+    hipError_t e = hipMalloc((void **)&dpk, n * sizeof(float));
+    for (int q = 0; q < s->nSelS && e == hipSuccess; q++) {      // device block is [q][nTs][nSensors]
+        hipLaunchKernelGGL(dft_series, dim3(grid_for(s->nSensors)), dim3(256), 0, s->stream,
+                           s->sensOut + (size_t)q * s->nTs * s->nSensors, 1L, (long)s->nSensors, (long)s->nSensors, s->nTs, bin,
+                           dre + 2 * (size_t)q * s->nSensors, dpk + (size_t)q * s->nSensors);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(outReIm, dre, 2 * n * sizeof(float), hipMemcpyDeviceToHost, s->stream);
+    if (e == hipSuccess && outPeak) e = hipMemcpyAsync(outPeak, dpk, n * sizeof(float), hipMemcpyDeviceToHost, s->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+    hipFree(dre); if (dpk) hipFree(dpk);
+    if (e != hipSuccess) BFD_FAIL(-10, std::string("bfd_get_sensor_dft: ") + hipGetErrorString(e));
+    return 0;
+}
+
+int bfd_dft_series(int32_t device, int64_t nSensors, int32_t nTs, const float *series, double dtSensor, double freq,
+                   float *outReIm, float *outPeak)
+{
+    if (nSensors < 0 || nTs <= 0 || (nSensors && (!series || !outReIm))) BFD_FAIL(-1, "bfd_dft_series: bad argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) BFD_FAIL(-3, "bfd_dft_series: no HIP device available (no CPU fallback)");
+    if (device < 0 || device >= ndev) BFD_FAIL(-3, "bfd_dft_series: device ordinal out of range");
+    if (!nSensors) return 0;
+    BFD_HIP(hipSetDevice(device));
+    const size_t n = (size_t)nSensors;
+    float *din = nullptr, *dre = nullptr, *dpk = nullptr;
+    hipError_t e = hipMalloc((void **)&din, n * nTs * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void **)&dre, 2 * n * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void **)&dpk, n * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(din, series, n * nTs * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(dft_series, dim3(grid_for((long)n)), dim3(256), 0, 0, din, (long)nTs, 1L, (long)n, nTs, dft_bin(nTs, dtSensor, freq), dre, dpk);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(outReIm, dre, 2 * n * sizeof(float), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && outPeak) e = hipMemcpy(outPeak, dpk, n * sizeof(float), hipMemcpyDeviceToHost);
+    if (din) hipFree(din); if (dre) hipFree(dre); if (dpk) hipFree(dpk);
+    if (e != hipSuccess) BFD_FAIL(-10, std::string("bfd_dft_series: ") + hipGetErrorString(e));
+    return 0;
 }
 
 int bfd_tile_counts(bfd_sim *s, int32_t *nLossless, int32_t *nLossy, int32_t *nSolid, int32_t *nUni, int32_t *nPml)

@@ -153,6 +153,15 @@ int32_t bfd_num_sensor_steps(bfd_sim *sim);
 int bfd_get_sensor_index(bfd_sim *sim, uint32_t *index);
 /* out[nSelSensors][nSensors][nTs] float32, maps in ascending BFD_MAP_* order (BASE:2507: FFT along axis 1) */
 int bfd_get_sensors(bfd_sim *sim, float *out);
+/* Single-frequency content of the recorded sensor series, computed on the device: replaces the host
+ * FFT + bin pick of CalculatePhaseData (BASE:2498-2520) without moving the (nSensor x nTs) block.
+ *   F[q][s] = (2/nTs) sum_n x[q][s][n] exp(-2 pi i bin n / nTs),  bin = argmin |fftfreq(nTs, DT*SensorSubSampling) - freq|
+ *   peak[q][s] = max_n x[q][s][n]                                                   (BASE:2518)
+ * outReIm: [nSelSensors][nSensors][2] float32, outPeak (may be NULL): [nSelSensors][nSensors]. */
+int bfd_get_sensor_dft(bfd_sim *sim, double freq, float *outReIm, float *outPeak);
+/* the same transform for a host series [nSensors][nTs] (row-major), sampling period dtSensor */
+int bfd_dft_series(int32_t device, int64_t nSensors, int32_t nTs, const float *series, double dtSensor, double freq,
+                   float *outReIm, float *outPeak);
 /* one accumulated volume of this slab into a strided (N1,N2,nk) float32 view */
 int bfd_get_map(bfd_sim *sim, int32_t kind, int32_t map, float *out, int64_t s1, int64_t s2, int64_t s3);
 /* raw state array a (0..14: Vx Vy Vz Sxx Syy Szz Sxy Sxz Syz Rxx Ryy Rzz Rxy Rxz Ryz), for tests */
