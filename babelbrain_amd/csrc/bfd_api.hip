@@ -667,46 +667,105 @@ int bfd_set_sensor_map(bfd_sim *s, const uint32_t *map, int64_t s1, int64_t s2, 
     return 0;
 }
 
-// variant 0/3: split the tiles into lossless-fluid / lossy-fluid / solid lists (bfd_kernels_v2.hip)
+// Build the run lists of the tiled kernels (bfd_kernels_v2.hip). Sub-tiles of 64 x 8 x 8 cells are
+// classified on the device; consecutive sub-tiles of one (bx,by) column with identical class merge into
+// runs that never cross a 32-plane chunk boundary. Variant 2: every sub-tile counts as solid (dense kernels).
 static int build_tile_lists(bfd_sim *s)
 {
-    int tx, ty, tz; bfd_tile_grid(s->d, &tx, &ty, &tz);
-    const int n = tx * ty * tz;
-    int rc = dev_alloc(s, &s->tiles.tileMat, (size_t)n, false);
-    if (!rc) rc = dev_alloc(s, &s->tiles.tileFlags, (size_t)n, false);
-    if (rc) return rc;
-    std::vector<int> flags(n), list;
-    if (s->cfg.kernelVariant == 2) {
-        flags.assign(n, 1);        // dense kernels everywhere: every tile goes to the "solid" list
-        BFD_HIP(hipMemcpyAsync(s->tiles.tileFlags, flags.data(), n * sizeof(int), hipMemcpyHostToDevice, s->stream));
-        BFD_HIP(hipMemsetAsync(s->tiles.tileMat, 0, n * sizeof(int), s->stream));
-    } else {
-        bfd_launch_classify(s->d, s->stream, s->tiles.tileFlags, s->tiles.tileMat);
-        BFD_HIP(hipMemcpyAsync(flags.data(), s->tiles.tileFlags, n * sizeof(int), hipMemcpyDeviceToHost, s->stream));
+    int tx, ty, nsub; bfd_tile_grid(s->d, &tx, &ty, &nsub);
+    const int n = tx * ty * nsub;
+    const int SUB = bfd_tile_subz(), perChunk = bfd_tile_zchunk() / SUB;
+    const int nChunks = (nsub + perChunk - 1) / perChunk;
+    std::vector<int> flags(n, 1), mats(n, 0);
+    if (s->cfg.kernelVariant != 2) {
+        int *dflags = nullptr, *dmats = nullptr;
+        BFD_HIP(hipMalloc((void **)&dflags, n * sizeof(int)));
+        hipError_t e = hipMalloc((void **)&dmats, n * sizeof(int));
+        if (e == hipSuccess) {
+            bfd_launch_classify(s->d, s->stream, dflags, dmats);
+            e = hipMemcpyAsync(flags.data(), dflags, n * sizeof(int), hipMemcpyDeviceToHost, s->stream);
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(mats.data(), dmats, n * sizeof(int), hipMemcpyDeviceToHost, s->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+        hipFree(dflags); if (dmats) hipFree(dmats);
+        if (e != hipSuccess) BFD_FAIL(-10, std::string("classify tiles: ") + hipGetErrorString(e));
     }
-    BFD_HIP(hipStreamSynchronize(s->stream));
-    list.reserve(n);
-    // flags: bit0 solid, bit1 lossy, bit2 UNI, bit3 PML
     bfd_tiles &T = s->tiles;
-    T.nFluid = T.nFluidB = T.nSolid = T.nSolidB = T.nLossless = T.nLossy = T.nUni = T.nPml = 0;
-    auto boundary = [&](int t) { const int bz = t / (tx * ty); return bz == 0 || bz == tz - 1; };
-    for (int pass = 0; pass < 2; pass++)
-        for (int t = 0; t < n; t++) if (!(flags[t] & 1) && boundary(t) == (pass == 0)) {
-            list.push_back(t); T.nFluid++;
-            if (pass == 0) T.nFluidB++;
-            if (flags[t] & 2) T.nLossy++; else T.nLossless++;
-            if (flags[t] & 4) T.nUni++;
-            if (flags[t] & 8) T.nPml++;
+    T.nFluid = T.nFluidB = T.nSolid = T.nSolidB = T.nLossless = T.nLossy = T.nSolidSub = T.nUni = T.nPml = 0;
+    std::vector<int4> lists[4];      // fluid boundary, fluid interior, solid boundary, solid interior
+    for (int txy = 0; txy < tx * ty; txy++)
+        for (int c = 0; c < nChunks; c++) {
+            const bool bnd = (c == 0 || c == nChunks - 1);
+            const int sb = c * perChunk, se = std::min(sb + perChunk, nsub);
+            int q = sb;
+            while (q < se) {
+                const int f = flags[(size_t)q * tx * ty + txy], m = mats[(size_t)q * tx * ty + txy];
+                const bool solid = f & 1;
+                int r = q + 1;
+                while (r < se) {
+                    const int f2 = flags[(size_t)r * tx * ty + txy], m2 = mats[(size_t)r * tx * ty + txy];
+                    if (solid ? !(f2 & 1) : (f2 != f || ((f & 4) && m2 != m))) break;
+                    r++;
+                }
+                const int kbeg = q * SUB, kend = std::min(r * SUB, s->d.nk);
+                int4 run; run.x = txy; run.y = kbeg | (kend << 16); run.z = solid ? 1 : f; run.w = m;
+                lists[(solid ? 2 : 0) + (bnd ? 0 : 1)].push_back(run);
+                for (int u = q; u < r; u++) {
+                    if (solid) T.nSolidSub++;
+                    else { if (f & 2) T.nLossy++; else T.nLossless++; if (f & 4) T.nUni++; if (f & 8) T.nPml++; }
+                }
+                q = r;
+            }
         }
-    for (int pass = 0; pass < 2; pass++)
-        for (int t = 0; t < n; t++) if ((flags[t] & 1) && boundary(t) == (pass == 0)) {
-            list.push_back(t); T.nSolid++;
-            if (pass == 0) T.nSolidB++;
-        }
-    rc = dev_alloc(s, &s->tiles.list, (size_t)n, false);
+    T.nFluidB = (int)lists[0].size(); T.nFluid = T.nFluidB + (int)lists[1].size();
+    T.nSolidB = (int)lists[2].size(); T.nSolid = T.nSolidB + (int)lists[3].size();
+    std::vector<int4> all;
+    for (int a = 0; a < 4; a++) all.insert(all.end(), lists[a].begin(), lists[a].end());
+    int rc = dev_alloc(s, &s->tiles.runs, all.size(), false);
     if (rc) return rc;
-    BFD_HIP(hipMemcpy(s->tiles.list, list.data(), n * sizeof(int), hipMemcpyHostToDevice));
+    BFD_HIP(hipMemcpy(s->tiles.runs, all.data(), all.size() * sizeof(int4), hipMemcpyHostToDevice));
+    s->tiles.rowFlags = nullptr; s->tiles.shearCells = nullptr; s->tiles.shearCoef = nullptr;
+    s->tiles.nShear = s->tiles.shearLowEnd = s->tiles.shearHighBeg = 0;
+    if (T.nSolid && s->cfg.kernelVariant != 2) {     // variant 2 stays monolithic and fully dense
+        // row classes inside solid runs
+        rc = dev_alloc(s, &s->tiles.rowFlags, (size_t)T.nSolid * bfd_tile_zchunk(), true);
+        if (rc) return rc;
+        bfd_launch_classify_rows(s->d, s->stream, s->tiles.runs + T.nFluid, T.nSolid, s->tiles.rowFlags);
+        // sparse shear list: cells with a solid centre, ascending index, + their edge coefficients
+        unsigned char *flag = nullptr; unsigned *sel = nullptr; int *dcount = nullptr; void *work = nullptr;
+        hipError_t e = hipMalloc((void **)&flag, s->nloc);
+        if (e == hipSuccess) e = hipMalloc((void **)&sel, s->nloc * sizeof(unsigned));
+        if (e == hipSuccess) e = hipMalloc((void **)&dcount, sizeof(int));
+        int count = 0;
+        if (e == hipSuccess) {
+            bfd_launch_mark_solid(s->d, s->stream, flag, (long)s->nloc);
+            size_t wbytes = 0;
+            hipcub::CountingInputIterator<unsigned> ids(0);
+            e = hipcub::DeviceSelect::Flagged(nullptr, wbytes, ids, flag, sel, dcount, (int)s->nloc, s->stream);
+            if (e == hipSuccess) e = hipMalloc(&work, std::max<size_t>(wbytes, 1));
+            if (e == hipSuccess) e = hipcub::DeviceSelect::Flagged(work, wbytes, ids, flag, sel, dcount, (int)s->nloc, s->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(&count, dcount, sizeof(int), hipMemcpyDeviceToHost, s->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+        }
+        std::vector<unsigned> hostCells((size_t)count);
+        if (e == hipSuccess && count) e = hipMemcpy(hostCells.data(), sel, (size_t)count * sizeof(unsigned), hipMemcpyDeviceToHost);
+        if (e == hipSuccess) {
+            rc = dev_alloc(s, &s->tiles.shearCells, (size_t)std::max(count, 1), false);
+            if (!rc) rc = dev_alloc(s, &s->tiles.shearCoef, 6 * (size_t)std::max(count, 1), false);
+            if (!rc && count) e = hipMemcpyAsync(s->tiles.shearCells, sel, (size_t)count * sizeof(unsigned), hipMemcpyDeviceToDevice, s->stream);
+            if (!rc && e == hipSuccess) bfd_launch_shear_coefficients(s->d, s->stream, s->tiles.shearCells, s->tiles.shearCoef, count);
+            if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+        }
+        if (flag) hipFree(flag); if (sel) hipFree(sel); if (dcount) hipFree(dcount); if (work) hipFree(work);
+        if (e != hipSuccess) BFD_FAIL(-10, std::string("shear list: ") + hipGetErrorString(e));
+        if (rc) return rc;
+        s->tiles.nShear = count;
+        const unsigned zc = (unsigned)bfd_tile_zchunk() * (unsigned)s->d.plane;
+        s->tiles.shearLowEnd = std::lower_bound(hostCells.begin(), hostCells.end(), zc) - hostCells.begin();
+        s->tiles.shearHighBeg = nChunks > 1 ? std::lower_bound(hostCells.begin(), hostCells.end(), zc * (unsigned)(nChunks - 1)) - hostCells.begin() : count;
+    }
     const int nC = T.nSolid;
+    const int tz = nChunks;
     // per-component normal stresses are needed only by solid tiles or by a Sigma** output selection
     const uint32_t sig = (1u << BFD_MAP_SIGMAXX) | (1u << BFD_MAP_SIGMAYY) | (1u << BFD_MAP_SIGMAZZ);
     s->d.collapsed = (nC == 0 && ((s->cfg.selMapsRMS | s->cfg.selMapsSensors) & sig) == 0) ? 1 : 0;
@@ -1048,7 +1107,7 @@ int bfd_tile_counts(bfd_sim *s, int32_t *nLossless, int32_t *nLossy, int32_t *nS
     int rc = check_ready(s); if (rc) return rc;
     if (nLossless) *nLossless = s->tilesReady ? s->tiles.nLossless : 0;
     if (nLossy) *nLossy = s->tilesReady ? s->tiles.nLossy : 0;
-    if (nSolid) *nSolid = s->tilesReady ? s->tiles.nSolid : 0;
+    if (nSolid) *nSolid = s->tilesReady ? s->tiles.nSolidSub : 0;
     if (nUni) *nUni = s->tilesReady ? s->tiles.nUni : 0;
     if (nPml) *nPml = s->tilesReady ? s->tiles.nPml : 0;
     return 0;

@@ -37,9 +37,12 @@ struct bfd_dev {
 };
 
 // tile lists of the class-specialised path (variant 3): device array
-// [fluid boundary | fluid interior | solid boundary | solid interior] (boundary = first/last z-chunk);
-// per tile: flags (bit0 solid, bit1 lossy, bit2 UNI, bit3 PML) and the material id of UNI tiles
-struct bfd_tiles { int *list; int *tileMat; int *tileFlags; int nFluid, nFluidB, nSolid, nSolidB, nLossless, nLossy, nUni, nPml; };
+// runs [fluid boundary | fluid interior | solid boundary | solid interior] (boundary = inside the first/last
+// 32 planes); run = (bx + tilesX*by, kbeg | kend<<16, flags: bit0 solid, bit1 lossy, bit2 UNI, bit3 PML, material
+// id of UNI runs). n* counters after nSolidB are in 64x8x8 sub-tiles, for reporting.
+struct bfd_tiles { int4 *runs; unsigned short *rowFlags /* per solid run x 32 planes, see stress_normal_solid */;
+                   unsigned *shearCells; float *shearCoef; long nShear, shearLowEnd, shearHighBeg;   /* sparse shear list */
+                   int nFluid, nFluidB, nSolid, nSolidB; int nLossless, nLossy, nSolidSub, nUni, nPml; };
 
 struct bfd_sim {
     bfd_config cfg;
@@ -85,8 +88,12 @@ void bfd_set_error(const std::string &s);
 // kernel launchers (bfd_kernels_*.hip)
 void bfd_launch_stress_v1(const bfd_dev &d, hipStream_t s);
 void bfd_launch_velocity_v1(const bfd_dev &d, hipStream_t s);
-void bfd_tile_grid(const bfd_dev &d, int *tilesX, int *tilesY, int *tilesZ);
+void bfd_tile_grid(const bfd_dev &d, int *tilesX, int *tilesY, int *subZ);
+int bfd_tile_subz(void);
 void bfd_launch_classify(const bfd_dev &d, hipStream_t s, int *flagsDev, int *tileMatDev);
+void bfd_launch_mark_solid(const bfd_dev &d, hipStream_t s, unsigned char *flag, long n);
+void bfd_launch_shear_coefficients(const bfd_dev &d, hipStream_t s, const unsigned *cells, float *coef, long n);
+void bfd_launch_classify_rows(const bfd_dev &d, hipStream_t s, const int4 *solidRuns, int nSolid, unsigned short *rowFlags);
 int bfd_tile_zchunk(void);
 // part: 0 = every tile, 1 = boundary tiles, 2 = interior tiles (variant 2 lists every tile as solid)
 void bfd_launch_stress_v2(const bfd_dev &d, hipStream_t s, const bfd_tiles *t, int part);

@@ -16,6 +16,7 @@
 //    share one L2.
 //  * Arithmetic is the canonical float32 sequence of oracle/fdtd_oracle.c (no contraction).
 #include "bfd_internal.h"
+#include <algorithm>
 
 namespace {
 
@@ -26,6 +27,11 @@ constexpr int LH = TY + 4;          // LDS rows
 constexpr int NTHREADS = TX * TY;   // 512
 constexpr int YT = 4 * TX;          // y-halo tasks per array (4 rows x 64)
 constexpr int XT = 4 * TY;          // x-halo tasks per array (4 cols x TY)
+constexpr int ZCHUNK = 32;          // longest z-run one workgroup marches
+#ifndef BFD_SUBZ
+#define BFD_SUBZ 8
+#endif
+constexpr int SUBZ = BFD_SUBZ;             // z granularity of the fluid/solid classification (runs are merged sub-tiles)
 #ifndef STRESS_WAVES_PER_SIMD
 #define STRESS_WAVES_PER_SIMD 4     // 2 workgroups of 8 waves per CU (<= 128 VGPRs); 6 or 8 spill and run 1.4-2.4x slower (measured)
 #endif
@@ -48,7 +54,7 @@ __device__ __forceinline__ float dplus4(float fm1, float f0, float fp1, float fp
     float t2 = fp2 - fm1;
     return BFD_CA * t1 - BFD_CB * t2;
 }
-__device__ __forceinline__ float cpml(float *__restrict__ psi, long idx, float a, float b, float D)
+__device__ __forceinline__ float cpml(float *__restrict__ psi, unsigned idx, float a, float b, float D)
 {
     float pn = b * psi[idx] + a * D;
     psi[idx] = pn;
@@ -93,21 +99,24 @@ __device__ __forceinline__ void xtask(int u, int arr, int i0, int j0, int N1, in
 // ------------------------------------------------------------------------------------------------
 // stress half-step
 // ------------------------------------------------------------------------------------------------
-template <int ZC>
-__global__ __launch_bounds__(NTHREADS, STRESS_WAVES_PER_SIMD) void stress_v2(bfd_dev d, int tilesX, int tilesY, int nblocks,
-                                                                             const int *__restrict__ list)
+// rowFlags (may be null): per run and plane, 2 bits per tile row (wave): bit0 = every cell of the row has a
+// fluid centre and no reflector -> the row takes the fluid arithmetic (one normal stress read, identical
+// result written to all three, no shear work); bit1 = additionally every cell has BP == 0 (no memory variable).
+__global__ __launch_bounds__(NTHREADS, STRESS_WAVES_PER_SIMD) void stress_v2(bfd_dev d, int tilesX, int nblocks,
+                                                                             const int4 *__restrict__ runs,
+                                                                             const unsigned short *__restrict__ rowFlags)
 {
     __shared__ float sV[2][3][LH * LW];
     const int N1 = d.N1, N2 = d.N2;
     const int pos = remap_block(blockIdx.x, nblocks);
-    const int tile = list ? list[pos] : pos;
-    const int bx = tile % tilesX, by = (tile / tilesX) % tilesY, bz = tile / (tilesX * tilesY);
+    const int4 run = runs[pos];
+    const int bx = run.x % tilesX, by = run.x / tilesX;
     const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * TX + tx;
     const int i0 = bx * TX, j0 = by * TY;
     const int i = i0 + tx, j = j0 + ty;
     const bool valid = (i < N1) && (j < N2);
     const long pl = d.plane;
-    const int kbeg = bz * ZC, kend = min(kbeg + ZC, d.nk);
+    const int kbeg = run.y & 0xFFFF, kend = run.y >> 16;
     const int P = d.P;
     const int own = (ty + 2) * LW + tx + 2;
     const unsigned cij = valid ? (unsigned)(j * N1 + i) : 0u;    // in-plane offset shared by every array
@@ -159,12 +168,15 @@ __global__ __launch_bounds__(NTHREADS, STRESS_WAVES_PER_SIMD) void stress_v2(bfd
         float *pSxx = d.Sxx + ko, *pSyy = d.Syy + ko, *pSzz = d.Szz + ko;
         float *pRxx = d.Rxx + ko, *pRyy = d.Ryy + ko, *pRzz = d.Rzz + ko;
         const uint16_t *pM = d.mat + ko;
+        const unsigned rf = rowFlags ? (rowFlags[pos * ZCHUNK + (kl - kbeg)] >> (2 * __builtin_amdgcn_readfirstlane(ty))) & 3u : 0u;
+        const bool rowFluid = rf & 1u, rowLossless = rf & 2u;       // wave-uniform
         unsigned mraw = 0;
         float sxx = 0, syy = 0, szz = 0, rxx = 0, ryy = 0, rzz = 0;
         if (valid) {
             mraw = pM[cij];
-            sxx = pSxx[cij]; syy = pSyy[cij]; szz = pSzz[cij];
-            rxx = pRxx[cij]; ryy = pRyy[cij]; rzz = pRzz[cij];
+            szz = pSzz[cij];
+            if (!rowLossless) rzz = pRzz[cij];
+            if (!rowFluid) { sxx = pSxx[cij]; syy = pSyy[cij]; rxx = pRxx[cij]; ryy = pRyy[cij]; }
         }
         float nvx = 0, nvy = 0, nvz = 0, nha = 0, nhb = 0;
         if (kl + 1 < kend) {
@@ -173,7 +185,37 @@ __global__ __launch_bounds__(NTHREADS, STRESS_WAVES_PER_SIMD) void stress_v2(bfd
             if (tb.ok) nhb = pb[ko + pl];
         }
 
-        if (valid) {
+        if (valid && rowFluid) {
+            // fluid row inside a solid tile: same arithmetic as stress_fluid_body, all three copies written
+            const float *sx = &sV[b][0][own], *sy = &sV[b][1][own];
+            float dxVx = dminus4(sx[-2], sx[-1], vx0, sx[1]);
+            float dyVy = dminus4(sy[-2 * LW], sy[-LW], vy0, sy[LW]);
+            float dzVz = dminus4(vzm2, vzm1, vz0, vzp1);
+            if (zi) {
+                const int xi = i < P ? i : i - (N1 - 2 * P);
+                dxVx = cpml(d.psi[0], (unsigned)((kl * N2 + j) * (2 * P) + xi), d.axI[i], d.bxI[i], dxVx);
+            }
+            if (zj) {
+                const int yj = j < P ? j : j - (N2 - 2 * P);
+                dyVy = cpml(d.psi[1], (unsigned)((kl * (2 * P) + yj) * N1 + i), d.ayI[j], d.byI[j], dyVy);
+            }
+            if (k < P || k >= d.N3 - P) {
+                const int zk = k < P ? k : k - (d.N3 - 2 * P);
+                dzVz = cpml(d.psi[2], (unsigned)(zk * d.plane) + cij, d.azI[k], d.bzI[k], dzVz);
+            }
+            const int m = mraw & BFD_MAT_MASK;
+            const float div = (dxVx + dyVy) + dzVz;
+            const float AP = d.AP[m];
+            float val;
+            if (rowLossless) {
+                val = szz + AP * div;
+            } else {
+                const float rn = c1 * rzz - d.BP[m] * div;
+                val = szz + (AP * div + 0.5f * (rzz + rn));
+                pRxx[cij] = rn; pRyy[cij] = rn; pRzz[cij] = rn;
+            }
+            pSxx[cij] = val; pSyy[cij] = val; pSzz[cij] = val;
+        } else if (valid) {
             const float *sx = &sV[b][0][own], *sy = &sV[b][1][own], *sz = &sV[b][2][own];
             float dxVx = dminus4(sx[-2], sx[-1], vx0, sx[1]);
             float dyVy = dminus4(sy[-2 * LW], sy[-LW], vy0, sy[LW]);
@@ -192,21 +234,21 @@ __global__ __launch_bounds__(NTHREADS, STRESS_WAVES_PER_SIMD) void stress_v2(bfd
                 const int m = mraw & BFD_MAT_MASK;
                 if (zi) {
                     const int xi = i < P ? i : i - (N1 - 2 * P);
-                    const long q = ((long)kl * N2 + j) * (2 * P) + xi;
+                    const unsigned q = (unsigned)((kl * N2 + j) * (2 * P) + xi);
                     dxVx = cpml(d.psi[0], q, d.axI[i], d.bxI[i], dxVx);
                     dxVy = cpml(d.psi[4], q, d.axH[i], d.bxH[i], dxVy);
                     dxVz = cpml(d.psi[6], q, d.axH[i], d.bxH[i], dxVz);
                 }
                 if (zj) {
                     const int yj = j < P ? j : j - (N2 - 2 * P);
-                    const long q = ((long)kl * (2 * P) + yj) * N1 + i;
+                    const unsigned q = (unsigned)((kl * (2 * P) + yj) * N1 + i);
                     dyVy = cpml(d.psi[1], q, d.ayI[j], d.byI[j], dyVy);
                     dyVx = cpml(d.psi[3], q, d.ayH[j], d.byH[j], dyVx);
                     dyVz = cpml(d.psi[8], q, d.ayH[j], d.byH[j], dyVz);
                 }
                 if (k < P || k >= d.N3 - P) {
                     const int zk = k < P ? k : k - (d.N3 - 2 * P);
-                    const long q = (long)zk * pl + cij;
+                    const unsigned q = (unsigned)(zk * d.plane) + cij;
                     dzVz = cpml(d.psi[2], q, d.azI[k], d.bzI[k], dzVz);
                     dzVx = cpml(d.psi[5], q, d.azH[k], d.bzH[k], dzVx);
                     dzVy = cpml(d.psi[7], q, d.azH[k], d.bzH[k], dzVy);
@@ -285,22 +327,21 @@ __global__ __launch_bounds__(NTHREADS, STRESS_WAVES_PER_SIMD) void stress_v2(bfd
 // velocity half-step (+ fused Pressure RMS / peak accumulation)
 // ------------------------------------------------------------------------------------------------
 // LDS set: 0 Sxx (x halo), 1 Syy (y halo), 2 Sxy (x and y halo), 3 Sxz (x halo), 4 Syz (y halo)
-template <int ZC, bool ACC>
-__global__ __launch_bounds__(NTHREADS, VELOCITY_WAVES_PER_SIMD) void velocity_v2(bfd_dev d, int tilesX, int tilesY, int nblocks,
+template <bool ACC>
+__global__ __launch_bounds__(NTHREADS, VELOCITY_WAVES_PER_SIMD) void velocity_v2(bfd_dev d, int tilesX, int nblocks,
                                                         float *__restrict__ accP, float *__restrict__ pkP,
-                                                        const int *__restrict__ list)
+                                                        const int4 *__restrict__ runs)
 {
     __shared__ float sS[2][5][LH * LW];
     const int N1 = d.N1, N2 = d.N2;
-    const int pos = remap_block(blockIdx.x, nblocks);
-    const int tile = list ? list[pos] : pos;
-    const int bx = tile % tilesX, by = (tile / tilesX) % tilesY, bz = tile / (tilesX * tilesY);
+    const int4 run = runs[remap_block(blockIdx.x, nblocks)];
+    const int bx = run.x % tilesX, by = run.x / tilesX;
     const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * TX + tx;
     const int i0 = bx * TX, j0 = by * TY;
     const int i = i0 + tx, j = j0 + ty;
     const bool valid = (i < N1) && (j < N2);
     const long pl = d.plane;
-    const int kbeg = bz * ZC, kend = min(kbeg + ZC, d.nk);
+    const int kbeg = run.y & 0xFFFF, kend = run.y >> 16;
     const int P = d.P;
     const int own = (ty + 2) * LW + tx + 2;
     const unsigned cij = valid ? (unsigned)(j * N1 + i) : 0u;
@@ -392,21 +433,21 @@ __global__ __launch_bounds__(NTHREADS, VELOCITY_WAVES_PER_SIMD) void velocity_v2
                 float dzSzz = dplus4(zzm1, zz0, zzp1, zzp2);
                 if (zi) {
                     const int xi = i < P ? i : i - (N1 - 2 * P);
-                    const long q = ((long)kl * N2 + j) * (2 * P) + xi;
+                    const unsigned q = (unsigned)((kl * N2 + j) * (2 * P) + xi);
                     dxSxx = cpml(d.psi[9], q, d.axH[i], d.bxH[i], dxSxx);
                     dxSxy = cpml(d.psi[12], q, d.axI[i], d.bxI[i], dxSxy);
                     dxSxz = cpml(d.psi[15], q, d.axI[i], d.bxI[i], dxSxz);
                 }
                 if (zj) {
                     const int yj = j < P ? j : j - (N2 - 2 * P);
-                    const long q = ((long)kl * (2 * P) + yj) * N1 + i;
+                    const unsigned q = (unsigned)((kl * (2 * P) + yj) * N1 + i);
                     dySxy = cpml(d.psi[10], q, d.ayI[j], d.byI[j], dySxy);
                     dySyy = cpml(d.psi[13], q, d.ayH[j], d.byH[j], dySyy);
                     dySyz = cpml(d.psi[16], q, d.ayI[j], d.byI[j], dySyz);
                 }
                 if (k < P || k >= d.N3 - P) {
                     const int zk = k < P ? k : k - (d.N3 - 2 * P);
-                    const long q = (long)zk * pl + cij;
+                    const unsigned q = (unsigned)(zk * d.plane) + cij;
                     dzSxz = cpml(d.psi[11], q, d.azI[k], d.bzI[k], dzSxz);
                     dzSyz = cpml(d.psi[14], q, d.azI[k], d.bzI[k], dzSyz);
                     dzSzz = cpml(d.psi[17], q, d.azH[k], d.bzH[k], dzSzz);
@@ -430,7 +471,6 @@ __global__ __launch_bounds__(NTHREADS, VELOCITY_WAVES_PER_SIMD) void velocity_v2
     }
 }
 
-constexpr int ZCHUNK = 32;
 
 // ------------------------------------------------------------------------------------------------
 // FLUID tiles: no solid cell within the tile grown by 2 cells in every direction. There
@@ -449,20 +489,18 @@ constexpr int ZCHUNK = 32;
 // switches on its tile's flags (block-uniform) into the matching instantiation.
 // All bodies are software pipelined: every value plane kl needs is in registers when its iteration starts
 // and the iteration issues the loads for plane kl+1 (CPML memory variables included).
-template <int ZC, bool LOSSY, bool COLLAPSED, bool UNI, bool PML>
-__device__ __forceinline__ void stress_fluid_body(const bfd_dev &d, int tilesX, int tilesY, int tile, int tm,
+template <bool LOSSY, bool COLLAPSED, bool UNI, bool PML>
+__device__ __forceinline__ void stress_fluid_body(const bfd_dev &d, int bx, int by, int kbeg, int kend, int tm,
                                                   float (*sV)[2][LH * LW])
 {
     // The three normal stresses are identical in a FLUID tile; Szz is the one that is read (it is
     // also the one whose ghost planes the Z-neighbour exchange carries), all three are written.
     const int N1 = d.N1, N2 = d.N2;
-    const int bx = tile % tilesX, by = (tile / tilesX) % tilesY, bz = tile / (tilesX * tilesY);
     const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * TX + tx;
     const int i0 = bx * TX, j0 = by * TY;
     const int i = i0 + tx, j = j0 + ty;
     const bool valid = (i < N1) && (j < N2);
     const long pl = d.plane;
-    const int kbeg = bz * ZC, kend = min(kbeg + ZC, d.nk);
     const int P = d.P;
     const int own = (ty + 2) * LW + tx + 2;
     const unsigned cij = valid ? (unsigned)(j * N1 + i) : 0u;
@@ -572,18 +610,16 @@ __device__ __forceinline__ void stress_fluid_body(const bfd_dev &d, int tilesX, 
     }
 }
 
-template <int ZC, bool ACC, bool UNI, bool PML>
-__device__ __forceinline__ void velocity_fluid_body(const bfd_dev &d, int tilesX, int tilesY, int tile, int tm,
+template <bool ACC, bool UNI, bool PML>
+__device__ __forceinline__ void velocity_fluid_body(const bfd_dev &d, int bx, int by, int kbeg, int kend, int tm,
                                                     float (*sS)[LH * LW], float *__restrict__ accP, float *__restrict__ pkP)
 {
     const int N1 = d.N1, N2 = d.N2;
-    const int bx = tile % tilesX, by = (tile / tilesX) % tilesY, bz = tile / (tilesX * tilesY);
     const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * TX + tx;
     const int i0 = bx * TX, j0 = by * TY;
     const int i = i0 + tx, j = j0 + ty;
     const bool valid = (i < N1) && (j < N2);
     const long pl = d.plane;
-    const int kbeg = bz * ZC, kend = min(kbeg + ZC, d.nk);
     const int P = d.P;
     const int own = (ty + 2) * LW + tx + 2;
     const unsigned cij = valid ? (unsigned)(j * N1 + i) : 0u;
@@ -703,61 +739,343 @@ __device__ __forceinline__ void velocity_fluid_body(const bfd_dev &d, int tilesX
     }
 }
 
-// ---- dispatchers: one launch for all fluid tiles; block-uniform switch on the tile's flags ----
-// tile flags: bit0 solid, bit1 lossy, bit2 UNI, bit3 PML
-template <int ZC, bool COLLAPSED>
-__global__ __launch_bounds__(NTHREADS, FLUID_WAVES_PER_SIMD) void stress_fluid(bfd_dev d, int tilesX, int tilesY, int nblocks,
-                                                                               const int *__restrict__ list,
-                                                                               const int *__restrict__ tileFlags,
-                                                                               const int *__restrict__ tileMat)
+// ------------------------------------------------------------------------------------------------
+// SOLID runs in the tiled path (variant 3): normal stresses by a pipelined marching kernel
+// (stress_normal_solid), shear stresses by a sparse per-cell kernel (stress_shear_sparse) over the list of
+// cells with a solid centre. Each kernel is lean (no long dependent chains behind a workgroup barrier),
+// which the monolithic stress_v2 is not. Values equal stress_v2's; CPML memory variables of the cross
+// derivatives are advanced only at listed cells (they feed nothing else).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NTHREADS, 4) void stress_normal_solid(bfd_dev d, int tilesX, int nblocks,
+                                                                   const int4 *__restrict__ runs,
+                                                                   const unsigned short *__restrict__ rowFlags)
 {
     __shared__ float sV[2][2][LH * LW];
-    const int tile = list[remap_block(blockIdx.x, nblocks)];
-    const int f = __builtin_amdgcn_readfirstlane(tileFlags[tile]);
-    const int tm = __builtin_amdgcn_readfirstlane(tileMat[tile]);
-    switch ((f >> 1) & 7) {
-    case 0: stress_fluid_body<ZC, false, COLLAPSED, false, false>(d, tilesX, tilesY, tile, tm, sV); break;
-    case 1: stress_fluid_body<ZC, true, COLLAPSED, false, false>(d, tilesX, tilesY, tile, tm, sV); break;
-    case 2: stress_fluid_body<ZC, false, COLLAPSED, true, false>(d, tilesX, tilesY, tile, tm, sV); break;
-    case 3: stress_fluid_body<ZC, true, COLLAPSED, true, false>(d, tilesX, tilesY, tile, tm, sV); break;
-    case 4: stress_fluid_body<ZC, false, COLLAPSED, false, true>(d, tilesX, tilesY, tile, tm, sV); break;
-    case 5: stress_fluid_body<ZC, true, COLLAPSED, false, true>(d, tilesX, tilesY, tile, tm, sV); break;
-    case 6: stress_fluid_body<ZC, false, COLLAPSED, true, true>(d, tilesX, tilesY, tile, tm, sV); break;
-    default: stress_fluid_body<ZC, true, COLLAPSED, true, true>(d, tilesX, tilesY, tile, tm, sV); break;
+    const int N1 = d.N1, N2 = d.N2;
+    const int pos = remap_block(blockIdx.x, nblocks);
+    const int4 run = runs[pos];
+    const int bx = run.x % tilesX, by = run.x / tilesX, kbeg = run.y & 0xFFFF, kend = run.y >> 16;
+    const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * TX + tx;
+    const int i0 = bx * TX, j0 = by * TY;
+    const int i = i0 + tx, j = j0 + ty;
+    const bool valid = (i < N1) && (j < N2);
+    const long pl = d.plane;
+    const int P = d.P;
+    const int own = (ty + 2) * LW + tx + 2;
+    const unsigned cij = valid ? (unsigned)(j * N1 + i) : 0u;
+    const int wrow = __builtin_amdgcn_readfirstlane(ty);
+
+    HaloTask t; t.lofs = -1; t.ok = false; t.arr = 0; t.gofs = 0;
+    if (tid < YT) ytask(tid, 1, i0, j0, N1, N2, t);
+    else if (tid < YT + XT) xtask(tid - YT, 0, i0, j0, N1, N2, t);
+    const bool has = t.lofs >= 0;
+    const float *ph = (t.arr == 0 ? d.Vx : d.Vy) + (t.ok ? t.gofs : 0);
+    float *lh = &sV[0][t.arr][has ? t.lofs : 0];
+    const float c1 = d.c1;
+
+    const bool zi = valid && (i < P || i >= N1 - P);
+    const bool zj = valid && (j < P || j >= N2 - P);
+    float ax = 0, bxc = 0, ay = 0, byc = 0, px = 0, py = 0, pz = 0;
+    unsigned qx = 0, qy = 0;
+    const unsigned dqx = (unsigned)(N2 * 2 * P), dqy = (unsigned)(2 * P * N1);
+    if (zi) { ax = d.axI[i]; bxc = d.bxI[i]; qx = (unsigned)((kbeg * N2 + j) * (2 * P) + (i < P ? i : i - (N1 - 2 * P))); px = d.psi[0][qx]; }
+    if (zj) { ay = d.ayI[j]; byc = d.byI[j]; qy = (unsigned)((kbeg * (2 * P) + (j < P ? j : j - (N2 - 2 * P))) * N1 + i); py = d.psi[1][qy]; }
+    {
+        const int kg = d.k0 + kbeg;
+        if (valid && (kg < P || kg >= d.N3 - P)) pz = d.psi[2][(unsigned)((kg < P ? kg : kg - (d.N3 - 2 * P)) * d.plane) + cij];
+    }
+
+    // row class of a plane: bit0 fluid row (one normal stress is read), bit1 lossless row (no memory variable)
+    auto rowClass = [&](int kl) -> unsigned { return (rowFlags[pos * ZCHUNK + (kl - kbeg)] >> (2 * wrow)) & 3u; };
+
+    float vx0 = 0, vy0 = 0, vzm2 = 0, vzm1 = 0, vz0 = 0, vzp1 = 0;
+    float sxx = 0, syy = 0, szz = 0, rxx = 0, ryy = 0, rzz = 0;
+    unsigned mraw = 0;
+    unsigned rc = rowClass(kbeg);
+    if (valid) {
+        const float *bVz = d.Vz + kbeg * pl;
+        vx0 = (d.Vx + kbeg * pl)[cij]; vy0 = (d.Vy + kbeg * pl)[cij];
+        vzm2 = (bVz - 2 * pl)[cij]; vzm1 = (bVz - pl)[cij]; vz0 = bVz[cij]; vzp1 = (bVz + pl)[cij];
+        mraw = (d.mat + kbeg * pl)[cij];
+        szz = (d.Szz + kbeg * pl)[cij];
+        if (!(rc & 2u)) rzz = (d.Rzz + kbeg * pl)[cij];
+        if (!(rc & 1u)) {
+            sxx = (d.Sxx + kbeg * pl)[cij]; syy = (d.Syy + kbeg * pl)[cij];
+            rxx = (d.Rxx + kbeg * pl)[cij]; ryy = (d.Ryy + kbeg * pl)[cij];
+        }
+    }
+    float hv = t.ok ? ph[kbeg * pl] : 0.0f;
+
+    for (int kl = kbeg; kl < kend; kl++) {
+        const int b = kl & 1;
+        const long ko = (long)kl * pl;
+        const int k = d.k0 + kl;
+        sV[b][0][own] = vx0; sV[b][1][own] = vy0;
+        if (has) lh[b * (2 * LH * LW)] = hv;
+        const int m = mraw & BFD_MAT_MASK;
+        float AP = 0, BP = 0, AS2 = 0, BS2 = 0;
+        if (valid) { AP = d.AP[m]; BP = d.BP[m]; if (!(rc & 1u)) { AS2 = d.AS2[m]; BS2 = d.BS2[m]; } }
+        __syncthreads();
+
+        float nvx = 0, nvy = 0, nvz = 0, nh = 0, nsxx = 0, nsyy = 0, nszz = 0, nrxx = 0, nryy = 0, nrzz = 0, npx = 0, npy = 0, npz = 0;
+        unsigned nmraw = 0, nrc = 3u;
+        if (kl + 1 < kend) {
+            nrc = rowClass(kl + 1);
+            if (valid) {
+                nvx = (d.Vx + ko + pl)[cij]; nvy = (d.Vy + ko + pl)[cij]; nvz = (d.Vz + ko + 2 * pl)[cij];
+                nmraw = (d.mat + ko + pl)[cij];
+                nszz = (d.Szz + ko + pl)[cij];
+                if (!(nrc & 2u)) nrzz = (d.Rzz + ko + pl)[cij];
+                if (!(nrc & 1u)) {
+                    nsxx = (d.Sxx + ko + pl)[cij]; nsyy = (d.Syy + ko + pl)[cij];
+                    nrxx = (d.Rxx + ko + pl)[cij]; nryy = (d.Ryy + ko + pl)[cij];
+                }
+            }
+            if (t.ok) nh = ph[ko + pl];
+            if (zi) npx = d.psi[0][qx + dqx];
+            if (zj) npy = d.psi[1][qy + dqy];
+            const int kn = k + 1;
+            if (valid && (kn < P || kn >= d.N3 - P)) npz = d.psi[2][(unsigned)((kn < P ? kn : kn - (d.N3 - 2 * P)) * d.plane) + cij];
+        }
+        if (valid) {
+            const float *sx = &sV[b][0][own], *sy = &sV[b][1][own];
+            float dxVx = dminus4(sx[-2], sx[-1], vx0, sx[1]);
+            float dyVy = dminus4(sy[-2 * LW], sy[-LW], vy0, sy[LW]);
+            float dzVz = dminus4(vzm2, vzm1, vz0, vzp1);
+            if (mraw & BFD_REFLECTOR_BIT) {
+                (d.Sxx + ko)[cij] = 0.f; (d.Syy + ko)[cij] = 0.f; (d.Szz + ko)[cij] = 0.f;
+                (d.Rxx + ko)[cij] = 0.f; (d.Ryy + ko)[cij] = 0.f; (d.Rzz + ko)[cij] = 0.f;
+                (d.Sxy + ko)[cij] = 0.f; (d.Sxz + ko)[cij] = 0.f; (d.Syz + ko)[cij] = 0.f;
+                (d.Rxy + ko)[cij] = 0.f; (d.Rxz + ko)[cij] = 0.f; (d.Ryz + ko)[cij] = 0.f;
+            } else {
+                if (zi) { const float pn = bxc * px + ax * dxVx; d.psi[0][qx] = pn; dxVx = dxVx + pn; }
+                if (zj) { const float pn = byc * py + ay * dyVy; d.psi[1][qy] = pn; dyVy = dyVy + pn; }
+                if (k < P || k >= d.N3 - P) {
+                    const float pn = d.bzI[k] * pz + d.azI[k] * dzVz;
+                    d.psi[2][(unsigned)((k < P ? k : k - (d.N3 - 2 * P)) * d.plane) + cij] = pn;
+                    dzVz = dzVz + pn;
+                }
+                const float sXY = dxVx + dyVy;
+                const float div = sXY + dzVz;
+                if (rc & 1u) {          // fluid row: the three normal stresses are identical
+                    float val;
+                    if (rc & 2u) val = szz + AP * div;
+                    else {
+                        const float rn = c1 * rzz - BP * div;
+                        val = szz + (AP * div + 0.5f * (rzz + rn));
+                        (d.Rxx + ko)[cij] = rn; (d.Ryy + ko)[cij] = rn; (d.Rzz + ko)[cij] = rn;
+                    }
+                    (d.Sxx + ko)[cij] = val; (d.Syy + ko)[cij] = val; (d.Szz + ko)[cij] = val;
+                } else {
+                    const float sYZ = dyVy + dzVz, sXZ = dxVx + dzVz;
+                    float rn;
+                    rn = c1 * rxx - (BP * div - BS2 * sYZ);
+                    (d.Sxx + ko)[cij] = sxx + ((AP * div - AS2 * sYZ) + 0.5f * (rxx + rn)); (d.Rxx + ko)[cij] = rn;
+                    rn = c1 * ryy - (BP * div - BS2 * sXZ);
+                    (d.Syy + ko)[cij] = syy + ((AP * div - AS2 * sXZ) + 0.5f * (ryy + rn)); (d.Ryy + ko)[cij] = rn;
+                    rn = c1 * rzz - (BP * div - BS2 * sXY);
+                    (d.Szz + ko)[cij] = szz + ((AP * div - AS2 * sXY) + 0.5f * (rzz + rn)); (d.Rzz + ko)[cij] = rn;
+                }
+            }
+        }
+        vx0 = nvx; vy0 = nvy;
+        vzm2 = vzm1; vzm1 = vz0; vz0 = vzp1; vzp1 = nvz;
+        hv = nh; mraw = nmraw; rc = nrc;
+        sxx = nsxx; syy = nsyy; szz = nszz; rxx = nrxx; ryy = nryy; rzz = nrzz;
+        px = npx; py = npy; pz = npz; qx += dqx; qy += dqy;
     }
 }
 
-template <int ZC, bool ACC>
-__global__ __launch_bounds__(NTHREADS, FLUID_WAVES_PER_SIMD) void velocity_fluid(bfd_dev d, int tilesX, int tilesY, int nblocks,
-                                                                                 const int *__restrict__ list,
-                                                                                 const int *__restrict__ tileFlags,
-                                                                                 const int *__restrict__ tileMat,
+// sparse shear update: one thread per listed cell (solid centre). coef[6*t..] = A,B of the xy, xz, yz edges
+// (0,0 where the 4-cell condition fails), computed once at setup with the canonical arithmetic.
+__device__ __forceinline__ float ldv(const float *__restrict__ a, int N1, int N2, int i, int j, long kofs)
+{
+    return (i >= 0 && i < N1 && j >= 0 && j < N2) ? a[kofs + (long)j * N1 + i] : 0.0f;
+}
+
+__global__ __launch_bounds__(256) void stress_shear_sparse(bfd_dev d, const unsigned *__restrict__ cells,
+                                                           const float *__restrict__ coef, long n)
+{
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    const int N1 = d.N1, N2 = d.N2, P = d.P;
+    const long pl = d.plane;
+    const unsigned c = cells[t];
+    const int i = (int)(c % (unsigned)N1), j = (int)((c / (unsigned)N1) % (unsigned)N2), kl = (int)(c / (unsigned)d.plane);
+    const long ko = (long)kl * pl;
+    const int k = d.k0 + kl;
+    const float Axy = coef[6 * t], Bxy = coef[6 * t + 1], Axz = coef[6 * t + 2], Bxz = coef[6 * t + 3], Ayz = coef[6 * t + 4], Byz = coef[6 * t + 5];
+    const float vx0 = d.Vx[c], vy0 = d.Vy[c], vz0 = d.Vz[c];
+    float dyVx = dplus4(ldv(d.Vx, N1, N2, i, j - 1, ko), vx0, ldv(d.Vx, N1, N2, i, j + 1, ko), ldv(d.Vx, N1, N2, i, j + 2, ko));
+    float dxVy = dplus4(ldv(d.Vy, N1, N2, i - 1, j, ko), vy0, ldv(d.Vy, N1, N2, i + 1, j, ko), ldv(d.Vy, N1, N2, i + 2, j, ko));
+    float dzVx = dplus4(d.Vx[c - pl], vx0, d.Vx[c + pl], d.Vx[c + 2 * pl]);
+    float dxVz = dplus4(ldv(d.Vz, N1, N2, i - 1, j, ko), vz0, ldv(d.Vz, N1, N2, i + 1, j, ko), ldv(d.Vz, N1, N2, i + 2, j, ko));
+    float dzVy = dplus4(d.Vy[c - pl], vy0, d.Vy[c + pl], d.Vy[c + 2 * pl]);
+    float dyVz = dplus4(ldv(d.Vz, N1, N2, i, j - 1, ko), vz0, ldv(d.Vz, N1, N2, i, j + 1, ko), ldv(d.Vz, N1, N2, i, j + 2, ko));
+    if (i < P || i >= N1 - P) {
+        const int xi = i < P ? i : i - (N1 - 2 * P);
+        const unsigned q = (unsigned)((kl * N2 + j) * (2 * P) + xi);
+        dxVy = cpml(d.psi[4], q, d.axH[i], d.bxH[i], dxVy);
+        dxVz = cpml(d.psi[6], q, d.axH[i], d.bxH[i], dxVz);
+    }
+    if (j < P || j >= N2 - P) {
+        const int yj = j < P ? j : j - (N2 - 2 * P);
+        const unsigned q = (unsigned)((kl * (2 * P) + yj) * N1 + i);
+        dyVx = cpml(d.psi[3], q, d.ayH[j], d.byH[j], dyVx);
+        dyVz = cpml(d.psi[8], q, d.ayH[j], d.byH[j], dyVz);
+    }
+    if (k < P || k >= d.N3 - P) {
+        const int zk = k < P ? k : k - (d.N3 - 2 * P);
+        const unsigned q = (unsigned)(zk * d.plane) + (unsigned)(j * N1 + i);
+        dzVx = cpml(d.psi[5], q, d.azH[k], d.bzH[k], dzVx);
+        dzVy = cpml(d.psi[7], q, d.azH[k], d.bzH[k], dzVy);
+    }
+    const float c1 = d.c1;
+    if (Axy != 0.f) {
+        const float e = dyVx + dxVy;
+        const float r = d.Rxy[c], rn = c1 * r - Bxy * e;
+        d.Sxy[c] = d.Sxy[c] + (Axy * e + 0.5f * (r + rn)); d.Rxy[c] = rn;
+    }
+    if (Axz != 0.f) {
+        const float e = dzVx + dxVz;
+        const float r = d.Rxz[c], rn = c1 * r - Bxz * e;
+        d.Sxz[c] = d.Sxz[c] + (Axz * e + 0.5f * (r + rn)); d.Rxz[c] = rn;
+    }
+    if (Ayz != 0.f) {
+        const float e = dzVy + dyVz;
+        const float r = d.Ryz[c], rn = c1 * r - Byz * e;
+        d.Syz[c] = d.Syz[c] + (Ayz * e + 0.5f * (r + rn)); d.Ryz[c] = rn;
+    }
+}
+
+// setup: flag cells with a solid, non-reflector centre; then the edge coefficients of the listed cells
+__global__ void mark_solid_cells(bfd_dev d, unsigned char *__restrict__ flag, long n)
+{
+    for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (long)gridDim.x * blockDim.x) {
+        const unsigned raw = d.mat[v];
+        flag[v] = (!(raw & BFD_REFLECTOR_BIT) && d.invMu[raw & BFD_MAT_MASK] > 0.f) ? 1 : 0;
+    }
+}
+__global__ void shear_coefficients(bfd_dev d, const unsigned *__restrict__ cells, float *__restrict__ coef, long n)
+{
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const int N1 = d.N1, N2 = d.N2;
+    const long pl = d.plane;
+    const unsigned c = cells[t];
+    const int i = (int)(c % (unsigned)N1), j = (int)((c / (unsigned)N1) % (unsigned)N2);
+    const long ko = (long)(c / (unsigned)d.plane) * pl;
+    const int i1 = min(i + 1, N1 - 1), j1 = min(j + 1, N2 - 1);
+    const long r0 = ko + (long)j * N1, r1 = ko + (long)j1 * N1;
+    const int m = d.mat[c] & BFD_MAT_MASK;
+    const int mx = d.mat[r0 + i1] & BFD_MAT_MASK, my = d.mat[r1 + i] & BFD_MAT_MASK, mz = d.mat[r0 + pl + i] & BFD_MAT_MASK;
+    const int mxy = d.mat[r1 + i1] & BFD_MAT_MASK, mxz = d.mat[r0 + pl + i1] & BFD_MAT_MASK, myz = d.mat[r1 + pl + i] & BFD_MAT_MASK;
+    const float iv0 = d.invMu[m], t0 = d.tauS[m], k2 = d.k2;
+    const float ivx = d.invMu[mx], ivy = d.invMu[my], ivz = d.invMu[mz];
+    float o[6] = {0, 0, 0, 0, 0, 0};
+    {
+        const float e4 = d.invMu[mxy];
+        if (ivx > 0.f && ivy > 0.f && e4 > 0.f) {
+            const float muH = 4.0f / ((iv0 + ivx) + (ivy + e4));
+            const float tau = 0.25f * ((t0 + d.tauS[mx]) + (d.tauS[my] + d.tauS[mxy]));
+            o[0] = muH * (1.0f + tau); o[1] = (muH * tau) * k2;
+        }
+    }
+    {
+        const float e4 = d.invMu[mxz];
+        if (ivx > 0.f && ivz > 0.f && e4 > 0.f) {
+            const float muH = 4.0f / ((iv0 + ivx) + (ivz + e4));
+            const float tau = 0.25f * ((t0 + d.tauS[mx]) + (d.tauS[mz] + d.tauS[mxz]));
+            o[2] = muH * (1.0f + tau); o[3] = (muH * tau) * k2;
+        }
+    }
+    {
+        const float e4 = d.invMu[myz];
+        if (ivy > 0.f && ivz > 0.f && e4 > 0.f) {
+            const float muH = 4.0f / ((iv0 + ivy) + (ivz + e4));
+            const float tau = 0.25f * ((t0 + d.tauS[my]) + (d.tauS[mz] + d.tauS[myz]));
+            o[4] = muH * (1.0f + tau); o[5] = (muH * tau) * k2;
+        }
+    }
+    for (int q = 0; q < 6; q++) coef[6 * t + q] = o[q];
+}
+
+// ---- dispatchers: one launch for all fluid runs; block-uniform switch on the run's flags ----
+// run = (x: bx + tilesX*by, y: kbeg | kend<<16, z: flags, w: material id of UNI runs)
+// flags: bit0 solid, bit1 lossy, bit2 UNI, bit3 PML
+template <bool COLLAPSED>
+__global__ __launch_bounds__(NTHREADS, FLUID_WAVES_PER_SIMD) void stress_fluid(bfd_dev d, int tilesX, int nblocks,
+                                                                               const int4 *__restrict__ runs)
+{
+    __shared__ float sV[2][2][LH * LW];
+    const int4 run = runs[remap_block(blockIdx.x, nblocks)];
+    const int bx = run.x % tilesX, by = run.x / tilesX, kbeg = run.y & 0xFFFF, kend = run.y >> 16, tm = run.w;
+    switch ((run.z >> 1) & 7) {
+    case 0: stress_fluid_body<false, COLLAPSED, false, false>(d, bx, by, kbeg, kend, tm, sV); break;
+    case 1: stress_fluid_body<true, COLLAPSED, false, false>(d, bx, by, kbeg, kend, tm, sV); break;
+    case 2: stress_fluid_body<false, COLLAPSED, true, false>(d, bx, by, kbeg, kend, tm, sV); break;
+    case 3: stress_fluid_body<true, COLLAPSED, true, false>(d, bx, by, kbeg, kend, tm, sV); break;
+    case 4: stress_fluid_body<false, COLLAPSED, false, true>(d, bx, by, kbeg, kend, tm, sV); break;
+    case 5: stress_fluid_body<true, COLLAPSED, false, true>(d, bx, by, kbeg, kend, tm, sV); break;
+    case 6: stress_fluid_body<false, COLLAPSED, true, true>(d, bx, by, kbeg, kend, tm, sV); break;
+    default: stress_fluid_body<true, COLLAPSED, true, true>(d, bx, by, kbeg, kend, tm, sV); break;
+    }
+}
+
+template <bool ACC>
+__global__ __launch_bounds__(NTHREADS, FLUID_WAVES_PER_SIMD) void velocity_fluid(bfd_dev d, int tilesX, int nblocks,
+                                                                                 const int4 *__restrict__ runs,
                                                                                  float *__restrict__ accP, float *__restrict__ pkP)
 {
     __shared__ float sS[2][LH * LW];
-    const int tile = list[remap_block(blockIdx.x, nblocks)];
-    const int f = __builtin_amdgcn_readfirstlane(tileFlags[tile]);
-    const int tm = __builtin_amdgcn_readfirstlane(tileMat[tile]);
-    switch ((f >> 2) & 3) {
-    case 0: velocity_fluid_body<ZC, ACC, false, false>(d, tilesX, tilesY, tile, tm, sS, accP, pkP); break;
-    case 1: velocity_fluid_body<ZC, ACC, true, false>(d, tilesX, tilesY, tile, tm, sS, accP, pkP); break;
-    case 2: velocity_fluid_body<ZC, ACC, false, true>(d, tilesX, tilesY, tile, tm, sS, accP, pkP); break;
-    default: velocity_fluid_body<ZC, ACC, true, true>(d, tilesX, tilesY, tile, tm, sS, accP, pkP); break;
+    const int4 run = runs[remap_block(blockIdx.x, nblocks)];
+    const int bx = run.x % tilesX, by = run.x / tilesX, kbeg = run.y & 0xFFFF, kend = run.y >> 16, tm = run.w;
+    switch ((run.z >> 2) & 3) {
+    case 0: velocity_fluid_body<ACC, false, false>(d, bx, by, kbeg, kend, tm, sS, accP, pkP); break;
+    case 1: velocity_fluid_body<ACC, true, false>(d, bx, by, kbeg, kend, tm, sS, accP, pkP); break;
+    case 2: velocity_fluid_body<ACC, false, true>(d, bx, by, kbeg, kend, tm, sS, accP, pkP); break;
+    default: velocity_fluid_body<ACC, true, true>(d, bx, by, kbeg, kend, tm, sS, accP, pkP); break;
     }
 }
 
-// one workgroup per tile. flags: bit0 = a solid cell within the tile grown by 2 cells; bit1 = a cell of the
-// tile relaxes (BP != 0); bit2 = UNI: one material and no reflector in the grown region; bit3 = PML: a cell
-// of the tile lies inside an absorbing-layer zone. tileMat[tile] = the id at the tile's first cell.
-template <int ZC>
+// one workgroup (64 x 8) per solid run: 2 bits per row and plane for stress_v2 (see there)
+__global__ __launch_bounds__(NTHREADS) void classify_rows(bfd_dev d, int tilesX, const int4 *__restrict__ runs,
+                                                          unsigned short *__restrict__ rowFlags)
+{
+    __shared__ unsigned bits;
+    const int4 run = runs[blockIdx.x];
+    const int bx = run.x % tilesX, by = run.x / tilesX, kbeg = run.y & 0xFFFF, kend = run.y >> 16;
+    const int i = bx * TX + threadIdx.x, j = by * TY + threadIdx.y;
+    const bool valid = i < d.N1 && j < d.N2;
+    for (int kl = kbeg; kl < kend; kl++) {
+        if (threadIdx.x == 0 && threadIdx.y == 0) bits = 0u;
+        __syncthreads();
+        bool solidish = false, lossy = false;
+        if (valid) {
+            const unsigned raw = d.mat[(long)kl * d.plane + (long)j * d.N1 + i];
+            const int m = raw & BFD_MAT_MASK;
+            solidish = (raw & BFD_REFLECTOR_BIT) || d.invMu[m] > 0.f;
+            lossy = d.BP[m] != 0.f;
+        }
+        const bool rowFluid = __ballot(solidish) == 0ull, rowLossless = rowFluid && __ballot(lossy) == 0ull;
+        if (threadIdx.x == 0) atomicOr(&bits, ((rowFluid ? 1u : 0u) | (rowLossless ? 2u : 0u)) << (2 * threadIdx.y));
+        __syncthreads();
+        if (threadIdx.x == 0 && threadIdx.y == 0) rowFlags[blockIdx.x * ZCHUNK + (kl - kbeg)] = (unsigned short)bits;
+        __syncthreads();
+    }
+}
+
+// one workgroup per 64 x 8 x SUBZ sub-tile. flags: bit0 = a solid cell within the sub-tile grown by 2 cells;
+// bit1 = a cell of the sub-tile relaxes (BP != 0); bit2 = UNI: one material and no reflector in the grown
+// region; bit3 = PML: a cell of the sub-tile lies inside an absorbing-layer zone. mat = id at its first cell.
 __global__ void classify_tiles(bfd_dev d, int tilesX, int tilesY, int *__restrict__ flags, int *__restrict__ tileMat)
 {
     const int tile = blockIdx.x;
     const int bx = tile % tilesX, by = (tile / tilesX) % tilesY, bz = tile / (tilesX * tilesY);
-    const int i0 = bx * TX - 2, j0 = by * TY - 2, k0 = bz * ZC - 2;
-    const int nzOwn = min(ZC, d.nk - bz * ZC);
+    const int i0 = bx * TX - 2, j0 = by * TY - 2, k0 = bz * SUBZ - 2;
+    const int nzOwn = min(SUBZ, d.nk - bz * SUBZ);
     const int nx = TX + 4, ny = TY + 4, nz = nzOwn + 4;
-    const unsigned first = d.mat[(long)(bz * ZC) * d.plane + (long)min(by * TY, d.N2 - 1) * d.N1 + min(bx * TX, d.N1 - 1)];
+    const unsigned first = d.mat[(long)(bz * SUBZ) * d.plane + (long)min(by * TY, d.N2 - 1) * d.N1 + min(bx * TX, d.N1 - 1)];
     int solid = 0, lossy = 0, mixed = (first & BFD_REFLECTOR_BIT) ? 1 : 0;
     for (int v = threadIdx.x; v < nx * ny * nz; v += blockDim.x) {
         const int li = v % nx, lj = (v / nx) % ny, lk = v / (nx * ny);
@@ -775,7 +1093,7 @@ __global__ void classify_tiles(bfd_dev d, int tilesX, int tilesY, int *__restric
     if (threadIdx.x == 0) {
         const int P = d.P;
         const int xa = bx * TX, xb = min(xa + TX, d.N1), ya = by * TY, yb = min(ya + TY, d.N2);
-        const int za = d.k0 + bz * ZC, zb = za + nzOwn;
+        const int za = d.k0 + bz * SUBZ, zb = za + nzOwn;
         const bool pml = xa < P || xb > d.N1 - P || ya < P || yb > d.N2 - P || za < P || zb > d.N3 - P;
         flags[tile] = solid | (lossy << 1) | (mixed ? 0 : 4) | (pml ? 8 : 0);
         tileMat[tile] = (int)(first & BFD_MAT_MASK);
@@ -784,24 +1102,39 @@ __global__ void classify_tiles(bfd_dev d, int tilesX, int tilesY, int *__restric
 
 }  // namespace
 
-void bfd_tile_grid(const bfd_dev &d, int *tilesX, int *tilesY, int *tilesZ)
+// tiles in x and y; sub-tiles of SUBZ planes in z; ZCHUNK = longest run a workgroup marches
+void bfd_tile_grid(const bfd_dev &d, int *tilesX, int *tilesY, int *subZ)
 {
-    *tilesX = (d.N1 + TX - 1) / TX; *tilesY = (d.N2 + TY - 1) / TY; *tilesZ = (d.nk + ZCHUNK - 1) / ZCHUNK;
+    *tilesX = (d.N1 + TX - 1) / TX; *tilesY = (d.N2 + TY - 1) / TY; *subZ = (d.nk + SUBZ - 1) / SUBZ;
+}
+int bfd_tile_zchunk(void) { return ZCHUNK; }
+int bfd_tile_subz(void) { return SUBZ; }
+
+void bfd_launch_classify_rows(const bfd_dev &d, hipStream_t s, const int4 *solidRuns, int nSolid, unsigned short *rowFlags)
+{
+    if (nSolid) hipLaunchKernelGGL(classify_rows, dim3(nSolid), dim3(TX, TY, 1), 0, s, d, (d.N1 + TX - 1) / TX, solidRuns, rowFlags);
+}
+
+void bfd_launch_mark_solid(const bfd_dev &d, hipStream_t s, unsigned char *flag, long n)
+{
+    hipLaunchKernelGGL(mark_solid_cells, dim3((unsigned)std::min<long>((n + 255) / 256, 8192)), dim3(256), 0, s, d, flag, n);
+}
+void bfd_launch_shear_coefficients(const bfd_dev &d, hipStream_t s, const unsigned *cells, float *coef, long n)
+{
+    if (n) hipLaunchKernelGGL(shear_coefficients, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d, cells, coef, n);
 }
 
 void bfd_launch_classify(const bfd_dev &d, hipStream_t s, int *flagsDev, int *tileMatDev)
 {
     int tx, ty, tz; bfd_tile_grid(d, &tx, &ty, &tz);
-    hipLaunchKernelGGL((classify_tiles<ZCHUNK>), dim3(tx * ty * tz), dim3(256), 0, s, d, tx, ty, flagsDev, tileMatDev);
+    hipLaunchKernelGGL(classify_tiles, dim3(tx * ty * tz), dim3(256), 0, s, d, tx, ty, flagsDev, tileMatDev);
 }
 
-#define BFD_LAUNCH(K, n, ...) hipLaunchKernelGGL(K, dim3(n), dim3(TX, TY, 1), 0, s, d, tilesX, tilesY, n, __VA_ARGS__)
+#define BFD_LAUNCH(K, n, ...) hipLaunchKernelGGL(K, dim3(n), dim3(TX, TY, 1), 0, s, d, tilesX, n, __VA_ARGS__)
 
-int bfd_tile_zchunk(void) { return ZCHUNK; }
-
-// tile list layout: [fluid boundary | fluid interior | solid boundary | solid interior]; "boundary" = the
-// first and the last z-chunk of the slab (the tiles whose planes a Z-neighbour reads).
-// part: 0 = every tile, 1 = boundary tiles, 2 = interior tiles
+// run list layout: [fluid boundary | fluid interior | solid boundary | solid interior]; "boundary" = runs
+// inside the first and the last ZCHUNK planes of the slab (the planes a Z-neighbour reads).
+// part: 0 = every run, 1 = boundary runs, 2 = interior runs
 static inline void part_range(int n, int nB, int part, int *off, int *cnt)
 {
     if (part == 1) { *off = 0; *cnt = nB; }
@@ -811,31 +1144,42 @@ static inline void part_range(int n, int nB, int part, int *off, int *cnt)
 
 void bfd_launch_stress_v2(const bfd_dev &d, hipStream_t s, const bfd_tiles *t, int part)
 {
-    int tilesX, tilesY, tilesZ; bfd_tile_grid(d, &tilesX, &tilesY, &tilesZ);
+    const int tilesX = (d.N1 + TX - 1) / TX;
     int off, n;
     part_range(t->nFluid, t->nFluidB, part, &off, &n);
     if (n) {
-        if (d.collapsed) BFD_LAUNCH((stress_fluid<ZCHUNK, true>), n, t->list + off, t->tileFlags, t->tileMat);
-        else BFD_LAUNCH((stress_fluid<ZCHUNK, false>), n, t->list + off, t->tileFlags, t->tileMat);
+        if (d.collapsed) BFD_LAUNCH((stress_fluid<true>), n, t->runs + off);
+        else BFD_LAUNCH((stress_fluid<false>), n, t->runs + off);
     }
     part_range(t->nSolid, t->nSolidB, part, &off, &n);
-    if (n) BFD_LAUNCH((stress_v2<ZCHUNK>), n, t->list + t->nFluid + off);
+    if (n) {
+        if (t->shearCells || !t->rowFlags) {
+            if (t->rowFlags) BFD_LAUNCH(stress_normal_solid, n, t->runs + t->nFluid + off, t->rowFlags + (size_t)off * ZCHUNK);
+            else BFD_LAUNCH(stress_v2, n, t->runs + t->nFluid + off, (const unsigned short *)nullptr);     // variant 2: monolithic
+        } else BFD_LAUNCH(stress_v2, n, t->runs + t->nFluid + off, t->rowFlags + (size_t)off * ZCHUNK);
+    }
+    if (t->shearCells && t->nShear) {     // sparse shear: cells sorted by index; [0,lowEnd) and [highBeg,n) are the boundary chunks
+        long b0 = 0, e0 = t->nShear, b1 = 0, e1 = 0;
+        if (part == 1) { e0 = t->shearLowEnd; b1 = t->shearHighBeg; e1 = t->nShear; }
+        else if (part == 2) { b0 = t->shearLowEnd; e0 = t->shearHighBeg; }
+        if (e0 > b0) hipLaunchKernelGGL(stress_shear_sparse, dim3((unsigned)((e0 - b0 + 255) / 256)), dim3(256), 0, s, d, t->shearCells + b0, t->shearCoef + 6 * b0, e0 - b0);
+        if (e1 > b1) hipLaunchKernelGGL(stress_shear_sparse, dim3((unsigned)((e1 - b1 + 255) / 256)), dim3(256), 0, s, d, t->shearCells + b1, t->shearCoef + 6 * b1, e1 - b1);
+    }
 }
 
 void bfd_launch_velocity_v2(const bfd_dev &d, hipStream_t s, float *accP, float *pkP, const bfd_tiles *t, int part)
 {
-    int tilesX, tilesY, tilesZ; bfd_tile_grid(d, &tilesX, &tilesY, &tilesZ);
+    const int tilesX = (d.N1 + TX - 1) / TX;
     const bool acc = accP || pkP;
     int off, n;
     part_range(t->nFluid, t->nFluidB, part, &off, &n);
     if (n) {
-        if (acc) BFD_LAUNCH((velocity_fluid<ZCHUNK, true>), n, t->list + off, t->tileFlags, t->tileMat, accP, pkP);
-        else BFD_LAUNCH((velocity_fluid<ZCHUNK, false>), n, t->list + off, t->tileFlags, t->tileMat, accP, pkP);
+        if (acc) BFD_LAUNCH((velocity_fluid<true>), n, t->runs + off, accP, pkP);
+        else BFD_LAUNCH((velocity_fluid<false>), n, t->runs + off, accP, pkP);
     }
     part_range(t->nSolid, t->nSolidB, part, &off, &n);
     if (n) {
-        const int *denseList = t->list + t->nFluid + off;
-        if (acc) BFD_LAUNCH((velocity_v2<ZCHUNK, true>), n, accP, pkP, denseList);
-        else BFD_LAUNCH((velocity_v2<ZCHUNK, false>), n, accP, pkP, denseList);
+        if (acc) BFD_LAUNCH((velocity_v2<true>), n, accP, pkP, t->runs + t->nFluid + off);
+        else BFD_LAUNCH((velocity_v2<false>), n, accP, pkP, t->runs + t->nFluid + off);
     }
 }

@@ -42,6 +42,7 @@ def parse():
     ap.add_argument('--size', type=int, nargs=3, default=None, help='override per-GPU grid N1 N2 N3')
     ap.add_argument('--variant', type=int, default=0, help='kernel variant (0 default, 1 simple, 2 LDS-tiled)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--lean-host', action='store_true', help='build the inputs slab-style (size-1 Ox/Oy/Oz) also at N=1: for 1024^3 on one GPU')
     ap.add_argument('--cpu-sample', type=int, nargs=4, default=[256, 256, 192, 24], help='N1 N2 N3 steps of the oracle sample')
     return ap.parse_args()
 
@@ -112,7 +113,7 @@ def main():
     N = (n1, n2, n3 * world)                       # weak scaling: one full grid per GPU
     nt = args.steps + args.warmup
     t0 = time.time()
-    if world == 1:
+    if world == 1 and not args.lean_host:
         a, k, info = H.make_problem(args.config, N=N, steps=nt, stable_dt_fn=dt_fn, forward=RayleighAndBHTE.ForwardSimple)
         local = None
     else:   # every rank builds only its own Z-slab of the domain

@@ -166,7 +166,7 @@ int bfd_dft_series(int32_t device, int64_t nSensors, int32_t nTs, const float *s
 int bfd_get_map(bfd_sim *sim, int32_t kind, int32_t map, float *out, int64_t s1, int64_t s2, int64_t s3);
 /* raw state array a (0..14: Vx Vy Vz Sxx Syy Szz Sxy Sxz Syz Rxx Ryy Rzz Rxy Rxz Ryz), for tests */
 int bfd_get_field(bfd_sim *sim, int32_t a, float *out, int64_t s1, int64_t s2, int64_t s3);
-/* number of 64x8x32-voxel tiles per class of the class-specialised kernels (variant 0/3):
+/* number of 64x8x8-voxel sub-tiles per class of the class-specialised kernels (variant 0/3):
  * lossless fluid, lossy fluid, solid, and among the fluid ones how many hold one material only (UNI)
  * and how many touch the absorbing layer (PML) (DESIGN.md "Tile classes"); zeros for variants 1, 2 */
 int bfd_tile_counts(bfd_sim *sim, int32_t *nLossless, int32_t *nLossy, int32_t *nSolid, int32_t *nUni, int32_t *nPml);
