@@ -345,6 +345,9 @@ __global__ __launch_bounds__(NTHREADS, VELOCITY_WAVES_PER_SIMD) void velocity_v2
     const int P = d.P;
     const int own = (ty + 2) * LW + tx + 2;
     const unsigned cij = valid ? (unsigned)(j * N1 + i) : 0u;
+    const unsigned cx = valid ? (unsigned)(j * N1 + min(i + 1, N1 - 1)) : 0u;      // (i+1, j)
+    const unsigned cy = valid ? (unsigned)(min(j + 1, N2 - 1) * N1 + i) : 0u;      // (i, j+1)
+    const bool accA = ACC && accP != nullptr, accK = ACC && pkP != nullptr;
 
     // halo tasks: [Syy-y, Sxy-y] 2*256 (task A: every thread), then [Syz-y] 256, [Sxx-x, Sxy-x, Sxz-x] 3*32
     HaloTask ta, tb;
@@ -378,6 +381,18 @@ __global__ __launch_bounds__(NTHREADS, VELOCITY_WAVES_PER_SIMD) void velocity_v2
         yzm2 = (byz - 2 * pl)[cij]; yzm1 = (byz - pl)[cij]; yz0 = byz[cij]; yzp1 = (byz + pl)[cij];
         sxx = (d.Sxx + kbeg * pl)[cij]; syy = (d.Syy + kbeg * pl)[cij]; sxy = (d.Sxy + kbeg * pl)[cij];
     }
+    // pipelined like the fluid bodies: V, accumulators and material ids of plane kl are in registers when its
+    // iteration starts (own id two planes ahead: the z face needs 1/rho of plane kl+1)
+    float vx = 0, vy = 0, vz = 0, av = 0, pv = 0, r0 = 0;
+    unsigned mraw = 0, mraw1 = 0, mx = 0, my = 0;
+    if (valid) {
+        const uint16_t *bM = d.mat + kbeg * pl;
+        vx = (d.Vx + kbeg * pl)[cij]; vy = (d.Vy + kbeg * pl)[cij]; vz = (d.Vz + kbeg * pl)[cij];
+        mraw = bM[cij]; mraw1 = (bM + pl)[cij]; mx = bM[cx]; my = bM[cy];
+        if (accA) av = (accP + kbeg * pl)[cij];
+        if (accK) pv = (pkP + kbeg * pl)[cij];
+        r0 = d.invRho[mraw & BFD_MAT_MASK];
+    }
     float ha = ta.ok ? pa[kbeg * pl] : 0.0f;
     float hb = tb.ok ? pb[kbeg * pl] : 0.0f;
 
@@ -389,18 +404,27 @@ __global__ __launch_bounds__(NTHREADS, VELOCITY_WAVES_PER_SIMD) void velocity_v2
         sS[b][0][own] = sxx; sS[b][1][own] = syy; sS[b][2][own] = sxy; sS[b][3][own] = xz0; sS[b][4][own] = yz0;
         la[bo] = ha;
         if (hasB) lb[bo] = hb;
+        float r1 = 0, rx = 0, ry = 0;
+        if (valid) {
+            r1 = d.invRho[mraw1 & BFD_MAT_MASK];       // plane kl+1, becomes r0 of the next iteration
+            rx = d.invRho[mx & BFD_MAT_MASK];
+            ry = d.invRho[my & BFD_MAT_MASK];
+        }
         __syncthreads();
 
         float *pVx = d.Vx + ko, *pVy = d.Vy + ko, *pVz = d.Vz + ko;
-        const uint16_t *pM = d.mat + ko;
-        unsigned mraw = 0;
-        float vx = 0, vy = 0, vz = 0;
-        if (valid) { mraw = pM[cij]; vx = pVx[cij]; vy = pVy[cij]; vz = pVz[cij]; }
         float nzz = 0, nxz = 0, nyz = 0, nxx = 0, nyy = 0, nxy = 0, nha = 0, nhb = 0;
+        float nvx = 0, nvy = 0, nvz = 0, nav = 0, npv = 0;
+        unsigned nm2 = 0, nmx = 0, nmy = 0;
+        if (valid) nm2 = (d.mat + ko + 2 * pl)[cij];              // ghost planes make kl+2 addressable
         if (kl + 1 < kend) {
             if (valid) {
                 nzz = (d.Szz + ko + 3 * pl)[cij]; nxz = (d.Sxz + ko + 2 * pl)[cij]; nyz = (d.Syz + ko + 2 * pl)[cij];
                 nxx = (d.Sxx + ko + pl)[cij]; nyy = (d.Syy + ko + pl)[cij]; nxy = (d.Sxy + ko + pl)[cij];
+                nvx = (pVx + pl)[cij]; nvy = (pVy + pl)[cij]; nvz = (pVz + pl)[cij];
+                nmx = (d.mat + ko + pl)[cx]; nmy = (d.mat + ko + pl)[cy];
+                if (accA) nav = (accP + ko + pl)[cij];
+                if (accK) npv = (pkP + ko + pl)[cij];
             }
             if (ta.ok) nha = pa[ko + pl];
             if (tb.ok) nhb = pb[ko + pl];
@@ -413,8 +437,8 @@ __global__ __launch_bounds__(NTHREADS, VELOCITY_WAVES_PER_SIMD) void velocity_v2
                 if (inner && k >= d.ND && k < d.N3 - d.ND) {
                     const float s = (sxx + syy) + zz0;
                     const float p = -s * (1.0f / 3.0f);
-                    if (accP) (accP + ko)[cij] = (accP + ko)[cij] + p * p;
-                    if (pkP) { const float ap = fabsf(p); if (ap > (pkP + ko)[cij]) (pkP + ko)[cij] = ap; }
+                    if (accA) (accP + ko)[cij] = av + p * p;
+                    if (accK) { const float ap = fabsf(p); if (ap > pv) (pkP + ko)[cij] = ap; }
                 }
             }
             if (mraw & BFD_REFLECTOR_BIT) {
@@ -452,12 +476,7 @@ __global__ __launch_bounds__(NTHREADS, VELOCITY_WAVES_PER_SIMD) void velocity_v2
                     dzSyz = cpml(d.psi[14], q, d.azI[k], d.bzI[k], dzSyz);
                     dzSzz = cpml(d.psi[17], q, d.azH[k], d.bzH[k], dzSzz);
                 }
-                const int m = mraw & BFD_MAT_MASK;
-                const int i1 = min(i + 1, N1 - 1), j1 = min(j + 1, N2 - 1);
-                const float r0 = d.invRho[m];
-                const float bxv = 0.5f * (r0 + d.invRho[pM[(unsigned)(j * N1 + i1)] & BFD_MAT_MASK]);
-                const float byv = 0.5f * (r0 + d.invRho[pM[(unsigned)(j1 * N1 + i)] & BFD_MAT_MASK]);
-                const float bzv = 0.5f * (r0 + d.invRho[(pM + pl)[cij] & BFD_MAT_MASK]);
+                const float bxv = 0.5f * (r0 + rx), byv = 0.5f * (r0 + ry), bzv = 0.5f * (r0 + r1);
                 pVx[cij] = vx + bxv * ((dxSxx + dySxy) + dzSxz);
                 pVy[cij] = vy + byv * ((dxSxy + dySyy) + dzSyz);
                 pVz[cij] = vz + bzv * ((dxSxz + dySyz) + dzSzz);
@@ -468,6 +487,8 @@ __global__ __launch_bounds__(NTHREADS, VELOCITY_WAVES_PER_SIMD) void velocity_v2
         yzm2 = yzm1; yzm1 = yz0; yz0 = yzp1; yzp1 = nyz;
         sxx = nxx; syy = nyy; sxy = nxy;
         ha = nha; hb = nhb;
+        vx = nvx; vy = nvy; vz = nvz; av = nav; pv = npv;
+        r0 = r1; mraw = mraw1; mraw1 = nm2; mx = nmx; my = nmy;
     }
 }
 
