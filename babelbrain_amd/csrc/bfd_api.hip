@@ -693,6 +693,8 @@ static int build_tile_lists(bfd_sim *s)
     bfd_tiles &T = s->tiles;
     T.nFluid = T.nFluidB = T.nSolid = T.nSolidB = T.nLossless = T.nLossy = T.nSolidSub = T.nUni = T.nPml = 0;
     std::vector<int4> lists[4];      // fluid boundary, fluid interior, solid boundary, solid interior
+    // list order: the z-chunks of one (bx,by) column are consecutive (they share their prologue planes), columns
+    // follow in x then y. Measured at 512^3: 4 % faster than z-chunk-slowest order (78.7 vs 75.4 Gvoxel-steps/s).
     for (int txy = 0; txy < tx * ty; txy++)
         for (int c = 0; c < nChunks; c++) {
             const bool bnd = (c == 0 || c == nChunks - 1);
