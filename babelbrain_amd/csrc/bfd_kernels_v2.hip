@@ -27,7 +27,10 @@ constexpr int LH = TY + 4;          // LDS rows
 constexpr int NTHREADS = TX * TY;   // 512
 constexpr int YT = 4 * TX;          // y-halo tasks per array (4 rows x 64)
 constexpr int XT = 4 * TY;          // x-halo tasks per array (4 cols x TY)
-constexpr int ZCHUNK = 32;          // longest z-run one workgroup marches
+#ifndef BFD_ZCHUNK
+#define BFD_ZCHUNK 32
+#endif
+constexpr int ZCHUNK = BFD_ZCHUNK;  // longest z-run one workgroup marches
 #ifndef BFD_SUBZ
 #define BFD_SUBZ 8
 #endif

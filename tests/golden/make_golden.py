@@ -177,6 +177,45 @@ def main():
     out['phase_fourier'] = slf._PressMapFourier
     out['phase_peak'] = slf._PressMapPeak
 
+    # (8) refocusing: BackPropagationRayleigh + CreateSourcesRefocus of the phased-array integration
+    #     (BabelIntegrationCONCAVE_PHASEDARRAY.py:407-484), with ForwardSimple (absent package) replaced by the
+    #     float64 Rayleigh sum of oracle/rayleigh_oracle.py -- pins the orchestration arithmetic around it
+    from TranscranialModeling import BabelIntegrationCONCAVE_PHASEDARRAY as CC
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import rayleigh_oracle as RO
+    rng = np.random.default_rng(11)
+    N1, N2, N3, pml, zsrc = 30, 28, 36, 12, 14
+    h = 4e-4
+    XDim = (np.arange(N1) - N1 / 2) * h
+    YDim = (np.arange(N2) - N2 / 2) * h
+    ZDim = (np.arange(N3) - zsrc) * h
+    smr = np.zeros((N1, N2), np.complex64)
+    smr[pml:-pml, pml:-pml] = (rng.normal(size=(N1 - 2 * pml, N2 - 2 * pml)) + 1j * rng.normal(size=(N1 - 2 * pml, N2 - 2 * pml)))
+    back = (rng.normal(size=(N1, N2)) + 1j * rng.normal(size=(N1, N2))).astype(np.complex64)
+    nElem, edims = 5, 7
+    elemc = np.stack([rng.uniform(-4e-3, 4e-3, nElem), rng.uniform(-4e-3, 4e-3, nElem), np.full(nElem, -6e-3)], 1).astype(np.float32)
+    cen = np.repeat(elemc, edims, axis=0) + rng.normal(scale=2e-4, size=(nElem * edims, 3)).astype(np.float32)
+    Tx = {'elemcenter': elemc, 'center': cen.astype(np.float32), 'ds': np.full((nElem * edims, 1), 1e-7, np.float32),
+          'NumberElems': nElem, 'elemdims': edims}
+    slf = SimpleNamespace(_SourceMapRayleigh=smr, _PressMapFourierBack=back, _XDim=XDim, _YDim=YDim, _ZDim=ZDim,
+                          _ZSourceLocation=zsrc, _SpatialStep=h, _Frequency=500e3, _Tx=Tx, _SourceAmpPa=2.5,
+                          BasePhasedArrayProgrammingRefocusing=np.zeros(nElem, np.complex64), _PMLThickness=pml,
+                          AdjustWeightAmplitudes=lambda: 1.0, _N1=N1, _N2=N2, _N3=N3, _TemporalStep=1 / 500e3 / 30,
+                          _TimeSimulation=150 / 500e3 / 30)
+    with mock.patch.object(CC, 'ForwardSimple', lambda k, c, d, u, r, deviceMetal=None: RO.ForwardSimple(k, c, d, u, r)):
+        CC.SimulationConditions.BackPropagationRayleigh(slf)
+    CC.SimulationConditions.CreateSourcesRefocus(slf)
+    out['refocus_args'] = np.array([N1, N2, N3, pml, zsrc, h, 500e3, 2.5, slf._TemporalStep, slf._TimeSimulation])
+    out['refocus_source_plane'] = smr
+    out['refocus_back_plane'] = back
+    out['refocus_elemcenter'] = elemc
+    out['refocus_center'] = cen.astype(np.float32)
+    out['refocus_ds'] = Tx['ds']
+    out['refocus_elem'] = np.array([nElem, edims])
+    out['refocus_programming'] = slf.BasePhasedArrayProgrammingRefocusing
+    out['refocus_plane'] = slf._SourceMapRayleighRefocus
+    out['refocus_pulse'] = slf._PulseSourceRefocus
+
     np.savez_compressed(os.path.join(HERE, 'harness_golden.npz'), **out)
     with open(os.path.join(HERE, 'harness_golden.json'), 'w') as fh:
         json.dump(meta, fh, indent=1, sort_keys=True, default=str)

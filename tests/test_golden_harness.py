@@ -98,3 +98,26 @@ def test_sensor_index_decode(golden):
     sm = np.zeros((N1, N2, N3), np.uint32)
     sm[i, j, k] = 1
     assert sm.sum() == len(i) and np.all(sm[12:-12, 12:-12, 15:-12] == 1)
+
+
+def test_refocusing_orchestration(golden):
+    """BackPropagationRayleigh + CreateSourcesRefocus (CONCAVE:407-484) as restated in babelbrain_amd/refocus.py,
+    with the same float64 Rayleigh sum the golden vectors were generated with."""
+    from babelbrain_amd import refocus
+    from oracle import rayleigh_oracle as RO
+    g, _ = golden
+    N1, N2, N3, pml, zsrc, h, f, amp, dt, T = g['refocus_args']
+    N1, N2, N3, pml, zsrc = int(N1), int(N2), int(N3), int(pml), int(zsrc)
+    XDim = (np.arange(N1) - N1 / 2) * h
+    YDim = (np.arange(N2) - N2 / 2) * h
+    ZDim = (np.arange(N3) - zsrc) * h
+    nElem, edims = g['refocus_elem']
+    Tx = {'elemcenter': g['refocus_elemcenter'], 'center': g['refocus_center'], 'ds': g['refocus_ds'],
+          'NumberElems': nElem, 'elemdims': edims}
+    plane, prog = refocus.back_propagation_rayleigh(g['refocus_source_plane'], g['refocus_back_plane'], XDim, YDim, ZDim, zsrc, h,
+                                                    f, Tx, amp, pml, forward=lambda k, c, d, u, r: RO.ForwardSimple(k, c, d, u, r))
+    np.testing.assert_allclose(prog, g['refocus_programming'], rtol=1e-6)
+    np.testing.assert_allclose(plane, g['refocus_plane'], rtol=1e-9, atol=1e-12)
+    pulse = refocus.refocus_sources(g['refocus_source_plane'], plane, f, dt, T)
+    assert pulse.shape == g['refocus_pulse'].shape
+    np.testing.assert_allclose(pulse, g['refocus_pulse'], rtol=1e-9, atol=1e-12)
