@@ -309,6 +309,21 @@ static void ftz_off(void)
     { unsigned int csr; __asm__ volatile("stmxcsr %0" : "=m"(csr)); csr &= ~0x8040u; __asm__ volatile("ldmxcsr %0" : : "m"(csr)); }
 }
 
+/* zero-filled allocation whose pages are first touched by the OpenMP team in the same plane order the
+ * half-step loops use, so on a multi-socket host every thread works on memory of its own NUMA node */
+static float *numa_zeros(size_t n, size_t planeElems)
+{
+    float *p = (float *)malloc(n * sizeof(float));
+    if (!p) return NULL;
+    const long nplanes = (long)((n + planeElems - 1) / planeElems);
+#pragma omp parallel for schedule(static)
+    for (long q = 0; q < nplanes; q++) {
+        const size_t a = (size_t)q * planeElems, b = a + planeElems < n ? a + planeElems : n;
+        memset(p + a, 0, (b - a) * sizeof(float));
+    }
+    return p;
+}
+
 BFO_EXPORT void bfo_destroy(bfo_sim *S)
 {
     if (!S) return;
@@ -350,11 +365,11 @@ BFO_EXPORT bfo_sim *bfo_create(const bfo_params *p, int k0, int nk, const uint32
     F->N1 = N1; F->N2 = N2; F->N3 = nk;
     F->P1 = (size_t)N1 + 4; F->P12 = F->P1 * ((size_t)N2 + 4);
     const size_t NP = F->P12 * ((size_t)nk + 4);
-    for (int a = 0; a < 15; a++) { F->f[a] = (float *)calloc(NP, sizeof(float)); if (!F->f[a]) goto fail; }
+    for (int a = 0; a < 15; a++) { F->f[a] = numa_zeros(NP, F->P12); if (!F->f[a]) goto fail; }
     /* CPML memory variables, slab-size unpadded (only layer voxels are ever touched):
        0..8  stress half-step: dxVx dyVy dzVz | dyVx dxVy | dzVx dxVz | dzVy dyVz
        9..17 velocity half-step: dxSxx dySxy dzSxz | dxSxy dySyy dzSyz | dxSxz dySyz dzSzz */
-    for (int a = 0; a < 18; a++) { S->psi[a] = (float *)calloc(N, sizeof(float)); if (!S->psi[a]) goto fail; }
+    for (int a = 0; a < 18; a++) { S->psi[a] = numa_zeros(N, plane); if (!S->psi[a]) goto fail; }
     const int Nmax = N1 > N2 ? (N1 > N3 ? N1 : N3) : (N2 > N3 ? N2 : N3);
     S->prof = (float *)calloc(12 * (size_t)Nmax, sizeof(float));
     if (!S->prof) goto fail;
@@ -386,8 +401,8 @@ BFO_EXPORT bfo_sim *bfo_create(const bfo_params *p, int k0, int nk, const uint32
         if (p->selMapsSensors & (1u << b)) S->selS[S->nSelS++] = b;
     }
     S->doRMS = (p->selRMSorPeak & 1) && S->nSelR; S->doPeak = (p->selRMSorPeak & 2) && S->nSelR;
-    if (S->doRMS) { S->acc = (float *)calloc((size_t)S->nSelR * N, sizeof(float)); if (!S->acc) goto fail; }
-    if (S->doPeak) { S->pk = (float *)calloc((size_t)S->nSelR * N, sizeof(float)); if (!S->pk) goto fail; }
+    if (S->doRMS) { S->acc = numa_zeros((size_t)S->nSelR * N, plane); if (!S->acc) goto fail; }
+    if (S->doPeak) { S->pk = numa_zeros((size_t)S->nSelR * N, plane); if (!S->pk) goto fail; }
     /* sensors: ascending x-fastest order */
     if (sensormap) for (size_t v = 0; v < N; v++) if (sensormap[v]) S->nSensors++;
     S->sensLin = (uint32_t *)malloc((S->nSensors + 1) * sizeof(uint32_t));
