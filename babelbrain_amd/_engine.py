@@ -45,6 +45,30 @@ class EngineError(RuntimeError):
 _lib = None
 
 
+def _preload_torch_hip_runtime():
+    """One HIP runtime per process. PyTorch-ROCm wheels bundle their own libamdhip64 (soname
+    libamdhip64.so.7, the one this library needs too). If this library were loaded first it would bind to
+    the system runtime and a later `import torch` would bring a second one, which then finds no GPU. So when
+    a torch wheel is installed its runtime is loaded first (a plain dlopen, torch itself is not imported);
+    multi-GPU runs (slab.py) hand torch streams and RCCL the engine's device memory and need the shared runtime."""
+    import importlib.util
+    import sys
+    if 'torch' in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec('torch')
+    except Exception:
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], 'lib', 'libamdhip64.so')
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load_library():
     """Load libbabelfdtd_hip.so; raises if it has not been built (python __graft_entry__.py build)."""
     global _lib
@@ -53,6 +77,7 @@ def load_library():
     if not os.path.exists(LIB_PATH):
         raise EngineError('HIP engine library missing: %s (build it with `make -C babelbrain_amd/csrc`); '
                           'there is no CPU fallback' % LIB_PATH)
+    _preload_torch_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     lib.bfd_last_error.restype = C.c_char_p
     lib.bfd_stable_dt.restype = C.c_double
