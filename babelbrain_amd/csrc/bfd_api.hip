@@ -674,7 +674,13 @@ static int build_tile_lists(bfd_sim *s)
 {
     int tx, ty, nsub; bfd_tile_grid(s->d, &tx, &ty, &nsub);
     const int n = tx * ty * nsub;
-    const int SUB = bfd_tile_subz(), perChunk = bfd_tile_zchunk() / SUB;
+    const int SUB = bfd_tile_subz();
+    // longest run one workgroup marches: 32 planes on big grids; shorter on small ones so that the launch still
+    // has a few thousand workgroups (measured: 256^3 49 -> 58, 128^3 29 -> 46, 320x320x384 60 -> 66 Gvoxel-steps/s)
+    const int t32 = tx * ty * ((s->d.nk + 31) / 32);
+    s->zchunk = t32 >= 6000 ? 32 : (t32 >= 1500 ? 16 : 8);
+    if (s->zchunk > bfd_tile_zchunk()) s->zchunk = bfd_tile_zchunk();
+    const int perChunk = s->zchunk / SUB;
     const int nChunks = (nsub + perChunk - 1) / perChunk;
     std::vector<int> flags(n, 1), mats(n, 0);
     if (s->cfg.kernelVariant != 2) {
@@ -762,7 +768,7 @@ static int build_tile_lists(bfd_sim *s)
         if (e != hipSuccess) BFD_FAIL(-10, std::string("shear list: ") + hipGetErrorString(e));
         if (rc) return rc;
         s->tiles.nShear = count;
-        const unsigned zc = (unsigned)bfd_tile_zchunk() * (unsigned)s->d.plane;
+        const unsigned zc = (unsigned)s->zchunk * (unsigned)s->d.plane;
         s->tiles.shearLowEnd = std::lower_bound(hostCells.begin(), hostCells.end(), zc) - hostCells.begin();
         s->tiles.shearHighBeg = nChunks > 1 ? std::lower_bound(hostCells.begin(), hostCells.end(), zc * (unsigned)(nChunks - 1)) - hostCells.begin() : count;
     }
@@ -772,7 +778,7 @@ static int build_tile_lists(bfd_sim *s)
     const uint32_t sig = (1u << BFD_MAP_SIGMAXX) | (1u << BFD_MAP_SIGMAYY) | (1u << BFD_MAP_SIGMAZZ);
     s->d.collapsed = (nC == 0 && ((s->cfg.selMapsRMS | s->cfg.selMapsSensors) & sig) == 0) ? 1 : 0;
     {   // sources of the first / last z-chunk (bfd_set_sources sorted them by voxel)
-        const uint32_t zc = (uint32_t)bfd_tile_zchunk() * (uint32_t)s->d.plane;
+        const uint32_t zc = (uint32_t)s->zchunk * (uint32_t)s->d.plane;
         std::vector<uint32_t> lin((size_t)s->nSrcVox);
         if (s->nSrcVox) BFD_HIP(hipMemcpy(lin.data(), s->srcLin, lin.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
         s->srcLowEnd = std::lower_bound(lin.begin(), lin.end(), zc) - lin.begin();

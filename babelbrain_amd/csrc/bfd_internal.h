@@ -58,7 +58,8 @@ struct bfd_sim {
     std::vector<void *> allocs;     // everything to free
     int64_t devBytes;
     bool haveMaterials, haveMap;
-    bfd_tiles tiles; bool tilesReady;   // variant 3
+    bfd_tiles tiles; bool tilesReady;   // variants 2, 3
+    int zchunk;                         // planes of the longest z-run (8, 16 or 32), chosen per grid
     double cmax;
     // sources
     int64_t nSrcVox, srcLowEnd, srcHighBeg;   // sources sorted by voxel: [0,lowEnd) first z-chunk, [highBeg,n) last z-chunk

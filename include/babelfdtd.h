@@ -127,7 +127,7 @@ int bfd_run(bfd_sim *sim, int32_t nSteps);
 int bfd_half_step_stress(bfd_sim *sim);
 int bfd_half_step_velocity(bfd_sim *sim);   /* also accumulates, records sensors, advances the step counter */
 /* the same half-steps in two parts, so a halo exchange can overlap the bulk of the work:
- * part 1 = the tiles of the first and last 32-plane z-chunk of the slab (everything a Z-neighbour reads),
+ * part 1 = the tiles of the first and last z-chunk (8-32 planes) of the slab (everything a Z-neighbour reads),
  * part 2 = all other tiles plus the end-of-step work; part 0 = both (the calls above). Per half-step call
  * part 1 then part 2. (kernelVariant 1: part 1 is empty.) */
 int bfd_half_step_stress_part(bfd_sim *sim, int32_t part);
