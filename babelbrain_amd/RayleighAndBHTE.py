@@ -81,3 +81,77 @@ def GenerateFocusTx(f, Foc, Diam, c, PPWSurface=4):
     return {'center': pts.astype(np.float32), 'ds': ds.reshape(-1, 1).astype(np.float32), 'normal': nrm.astype(np.float32),
             'elemcenter': np.zeros((1, 3), np.float32), 'VertDisplay': pts.astype(np.float32).copy(),
             'FaceDisplay': np.zeros((0, 4), np.int64), 'NumberElems': 1, 'Aperture': Diam, 'FocalLength': Foc}
+
+
+# ------------------------------------------------------------------------------------------------
+# BHTE: Pennes bio-heat equation + CEM43 dose on the device (bfd_bhte_run)
+# ------------------------------------------------------------------------------------------------
+def bhte_coefficients(MaterialList, dx, dt, DutyCycle=1.0, blood_rho=1050.0, blood_ct=3617.0):
+    """Per-material float32 coefficients of the explicit scheme (documented in csrc/bfd_bhte.hip):
+    cd = dt k/(rho c dx^2), cp = dt rho_b c_b w/(6e7 c) with w in mL/min/kg, and the factor qf that turns
+    p^2 into the temperature increment of one ON step: qf = dt DutyCycle Absorption Attenuation/(rho^2 c_s c)."""
+    rho = np.asarray(MaterialList['Density'], np.float64)
+    ct = np.asarray(MaterialList['SpecificHeat'], np.float64)
+    cd = dt * np.asarray(MaterialList['Conductivity'], np.float64) / (rho * ct * dx ** 2)
+    cp = dt * blood_rho * blood_ct * np.asarray(MaterialList['Perfusion'], np.float64) / (6e7 * ct)
+    qf = (dt * DutyCycle * np.asarray(MaterialList['Absorption'], np.float64) * np.asarray(MaterialList['Attenuation'], np.float64)
+          / (rho * np.asarray(MaterialList['SoS'], np.float64)) / (rho * ct))
+    if cd.max() > 1.0 / 6.0:
+        raise ValueError('BHTE time step too large: dt k/(rho c dx^2) = %.3f > 1/6' % cd.max())
+    return cd.astype(np.float32), cp.astype(np.float32), qf.astype(np.float32)
+
+
+def BHTE(Pressure, MaterialMap, MaterialList, dx, TotalDurationSteps, nStepsOn, LocationMonitoring,
+         nFactorMonitoring=1, dt=0.1, blood_rho=1050, blood_ct=3617, stableTemp=37.0, DutyCycle=1.0,
+         Backend='HIP', MonitoringPointsMap=None, initT0=None, initDose=None):
+    """Same call as the reference makes (CalculateTemperatureEffects.py:365-456, 960). Pressure: amplitude map
+    (N1,N2,N3) Pa; MaterialMap: integer ids; MaterialList: dict of per-material arrays 'Density', 'SoS',
+    'Attenuation' (Np/m), 'SpecificHeat', 'Conductivity', 'Perfusion' (mL/min/kg), 'Absorption' (fraction of the
+    attenuation that heats), 'InitTemperature'. Returns (ResTemp, ResDose, MonitorSlice, Qarr[, TemperaturePoints])."""
+    global last_kernel_ms
+    lib = _engine.load_library()
+    P = np.asarray(Pressure)
+    N1, N2, N3 = P.shape
+    mm = np.asarray(MaterialMap)
+    nMat = len(MaterialList['Density'])
+    if mm.max() >= nMat or nMat > 256:
+        raise ValueError('MaterialMap ids must index MaterialList (at most 256 materials)')
+    cd, cp, qf = bhte_coefficients(MaterialList, dx, dt, DutyCycle, blood_rho, blood_ct)
+
+    def xf(a, dtype):
+        return np.ascontiguousarray(np.asarray(a).transpose(2, 1, 0), dtype=dtype)
+    mat = xf(mm, np.uint8)
+    p32 = xf(P, np.float32)
+    q = (p32 * p32) * qf[mat]                                    # float32, same operation order as the oracle
+    T = xf(initT0, np.float32) if initT0 is not None else np.asarray(MaterialList['InitTemperature'], np.float32)[mat]
+    T = np.ascontiguousarray(T, np.float32)
+    dose = xf(initDose, np.float32) if initDose is not None else np.zeros((N3, N2, N1), np.float32)
+    nSteps = int(TotalDurationSteps)
+    fm = max(int(nFactorMonitoring), 1)
+    slice_ok = LocationMonitoring is not None and int(LocationMonitoring) >= 0
+    nS = (nSteps + fm - 1) // fm if slice_ok else 0
+    mon = np.zeros((N1, N3, nS), np.float32) if slice_ok else None
+    idx = pts = None
+    if MonitoringPointsMap is not None:
+        mp = xf(MonitoringPointsMap, np.uint32).ravel()
+        lin = np.flatnonzero(mp)
+        order = np.argsort(mp[lin], kind='stable')               # point ids 1..n label the rows
+        idx = np.ascontiguousarray(lin[order], np.uint32)
+        pts = np.zeros((len(idx), nSteps), np.float32)
+    ms = C.c_double()
+
+    def ptr(a):
+        return None if a is None else a.ctypes.data_as(C.c_void_p)
+    rc = lib.bfd_bhte_run(_device, N1, N2, N3, nMat, ptr(mat), ptr(cd), ptr(cp), ptr(q), ptr(T), ptr(dose), float(stableTemp),
+                          float(dt), nSteps, int(nStepsOn), int(LocationMonitoring) if slice_ok else -1, fm, ptr(mon),
+                          0 if idx is None else len(idx), ptr(idx), ptr(pts), C.byref(ms))
+    if rc != 0:
+        raise _engine.EngineError('bfd_bhte_run failed (rc=%d): %s' % (rc, lib.bfd_last_error().decode()))
+    last_kernel_ms = ms.value
+
+    def vol(a):
+        return np.ascontiguousarray(a.transpose(2, 1, 0))
+    out = (vol(T), vol(dose), mon if slice_ok else np.zeros((0,), np.float32), vol(q))
+    if MonitoringPointsMap is not None:
+        out = out + (pts,)
+    return out

@@ -182,6 +182,16 @@ int64_t bfd_device_bytes(bfd_sim *sim);
 int bfd_rayleigh_forward(int32_t device, int64_t nSrc, const float *center, const float *ds, const float *u0,
                          double kReal, double kImag, int64_t nPts, const float *rf, float *out, double *kernelMs);
 
+/* ---- Pennes bio-heat equation + CEM43 dose: replaces BabelViscoFDTD.tools.RayleighAndBHTE.BHTE ----
+ * (call sites ThermalModeling/CalculateTemperatureEffects.py:365-456, 960). Volumes x-fastest float32, mat = uint8
+ * ids into cd/cp (per material: dt k/(rho c dx^2) and dt rho_b c_b w/(6e7 c)); q = temperature increment of one ON
+ * step; T and dose are updated in place; faces of the volume keep their temperature. monitorSlice (may be NULL):
+ * [N1][N3][ceil(nSteps/nFactorMonitoring)] of plane j = sliceJ; points (may be NULL): [nPoints][nSteps]. */
+int bfd_bhte_run(int32_t device, int32_t N1, int32_t N2, int32_t N3, int32_t nMat, const unsigned char *mat,
+                 const float *cd, const float *cp, const float *q, float *T, float *dose, float Tcore, double dt,
+                 int32_t nSteps, int32_t nStepsOn, int32_t sliceJ, int32_t nFactorMonitoring, float *monitorSlice,
+                 int64_t nPoints, const uint32_t *pointIndex, float *points, double *kernelMs);
+
 #ifdef __cplusplus
 }
 #endif
