@@ -1,0 +1,20 @@
+"""One production-shaped drop-in call at C3 (512^3, nt from the caller's time plan, full sensor volume):
+wall time of PropagationModel.StaggeredFDTD_3D_with_relaxation including upload, layout conversion, the step loop
+and the download of the sensor block and maps -- the PCIe-inclusive rate quoted in DESIGN.md."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from babelbrain_amd import harness as H, PropagationModel, _engine, RayleighAndBHTE
+t0 = time.time()
+a, k, info = H.make_problem('C3', stable_dt_fn=lambda ml, f, h, c: _engine.stable_dt(ml, f, True, h, c), forward=RayleighAndBHTE.ForwardSimple)
+t1 = time.time()
+print('inputs built in %.1f s: nt=%d ppp=%d sub=%d start=%d PulseSource %.1f GB' % (t1 - t0, info['nt'], info['ppp'], k['SensorSubSampling'], k['SensorStart'], a[4].nbytes / 1e9), flush=True)
+pm = PropagationModel()
+t2 = time.time()
+out = pm.StaggeredFDTD_3D_with_relaxation(*a, SILENT=True, ReturnSensorDFT=True, **k)
+t3 = time.time()
+N = 512 ** 3
+tm = pm.last_timing
+print('call wall %.2f s; step loop (device) %.2f s; voxel-steps %.3e' % (t3 - t2, tm['total_ms'] / 1e3, N * info['nt']))
+print('device-only %.0f Mvoxel-steps/s; PCIe-inclusive (whole call) %.0f Mvoxel-steps/s' % (N * info['nt'] / tm['total_ms'] / 1e3, N * info['nt'] / (t3 - t2) / 1e6))
+print('sensor block', out[0]['Pressure'].shape, '%.1f GB' % (out[0]['Pressure'].nbytes / 1e9), 'RMS max', float(out[2]['Pressure'].max()))
