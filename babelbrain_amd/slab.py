@@ -44,11 +44,14 @@ class HipSlab:
     """One slab on one MI355X; halo tensors alias the engine's own device memory (zero copy)."""
     supports_parts = True     # half-steps can run boundary tiles first, so the exchange overlaps the interior
 
-    def __init__(self, engine, device):
+    def __init__(self, engine, device, host_staging=False):
+        """host_staging=True: halos travel through pinned host tensors (for the gloo backend: a debugging
+        aid that lets several ranks share one GPU; RCCL refuses that). Default: zero-copy device tensors."""
         import torch
         self.eng = engine
         self.torch = torch
         self.device = device
+        self.host_staging = host_staging
         torch.cuda.set_device(device)
         # run the engine on torch's current stream so RCCL work orders against the kernels
         engine.set_stream(torch.cuda.current_stream(device).cuda_stream)
@@ -59,18 +62,26 @@ class HipSlab:
                     for send in (0, 1):
                         ptr, nbytes = engine.halo_region(g, f, side, send)
                         self._t[(g, f, side, send)] = torch.as_tensor(_DevBuf(ptr, nbytes // 4), device='cuda:%d' % device)
+        self._h = {key: torch.empty(t.numel(), dtype=torch.float32).pin_memory() for key, t in self._t.items()} if host_staging else None
 
     def halo(self, group, f, side, send):
-        return self._t[(group, f, side, int(send))]
+        return (self._h if self.host_staging else self._t)[(group, f, side, int(send))]
 
     def halo_fields(self):
         return self.eng.halo_fields()
 
     def before_send(self, group):
-        pass
+        if self.host_staging:
+            for f in range(3):
+                for side in (0, 1):
+                    self._h[(group, f, side, 1)].copy_(self._t[(group, f, side, 1)])
+            self.torch.cuda.synchronize(self.device)
 
     def after_recv(self, group, sides):
-        pass
+        if self.host_staging:
+            for f in range(3):
+                for side in sides:
+                    self._t[(group, f, side, 0)].copy_(self._h[(group, f, side, 0)])
 
     def half_step_stress(self, part=0):
         self.eng.half_step_stress(part)
@@ -160,7 +171,7 @@ class SlabRunner:
             self.step()
 
 
-def create_hip_slab(args, kwargs, rank, world, device, kernelVariant=0, local=None):
+def create_hip_slab(args, kwargs, rank, world, device, kernelVariant=0, local=None, host_staging=False):
     """Build the engine for this rank's slab from the same arguments the reference passes to
     StaggeredFDTD_3D_with_relaxation (BASE:2338-2365). Returns (HipSlab, info).
     local=(N3, k0, nk, gl, gh): the volumes in `args` are already this rank's slab (MaterialMap with
@@ -203,7 +214,7 @@ def create_hip_slab(args, kwargs, rank, world, device, kernelVariant=0, local=No
     eng.set_sources(lin, row, wx, wy, wz, PulseSource)
     eng.set_sensor_map(np.ascontiguousarray(np.asarray(SensorMap)[:, :, ks]))
     info = dict(k0=k0, nk=nk, nt=nt, DT=DT, N=(N1, N2, N3))
-    return HipSlab(eng, device), info
+    return HipSlab(eng, device, host_staging=host_staging), info
 
 
 def collect_slab_outputs(eng, kwargs, info):

@@ -42,6 +42,7 @@ def parse():
     ap.add_argument('--size', type=int, nargs=3, default=None, help='override per-GPU grid N1 N2 N3')
     ap.add_argument('--variant', type=int, default=0, help='kernel variant (0 default, 1 simple, 2 LDS-tiled)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--debug-gloo-shared-gpu', action='store_true', help='debug only: N ranks on GPU 0, gloo backend, halos staged through the host (validates the multi-rank code path on a 1-GPU box)')
     ap.add_argument('--lean-host', action='store_true', help='build the inputs slab-style (size-1 Ox/Oy/Oz) also at N=1: for 1024^3 on one GPU')
     ap.add_argument('--cpu-sample', type=int, nargs=4, default=[384, 384, 256, 64], help='N1 N2 N3 steps of the oracle sample')
     return ap.parse_args()
@@ -114,11 +115,17 @@ def main():
     from babelbrain_amd import _engine, harness as H, slab, RayleighAndBHTE
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (the HIP engine has no CPU fallback)')
+    shared = args.debug_gloo_shared_gpu
+    if shared:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+        if shared:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        else:
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
 
     def dt_fn(ml, f, h, acfl):
         return _engine.stable_dt(ml, f, True, h, acfl)
@@ -137,9 +144,9 @@ def main():
         a, k, info = H.make_problem(args.config, N=N, steps=nt, stable_dt_fn=dt_fn, zslab=(k0, nk), forward=RayleighAndBHTE.ForwardSimple)
         local = (N[2], k0, nk) + tuple(info['ghost'])
     t_build = time.time() - t0
-    s, sinfo = slab.create_hip_slab(a, k, rank, world, local_rank, kernelVariant=args.variant, local=local)
+    s, sinfo = slab.create_hip_slab(a, k, rank, world, local_rank, kernelVariant=args.variant, local=local, host_staging=shared)
     eng = s.eng
-    runner = slab.SlabRunner(s, rank, world, dist)
+    runner = slab.SlabRunner(s, rank, world, dist, overlap=False if shared else None)
     del a
     nvox_rank = float(n1) * n2 * sinfo['nk']
 
@@ -158,7 +165,7 @@ def main():
     wall = time.perf_counter() - t0
     tm = eng.timing_end()
     if world > 1:
-        w = torch.tensor([wall], dtype=torch.float64, device='cuda')
+        w = torch.tensor([wall], dtype=torch.float64, device='cpu' if shared else 'cuda')
         dist.all_reduce(w, op=dist.ReduceOp.MAX)
         wall = float(w.item())
     total_vox = float(n1) * n2 * n3 * world
