@@ -42,6 +42,7 @@ def parse():
     ap.add_argument('--size', type=int, nargs=3, default=None, help='override per-GPU grid N1 N2 N3')
     ap.add_argument('--variant', type=int, default=0, help='kernel variant (0 default, 1 simple, 2 LDS-tiled)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-dense-reference', action='store_true', help='skip the extra timing of the dense kernels (variant 2) at N=1')
     ap.add_argument('--debug-gloo-shared-gpu', action='store_true', help='debug only: N ranks on GPU 0, gloo backend, halos staged through the host (validates the multi-rank code path on a 1-GPU box)')
     ap.add_argument('--lean-host', action='store_true', help='build the inputs slab-style (size-1 Ox/Oy/Oz) also at N=1: for 1024^3 on one GPU')
     ap.add_argument('--cpu-sample', type=int, nargs=4, default=[384, 384, 256, 64], help='N1 N2 N3 steps of the oracle sample')
@@ -147,7 +148,6 @@ def main():
     s, sinfo = slab.create_hip_slab(a, k, rank, world, local_rank, kernelVariant=args.variant, local=local, host_staging=shared)
     eng = s.eng
     runner = slab.SlabRunner(s, rank, world, dist, overlap=False if shared else None)
-    del a
     nvox_rank = float(n1) * n2 * sinfo['nk']
 
     def barrier():
@@ -207,6 +207,26 @@ def main():
                               'device_ms_per_step': step_dev * 1e3, 'other_ms_per_step': tm['other_ms'] / args.steps},
             'device_bytes': int(eng.device_bytes), 'host_build_s': t_build,
         }
+        if world == 1 and not args.no_dense_reference and args.variant in (0, 3):
+            # the same workload on the dense LDS-tiled kernels (variant 2: every array of every voxel is read and
+            # written, no fluid-tile shortcuts) -- the like-for-like figure against the 172 B algorithmic count
+            try:
+                eng.close()
+                s2, _ = slab.create_hip_slab(a, k, 0, 1, local_rank, kernelVariant=2, local=local)
+                r2 = slab.SlabRunner(s2, 0, 1, None)
+                r2.run(args.warmup)
+                torch.cuda.synchronize()
+                s2.eng.timing_begin(False)
+                r2.run(args.steps)
+                t2 = s2.eng.timing_end()
+                ms2 = t2['total_ms'] / args.steps
+                ach2 = BYTES_STEP * nvox_rank / (ms2 * 1e-3) / 1e9
+                line['dense_reference'] = {'kernel_variant': 2, 'value': total_vox / (ms2 * 1e-3) / 1e6, 'unit': 'Mvoxel-steps/s',
+                                           'device_ms_per_step': ms2, 'roofline_step': {'achieved': ach2, 'frac': ach2 / HBM_PEAK_GBS,
+                                                                                        'algorithmic_bytes_per_voxel_step': BYTES_STEP}}
+                s2.eng.close()
+            except Exception as e:
+                line['dense_reference'] = {'value': None, 'error': repr(e)}
         if not args.no_cpu_baseline and world == 1:
             try:
                 line['cpu_baseline'] = cpu_baseline(args, dt_fn)
