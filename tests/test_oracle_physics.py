@@ -1,4 +1,4 @@
-"""Physics known-answer tests of the CPU oracle (SURVEY.md 8c, K1-K5 + K7).
+"""Physics known-answer tests of the CPU oracle.
 
 The reference holds no golden field for its solver (parity unpinned), so the oracle earns trust
 here: analytic answers for phase speed, attenuation, transmission, absorbing-layer reflection, a
@@ -180,3 +180,42 @@ def test_K5_K7_focus_against_rayleigh_with_reference_correction():
     for cfl in (0.15, 0.2, 0.24, 0.3):
         dtx = cfl * h / 1500.0
         assert abs(H.dispersion_correction(dtx, dt_water) / (2 * cfl) - 1) < 0.03
+
+
+def test_K6_reciprocity_through_a_solid_plate():
+    """Calls 1 and 2 of the refocusing loop rely on reciprocity (BASE:2372-2429: a point stress source
+    at the focus recorded on the source plane stands for the plane radiating to the focus). A pressure
+    (isotropic stress) source at A recorded as pressure at B must equal the swapped experiment, through
+    an absorbing viscoelastic plate with shear and a density contrast, absorbing layers included.
+    The additive stress source s(t) is a volume injection s/K with K = rho c^2 of the source voxel, so
+    the symmetric quantity is K_src * p_rcv."""
+    h = 1500.0 / F0 / 6
+    ppp = 25
+    dt = 1 / F0 / ppp
+    N = (52, 48, 72)
+    bone = [1896.5, 2476.0, 1542.0, 81.0, 164.0]
+    brain = [1041.0, 1562.0, 0.0, 0.0, 0.0]      # lossless at the end points: K is then exactly rho c^2 (a lossy voxel's
+    mm = np.zeros(N, np.uint32)                  # unrelaxed modulus differs from it by O(1/Q))
+    ii, jj, kk = np.meshgrid(np.arange(N[0]), np.arange(N[1]), np.arange(N[2]), indexing='ij')
+    mm[(kk + 0.35 * ii - 0.2 * jj > 30) & (kk + 0.35 * ii - 0.2 * jj < 44)] = 1      # tilted plate, 3 cells+ thick everywhere
+    mm[(kk + 0.35 * ii - 0.2 * jj >= 44)] = 2
+    A = (18, 20, 16)
+    B = (33, 29, 57)
+    assert mm[A] == 0 and mm[B] == 2
+    nt = ppp * 16
+    pulse = np.zeros((1, nt + 1))
+    nb = 4 * ppp
+    pulse[0, :nb] = np.sin(2 * np.pi * F0 * np.arange(nb) * dt) * np.hanning(nb)
+
+    def shot(src, rcv):
+        smap = np.zeros(N, np.uint32); smap[src] = 1
+        sensor = np.zeros(N, np.uint32); sensor[rcv] = 1
+        S, L, R, I = _run(mm, [WATER, bone, brain], h, dt, nt, smap, pulse, sensor, sub=1, start=0, TypeSource=2, Ox=np.array([1]))
+        return S['Pressure'][0].astype(np.float64)
+
+    pab = shot(A, B) * (WATER[0] * WATER[1] ** 2)
+    pba = shot(B, A) * (brain[0] * brain[1] ** 2)
+    assert np.abs(pab).max() > 0
+    err = np.sqrt(np.sum((pab - pba) ** 2) / np.sum(pab ** 2))
+    print('K6: reciprocity rel-L2 %.2e, peak %.3e' % (err, np.abs(pab).max()))
+    assert err < 1e-5, err
