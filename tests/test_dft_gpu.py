@@ -36,3 +36,46 @@ def test_engine_sensor_dft_matches_host_fft():
         assert np.abs(ref).max() > 0
         assert rel_l2(got.real, ref.real) < 1e-6 and rel_l2(got.imag, ref.imag) < 1e-6
         assert np.array_equal(Inp['SensorPeak'][name], S[name].max(axis=1))
+
+
+def test_solver_to_data_for_sim_file(tmp_path):
+    """The acoustic step end to end on this package: solver call with on-device DFT -> volumes
+    (CalculatePhaseData's outputs) -> caller scaling -> DataForSim (BASE:2812-2885) -> HDF5 -> read back."""
+    from babelbrain_amd import PropagationModel, results as R, datafile as DF
+    try:
+        DF.backend()
+    except ImportError:
+        pytest.skip('no HDF5 library on this machine')
+    N1, N2, N3 = 56, 52, 80
+    a, k, info = H.make_problem('C2', N=(N1, N2, N3), steps=700, stable_dt_fn=oracle_dt)
+    out = PropagationModel().StaggeredFDTD_3D_with_relaxation(*a, SILENT=True, ReturnSensorDFT=True, **k)
+    rms, Inp = out[2], out[-1]
+    corr = 1.07
+    four, phase, peak = H.phase_maps(Inp['SensorDFT']['Pressure'] * corr, Inp['SensorPeak']['Pressure'] * corr,
+                                     Inp['IndexSensorMap'], N1, N2, N3)
+    in_peak = rms['Pressure'] * np.float32(corr * np.sqrt(2))                 # BASE:2439-2440
+    zsrc = info['zsrc']
+    crop = R.Crop(12, 12, 12, 12, 12, 12)
+    h = a[5]
+    focal = (N1 // 2, N2 // 2, N3 - 20)
+    mm = a[0]
+    d = R.data_for_sim(crop, zsrc, in_peak.copy(), four.copy(), mm, focal, a[1], (np.arange(N1) - N1 / 2) * h,
+                       (np.arange(N2) - N2 / 2) * h, (np.arange(N3) - zsrc) * h, h, 4e-2)
+    d['bDoRefocusing'] = False
+    fn = str(tmp_path / 'case_DataForSim.h5')
+    DF.SaveToH5py(d, fn)
+    r = DF.ReadFromH5py(fn)
+    assert sorted(r) == sorted(d)
+    for key in ('p_amp', 'p_complex', 'MaterialMap', 'x_vec', 'z_vec', 'TargetLocation', 'Material'):
+        assert np.array_equal(r[key], d[key]) and r[key].dtype == np.asarray(d[key]).dtype, key
+    assert r['p_amp'].shape == (N1 - 24, N2 - 24, N3 - 24) and r['p_amp'].dtype == np.float32 and r['p_complex'].dtype == np.complex64
+    # amplitude of the DFT map and sqrt(2)*RMS agree where the field is steady (same quantity two ways, BASE:2520 vs 2440)
+    amp = np.abs(r['p_complex'])
+    sel = r['p_amp'] > 0.2 * r['p_amp'].max()
+    assert sel.sum() > 100
+    assert np.median(np.abs(amp[sel] / r['p_amp'][sel] - 1)) < 0.02
+    # Z is flipped on the way out: nothing at or before the source plane -> zeros at the far end of the file's z axis
+    nz_zero = zsrc + 1 - 12
+    if nz_zero > 0:
+        assert not r['p_amp'][:, :, -nz_zero:].any()
+    assert r['bDoRefocusing'] is False

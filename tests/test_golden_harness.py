@@ -121,3 +121,42 @@ def test_refocusing_orchestration(golden):
     pulse = refocus.refocus_sources(g['refocus_source_plane'], plane, f, dt, T)
     assert pulse.shape == g['refocus_pulse'].shape
     np.testing.assert_allclose(pulse, g['refocus_pulse'], rtol=1e-9, atol=1e-12)
+
+
+def test_return_results_and_data_for_sim(golden):
+    """BASE:2729-2896 on the reference's own output: full-solution volumes and every DataForSim entry."""
+    from babelbrain_amd import results as R
+    g, meta = golden
+    a = [int(v) for v in g['rr_args']]
+    N1, N2, N3, pml, zsrc = a[:5]
+    crop = R.Crop(*a[5:11], *a[11:14])
+    focal = a[14:17]
+    orig = g['rr_in_SkullMaskDataOrig'].shape
+    full_p, full_ph, mask = R.full_solution_maps(g['rr_in_InPeakValue'].copy(), g['rr_in_PhaseMap'].copy(), crop, orig, zsrc)
+    assert np.array_equal(full_p, g['rr_out_FullSolutionPressure'])
+    assert np.array_equal(full_ph, g['rr_out_FullSolutionPhase'])
+    assert np.array_equal(mask, g['rr_out_MaskCalcRegions'])
+    rp, rph, _ = R.full_solution_maps(g['rr_in_InPeakValueRefocus'].copy(), g['rr_in_PhaseMapRefocus'].copy(), crop, orig, zsrc)
+    assert np.array_equal(rp, g['rr_out_FullSolutionPressureRefocus'])
+    assert np.array_equal(rph, g['rr_out_FullSolutionPhaseRefocus'])
+    amp, overlay, wph = R.rayleigh_water_maps(g['rr_in_u2RayleighField'].copy(), crop, orig, zsrc, g['rr_in_SkullMaskDataOrig'])
+    assert np.array_equal(amp, g['rr_out_RayleighWater'])
+    assert np.array_equal(overlay, g['rr_out_RayleighWaterOverlay'])
+    assert np.array_equal(wph, g['rr_out_RayleighWaterPhase'])
+
+    h = 4e-4
+    d = R.data_for_sim(crop, zsrc, g['rr_in_InPeakValue'].copy(), g['rr_in_PressMapFourier'].copy(), g['rr_in_MaterialMap'], focal,
+                       g['rr_dfs_Material'], (np.arange(N1) - N1 / 2) * h, (np.arange(N2) - N2 / 2) * h, (np.arange(N3) - zsrc) * h,
+                       h, 4e-2, PMLThickness=pml, SourceMapRayleigh=g['rr_in_SourceMapRayleigh'],
+                       InPeakValueRefocus=g['rr_in_InPeakValueRefocus'].copy(), PressMapFourierRefocus=g['rr_in_PressMapFourierRefocus'].copy(),
+                       PressMapFourierBack=g['rr_in_PressMapFourierBack'])
+    want = meta['data_for_sim_keys']
+    assert sorted(d) == sorted(want)
+    for k in want:
+        ref = g['rr_dfs_' + k]
+        got = np.asarray(d[k])
+        assert '%s%s' % (got.dtype, list(got.shape)) == want[k], k
+        assert np.array_equal(got, ref), k
+    # the coarser copy of Step10_GetResults (BASE:1520-1536) keeps the documented keys consistent
+    d2 = R.subsample_data_for_sim(dict(d), 2, bDoRefocusing=True)
+    assert d2['p_amp'].shape == tuple((s + 1) // 2 for s in d['p_amp'].shape) and d2['SpatialStep'] == 2 * h
