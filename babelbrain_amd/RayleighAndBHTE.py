@@ -101,19 +101,29 @@ def bhte_coefficients(MaterialList, dx, dt, DutyCycle=1.0, blood_rho=1050.0, blo
     return cd.astype(np.float32), cp.astype(np.float32), qf.astype(np.float32)
 
 
-def BHTE(Pressure, MaterialMap, MaterialList, dx, TotalDurationSteps, nStepsOn, LocationMonitoring,
-         nFactorMonitoring=1, dt=0.1, blood_rho=1050, blood_ct=3617, stableTemp=37.0, DutyCycle=1.0,
-         Backend='HIP', MonitoringPointsMap=None, initT0=None, initDose=None):
-    """Same call as the reference makes (CalculateTemperatureEffects.py:365-456, 960). Pressure: amplitude map
-    (N1,N2,N3) Pa; MaterialMap: integer ids; MaterialList: dict of per-material arrays 'Density', 'SoS',
-    'Attenuation' (Np/m), 'SpecificHeat', 'Conductivity', 'Perfusion' (mL/min/kg), 'Absorption' (fraction of the
-    attenuation that heats), 'InitTemperature'. Returns (ResTemp, ResDose, MonitorSlice, Qarr[, TemperaturePoints])."""
+def field_schedule(nStepsOnOffList, TotalDurationSteps):
+    """Which pressure field heats during each step: field n is on for nStepsOnOffList[n,0] steps, then nothing for
+    nStepsOnOffList[n,1] steps, then field n+1 ...; the sequence repeats until TotalDurationSteps (the caller builds
+    equal slots per focal spot, CalculateTemperatureEffects.py:715-736). -1 = no heating. Documented restatement:
+    the package that defines it is absent from the reference tree."""
+    oo = np.asarray(nStepsOnOffList, np.int64).reshape(-1, 2)
+    if np.any(oo < 0) or oo.sum() <= 0:
+        raise ValueError('nStepsOnOffList needs non-negative step counts and a non-empty cycle')
+    cycle = np.concatenate([np.concatenate([np.full(on, n, np.int32), np.full(off, -1, np.int32)]) for n, (on, off) in enumerate(oo)])
+    reps = -(-int(TotalDurationSteps) // len(cycle)) if TotalDurationSteps > 0 else 0
+    return np.ascontiguousarray(np.tile(cycle, reps)[:int(TotalDurationSteps)], np.int32)
+
+
+def _bhte_run(fields, sched, MaterialMap, MaterialList, dx, LocationMonitoring, nFactorMonitoring, dt, blood_rho, blood_ct,
+              stableTemp, DutyCycle, MonitoringPointsMap, initT0, initDose):
     global last_kernel_ms
     lib = _engine.load_library()
-    P = np.asarray(Pressure)
-    N1, N2, N3 = P.shape
+    P = np.asarray(fields)
+    nF, N1, N2, N3 = P.shape
     mm = np.asarray(MaterialMap)
     nMat = len(MaterialList['Density'])
+    if mm.shape != (N1, N2, N3):
+        raise ValueError('MaterialMap must have the shape of the pressure field(s)')
     if mm.max() >= nMat or nMat > 256:
         raise ValueError('MaterialMap ids must index MaterialList (at most 256 materials)')
     cd, cp, qf = bhte_coefficients(MaterialList, dx, dt, DutyCycle, blood_rho, blood_ct)
@@ -121,12 +131,14 @@ def BHTE(Pressure, MaterialMap, MaterialList, dx, TotalDurationSteps, nStepsOn, 
     def xf(a, dtype):
         return np.ascontiguousarray(np.asarray(a).transpose(2, 1, 0), dtype=dtype)
     mat = xf(mm, np.uint8)
-    p32 = xf(P, np.float32)
-    q = (p32 * p32) * qf[mat]                                    # float32, same operation order as the oracle
+    q = np.empty((nF, N3, N2, N1), np.float32)
+    for n in range(nF):
+        p32 = xf(P[n], np.float32)
+        q[n] = (p32 * p32) * qf[mat]                             # float32, same operation order as the oracle
     T = xf(initT0, np.float32) if initT0 is not None else np.asarray(MaterialList['InitTemperature'], np.float32)[mat]
     T = np.ascontiguousarray(T, np.float32)
     dose = xf(initDose, np.float32) if initDose is not None else np.zeros((N3, N2, N1), np.float32)
-    nSteps = int(TotalDurationSteps)
+    nSteps = len(sched)
     fm = max(int(nFactorMonitoring), 1)
     slice_ok = LocationMonitoring is not None and int(LocationMonitoring) >= 0
     nS = (nSteps + fm - 1) // fm if slice_ok else 0
@@ -139,19 +151,58 @@ def BHTE(Pressure, MaterialMap, MaterialList, dx, TotalDurationSteps, nStepsOn, 
         idx = np.ascontiguousarray(lin[order], np.uint32)
         pts = np.zeros((len(idx), nSteps), np.float32)
     ms = C.c_double()
+    sched = np.ascontiguousarray(sched, np.int32)
+    if sched.size == 0:
+        sched = np.full(1, -1, np.int32)
 
     def ptr(a):
         return None if a is None else a.ctypes.data_as(C.c_void_p)
-    rc = lib.bfd_bhte_run(_device, N1, N2, N3, nMat, ptr(mat), ptr(cd), ptr(cp), ptr(q), ptr(T), ptr(dose), float(stableTemp),
-                          float(dt), nSteps, int(nStepsOn), int(LocationMonitoring) if slice_ok else -1, fm, ptr(mon),
-                          0 if idx is None else len(idx), ptr(idx), ptr(pts), C.byref(ms))
+    rc = lib.bfd_bhte_run_fields(_device, N1, N2, N3, nMat, ptr(mat), ptr(cd), ptr(cp), nF, ptr(q), ptr(T), ptr(dose), float(stableTemp),
+                                 float(dt), nSteps, ptr(sched), int(LocationMonitoring) if slice_ok else -1, fm, ptr(mon),
+                                 0 if idx is None else len(idx), ptr(idx), ptr(pts), C.byref(ms))
     if rc != 0:
-        raise _engine.EngineError('bfd_bhte_run failed (rc=%d): %s' % (rc, lib.bfd_last_error().decode()))
+        raise _engine.EngineError('bfd_bhte_run_fields failed (rc=%d): %s' % (rc, lib.bfd_last_error().decode()))
     last_kernel_ms = ms.value
 
     def vol(a):
         return np.ascontiguousarray(a.transpose(2, 1, 0))
-    out = (vol(T), vol(dose), mon if slice_ok else np.zeros((0,), np.float32), vol(q))
+    qout = np.stack([vol(q[n]) for n in range(nF)])
+    out = (vol(T), vol(dose), mon if slice_ok else np.zeros((0,), np.float32), qout)
     if MonitoringPointsMap is not None:
         out = out + (pts,)
     return out
+
+
+def BHTE(Pressure, MaterialMap, MaterialList, dx, TotalDurationSteps, nStepsOn, LocationMonitoring,
+         nFactorMonitoring=1, dt=0.1, blood_rho=1050, blood_ct=3617, stableTemp=37.0, DutyCycle=1.0,
+         Backend='HIP', MonitoringPointsMap=None, initT0=None, initDose=None):
+    """Same call as the reference makes (CalculateTemperatureEffects.py:365-456, 960). Pressure: amplitude map
+    (N1,N2,N3) Pa; MaterialMap: integer ids; MaterialList: dict of per-material arrays 'Density', 'SoS',
+    'Attenuation' (Np/m), 'SpecificHeat', 'Conductivity', 'Perfusion' (mL/min/kg), 'Absorption' (fraction of the
+    attenuation that heats), 'InitTemperature'. Returns (ResTemp, ResDose, MonitorSlice, Qarr[, TemperaturePoints])."""
+    P = np.asarray(Pressure)
+    if P.ndim != 3:
+        raise ValueError('Pressure must be a 3-D amplitude map')
+    nSteps = int(TotalDurationSteps)
+    sched = np.full(nSteps, -1, np.int32)
+    sched[:max(min(int(nStepsOn), nSteps), 0)] = 0
+    out = _bhte_run(P[None], sched, MaterialMap, MaterialList, dx, LocationMonitoring, nFactorMonitoring, dt, blood_rho, blood_ct,
+                    stableTemp, DutyCycle, MonitoringPointsMap, initT0, initDose)
+    return out[:3] + (out[3][0],) + out[4:]
+
+
+def BHTEMultiplePressureFields(PressureFields, MaterialMap, MaterialList, dx, TotalDurationSteps, nStepsOnOffList, LocationMonitoring,
+                               nFactorMonitoring=1, dt=0.1, blood_rho=1050, blood_ct=3617, stableTemp=37.0, Backend='HIP',
+                               MonitoringPointsMap=None, initT0=None, initDose=None):
+    """Same call as the reference makes for steered multi-point sonications (CalculateTemperatureEffects.py:381-394,
+    978-990): PressureFields (nFields,N1,N2,N3) Pa, nStepsOnOffList (nFields,2) int = steps on / off per field (see
+    `field_schedule`). No DutyCycle argument: the on/off schedule is the duty cycle. Qarr comes back per field."""
+    P = np.asarray(PressureFields)
+    if P.ndim != 4:
+        raise ValueError('PressureFields must be (nFields, N1, N2, N3)')
+    oo = np.asarray(nStepsOnOffList).reshape(-1, 2)
+    if oo.shape[0] != P.shape[0]:
+        raise ValueError('nStepsOnOffList needs one (on, off) row per pressure field')
+    sched = field_schedule(oo, int(TotalDurationSteps))
+    return _bhte_run(P, sched, MaterialMap, MaterialList, dx, LocationMonitoring, nFactorMonitoring, dt, blood_rho, blood_ct,
+                     stableTemp, 1.0, MonitoringPointsMap, initT0, initDose)

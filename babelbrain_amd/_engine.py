@@ -25,7 +25,7 @@ ABI_SYMBOLS = [
     'bfd_set_material_map', 'bfd_set_reflector', 'bfd_set_sources', 'bfd_set_sensor_map', 'bfd_run',
     'bfd_half_step_stress', 'bfd_half_step_velocity', 'bfd_half_step_stress_part', 'bfd_half_step_velocity_part', 'bfd_sync', 'bfd_current_step', 'bfd_halo_region',
     'bfd_timing_begin', 'bfd_timing_end', 'bfd_num_sensors', 'bfd_num_sensor_steps', 'bfd_get_sensor_index',
-    'bfd_get_sensors', 'bfd_get_map', 'bfd_get_field', 'bfd_tile_counts', 'bfd_device_bytes', 'bfd_rayleigh_forward', 'bfd_get_sensor_dft', 'bfd_dft_series', 'bfd_bhte_run',
+    'bfd_get_sensors', 'bfd_get_map', 'bfd_get_field', 'bfd_tile_counts', 'bfd_device_bytes', 'bfd_rayleigh_forward', 'bfd_get_sensor_dft', 'bfd_dft_series', 'bfd_bhte_run', 'bfd_bhte_run_fields',
 ]
 
 
@@ -120,6 +120,9 @@ def load_library():
     lib.bfd_bhte_run.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                  C.c_void_p, C.c_void_p, C.c_float, C.c_double, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                  C.c_int64, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
+    lib.bfd_bhte_run_fields.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_double, C.c_int32, C.c_void_p, C.c_int32, C.c_int32,
+                                        C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
     lib.bfd_get_sensor_dft.argtypes = [C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]
     lib.bfd_dft_series.argtypes = [C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_double, C.c_double, C.c_void_p, C.c_void_p]
     lib.bfd_rayleigh_forward.argtypes = [C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double,

@@ -58,14 +58,20 @@ __global__ void gather_slice(const float *__restrict__ T, float *__restrict__ ou
 // T, dose: in/out (initial -> final). q: heat increment per ON step (already multiplied by dt*duty/(rho c)).
 // monitorSlice (may be NULL): [N1][N3][nSliceSamples], plane j = sliceJ sampled every nFactorMonitoring steps.
 // points (may be NULL): [nPoints][nSteps], temperature after every step at the listed voxels.
-extern "C" int bfd_bhte_run(int32_t device, int32_t N1, int32_t N2, int32_t N3, int32_t nMat, const unsigned char *mat,
-                            const float *cd, const float *cp, const float *q, float *T, float *dose, float Tcore, double dt,
-                            int32_t nSteps, int32_t nStepsOn, int32_t sliceJ, int32_t nFactorMonitoring, float *monitorSlice,
-                            int64_t nPoints, const uint32_t *pointIndex, float *points, double *kernelMs)
+// q: nFields volumes, one per pressure field (BHTEMultiplePressureFields: steered multi-point sonications,
+// CalculateTemperatureEffects.py:381, 978). fieldOfStep[s] = which of them heats during step s, -1 = none.
+extern "C" int bfd_bhte_run_fields(int32_t device, int32_t N1, int32_t N2, int32_t N3, int32_t nMat, const unsigned char *mat,
+                                   const float *cd, const float *cp, int32_t nFields, const float *q, float *T, float *dose,
+                                   float Tcore, double dt, int32_t nSteps, const int32_t *fieldOfStep, int32_t sliceJ,
+                                   int32_t nFactorMonitoring, float *monitorSlice, int64_t nPoints, const uint32_t *pointIndex,
+                                   float *points, double *kernelMs)
 {
-    if (N1 < 3 || N2 < 3 || N3 < 3 || nMat < 1 || nMat > 256 || !mat || !cd || !cp || !q || !T || !dose || nSteps < 0) {
+    if (N1 < 3 || N2 < 3 || N3 < 3 || nMat < 1 || nMat > 256 || nFields < 1 || !mat || !cd || !cp || !q || !T || !dose || nSteps < 0 ||
+        (nSteps > 0 && !fieldOfStep)) {
         bfd_set_error("bfd_bhte_run: bad argument"); return -1;
     }
+    for (int s = 0; s < nSteps; s++)
+        if (fieldOfStep[s] < -1 || fieldOfStep[s] >= nFields) { bfd_set_error("bfd_bhte_run: fieldOfStep entry out of range"); return -1; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { bfd_set_error("bfd_bhte_run: no HIP device available (no CPU fallback)"); return -3; }
     if (device < 0 || device >= ndev) { bfd_set_error("bfd_bhte_run: device ordinal out of range"); return -3; }
@@ -80,7 +86,7 @@ extern "C" int bfd_bhte_run(int32_t device, int32_t N1, int32_t N2, int32_t N3, 
     hipError_t e = A((void **)&dT[0], n * 4);
     if (e == hipSuccess) e = A((void **)&dT[1], n * 4);
     if (e == hipSuccess) e = A((void **)&dDose, n * 4);
-    if (e == hipSuccess) e = A((void **)&dq, n * 4);
+    if (e == hipSuccess) e = A((void **)&dq, n * 4 * (size_t)nFields);
     if (e == hipSuccess) e = A((void **)&dmat, n);
     if (e == hipSuccess) e = A((void **)&dcd, nMat * 4);
     if (e == hipSuccess) e = A((void **)&dcp, nMat * 4);
@@ -88,7 +94,7 @@ extern "C" int bfd_bhte_run(int32_t device, int32_t N1, int32_t N2, int32_t N3, 
     if (e == hipSuccess && nPoints && points) { e = A((void **)&dIdx, nPoints * 4); if (e == hipSuccess) e = A((void **)&dPts, (size_t)nPoints * nSteps * 4); }
     if (e == hipSuccess) e = hipMemcpy(dT[0], T, n * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(dDose, dose, n * 4, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(dq, q, n * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dq, q, n * 4 * (size_t)nFields, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(dmat, mat, n, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(dcd, cd, nMat * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(dcp, cp, nMat * 4, hipMemcpyHostToDevice);
@@ -100,7 +106,8 @@ extern "C" int bfd_bhte_run(int32_t device, int32_t N1, int32_t N2, int32_t N3, 
         const dim3 block(64, 4, 1), grid((N1 + 63) / 64, (N2 + 3) / 4, N3);
         const float dtMin = (float)(dt / 60.0);
         for (int s = 0; s < nSteps; s++) {
-            hipLaunchKernelGGL(bhte_step, grid, block, 0, 0, dT[cur], dT[1 - cur], dDose, dq, dmat, dcd, dcp, N1, N2, N3, Tcore, s < nStepsOn ? 1 : 0, dtMin);
+            const int f = fieldOfStep[s];
+            hipLaunchKernelGGL(bhte_step, grid, block, 0, 0, dT[cur], dT[1 - cur], dDose, dq + (f < 0 ? 0 : (size_t)f * n), dmat, dcd, dcp, N1, N2, N3, Tcore, f >= 0 ? 1 : 0, dtMin);
             cur = 1 - cur;
             if (dPts) hipLaunchKernelGGL(gather_points, dim3((unsigned)((nPoints + 255) / 256)), dim3(256), 0, 0, dT[cur], dIdx, dPts, (long)nPoints, (long)nSteps, (long)s);
             if (dSlice && s % fm == 0) hipLaunchKernelGGL(gather_slice, dim3(256), dim3(256), 0, 0, dT[cur], dSlice, N1, N2, N3, sliceJ, (long)(s / fm), nSamples);
@@ -119,4 +126,17 @@ extern "C" int bfd_bhte_run(int32_t device, int32_t N1, int32_t N2, int32_t N3, 
     for (void *p : allocs) hipFree(p);
     if (e != hipSuccess) { bfd_set_error(std::string("bfd_bhte_run: ") + hipGetErrorString(e)); return -10; }
     return 0;
+}
+
+// One pressure field heating during the first nStepsOn steps (the reference's BHTE call).
+extern "C" int bfd_bhte_run(int32_t device, int32_t N1, int32_t N2, int32_t N3, int32_t nMat, const unsigned char *mat,
+                            const float *cd, const float *cp, const float *q, float *T, float *dose, float Tcore, double dt,
+                            int32_t nSteps, int32_t nStepsOn, int32_t sliceJ, int32_t nFactorMonitoring, float *monitorSlice,
+                            int64_t nPoints, const uint32_t *pointIndex, float *points, double *kernelMs)
+{
+    if (nSteps < 0) { bfd_set_error("bfd_bhte_run: bad argument"); return -1; }
+    std::vector<int32_t> sched((size_t)nSteps + 1, -1);
+    for (int s = 0; s < nSteps && s < nStepsOn; s++) sched[s] = 0;
+    return bfd_bhte_run_fields(device, N1, N2, N3, nMat, mat, cd, cp, 1, q, T, dose, Tcore, dt, nSteps, sched.data(), sliceJ,
+                               nFactorMonitoring, monitorSlice, nPoints, pointIndex, points, kernelMs);
 }

@@ -192,6 +192,15 @@ int bfd_bhte_run(int32_t device, int32_t N1, int32_t N2, int32_t N3, int32_t nMa
                  int32_t nSteps, int32_t nStepsOn, int32_t sliceJ, int32_t nFactorMonitoring, float *monitorSlice,
                  int64_t nPoints, const uint32_t *pointIndex, float *points, double *kernelMs);
 
+/* Several pressure fields heating in turn: replaces BabelViscoFDTD.tools.RayleighAndBHTE.BHTEMultiplePressureFields
+ * (call sites ThermalModeling/CalculateTemperatureEffects.py:381, 978; schedule built at :715-736). q holds nFields
+ * volumes back to back; fieldOfStep[s] in [-1, nFields) names the field that heats during step s (-1 = none). */
+int bfd_bhte_run_fields(int32_t device, int32_t N1, int32_t N2, int32_t N3, int32_t nMat, const unsigned char *mat,
+                        const float *cd, const float *cp, int32_t nFields, const float *q, float *T, float *dose,
+                        float Tcore, double dt, int32_t nSteps, const int32_t *fieldOfStep, int32_t sliceJ,
+                        int32_t nFactorMonitoring, float *monitorSlice, int64_t nPoints, const uint32_t *pointIndex,
+                        float *points, double *kernelMs);
+
 #ifdef __cplusplus
 }
 #endif

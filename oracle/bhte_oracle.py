@@ -6,13 +6,17 @@ documented explicit scheme of csrc/bfd_bhte.hip restated with numpy float32 arra
 import numpy as np
 
 
-def bhte(T0, dose0, q, mat, cd, cp, Tcore, dt, nSteps, nStepsOn):
-    """All arrays (N1,N2,N3); cd, cp per material float32; q = increment of one ON step. Returns (T, dose)."""
+def bhte(T0, dose0, q, mat, cd, cp, Tcore, dt, nSteps, nStepsOn, field_of_step=None):
+    """All arrays (N1,N2,N3); cd, cp per material float32; q = increment of one ON step. Returns (T, dose).
+    With field_of_step (length nSteps, -1 = no heating) q is (nFields,N1,N2,N3) and nStepsOn is ignored."""
     T = np.array(T0, np.float32)
     dose = np.array(dose0, np.float32)
     cdv = np.asarray(cd, np.float32)[mat][1:-1, 1:-1, 1:-1]
     cpv = np.asarray(cp, np.float32)[mat][1:-1, 1:-1, 1:-1]
-    qi = np.asarray(q, np.float32)[1:-1, 1:-1, 1:-1]
+    qa = np.asarray(q, np.float32)
+    if field_of_step is None:
+        qa = qa[None]
+        field_of_step = [0 if s < nStepsOn else -1 for s in range(nSteps)]
     Tc = np.float32(Tcore)
     dtm = np.float32(dt / 60.0)
     for s in range(nSteps):
@@ -20,8 +24,8 @@ def bhte(T0, dose0, q, mat, cd, cp, Tcore, dt, nSteps, nStepsOn):
         sm = ((((T[:-2, 1:-1, 1:-1] + T[2:, 1:-1, 1:-1]) + T[1:-1, :-2, 1:-1]) + T[1:-1, 2:, 1:-1]) + T[1:-1, 1:-1, :-2]) + T[1:-1, 1:-1, 2:]
         tn = c + cdv * (sm - np.float32(6.0) * c)
         tn = tn + cpv * (Tc - c)
-        if s < nStepsOn:
-            tn = tn + qi
+        if field_of_step[s] >= 0:
+            tn = tn + qa[field_of_step[s]][1:-1, 1:-1, 1:-1]
         Tn = T.copy()
         Tn[1:-1, 1:-1, 1:-1] = tn
         T = Tn

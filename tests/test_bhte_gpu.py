@@ -73,3 +73,49 @@ def test_bhte_analytic_limits():
     assert abs(T[11, 12, 12] - T[13, 12, 12]) < 1e-6 and abs(T[12, 11, 12] - T[12, 12, 13]) < 1e-6
     with pytest.raises(ValueError):
         R.BHTE(p, mm, d, 1e-4, 10, 0, -1, dt=1.0)
+
+
+def test_multiple_pressure_fields_schedule_and_oracle():
+    """BHTEMultiplePressureFields (CalculateTemperatureEffects.py:381-394, 978-990): three steered focal spots
+    heating in turn, schedule built like the caller does (equal on/off slots, :715-736)."""
+    from babelbrain_amd import RayleighAndBHTE as R
+    # the schedule itself (host logic)
+    s = R.field_schedule(np.array([[2, 1], [1, 2]]), 10)
+    assert s.tolist() == [0, 0, -1, 1, -1, -1, 0, 0, -1, 1]
+    assert R.field_schedule([[3, 0]], 4).tolist() == [0, 0, 0, 0]
+    with pytest.raises(ValueError):
+        R.field_schedule([[0, 0]], 4)
+
+    rng = np.random.default_rng(9)
+    N = (36, 40, 44)
+    ml = _materials()
+    mm = rng.integers(0, 5, N).astype(np.uint8)
+    x, y, z = np.meshgrid(*[np.arange(n) - n / 2 for n in N], indexing='ij')
+    fields = np.stack([4.0e6 * np.exp(-((x - cx) ** 2 + (y - cy) ** 2 + (z / 2) ** 2) / 25.0) for cx, cy in ((-6, 0), (5, 4), (0, -7))])
+    onoff = np.array([[7, 5], [7, 5], [7, 5]], np.int32)
+    dx, dt, nS = 4e-4, 0.02, 130
+    mpm = np.zeros(N, np.uint32); mpm[12, 20, 22] = 1; mpm[23, 24, 22] = 2
+    T, D, mon, Q, pts = R.BHTEMultiplePressureFields(fields, mm, ml, dx, nS, onoff, 20, nFactorMonitoring=13, dt=dt, MonitoringPointsMap=mpm)
+    cd, cp, qf = R.bhte_coefficients(ml, dx, dt, 1.0)
+    q = np.stack([(f.astype(np.float32) ** 2) * qf[mm] for f in fields])
+    sched = R.field_schedule(onoff, nS)
+    T0 = np.full(N, 37.0, np.float32)
+    To, Do = BO.bhte(T0, np.zeros(N, np.float32), q, mm, cd, cp, 37.0, dt, nS, 0, field_of_step=sched)
+    assert To.max() > 39.0
+    assert rel_l2(T - 37.0, To - 37.0) < 1e-5 and rel_l2(D, Do) < 1e-5
+    assert Q.shape == fields.shape and np.array_equal(Q, q)
+    assert mon.shape == (N[0], N[2], 10) and pts.shape == (2, nS)
+    # each monitored point heats fastest while its own focal spot is on
+    rise = np.diff(np.concatenate([[37.0], pts[0]]))
+    assert rise[sched == 0].mean() > 3 * rise[sched == 1].mean()
+    # one field through the multi-field entry point == the single-field call with the same on-steps and duty cycle 1
+    T1, D1, _, Q1 = R.BHTEMultiplePressureFields(fields[:1], mm, ml, dx, 60, [[40, 20]], -1, dt=dt)
+    T2, D2, _, Q2 = R.BHTE(fields[0], mm, ml, dx, 60, 40, -1, dt=dt, DutyCycle=1.0)
+    assert np.array_equal(T1, T2) and np.array_equal(D1, D2) and np.array_equal(Q1[0], Q2)
+    # continuation from a previous group (initT0/initDose) is the same as one longer run (schedule phase restarts)
+    Ta, Da, _, _ = R.BHTEMultiplePressureFields(fields, mm, ml, dx, 36, onoff, -1, dt=dt)
+    Tb, Db, _, _ = R.BHTEMultiplePressureFields(fields, mm, ml, dx, 36, onoff, -1, dt=dt, initT0=Ta, initDose=Da)
+    Tc, Dc, _, _ = R.BHTEMultiplePressureFields(fields, mm, ml, dx, 72, onoff, -1, dt=dt)
+    assert np.array_equal(Tb, Tc) and np.array_equal(Db, Dc)
+    with pytest.raises(ValueError):
+        R.BHTEMultiplePressureFields(fields, mm, ml, dx, 10, [[1, 1]], -1, dt=dt)
