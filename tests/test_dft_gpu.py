@@ -47,7 +47,7 @@ def test_solver_to_data_for_sim_file(tmp_path):
     except ImportError:
         pytest.skip('no HDF5 library on this machine')
     N1, N2, N3 = 56, 52, 80
-    a, k, info = H.make_problem('C2', N=(N1, N2, N3), steps=700, stable_dt_fn=oracle_dt)
+    a, k, info = H.make_problem('C2', N=(N1, N2, N3), steps=720, stable_dt_fn=oracle_dt)
     out = PropagationModel().StaggeredFDTD_3D_with_relaxation(*a, SILENT=True, ReturnSensorDFT=True, **k)
     rms, Inp = out[2], out[-1]
     corr = 1.07
