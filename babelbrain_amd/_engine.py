@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libbabelfdtd_hip.so')
+# BABELFDTD_HIP_LIB: another build of the same library (A/B kernel experiments, scripts/ab_build.sh)
+LIB_PATH = os.environ.get('BABELFDTD_HIP_LIB') or os.path.join(_HERE, 'libbabelfdtd_hip.so')
 
 MAP_BITS = {'Vx': 0, 'Vy': 1, 'Vz': 2, 'Sigmaxx': 3, 'Sigmayy': 4, 'Sigmazz': 5,
             'Sigmaxy': 6, 'Sigmaxz': 7, 'Sigmayz': 8, 'Pressure': 9, 'ALLV': 10}

@@ -675,10 +675,12 @@ static int build_tile_lists(bfd_sim *s)
     int tx, ty, nsub; bfd_tile_grid(s->d, &tx, &ty, &nsub);
     const int n = tx * ty * nsub;
     const int SUB = bfd_tile_subz();
-    // longest run one workgroup marches: 32 planes on big grids; shorter on small ones so that the launch still
-    // has a few thousand workgroups (measured: 256^3 49 -> 58, 128^3 29 -> 46, 320x320x384 60 -> 66 Gvoxel-steps/s)
+    // longest run one workgroup marches: 16 planes; 8 on small grids so that the launch still has a few thousand
+    // workgroups (measured: 256^3 49 -> 58, 128^3 29 -> 46 Gvoxel-steps/s). 32 was best at 512^3 while the z-chunks of
+    // a column were consecutive in the list; under the banded order 16 is 2.5 % faster than 32 and 3 % faster than 8.
     const int t32 = tx * ty * ((s->d.nk + 31) / 32);
-    s->zchunk = t32 >= 6000 ? 32 : (t32 >= 1500 ? 16 : 8);
+    s->zchunk = t32 >= 1500 ? 16 : 8;
+    if (const char *ev = getenv("BFD_ZRUN")) { const int z = atoi(ev); if (z >= SUB && z % SUB == 0) s->zchunk = z; }   // tuning experiments
     if (s->zchunk > bfd_tile_zchunk()) s->zchunk = bfd_tile_zchunk();
     const int perChunk = s->zchunk / SUB;
     const int nChunks = (nsub + perChunk - 1) / perChunk;
@@ -705,10 +707,31 @@ static int build_tile_lists(bfd_sim *s)
     const int hiStart = std::max(((nkl - 2) / SUB) * SUB, lowPlanes);
     auto subBnd = [&](int q) { return q * SUB < lowPlanes || std::min((q + 1) * SUB, nkl) > hiStart; };
     std::vector<int4> lists[4];      // fluid boundary, fluid interior, solid boundary, solid interior
-    // list order: the z-chunks of one (bx,by) column are consecutive (they share their prologue planes), columns
-    // follow in x then y. Measured at 512^3: 4 % faster than z-chunk-slowest order (78.7 vs 75.4 Gvoxel-steps/s).
-    for (int txy = 0; txy < tx * ty; txy++)
-        for (int c = 0; c < nChunks; c++) {
+    // List order = what is in flight together. The launch gives XCD e the e-th contiguous eighth of the list
+    // (remap_block) and an XCD keeps ~100 workgroups in flight, all marching in z at the same pace; a halo line
+    // (128 B for 2 or 3 floats of a neighbour tile's row) is an L2 hit only if that neighbour is in flight on the
+    // same XCD. Default (2): eight y-bands, inside a band z-chunk slowest, then by, bx fastest -> x neighbours are
+    // 1 apart, y neighbours tilesX apart. Measured at 512^3 (rocprofv3 FETCH/WRITE_SIZE, water): stress traffic
+    // 3.55 -> 3.10 GB and 79 -> 88 Gvoxel-steps/s against (0) column order (z-chunks of a column consecutive);
+    // (1) z-chunk slowest over the whole plane moves as few bytes but piles the absorbing-layer and lossy
+    // z-levels onto single XCDs (C3: 75 -> 72). BFD_RUN_ORDER=0/1 select the other orders for experiments.
+    std::vector<std::pair<int, int>> seq;       // (column, z-chunk) in list order
+    {
+        const char *ev = getenv("BFD_RUN_ORDER");
+        const int mode = ev ? atoi(ev) : 2;
+        if (mode == 1) {            // z-chunk slowest
+            for (int c = 0; c < nChunks; c++) for (int txy = 0; txy < tx * ty; txy++) seq.push_back({txy, c});
+        } else if (mode == 0) {     // column order
+            for (int txy = 0; txy < tx * ty; txy++) for (int c = 0; c < nChunks; c++) seq.push_back({txy, c});
+        } else {                    // 8 y-bands (one per XCD part), inside a band z-chunk slowest
+            for (int e = 0; e < 8; e++) {
+                const int y0 = (int)((long)ty * e / 8), y1 = (int)((long)ty * (e + 1) / 8);
+                for (int c = 0; c < nChunks; c++) for (int by = y0; by < y1; by++) for (int bx = 0; bx < tx; bx++) seq.push_back({by * tx + bx, c});
+            }
+        }
+    }
+    for (const auto &pc : seq) {
+        const int txy = pc.first, c = pc.second;
             const int sb = c * perChunk, se = std::min(sb + perChunk, nsub);
             int q = sb;
             while (q < se) {
