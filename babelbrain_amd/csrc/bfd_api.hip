@@ -166,6 +166,17 @@ __global__ void transpose_pulse(const double *__restrict__ in, float *__restrict
     }
 }
 
+// does cell c (local linear index) hold only the Szz/Rzz copy of its normal stresses?
+__device__ __forceinline__ bool normal_collapsed(const bfd_dev &d, long c)
+{
+    if (d.collapsed) return true;
+    if (!d.lean) return false;
+    const int kl = (int)(c / d.plane);
+    const int r = (int)(c - (long)kl * d.plane);
+    const int j = r / d.N1, i = r - j * d.N1;
+    return d.lean[((long)(kl / BFD_SUBZ) * d.tilesY + j / BFD_TILE_Y) * d.tilesX + i / BFD_TILE_X] != 0;
+}
+
 __device__ __forceinline__ float map_value(const bfd_dev &d, int sel, long c)
 {
     switch (sel) {
@@ -180,7 +191,7 @@ __device__ __forceinline__ float map_value(const bfd_dev &d, int sel, long c)
     case BFD_MAP_SIGMAYZ: return d.Syz[c];
     case BFD_MAP_PRESSURE: {
         const float zz = d.Szz[c];
-        const float s = d.collapsed ? (zz + zz) + zz : (d.Sxx[c] + d.Syy[c]) + zz;
+        const float s = normal_collapsed(d, c) ? (zz + zz) + zz : (d.Sxx[c] + d.Syy[c]) + zz;
         return -s * (1.0f / 3.0f);
     }
     default: return 0.0f;
@@ -190,6 +201,7 @@ __device__ __forceinline__ float map_value(const bfd_dev &d, int sel, long c)
 __global__ void expand_normal(bfd_dev d, long n)
 {
     for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (long)gridDim.x * blockDim.x) {
+        if (!normal_collapsed(d, v)) continue;
         const float s = d.Szz[v], r = d.Rzz[v];
         d.Sxx[v] = s; d.Syy[v] = s; d.Rxx[v] = r; d.Ryy[v] = r;
     }
@@ -699,7 +711,34 @@ static int build_tile_lists(bfd_sim *s)
         if (e != hipSuccess) BFD_FAIL(-10, std::string("classify tiles: ") + hipGetErrorString(e));
     }
     bfd_tiles &T = s->tiles;
-    T.nFluid = T.nFluidB = T.nSolid = T.nSolidB = T.nLossless = T.nLossy = T.nSolidSub = T.nUni = T.nPml = 0;
+    T.nFluid = T.nFluidB = T.nSolid = T.nSolidB = T.nLossless = T.nLossy = T.nSolidSub = T.nUni = T.nPml = T.nLean = 0;
+    // per-component normal stresses are needed only by solid tiles or by a Sigma** output selection
+    const uint32_t sig = (1u << BFD_MAP_SIGMAXX) | (1u << BFD_MAP_SIGMAYY) | (1u << BFD_MAP_SIGMAZZ);
+    const bool sigmaOut = ((s->cfg.selMapsRMS | s->cfg.selMapsSensors) & sig) != 0;
+    // LEAN fluid sub-tiles of a slab that has solid ones: Sxx/Syy of a cell are read only by the x / y derivative
+    // of the velocity update of a cell at most 2 cells away in the same plane, and a FLUID tile reads Szz instead,
+    // so a fluid sub-tile without a solid sub-tile beside it in x or y keeps just Szz/Rzz (bit4)
+    s->d.lean = nullptr; s->d.tilesX = tx; s->d.tilesY = ty;
+    if (s->cfg.kernelVariant != 2 && !sigmaOut) {
+        std::vector<unsigned char> lean((size_t)n, 0);
+        bool anySolid = false, anyLean = false;
+        for (int q = 0; q < nsub; q++)
+            for (int by = 0; by < ty; by++)
+                for (int bx = 0; bx < tx; bx++) {
+                    const size_t id = ((size_t)q * ty + by) * tx + bx;
+                    if (flags[id] & 1) { anySolid = true; continue; }
+                    auto solidAt = [&](int x, int y) { return x >= 0 && x < tx && y >= 0 && y < ty && (flags[((size_t)q * ty + y) * tx + x] & 1); };
+                    if (!solidAt(bx - 1, by) && !solidAt(bx + 1, by) && !solidAt(bx, by - 1) && !solidAt(bx, by + 1)) { lean[id] = 1; anyLean = true; }
+                }
+        if (anySolid && anyLean) {
+            unsigned char *dl = nullptr;
+            int rcl = dev_alloc(s, &dl, (size_t)n, false);
+            if (rcl) return rcl;
+            BFD_HIP(hipMemcpy(dl, lean.data(), (size_t)n, hipMemcpyHostToDevice));
+            s->d.lean = dl;
+            for (int id = 0; id < n; id++) if (lean[id]) flags[id] |= 16;
+        }
+    }
     // "boundary" sub-tiles hold the 2 first / 2 last planes of the slab (what a Z-neighbour reads): they form the
     // small part 1 of a split half-step; everything else is part 2. lowPlanes / hiStart delimit them in planes.
     const int nkl = s->d.nk;
@@ -750,7 +789,7 @@ static int build_tile_lists(bfd_sim *s)
                 lists[(solid ? 2 : 0) + (bnd ? 0 : 1)].push_back(run);
                 for (int u = q; u < r; u++) {
                     if (solid) T.nSolidSub++;
-                    else { if (f & 2) T.nLossy++; else T.nLossless++; if (f & 4) T.nUni++; if (f & 8) T.nPml++; }
+                    else { if (f & 2) T.nLossy++; else T.nLossless++; if (f & 4) T.nUni++; if (f & 8) T.nPml++; if (f & 16) T.nLean++; }
                 }
                 q = r;
             }
@@ -802,9 +841,7 @@ static int build_tile_lists(bfd_sim *s)
         s->tiles.shearHighBeg = std::lower_bound(hostCells.begin(), hostCells.end(), (unsigned)hiStart * (unsigned)s->d.plane) - hostCells.begin();
     }
     const int nC = T.nSolid;
-    // per-component normal stresses are needed only by solid tiles or by a Sigma** output selection
-    const uint32_t sig = (1u << BFD_MAP_SIGMAXX) | (1u << BFD_MAP_SIGMAYY) | (1u << BFD_MAP_SIGMAZZ);
-    s->d.collapsed = (nC == 0 && ((s->cfg.selMapsRMS | s->cfg.selMapsSensors) & sig) == 0) ? 1 : 0;
+    s->d.collapsed = (nC == 0 && !sigmaOut) ? 1 : 0;
     {   // sources of the first / last z-chunk (bfd_set_sources sorted them by voxel)
         std::vector<uint32_t> lin((size_t)s->nSrcVox);
         if (s->nSrcVox) BFD_HIP(hipMemcpy(lin.data(), s->srcLin, lin.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
@@ -1061,7 +1098,7 @@ int bfd_get_map(bfd_sim *s, int32_t kind, int32_t map, float *out, int64_t s1, i
 
 static void expand_if_collapsed(bfd_sim *s)
 {
-    if (s->d.collapsed)
+    if (s->d.collapsed || s->d.lean)
         hipLaunchKernelGGL(expand_normal, dim3(grid_for((long)s->nloc)), dim3(256), 0, s->stream, s->d, (long)s->nloc);
 }
 
@@ -1145,6 +1182,13 @@ int bfd_tile_counts(bfd_sim *s, int32_t *nLossless, int32_t *nLossy, int32_t *nS
     if (nSolid) *nSolid = s->tilesReady ? s->tiles.nSolidSub : 0;
     if (nUni) *nUni = s->tilesReady ? s->tiles.nUni : 0;
     if (nPml) *nPml = s->tilesReady ? s->tiles.nPml : 0;
+    return 0;
+}
+
+int bfd_tile_count_lean(bfd_sim *s, int32_t *nLean)
+{
+    int rc = check_ready(s); if (rc) return rc;
+    if (nLean) *nLean = !s->tilesReady ? 0 : (s->d.collapsed ? s->tiles.nLossless + s->tiles.nLossy : s->tiles.nLean);
     return 0;
 }
 

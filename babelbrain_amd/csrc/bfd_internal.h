@@ -13,6 +13,14 @@
 #define BFD_CA 1.125f
 #define BFD_CB (1.0f / 24.0f)
 
+// tile geometry of the class-specialised kernels (bfd_kernels_v2.hip): 64 x 8 cells per workgroup plane,
+// classification in sub-tiles of BFD_SUBZ planes
+#define BFD_TILE_X 64
+#define BFD_TILE_Y 8
+#ifndef BFD_SUBZ
+#define BFD_SUBZ 8
+#endif
+
 // device-side view of one slab; passed by value to kernels
 struct bfd_dev {
     int N1, N2, N3;        // global dims
@@ -34,15 +42,19 @@ struct bfd_dev {
     float *psi[18];
     // 1: every tile of the slab is FLUID and only Szz/Rzz of the (identical) normal stresses are kept
     int collapsed;
+    // slab with solid tiles: per 64x8x8 sub-tile, 1 = LEAN fluid sub-tile (keeps only Szz/Rzz like a collapsed slab:
+    // no solid sub-tile beside it in x or y, the only places its Sxx/Syy would be read from). null = none.
+    const unsigned char *lean;
+    int tilesX, tilesY;
 };
 
 // tile lists of the class-specialised path (variant 3): device array
 // runs [fluid boundary | fluid interior | solid boundary | solid interior] (boundary = inside the first/last
-// 32 planes); run = (bx + tilesX*by, kbeg | kend<<16, flags: bit0 solid, bit1 lossy, bit2 UNI, bit3 PML, material
+// 32 planes); run = (bx + tilesX*by, kbeg | kend<<16, flags: bit0 solid, bit1 lossy, bit2 UNI, bit3 PML, bit4 LEAN, material
 // id of UNI runs). n* counters after nSolidB are in 64x8x8 sub-tiles, for reporting.
 struct bfd_tiles { int4 *runs; unsigned short *rowFlags /* per solid run x 32 planes, see stress_normal_solid */;
                    unsigned *shearCells; float *shearCoef; long nShear, shearLowEnd, shearHighBeg;   /* sparse shear list */
-                   int nFluid, nFluidB, nSolid, nSolidB; int nLossless, nLossy, nSolidSub, nUni, nPml; };
+                   int nFluid, nFluidB, nSolid, nSolidB; int nLossless, nLossy, nSolidSub, nUni, nPml, nLean; };
 
 struct bfd_sim {
     bfd_config cfg;

@@ -20,8 +20,8 @@
 
 namespace {
 
-constexpr int TX = 64;
-constexpr int TY = 8;
+constexpr int TX = BFD_TILE_X;
+constexpr int TY = BFD_TILE_Y;
 constexpr int LW = TX + 4;          // LDS row length (floats)
 constexpr int LH = TY + 4;          // LDS rows
 constexpr int NTHREADS = TX * TY;   // 512
@@ -31,9 +31,6 @@ constexpr int XT = 4 * TY;          // x-halo tasks per array (4 cols x TY)
 #define BFD_ZCHUNK 32
 #endif
 constexpr int ZCHUNK = BFD_ZCHUNK;  // longest z-run one workgroup marches
-#ifndef BFD_SUBZ
-#define BFD_SUBZ 8
-#endif
 constexpr int SUBZ = BFD_SUBZ;             // z granularity of the fluid/solid classification (runs are merged sub-tiles)
 #ifndef STRESS_WAVES_PER_SIMD
 #define STRESS_WAVES_PER_SIMD 4     // 2 workgroups of 8 waves per CU (<= 128 VGPRs); 6 or 8 spill and run 1.4-2.4x slower (measured)
@@ -1026,13 +1023,10 @@ __global__ void shear_coefficients(bfd_dev d, const unsigned *__restrict__ cells
 
 // ---- dispatchers: one launch for all fluid runs; block-uniform switch on the run's flags ----
 // run = (x: bx + tilesX*by, y: kbeg | kend<<16, z: flags, w: material id of UNI runs)
-// flags: bit0 solid, bit1 lossy, bit2 UNI, bit3 PML
+// flags: bit0 solid, bit1 lossy, bit2 UNI, bit3 PML, bit4 LEAN
 template <bool COLLAPSED>
-__global__ __launch_bounds__(NTHREADS, FLUID_WAVES_PER_SIMD) void stress_fluid(bfd_dev d, int tilesX, int nblocks,
-                                                                               const int4 *__restrict__ runs)
+__device__ __forceinline__ void stress_fluid_switch(const bfd_dev &d, const int4 &run, int tilesX, float (*sV)[2][LH * LW])
 {
-    __shared__ float sV[2][2][LH * LW];
-    const int4 run = runs[remap_block(blockIdx.x, nblocks)];
     const int bx = run.x % tilesX, by = run.x / tilesX, kbeg = run.y & 0xFFFF, kend = run.y >> 16, tm = run.w;
     switch ((run.z >> 1) & 7) {
     case 0: stress_fluid_body<false, COLLAPSED, false, false>(d, bx, by, kbeg, kend, tm, sV); break;
@@ -1044,6 +1038,18 @@ __global__ __launch_bounds__(NTHREADS, FLUID_WAVES_PER_SIMD) void stress_fluid(b
     case 6: stress_fluid_body<false, COLLAPSED, true, true>(d, bx, by, kbeg, kend, tm, sV); break;
     default: stress_fluid_body<true, COLLAPSED, true, true>(d, bx, by, kbeg, kend, tm, sV); break;
     }
+}
+
+// COLLAPSED = true: all-fluid slab, every run keeps only Szz/Rzz. false: slab with solid tiles; runs flagged LEAN
+// (bit4) still take the collapsed bodies, the others write all three normal stresses.
+template <bool COLLAPSED>
+__global__ __launch_bounds__(NTHREADS, FLUID_WAVES_PER_SIMD) void stress_fluid(bfd_dev d, int tilesX, int nblocks,
+                                                                               const int4 *__restrict__ runs)
+{
+    __shared__ float sV[2][2][LH * LW];
+    const int4 run = runs[remap_block(blockIdx.x, nblocks)];
+    if (COLLAPSED || (run.z & 16)) stress_fluid_switch<true>(d, run, tilesX, sV);
+    else stress_fluid_switch<false>(d, run, tilesX, sV);
 }
 
 template <bool ACC>

@@ -170,6 +170,9 @@ int bfd_get_field(bfd_sim *sim, int32_t a, float *out, int64_t s1, int64_t s2, i
  * lossless fluid, lossy fluid, solid, and among the fluid ones how many hold one material only (UNI)
  * and how many touch the absorbing layer (PML) (DESIGN.md "Tile classes"); zeros for variants 1, 2 */
 int bfd_tile_counts(bfd_sim *sim, int32_t *nLossless, int32_t *nLossy, int32_t *nSolid, int32_t *nUni, int32_t *nPml);
+/* fluid sub-tiles that keep a single copy of their three identical normal stresses: all of them in an all-fluid
+ * slab, those without a solid sub-tile beside them in x or y otherwise; 0 when a Sigma** output is selected */
+int bfd_tile_count_lean(bfd_sim *sim, int32_t *nLean);
 /* device memory this sim holds, bytes */
 int64_t bfd_device_bytes(bfd_sim *sim);
 

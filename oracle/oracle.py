@@ -38,9 +38,26 @@ def build(force=False):
     return so
 
 
+def default_threads():
+    """Threads of a run that does not name a count: BABEL_ORACLE_THREADS, else at most 16 of the CPUs this process
+    may use. The GPU boxes show 256 hardware threads; a static OpenMP team of that size on a 50^3 test grid spends
+    its time in barriers (the bench's probe finds 16 fastest even at 384x384x256) and stalls for minutes when the
+    box throttles the CPU share."""
+    ev = os.environ.get('BABEL_ORACLE_THREADS')
+    if ev:
+        return max(int(ev), 1)
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(min(n, 16), 1)
+
+
 def lib():
     global _LIB
     if _LIB is None:
+        # idle team members sleep instead of spinning (read by libgomp when it starts)
+        os.environ.setdefault('OMP_WAIT_POLICY', 'PASSIVE')
         _LIB = C.CDLL(build())
         _LIB.bfo_stable_dt.restype = C.c_double
         _LIB.bfo_stable_dt.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_double, C.c_double]
@@ -123,7 +140,7 @@ def StaggeredFDTD_3D_with_relaxation(MaterialMap, MaterialList, Frequency, Sourc
     p = _Params(N1=N1, N2=N2, N3=N3, nMat=ml.shape[0], NDelta=NDelta, nt=nt, typeSource=TypeSource,
                 lengthSource=pulse.shape[1], nSources=pulse.shape[0], sensorSub=SensorSubSampling,
                 sensorStart=SensorStart, selRMSorPeak=SelRMSorPeak, selMapsRMS=_mask(selR),
-                selMapsSensors=_mask(selS), qfactorCorrection=int(bool(QfactorCorrection)), nthreads=nthreads,
+                selMapsSensors=_mask(selS), qfactorCorrection=int(bool(QfactorCorrection)), nthreads=nthreads or default_threads(),
                 h=SpatialStep, dt=DT, freq=Frequency, reflectionLimit=ReflectionLimit)
     mm = _xfast(MaterialMap, np.uint32)
     sm = _xfast(SourceMap, np.uint32)
@@ -194,7 +211,7 @@ class OracleSlab:
                     typeSource=kwargs.get('TypeSource', 0), lengthSource=pulse.shape[1], nSources=pulse.shape[0],
                     sensorSub=self.sub, sensorStart=self.start, selRMSorPeak=self.mode, selMapsRMS=_mask(self.selR),
                     selMapsSensors=_mask(self.selS), qfactorCorrection=int(bool(kwargs.get('QfactorCorrection', True))),
-                    nthreads=nthreads, h=SpatialStep, dt=DT, freq=Frequency,
+                    nthreads=nthreads or default_threads(), h=SpatialStep, dt=DT, freq=Frequency,
                     reflectionLimit=kwargs.get('ReflectionLimit', 1e-5))
         gl, gh = min(2, k0), min(2, N3 - (k0 + nk))
         mm = _xfast(np.asarray(MaterialMap)[:, :, k0 - gl:k0 + nk + gh], np.uint32)
