@@ -56,10 +56,7 @@ def cpu_baseline(args, dt_fn):
     from oracle import oracle as O
     n1, n2, n3, steps = args.cpu_sample
     a, k, info = H.make_problem(args.config, N=(n1, n2, n3), steps=steps, stable_dt_fn=dt_fn, accumulate_all_steps=True)
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        cores = os.cpu_count()
+    cores = O.usable_cpus()
     # the box may grant fewer CPUs than it shows (cgroup quota): probe a few thread counts on 3 steps and
     # time the sample with the best one (measured on the GPU box: 16 threads 645, 64 threads 225, 256 threads 13)
     if 'OMP_NUM_THREADS' in os.environ:

@@ -46,11 +46,22 @@ def default_threads():
     ev = os.environ.get('BABEL_ORACLE_THREADS')
     if ev:
         return max(int(ev), 1)
+    return max(min(usable_cpus(), 16), 1)
+
+
+def usable_cpus():
+    """CPUs this process can really run on: affinity mask, capped by the cgroup CPU quota (cpu.max) if one is set."""
     try:
         n = len(os.sched_getaffinity(0))
     except AttributeError:
         n = os.cpu_count() or 1
-    return max(min(n, 16), 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if quota != 'max':
+            n = min(n, max(int(int(quota) / int(period)), 1))
+    except (OSError, ValueError):
+        pass
+    return n
 
 
 def lib():
