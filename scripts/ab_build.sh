@@ -5,7 +5,7 @@ set -e
 cd "$(dirname "$0")/.."
 mkdir -p ab
 tmp=$(mktemp -d)
-git archive HEAD babelbrain_amd/csrc include | tar -x -C "$tmp"
+git archive ${AB_BASE:-HEAD} babelbrain_amd/csrc include | tar -x -C "$tmp"
 make -s -C "$tmp/babelbrain_amd/csrc" > /dev/null
 cp "$tmp/babelbrain_amd/libbabelfdtd_hip.so" ab/libA.so
 rm -rf "$tmp"

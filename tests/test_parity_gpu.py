@@ -207,3 +207,34 @@ def test_lean_fluid_tiles_beside_solid_ones():
     eng.set_material_map(mm, 0, 0)
     assert eng.tile_counts()['lean_fluid'] == 0
     eng.close()
+
+
+@pytest.mark.parametrize('variant', [1, 2, 3])
+@pytest.mark.parametrize('N', [(27, 27, 27), (29, 66, 31), (130, 27, 40)])
+def test_smallest_and_ragged_grids(variant, N):
+    """Edge sizes: barely larger than the two absorbing layers (2*(NDelta+1)+1), tile-ragged in x (65..129 -> a tile
+    with 1-2 live columns) and in y; a point source in the only interior cell region, every cell a sensor, solid
+    block touching the layer."""
+    N1, N2, N3 = N
+    rng = np.random.default_rng(N1 * 1000 + N2)
+    h = 1102.515 / 500e3 / 6
+    M = H.MATERIALS[500e3]
+    ml = np.array([M['Water'], M['Cortical'], M['Brain']], float)
+    mm = np.zeros(N, np.uint32)
+    mm[N1 // 2:, :, N3 // 2:] = 1
+    mm[:N1 // 3, N2 // 2:, :] = 2
+    dt = oracle_dt(ml, 500e3, h, 0.9)
+    nt = 40
+    smap = np.zeros(N, np.uint32)
+    smap[13, 13, 13] = 1
+    smap[N1 - 14, N2 - 14, 13] = 2
+    pulse = np.sin(2 * np.pi * 500e3 * dt * np.arange(nt + 1))[None, :] * np.array([[1.0], [0.5]])
+    sensor = np.ones(N, np.uint32)
+    Oz = rng.uniform(0.5, 1.0, N) / 1.5e6
+    kw = dict(Ox=np.zeros(N), Oy=rng.uniform(0, 1, N) / 1.5e6, Oz=Oz, NDelta=12, DT=dt, SensorSubSampling=3, SensorStart=2,
+              SelMapsRMSPeakList=['Pressure', 'Vx', 'Sigmaxy'], SelMapsSensorsList=['Pressure'], SelRMSorPeak=3, TypeSource=0,
+              QfactorCorrection=True, QCorrection=1.0)
+    oh, orf = run_both((mm, ml, 500e3, smap, pulse, h, nt * dt, sensor), kw, variant)
+    compare_runs(oh, orf, TOL, both=True)
+    assert np.abs(orf[0]['Pressure']).max() > 0
+    assert oh[0]['Pressure'].shape[0] == N1 * N2 * N3
