@@ -210,10 +210,10 @@ def test_lean_fluid_tiles_beside_solid_ones():
 
 
 @pytest.mark.parametrize('variant', [1, 2, 3])
-@pytest.mark.parametrize('N', [(27, 27, 27), (29, 66, 31), (130, 27, 40)])
+@pytest.mark.parametrize('N', [(30, 30, 30), (31, 66, 33), (130, 30, 40)])
 def test_smallest_and_ragged_grids(variant, N):
-    """Edge sizes: barely larger than the two absorbing layers (2*(NDelta+1)+1), tile-ragged in x (65..129 -> a tile
-    with 1-2 live columns) and in y; a point source in the only interior cell region, every cell a sensor, solid
+    """Edge sizes: the smallest grid the engine accepts (2*(NDelta+1)+4 = 30 per axis; smaller ones are refused, see
+    test_error_paths_raise), tile-ragged in x (130 -> a third tile with 2 live columns) and in y; a point source in the only interior cell region, every cell a sensor, solid
     block touching the layer."""
     N1, N2, N3 = N
     rng = np.random.default_rng(N1 * 1000 + N2)
