@@ -313,7 +313,41 @@ __global__ void inject_sources(bfd_dev d, int typeSource, const uint32_t *__rest
     }
 }
 
+// graph replay: the step counter lives on the device
+__global__ void inject_sources_at(bfd_dev d, int typeSource, const uint32_t *__restrict__ lin, const uint32_t *__restrict__ row,
+                                  const float *__restrict__ wx, const float *__restrict__ wy, const float *__restrict__ wz,
+                                  const float *__restrict__ pulseT, const int *__restrict__ stepDev, int nSources, int lengthSource, long nVox)
+{
+    const int step = *stepDev;
+    if (step >= lengthSource) return;
+    const float *pulseAtStep = pulseT + (size_t)step * nSources;
+    for (long s = (long)blockIdx.x * blockDim.x + threadIdx.x; s < nVox; s += (long)gridDim.x * blockDim.x) {
+        const long c = lin[s];
+        const float val = pulseAtStep[row[s]];
+        const float x = wx ? wx[s] : 1.0f;
+        if (typeSource >= 2) {
+            const float v = val * x;
+            if (typeSource == 2) { d.Sxx[c] = d.Sxx[c] + v; d.Syy[c] = d.Syy[c] + v; d.Szz[c] = d.Szz[c] + v; }
+            else { d.Sxx[c] = v; d.Syy[c] = v; d.Szz[c] = v; }
+        } else {
+            const float y = wy ? wy[s] : 1.0f, z = wz ? wz[s] : 1.0f;
+            if (typeSource == 0) { d.Vx[c] = d.Vx[c] + val * x; d.Vy[c] = d.Vy[c] + val * y; d.Vz[c] = d.Vz[c] + val * z; }
+            else { d.Vx[c] = val * x; d.Vy[c] = val * y; d.Vz[c] = val * z; }
+        }
+    }
+}
+__global__ void set_step(int *stepDev, int v) { *stepDev = v; }
+__global__ void advance_step(int *stepDev) { *stepDev = *stepDev + 1; }
+
 inline int grid_for(long n, int block = 256) { return (int)std::min<long>((n + block - 1) / block, 256L * 32); }
+
+// inputs changed: a recorded step graph holds stale pointers
+static void drop_step_graph(bfd_sim *s)
+{
+    if (s->stepGraph) { hipGraphExecDestroy(s->stepGraph); s->stepGraph = nullptr; }
+    if (s->graphState == 1) s->graphState = 0;
+    s->stepDevValid = false;
+}
 
 template <typename T>
 int dev_alloc(bfd_sim *s, T **p, size_t count, bool zero = true)
@@ -471,6 +505,8 @@ void bfd_destroy(bfd_sim *s)
     if (!s) return;
     hipSetDevice(s->cfg.device);
     hipDeviceSynchronize();
+    if (s->stepGraph) hipGraphExecDestroy(s->stepGraph);
+    if (s->captureStream) hipStreamDestroy(s->captureStream);
     for (void *p : s->allocs) hipFree(p);
     for (hipEvent_t e : s->evPool) hipEventDestroy(e);
     for (hipEvent_t e : s->evStress) hipEventDestroy(e);
@@ -535,7 +571,7 @@ int bfd_set_materials(bfd_sim *s, const double *matlist, const double *qcorr)
     d.axI = bx; d.bxI = bx + d.N1; d.axH = bx + 2 * d.N1; d.bxH = bx + 3 * d.N1;
     d.ayI = by; d.byI = by + d.N2; d.ayH = by + 2 * d.N2; d.byH = by + 3 * d.N2;
     d.azI = bz; d.bzI = bz + d.N3; d.azH = bz + 2 * d.N3; d.bzH = bz + 3 * d.N3;
-    s->haveMaterials = true; s->tilesReady = false;
+    s->haveMaterials = true; s->tilesReady = false; drop_step_graph(s);
     return 0;
 }
 
@@ -569,7 +605,7 @@ int bfd_set_material_map(bfd_sim *s, const uint32_t *map, int64_t s1, int64_t s2
     hipFree(tmp); if (flag) hipFree(flag);
     if (e != hipSuccess) BFD_FAIL(-10, std::string("bfd_set_material_map: ") + hipGetErrorString(e));
     if (hflag) BFD_FAIL(-5, "bfd_set_material_map: MaterialMap holds an id >= number of MaterialList rows");
-    s->haveMap = true; s->tilesReady = false;
+    s->haveMap = true; s->tilesReady = false; drop_step_graph(s);
     return 0;
 }
 
@@ -589,6 +625,7 @@ int bfd_set_reflector(bfd_sim *s, const uint32_t *mask, int64_t s1, int64_t s2, 
                        s->matBase + 2 * (size_t)d.plane, d.N1, d.N2, d.nk, mask ? 0 : 1);
     BFD_HIP(hipStreamSynchronize(s->stream));
     if (tmp) hipFree(tmp);
+    s->tilesReady = false; drop_step_graph(s);      // reflector cells end the UNI class of their tiles
     return 0;
 }
 
@@ -605,7 +642,7 @@ int bfd_set_sources(bfd_sim *s, int64_t nVox, const uint32_t *localIndex, const 
         if ((int)row[v] >= nSources) BFD_FAIL(-2, "bfd_set_sources: SourceMap id exceeds PulseSource rows");
     }
     s->nSrcVox = nVox; s->nSources = nSources; s->lengthSource = lengthSource;
-    s->srcLowEnd = 0; s->srcHighBeg = nVox; s->tilesReady = false;
+    s->srcLowEnd = 0; s->srcHighBeg = nVox; s->tilesReady = false; drop_step_graph(s);
     if (nVox == 0) return 0;
     // keep the source voxels sorted by voxel index: the boundary/interior split of a half-step injects
     // the sources of the first and last z-chunk separately (build_tile_lists)
@@ -934,6 +971,7 @@ static int velocity_part(bfd_sim *s, int part)
     }
     BFD_HIP(hipGetLastError());
     s->step++;
+    s->stepDevValid = false;
     return 0;
 }
 
@@ -942,11 +980,77 @@ int bfd_half_step_velocity(bfd_sim *s) { return velocity_part(s, 0); }
 int bfd_half_step_stress_part(bfd_sim *s, int32_t part) { return stress_part(s, part); }
 int bfd_half_step_velocity_part(bfd_sim *s, int32_t part) { return velocity_part(s, part); }
 
+// One plain time step recorded into the capture stream: same launches as stress_part / velocity_part (part 0),
+// sources indexed by the device step counter, which the last node advances.
+static void record_plain_step(bfd_sim *s, hipStream_t cs)
+{
+    const bfd_dev &d = s->d;
+    auto inject = [&]() {
+        if (!s->nSrcVox) return;
+        hipLaunchKernelGGL(inject_sources_at, dim3(grid_for(s->nSrcVox)), dim3(256), 0, cs, d, s->cfg.typeSource, s->srcLin, s->srcRow,
+                           s->srcW[0], s->srcW[1], s->srcW[2], s->pulseT, s->stepDev, s->nSources, s->lengthSource, (long)s->nSrcVox);
+    };
+    if (s->cfg.kernelVariant == 1) bfd_launch_stress_v1(d, cs); else bfd_launch_stress_v2(d, cs, &s->tiles, 0);
+    if (s->cfg.typeSource >= 2) inject();
+    if (s->cfg.kernelVariant == 1) bfd_launch_velocity_v1(d, cs); else bfd_launch_velocity_v2(d, cs, nullptr, nullptr, &s->tiles, 0);
+    if (s->cfg.typeSource < 2) inject();
+    hipLaunchKernelGGL(advance_step, dim3(1), dim3(1), 0, cs, s->stepDev);
+}
+
+static void build_step_graph(bfd_sim *s)
+{
+    s->graphState = -1;
+    if (!s->stepDev && dev_alloc(s, &s->stepDev, 1, true)) return;
+    if (!s->captureStream && hipStreamCreateWithFlags(&s->captureStream, hipStreamNonBlocking) != hipSuccess) { s->captureStream = nullptr; return; }
+    hipGraph_t g = nullptr;
+    if (hipStreamBeginCapture(s->captureStream, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); return; }
+    for (int q = 0; q < BFD_GRAPH_STEPS; q++) record_plain_step(s, s->captureStream);
+    if (hipStreamEndCapture(s->captureStream, &g) != hipSuccess || !g) { (void)hipGetLastError(); return; }
+    const hipError_t e = hipGraphInstantiate(&s->stepGraph, g, nullptr, nullptr, 0);
+    hipGraphDestroy(g);
+    if (e != hipSuccess) { s->stepGraph = nullptr; (void)hipGetLastError(); return; }
+    s->graphState = 1;
+}
+
+// steps [n, n+G) neither accumulate nor sample sensors
+static bool plain_steps(const bfd_sim *s, int n, int G)
+{
+    if (s->timing && s->perKernel) return false;
+    if ((s->acc || s->pk) && n + G > s->accStart) return false;
+    if (s->nSensors && s->sensOut) {
+        const int sub = s->cfg.sensorSub;
+        const int last = n + G - 1;
+        // a sample is taken at step m when m % sub == 0 and m / sub in [sensorStart, sensorStart + nTs)
+        const int firstCol = (n + sub - 1) / sub, lastCol = last / sub;
+        if (lastCol >= firstCol && lastCol >= s->cfg.sensorStart && firstCol < s->cfg.sensorStart + s->nTs) return false;
+    }
+    return true;
+}
+
 int bfd_run(bfd_sim *s, int32_t nSteps)
 {
-    for (int n = 0; n < nSteps; n++) {
-        int rc = bfd_half_step_stress(s); if (rc) return rc;
+    int rc = check_ready(s); if (rc) return rc;
+    // Graph replay is opt-in (BFD_USE_GRAPH=1): on ROCm 7.2 / MI355X replaying the 8-step graph is SLOWER than the same
+    // launches issued directly (water, no accumulation: 128^3 38.8 vs 31.3 us/step, 256^3 210 vs 196 us/step), the
+    // in-order stream already keeps the GPU fed from one host thread. Kept for runtimes where that changes.
+    const char *ug = getenv("BFD_USE_GRAPH");
+    const bool useGraph = ug && atoi(ug) != 0;
+    int n = 0;
+    while (n < nSteps) {
+        if (useGraph && nSteps - n >= BFD_GRAPH_STEPS && s->graphState >= 0 && plain_steps(s, s->step, BFD_GRAPH_STEPS)) {
+            BFD_HIP(hipSetDevice(s->cfg.device));
+            if (s->graphState == 0) build_step_graph(s);
+            if (s->graphState == 1) {
+                if (!s->stepDevValid) { hipLaunchKernelGGL(set_step, dim3(1), dim3(1), 0, s->stream, s->stepDev, s->step); s->stepDevValid = true; }
+                if (hipGraphLaunch(s->stepGraph, s->stream) == hipSuccess) { s->step += BFD_GRAPH_STEPS; n += BFD_GRAPH_STEPS; continue; }
+                (void)hipGetLastError();
+                s->graphState = -1;          // this runtime cannot replay into the engine's stream: direct launches from here on
+            }
+        }
+        s->stepDevValid = false;
+        rc = bfd_half_step_stress(s); if (rc) return rc;
         rc = bfd_half_step_velocity(s); if (rc) return rc;
+        n++;
     }
     return 0;
 }

@@ -86,7 +86,15 @@ struct bfd_sim {
     hipEvent_t evBegin, evEnd;
     std::vector<hipEvent_t> evStress, evVelocity;  // pairs
     std::vector<hipEvent_t> evPool;
+    // optional hipGraph replay of "plain" time steps (no accumulation, no sensor sample, no per-kernel timing) in
+    // bfd_run, BFD_USE_GRAPH=1; measured slower than direct launches on ROCm 7.2, so off by default (see bfd_run)
+    int *stepDev;                   // device copy of the step counter (sources index their pulse with it inside a graph)
+    hipGraphExec_t stepGraph;       // BFD_GRAPH_STEPS time steps
+    hipStream_t captureStream;
+    int graphState;                 // 0 not tried, 1 ready, -1 unavailable (direct launches are used)
+    bool stepDevValid;
 };
+#define BFD_GRAPH_STEPS 8
 
 void bfd_set_error(const std::string &s);
 #define BFD_HIP(call)                                                                              \

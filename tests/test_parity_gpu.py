@@ -238,3 +238,53 @@ def test_smallest_and_ragged_grids(variant, N):
     compare_runs(oh, orf, TOL, both=True)
     assert np.abs(orf[0]['Pressure']).max() > 0
     assert oh[0]['Pressure'].shape[0] == N1 * N2 * N3
+
+
+def test_graph_replay_equals_direct_launches(monkeypatch):
+    """With BFD_USE_GRAPH=1 bfd_run replays the plain steps (before the accumulation / sensor window) from a hipGraph
+    of 8 steps with a device-side step counter (off by default: measured slower than direct launches). Same results
+    bit for bit, also when the run is cut into pieces and when the inputs are replaced in between."""
+    from babelbrain_amd import _engine
+    from babelbrain_amd.PropagationModel import compact_sources
+    a, k, info = H.make_problem('C2', N=(64, 60, 72), steps=230, stable_dt_fn=oracle_dt)
+    mm, ml, f, smap, pulse, h, T, sensor = a
+    N1, N2, N3 = mm.shape
+    assert k['SensorStart'] * k['SensorSubSampling'] > 64          # plenty of plain steps at the start
+
+    def run(pieces, src_scale=1.0):
+        eng = _engine.Engine(N1, N2, N3, len(ml), h, k['DT'], f, info['nt'], sensorSub=k['SensorSubSampling'],
+                             sensorStart=k['SensorStart'], selMapsRMS=['Pressure'], selMapsSensors=['Pressure', 'Vz'], kernelVariant=3)
+        eng.set_materials(ml, k['QCorrection'])
+        eng.set_material_map(mm, 0, 0)
+        eng.set_sources(*compact_sources(smap, k['Ox'], k['Oy'], k['Oz']), pulse)
+        eng.set_sensor_map(sensor)
+        done = 0
+        for i, n in enumerate(pieces):
+            if i == 1 and src_scale != 1.0:
+                eng.set_sources(*compact_sources(smap, k['Ox'], k['Oy'], k['Oz']), pulse * src_scale)
+            eng.run(n)
+            done += n
+        assert done == info['nt'] and eng.step == info['nt']
+        out = (eng.sensors().copy(), eng.get_map(_engine.KIND_RMS, 'Pressure'), eng.get_field('Vz'), eng.get_field('Sxy'))
+        eng.close()
+        return out
+
+    ref = None
+    for use_graph in (None, '1'):
+        if use_graph:
+            monkeypatch.setenv('BFD_USE_GRAPH', use_graph)
+        else:
+            monkeypatch.delenv('BFD_USE_GRAPH', raising=False)
+        whole = run([info['nt']])
+        parts = run([19, 3, 40, 1, info['nt'] - 63])
+        scaled = run([30, info['nt'] - 30], src_scale=0.5)
+        for x, y in zip(whole, parts):
+            assert np.array_equal(x, y)
+        if ref is None:
+            ref = (whole, scaled)
+            assert np.abs(whole[1]).max() > 0 and not np.array_equal(whole[1], scaled[1])
+        else:
+            for x, y in zip(ref[0], whole):
+                assert np.array_equal(x, y)
+            for x, y in zip(ref[1], scaled):
+                assert np.array_equal(x, y)
