@@ -438,7 +438,7 @@ int bfd_create(const bfd_config *cfg, bfd_sim **out)
     if (cfg->sensorSub <= 0 || cfg->sensorStart < 0 || cfg->nt < 0) BFD_FAIL(-2, "bfd_create: bad sensor sampling / nt");
     if (cfg->typeSource < 0 || cfg->typeSource > 3) BFD_FAIL(-2, "bfd_create: TypeSource must be 0..3");
     if (cfg->selRMSorPeak < 0 || cfg->selRMSorPeak > 3) BFD_FAIL(-2, "bfd_create: SelRMSorPeak must be 0..3");
-    if ((long)cfg->N1 * cfg->N2 * (cfg->nk + 4) >= (1L << 32)) BFD_FAIL(-2, "bfd_create: slab exceeds 2^32 voxels");
+    if ((long)cfg->N1 * cfg->N2 * (cfg->nk + 4) >= (1L << 31)) BFD_FAIL(-2, "bfd_create: slab exceeds 2^31 voxels (split it into Z-slabs)");
     if (!(cfg->h > 0) || !(cfg->dt > 0) || !(cfg->freq > 0) || !(cfg->reflectionLimit > 0 && cfg->reflectionLimit < 1))
         BFD_FAIL(-2, "bfd_create: h, dt, freq must be > 0 and 0 < reflectionLimit < 1");
     int ndev = 0;
