@@ -26,7 +26,7 @@ ABI_SYMBOLS = [
     'bfd_set_material_map', 'bfd_set_reflector', 'bfd_set_sources', 'bfd_set_sensor_map', 'bfd_run',
     'bfd_half_step_stress', 'bfd_half_step_velocity', 'bfd_half_step_stress_part', 'bfd_half_step_velocity_part', 'bfd_sync', 'bfd_current_step', 'bfd_halo_region',
     'bfd_timing_begin', 'bfd_timing_end', 'bfd_num_sensors', 'bfd_num_sensor_steps', 'bfd_get_sensor_index',
-    'bfd_get_sensors', 'bfd_get_map', 'bfd_get_field', 'bfd_tile_counts', 'bfd_tile_count_lean', 'bfd_device_bytes', 'bfd_rayleigh_forward', 'bfd_get_sensor_dft', 'bfd_dft_series', 'bfd_bhte_run', 'bfd_bhte_run_fields',
+    'bfd_get_sensors', 'bfd_get_map', 'bfd_get_field', 'bfd_tile_counts', 'bfd_tile_count_lean', 'bfd_tile_count_fused', 'bfd_device_bytes', 'bfd_rayleigh_forward', 'bfd_get_sensor_dft', 'bfd_dft_series', 'bfd_bhte_run', 'bfd_bhte_run_fields',
 ]
 
 
@@ -117,6 +117,7 @@ def load_library():
     lib.bfd_device_bytes.argtypes = [C.c_void_p]
     lib.bfd_tile_counts.argtypes = [C.c_void_p] + [C.POINTER(C.c_int32)] * 5
     lib.bfd_tile_count_lean.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+    lib.bfd_tile_count_fused.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
     lib.bfd_device_bytes.restype = C.c_int64
     lib.bfd_device_name.argtypes = [C.c_int, C.c_char_p, C.c_int]
     lib.bfd_bhte_run.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -307,7 +308,7 @@ class Engine:
     def halo_fields(self):
         """Which fields of each halo group this slab reads from its Z-neighbours' planes:
         an all-fluid slab (tiled kernels, no solid tile) needs only Vz and Szz."""
-        if self.cfg.kernelVariant in (0, 3) and self.tile_counts()['solid'] == 0:
+        if self.cfg.kernelVariant in (0, 3, 4) and self.tile_counts()['solid'] == 0:
             return {HALO_VELOCITY: [2], HALO_STRESS: [2]}
         return {HALO_VELOCITY: [0, 1, 2], HALO_STRESS: [0, 1, 2]}
 
@@ -377,8 +378,10 @@ class Engine:
         _check(self.lib.bfd_tile_counts(self.h, *[C.byref(x) for x in n]), 'bfd_tile_counts')
         lean = C.c_int32()
         _check(self.lib.bfd_tile_count_lean(self.h, C.byref(lean)), 'bfd_tile_count_lean')
+        fused = C.c_int32()
+        _check(self.lib.bfd_tile_count_fused(self.h, C.byref(fused)), 'bfd_tile_count_fused')
         return {'lossless_fluid': n[0].value, 'lossy_fluid': n[1].value, 'solid': n[2].value,
-                'uniform_fluid': n[3].value, 'pml_fluid': n[4].value, 'lean_fluid': lean.value}
+                'uniform_fluid': n[3].value, 'pml_fluid': n[4].value, 'lean_fluid': lean.value, 'fused_fluid': fused.value}
 
     @property
     def device_bytes(self):

@@ -437,6 +437,7 @@ int bfd_create(const bfd_config *cfg, bfd_sim **out)
     if (cfg->nMat <= 0 || cfg->nMat > (int)BFD_MAT_MASK) BFD_FAIL(-2, "bfd_create: nMat must be in 1..32767");
     if (cfg->sensorSub <= 0 || cfg->sensorStart < 0 || cfg->nt < 0) BFD_FAIL(-2, "bfd_create: bad sensor sampling / nt");
     if (cfg->typeSource < 0 || cfg->typeSource > 3) BFD_FAIL(-2, "bfd_create: TypeSource must be 0..3");
+    if (cfg->kernelVariant < 0 || cfg->kernelVariant > 4) BFD_FAIL(-2, "bfd_create: kernelVariant must be 0..4");
     if (cfg->selRMSorPeak < 0 || cfg->selRMSorPeak > 3) BFD_FAIL(-2, "bfd_create: SelRMSorPeak must be 0..3");
     if ((long)cfg->N1 * cfg->N2 * (cfg->nk + 4) >= (1L << 31)) BFD_FAIL(-2, "bfd_create: slab exceeds 2^31 voxels (split it into Z-slabs)");
     if (!(cfg->h > 0) || !(cfg->dt > 0) || !(cfg->freq > 0) || !(cfg->reflectionLimit > 0 && cfg->reflectionLimit < 1))
@@ -475,6 +476,17 @@ int bfd_create(const bfd_config *cfg, bfd_sim **out)
     }
     if (!rc) rc = dev_alloc(s, &s->matBase, s->nalloc);
     if (!rc) d.mat = s->matBase + 2 * (size_t)d.plane;
+    d.VxW = d.Vx; d.VyW = d.Vy; d.VzW = d.Vz; d.SzzW = d.Szz; d.RzzW = d.Rzz;
+    // variant 4 (fused fluid time step) needs the old fields to survive the step: second copies of V, Szz, Rzz. A
+    // Z-slab keeps the in-place update (its neighbours alias the halo planes once), i.e. behaves like variant 3.
+    s->pingpong = cfg->kernelVariant == 4 && cfg->k0 == 0 && cfg->nk == cfg->N3;
+    if (s->pingpong) {
+        float **wp[5] = {&d.VxW, &d.VyW, &d.VzW, &d.SzzW, &d.RzzW};
+        for (int a = 0; a < 5 && !rc; a++) {
+            rc = dev_alloc(s, &s->ppBase[a], s->nalloc);
+            if (!rc) *wp[a] = s->ppBase[a] + 2 * (size_t)d.plane;
+        }
+    }
     // CPML memory variables
     const bool zTouch = (d.k0 < P) || (d.k0 + d.nk > d.N3 - P);
     static const int dirOf[18] = {0, 1, 2, 1, 0, 2, 0, 2, 1, 0, 1, 2, 0, 1, 2, 0, 1, 2};
@@ -748,7 +760,7 @@ static int build_tile_lists(bfd_sim *s)
         if (e != hipSuccess) BFD_FAIL(-10, std::string("classify tiles: ") + hipGetErrorString(e));
     }
     bfd_tiles &T = s->tiles;
-    T.nFluid = T.nFluidB = T.nSolid = T.nSolidB = T.nLossless = T.nLossy = T.nSolidSub = T.nUni = T.nPml = T.nLean = 0;
+    T.nFluid = T.nFluidB = T.nSolid = T.nSolidB = T.nFused = T.nLossless = T.nLossy = T.nSolidSub = T.nUni = T.nPml = T.nLean = T.nFusedSub = 0;
     // per-component normal stresses are needed only by solid tiles or by a Sigma** output selection
     const uint32_t sig = (1u << BFD_MAP_SIGMAXX) | (1u << BFD_MAP_SIGMAYY) | (1u << BFD_MAP_SIGMAZZ);
     const bool sigmaOut = ((s->cfg.selMapsRMS | s->cfg.selMapsSensors) & sig) != 0;
@@ -782,7 +794,20 @@ static int build_tile_lists(bfd_sim *s)
     const int lowPlanes = std::min(SUB, nkl);
     const int hiStart = std::max(((nkl - 2) / SUB) * SUB, lowPlanes);
     auto subBnd = [&](int q) { return q * SUB < lowPlanes || std::min((q + 1) * SUB, nkl) > hiStart; };
-    std::vector<int4> lists[4];      // fluid boundary, fluid interior, solid boundary, solid interior
+    std::vector<int4> lists[5];      // fluid boundary, fluid interior, solid boundary, solid interior, fused fluid
+    // runs of the fused kernel (variant 4, see fused_fluid_body): fluid + UNI + single-copy normal stresses, nothing of
+    // the absorbing layer within 2 cells, not a boundary sub-tile, sources of velocity type (bit5)
+    if (s->pingpong && s->cfg.typeSource < 2 && !sigmaOut) {
+        bool anySolid = false;
+        for (int id = 0; id < n; id++) anySolid = anySolid || (flags[id] & 1);
+        for (int q = 0; q < nsub; q++) {
+            if (subBnd(q)) continue;
+            for (int txy = 0; txy < tx * ty; txy++) {
+                int &f = flags[(size_t)q * tx * ty + txy];
+                if (!(f & 1) && (f & 4) && !(f & 64) && (!anySolid || (f & 16))) f |= 32;
+            }
+        }
+    }
     // List order = what is in flight together. The launch gives XCD e the e-th contiguous eighth of the list
     // (remap_block) and an XCD keeps ~100 workgroups in flight, all marching in z at the same pace; a halo line
     // (128 B for 2 or 3 floats of a neighbour tile's row) is an L2 hit only if that neighbour is in flight on the
@@ -823,18 +848,19 @@ static int build_tile_lists(bfd_sim *s)
                 }
                 const int kbeg = q * SUB, kend = std::min(r * SUB, s->d.nk);
                 int4 run; run.x = txy; run.y = kbeg | (kend << 16); run.z = solid ? 1 : f; run.w = m;
-                lists[(solid ? 2 : 0) + (bnd ? 0 : 1)].push_back(run);
+                lists[(!solid && (f & 32)) ? 4 : (solid ? 2 : 0) + (bnd ? 0 : 1)].push_back(run);
                 for (int u = q; u < r; u++) {
                     if (solid) T.nSolidSub++;
-                    else { if (f & 2) T.nLossy++; else T.nLossless++; if (f & 4) T.nUni++; if (f & 8) T.nPml++; if (f & 16) T.nLean++; }
+                    else { if (f & 2) T.nLossy++; else T.nLossless++; if (f & 4) T.nUni++; if (f & 8) T.nPml++; if (f & 16) T.nLean++; if (f & 32) T.nFusedSub++; }
                 }
                 q = r;
             }
         }
     T.nFluidB = (int)lists[0].size(); T.nFluid = T.nFluidB + (int)lists[1].size();
     T.nSolidB = (int)lists[2].size(); T.nSolid = T.nSolidB + (int)lists[3].size();
+    T.nFused = (int)lists[4].size();
     std::vector<int4> all;
-    for (int a = 0; a < 4; a++) all.insert(all.end(), lists[a].begin(), lists[a].end());
+    for (int a = 0; a < 5; a++) all.insert(all.end(), lists[a].begin(), lists[a].end());
     int rc = dev_alloc(s, &s->tiles.runs, all.size(), false);
     if (rc) return rc;
     BFD_HIP(hipMemcpy(s->tiles.runs, all.data(), all.size() * sizeof(int4), hipMemcpyHostToDevice));
@@ -901,7 +927,17 @@ static int check_ready(bfd_sim *s)
 }
 
 // sources of one part of a half-step: part 0 all, 1 = first+last z-chunk, 2 = the chunks between
-static void inject_part(bfd_sim *s, int part)
+// Views of the fields for the launches of one time step when V, Szz, Rzz are kept in two copies (variant 4): kernels
+// read d.X and write d.XW. After the stress half-step the new Szz/Rzz are the W copies; after the velocity half-step
+// so are the new V; swap_fields() then makes the W copies current. In-place variants: W == X, all views equal d.
+static bfd_dev new_stress_view(const bfd_dev &d) { bfd_dev v = d; v.Szz = d.SzzW; v.Rzz = d.RzzW; return v; }
+static bfd_dev new_velocity_view(const bfd_dev &d) { bfd_dev v = d; v.Vx = d.VxW; v.Vy = d.VyW; v.Vz = d.VzW; return v; }
+static void swap_fields(bfd_dev &d)
+{
+    std::swap(d.Vx, d.VxW); std::swap(d.Vy, d.VyW); std::swap(d.Vz, d.VzW); std::swap(d.Szz, d.SzzW); std::swap(d.Rzz, d.RzzW);
+}
+
+static void inject_part(bfd_sim *s, int part, const bfd_dev &view)
 {
     const int64_t n = s->nSrcVox;
     int64_t beg[2] = {0, 0}, end[2] = {0, 0};
@@ -912,7 +948,7 @@ static void inject_part(bfd_sim *s, int part)
     for (int r = 0; r < 2; r++) {
         const int64_t c = end[r] - beg[r];
         if (c <= 0) continue;
-        hipLaunchKernelGGL(inject_sources, dim3(grid_for(c)), dim3(256), 0, s->stream, s->d, s->cfg.typeSource,
+        hipLaunchKernelGGL(inject_sources, dim3(grid_for(c)), dim3(256), 0, s->stream, view, s->cfg.typeSource,
                            s->srcLin + beg[r], s->srcRow + beg[r], s->srcW[0] ? s->srcW[0] + beg[r] : nullptr,
                            s->srcW[1] ? s->srcW[1] + beg[r] : nullptr, s->srcW[2] ? s->srcW[2] + beg[r] : nullptr, pulse, (long)c);
     }
@@ -927,10 +963,11 @@ static int stress_part(bfd_sim *s, int part)
     BFD_HIP(hipSetDevice(s->cfg.device));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (s->timing && s->perKernel) { e0 = get_event(s); e1 = get_event(s); hipEventRecord(e0, s->stream); }
+    if (s->pingpong && part != 0) BFD_FAIL(-2, "split half-steps are not available with kernelVariant 4 on a whole domain");
     if (s->cfg.kernelVariant == 1) { if (part != 1) bfd_launch_stress_v1(s->d, s->stream); }
     else bfd_launch_stress_v2(s->d, s->stream, &s->tiles, part);
     if (e0) { hipEventRecord(e1, s->stream); s->evStress.push_back(e0); s->evStress.push_back(e1); }
-    if (s->nSrcVox && s->cfg.typeSource >= 2 && s->step < s->lengthSource) inject_part(s, part);
+    if (s->nSrcVox && s->cfg.typeSource >= 2 && s->step < s->lengthSource) inject_part(s, part, new_stress_view(s->d));
     BFD_HIP(hipGetLastError());
     return 0;
 }
@@ -949,11 +986,19 @@ static int velocity_part(bfd_sim *s, int part)
     if (accNow && s->cfg.kernelVariant != 1)
         for (int q = 0; q < s->nSelR; q++) if (s->selR[q] == BFD_MAP_PRESSURE) qP = q;
     if (s->cfg.kernelVariant == 1) { if (part != 1) bfd_launch_velocity_v1(d, s->stream); }
-    else bfd_launch_velocity_v2(d, s->stream, (qP >= 0 && s->acc) ? s->acc + (size_t)qP * s->nloc : nullptr,
-                                (qP >= 0 && s->pk) ? s->pk + (size_t)qP * s->nloc : nullptr, &s->tiles, part);
+    else {
+        float *accP = (qP >= 0 && s->acc) ? s->acc + (size_t)qP * s->nloc : nullptr;
+        float *pkP = (qP >= 0 && s->pk) ? s->pk + (size_t)qP * s->nloc : nullptr;
+        if (s->pingpong) {
+            if (part != 0) BFD_FAIL(-2, "split half-steps are not available with kernelVariant 4 on a whole domain");
+            bfd_launch_fused(d, s->stream, accP, pkP, &s->tiles);        // both half-steps of its runs: old fields -> W copies
+        }
+        bfd_launch_velocity_v2(new_stress_view(d), s->stream, accP, pkP, &s->tiles, part);
+    }
     if (e0) { hipEventRecord(e1, s->stream); s->evVelocity.push_back(e0); s->evVelocity.push_back(e1); }
-    if (s->nSrcVox && s->cfg.typeSource < 2 && s->step < s->lengthSource) inject_part(s, part);
+    if (s->nSrcVox && s->cfg.typeSource < 2 && s->step < s->lengthSource) inject_part(s, part, new_velocity_view(d));
     if (part == 1) { BFD_HIP(hipGetLastError()); return 0; }
+    if (s->pingpong) swap_fields(s->d);
     // end of the time step: remaining accumulators, sensors
     if (accNow && !(qP >= 0 && s->nSelR == 1)) {
         SelList L; L.n = s->nSelR; memcpy(L.sel, s->selR, sizeof L.sel);
@@ -1015,7 +1060,7 @@ static void build_step_graph(bfd_sim *s)
 // steps [n, n+G) neither accumulate nor sample sensors
 static bool plain_steps(const bfd_sim *s, int n, int G)
 {
-    if (s->timing && s->perKernel) return false;
+    if ((s->timing && s->perKernel) || s->pingpong) return false;
     if ((s->acc || s->pk) && n + G > s->accStart) return false;
     if (s->nSensors && s->sensOut) {
         const int sub = s->cfg.sensorSub;
@@ -1211,7 +1256,9 @@ int bfd_get_field(bfd_sim *s, int32_t a, float *out, int64_t s1, int64_t s2, int
     if (!s || !out || a < 0 || a > 14) BFD_FAIL(-1, "bfd_get_field: bad argument");
     BFD_HIP(hipSetDevice(s->cfg.device));
     expand_if_collapsed(s);
-    return download_volume(s, s->stateBase[a] + 2 * (size_t)s->d.plane, out, s1, s2, s3);
+    const bfd_dev &d = s->d;
+    float *cur[15] = {d.Vx, d.Vy, d.Vz, d.Sxx, d.Syy, d.Szz, d.Sxy, d.Sxz, d.Syz, d.Rxx, d.Ryy, d.Rzz, d.Rxy, d.Rxz, d.Ryz};
+    return download_volume(s, cur[a], out, s1, s2, s3);
 }
 
 // numpy.fft.fftfreq(n, d) bin closest to freq (first minimum, like np.argmin; BASE:2498-2499)
@@ -1293,6 +1340,13 @@ int bfd_tile_count_lean(bfd_sim *s, int32_t *nLean)
 {
     int rc = check_ready(s); if (rc) return rc;
     if (nLean) *nLean = !s->tilesReady ? 0 : (s->d.collapsed ? s->tiles.nLossless + s->tiles.nLossy : s->tiles.nLean);
+    return 0;
+}
+
+int bfd_tile_count_fused(bfd_sim *s, int32_t *nFused)
+{
+    int rc = check_ready(s); if (rc) return rc;
+    if (nFused) *nFused = s->tilesReady ? s->tiles.nFusedSub : 0;
     return 0;
 }
 

@@ -46,6 +46,9 @@ struct bfd_dev {
     // no solid sub-tile beside it in x or y, the only places its Sxx/Syy would be read from). null = none.
     const unsigned char *lean;
     int tilesX, tilesY;
+    // write targets of the fields that variant 4 keeps in two copies (V, Szz, Rzz); equal to the read pointers in
+    // every other variant (in-place update). Kernels read d.X and write d.XW.
+    float *VxW, *VyW, *VzW, *SzzW, *RzzW;
 };
 
 // tile lists of the class-specialised path (variant 3): device array
@@ -54,7 +57,8 @@ struct bfd_dev {
 // id of UNI runs). n* counters after nSolidB are in 64x8x8 sub-tiles, for reporting.
 struct bfd_tiles { int4 *runs; unsigned short *rowFlags /* per solid run x 32 planes, see stress_normal_solid */;
                    unsigned *shearCells; float *shearCoef; long nShear, shearLowEnd, shearHighBeg;   /* sparse shear list */
-                   int nFluid, nFluidB, nSolid, nSolidB; int nLossless, nLossy, nSolidSub, nUni, nPml, nLean; };
+                   int nFluid, nFluidB, nSolid, nSolidB, nFused /* runs of the fused kernel, after the solid runs */;
+                   int nLossless, nLossy, nSolidSub, nUni, nPml, nLean, nFusedSub; };
 
 struct bfd_sim {
     bfd_config cfg;
@@ -70,7 +74,9 @@ struct bfd_sim {
     std::vector<void *> allocs;     // everything to free
     int64_t devBytes;
     bool haveMaterials, haveMap;
-    bfd_tiles tiles; bool tilesReady;   // variants 2, 3
+    bfd_tiles tiles; bool tilesReady;   // variants 2, 3, 4
+    bool pingpong;                      // variant 4 on a whole domain: second copies of V, Szz, Rzz (ppBase), swapped every step
+    float *ppBase[5];
     int zchunk;                         // planes of the longest z-run (8, 16 or 32), chosen per grid
     double cmax;
     // sources
@@ -110,6 +116,7 @@ void bfd_set_error(const std::string &s);
 void bfd_launch_stress_v1(const bfd_dev &d, hipStream_t s);
 void bfd_launch_velocity_v1(const bfd_dev &d, hipStream_t s);
 void bfd_tile_grid(const bfd_dev &d, int *tilesX, int *tilesY, int *subZ);
+void bfd_launch_fused(const bfd_dev &d, hipStream_t s, float *accP, float *pkP, const bfd_tiles *t);
 int bfd_tile_subz(void);
 void bfd_launch_classify(const bfd_dev &d, hipStream_t s, int *flagsDev, int *tileMatDev);
 void bfd_launch_mark_solid(const bfd_dev &d, hipStream_t s, unsigned char *flag, long n);

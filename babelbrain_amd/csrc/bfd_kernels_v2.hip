@@ -412,7 +412,8 @@ __global__ __launch_bounds__(NTHREADS, VELOCITY_WAVES_PER_SIMD) void velocity_v2
         }
         __syncthreads();
 
-        float *pVx = d.Vx + ko, *pVy = d.Vy + ko, *pVz = d.Vz + ko;
+        const float *pVx = d.Vx + ko, *pVy = d.Vy + ko, *pVz = d.Vz + ko;
+        float *wVx = d.VxW + ko, *wVy = d.VyW + ko, *wVz = d.VzW + ko;
         float nzz = 0, nxz = 0, nyz = 0, nxx = 0, nyy = 0, nxy = 0, nha = 0, nhb = 0;
         float nvx = 0, nvy = 0, nvz = 0, nav = 0, npv = 0;
         unsigned nm2 = 0, nmx = 0, nmy = 0;
@@ -442,7 +443,7 @@ __global__ __launch_bounds__(NTHREADS, VELOCITY_WAVES_PER_SIMD) void velocity_v2
                 }
             }
             if (mraw & BFD_REFLECTOR_BIT) {
-                pVx[cij] = 0.f; pVy[cij] = 0.f; pVz[cij] = 0.f;
+                wVx[cij] = 0.f; wVy[cij] = 0.f; wVz[cij] = 0.f;
             } else {
                 const float *pxx = &sS[b][0][own], *pyy = &sS[b][1][own], *pxy = &sS[b][2][own];
                 const float *pxz = &sS[b][3][own], *pyz = &sS[b][4][own];
@@ -477,9 +478,9 @@ __global__ __launch_bounds__(NTHREADS, VELOCITY_WAVES_PER_SIMD) void velocity_v2
                     dzSzz = cpml(d.psi[17], q, d.azH[k], d.bzH[k], dzSzz);
                 }
                 const float bxv = 0.5f * (r0 + rx), byv = 0.5f * (r0 + ry), bzv = 0.5f * (r0 + r1);
-                pVx[cij] = vx + bxv * ((dxSxx + dySxy) + dzSxz);
-                pVy[cij] = vy + byv * ((dxSxy + dySyy) + dzSyz);
-                pVz[cij] = vz + bzv * ((dxSxz + dySyz) + dzSzz);
+                wVx[cij] = vx + bxv * ((dxSxx + dySxy) + dzSxz);
+                wVy[cij] = vy + byv * ((dxSxy + dySyy) + dzSyz);
+                wVz[cij] = vz + bzv * ((dxSxz + dySyz) + dzSzz);
             }
         }
         zzm1 = zz0; zz0 = zzp1; zzp1 = zzp2; zzp2 = nzz;
@@ -617,10 +618,10 @@ __device__ __forceinline__ void stress_fluid_body(const bfd_dev &d, int bx, int 
             }
             // COLLAPSED (no solid tile in the slab, no per-component stress output selected): nobody
             // reads Sxx/Syy/Rxx/Ryy, so only the Szz/Rzz copy is kept (expanded on demand, bfd_api.hip)
-            (d.Szz + ko)[cij] = val;
+            (d.SzzW + ko)[cij] = val;
             if (!COLLAPSED) { (d.Sxx + ko)[cij] = val; (d.Syy + ko)[cij] = val; }
             if (LOSSY) {
-                (d.Rzz + ko)[cij] = rn;
+                (d.RzzW + ko)[cij] = rn;
                 if (!COLLAPSED) { (d.Rxx + ko)[cij] = rn; (d.Ryy + ko)[cij] = rn; }
             }
         }
@@ -733,7 +734,7 @@ __device__ __forceinline__ void velocity_fluid_body(const bfd_dev &d, int bx, in
                 }
             }
             if (!UNI && (mraw & BFD_REFLECTOR_BIT)) {
-                (d.Vx + ko)[cij] = 0.f; (d.Vy + ko)[cij] = 0.f; (d.Vz + ko)[cij] = 0.f;
+                (d.VxW + ko)[cij] = 0.f; (d.VyW + ko)[cij] = 0.f; (d.VzW + ko)[cij] = 0.f;
             } else {
                 const float *p = &sS[b][own];
                 float dx = dplus4(p[-1], s0, p[1], p[2]);
@@ -748,9 +749,9 @@ __device__ __forceinline__ void velocity_fluid_body(const bfd_dev &d, int bx, in
                         dz = dz + pn;
                     }
                 }
-                (d.Vx + ko)[cij] = vx + (0.5f * (r0 + rx)) * dx;
-                (d.Vy + ko)[cij] = vy + (0.5f * (r0 + ry)) * dy;
-                (d.Vz + ko)[cij] = vz + (0.5f * (r0 + r1)) * dz;
+                (d.VxW + ko)[cij] = vx + (0.5f * (r0 + rx)) * dx;
+                (d.VyW + ko)[cij] = vy + (0.5f * (r0 + ry)) * dy;
+                (d.VzW + ko)[cij] = vz + (0.5f * (r0 + r1)) * dz;
             }
         }
         sm1 = s0; s0 = sp1; sp1 = sp2; sp2 = ns;
@@ -758,6 +759,180 @@ __device__ __forceinline__ void velocity_fluid_body(const bfd_dev &d, int bx, in
         r0 = r1; mraw = mraw1; mraw1 = nm2; mx = nmx; my = nmy;
         px = npx; py = npy; pz = npz; qx += dqx; qy += dqy;
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// FUSED time step of a fluid run (variant 4): stress and velocity half-steps of the tile in ONE pass, so V, Szz
+// (and Rzz) are read once and written once per time step (40 B/voxel with the RMS accumulator instead of 22 + 38).
+// The velocity update of the tile needs the NEW stress two cells around it and two planes ahead: the workgroup
+// recomputes it there (68 x 12 region per plane, z-run extended by 1 plane below and 2 above) from the OLD fields,
+// which is why this variant keeps two copies of V, Szz, Rzz (read from d.X, written to d.XW, swapped after the
+// step) -- a neighbour tile must still find the old values after this one has finished.
+// Eligible runs (flag bit5, set at setup): FLUID and LEAN/collapsed, UNI (one material, no reflector in the region
+// grown by 2 cells in x, y, z), no absorbing-layer cell in that grown region, not the first/last sub-tile of the
+// slab, sources of velocity type. Then every recomputed cell follows the same one-material arithmetic as its owner
+// computes for it, and every index stays inside the domain. Same operation order as stress_fluid_body /
+// velocity_fluid_body (UNI, non-PML flavours): results are bit-identical.
+// ------------------------------------------------------------------------------------------------
+constexpr int FR_W = TX + 4, FR_H = TY + 4, FR_N = FR_W * FR_H;      // region grown by 2: 68 x 12 = 816 cells
+constexpr int FVX_W = TX + 8;                                       // Vx tile: columns i0-4 .. i0+67 (71 used)
+constexpr int FVY_H = TY + 8;                                       // Vy tile: rows j0-4 .. j0+10 (15 used)
+constexpr int FVX_N = FR_H * FVX_W, FVY_N = FVY_H * FR_W;           // 864, 1088
+constexpr int FEXTRA = FR_N - NTHREADS;                             // 304 ring cells, one per thread tid < 304
+#ifndef FUSED_WAVES_PER_SIMD
+#define FUSED_WAVES_PER_SIMD 4
+#endif
+
+template <bool LOSSY, bool ACC>
+__device__ __forceinline__ void fused_fluid_body(const bfd_dev &d, int bx, int by, int kbeg, int kend, int tm,
+                                                 float *__restrict__ sVx, float *__restrict__ sVy, float *__restrict__ sS,
+                                                 float *__restrict__ accP, float *__restrict__ pkP)
+{
+    const int N1 = d.N1;
+    const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * TX + tx;
+    const int i0 = bx * TX, j0 = by * TY;
+    const long pl = d.plane;
+    const float AP = d.AP[tm], BP = d.BP[tm], ru = d.invRho[tm], c1 = d.c1;
+    const bool accA = ACC && accP != nullptr, accK = ACC && pkP != nullptr;
+
+    // own cell and (tid < 304) one cell of the ring: region coordinates (lx, ly), in-plane global offsets
+    const int rOwn = (ty + 2) * FR_W + tx + 2;
+    const unsigned cOwn = (unsigned)((j0 + ty) * N1 + i0 + tx);
+    const bool hasX = tid < FEXTRA;
+    int lxX = 0, lyX = 0;
+    if (tid < 2 * FR_W) { lyX = tid / FR_W; lxX = tid % FR_W; }
+    else if (tid < 4 * FR_W) { const int u = tid - 2 * FR_W; lyX = TY + 2 + u / FR_W; lxX = u % FR_W; }
+    else { const int u = tid - 4 * FR_W, c = u & 3; lyX = 2 + (u >> 2); lxX = c < 2 ? c : TX + c; }
+    const int rX = lyX * FR_W + lxX;
+    const unsigned cX = hasX ? (unsigned)((j0 - 2 + lyX) * N1 + i0 - 2 + lxX) : cOwn;
+    // tile loads: Vx tile element e -> row e / 72 (j0-2+row), col e % 72 (i0-4+col); Vy tile e -> row e / 68 (j0-4+row), col (i0-2+col)
+    const int ex1 = tid + NTHREADS;
+    const bool hx1 = ex1 < FVX_N;
+    const unsigned gx0 = (unsigned)((j0 - 2 + tid / FVX_W) * N1 + i0 - 4 + tid % FVX_W);
+    const unsigned gx1 = hx1 ? (unsigned)((j0 - 2 + ex1 / FVX_W) * N1 + i0 - 4 + ex1 % FVX_W) : gx0;
+    const int ey1 = tid + NTHREADS, ey2 = tid + 2 * NTHREADS;
+    const bool hy2 = ey2 < FVY_N;
+    const unsigned gy0 = (unsigned)((j0 - 4 + tid / FR_W) * N1 + i0 - 2 + tid % FR_W);
+    const unsigned gy1 = (unsigned)((j0 - 4 + ey1 / FR_W) * N1 + i0 - 2 + ey1 % FR_W);
+    const unsigned gy2 = hy2 ? (unsigned)((j0 - 4 + ey2 / FR_W) * N1 + i0 - 2 + ey2 % FR_W) : gy0;
+
+    const int pFirst = kbeg - 1, pEnd = kend + 2;       // stress planes [kbeg-1, kend+2)
+    // registers for plane p: tile values to stage, z-queues of Vz (p-2..p+1) and old Szz/Rzz of the two cells
+    float tx0, tx1 = 0, ty0, ty1, ty2 = 0;
+    float ozm2, ozm1, oz0, ozp1, xzm2 = 0, xzm1 = 0, xz0 = 0, xzp1 = 0;
+    float oS, oR = 0, xS = 0, xR = 0;
+    {
+        const long k0 = (long)pFirst * pl;
+        tx0 = (d.Vx + k0)[gx0]; if (hx1) tx1 = (d.Vx + k0)[gx1];
+        ty0 = (d.Vy + k0)[gy0]; ty1 = (d.Vy + k0)[gy1]; if (hy2) ty2 = (d.Vy + k0)[gy2];
+        const float *bz = d.Vz + k0;
+        ozm2 = (bz - 2 * pl)[cOwn]; ozm1 = (bz - pl)[cOwn]; oz0 = bz[cOwn]; ozp1 = (bz + pl)[cOwn];
+        oS = (d.Szz + k0)[cOwn]; if (LOSSY) oR = (d.Rzz + k0)[cOwn];
+        if (hasX) {
+            xzm2 = (bz - 2 * pl)[cX]; xzm1 = (bz - pl)[cX]; xz0 = bz[cX]; xzp1 = (bz + pl)[cX];
+            xS = (d.Szz + k0)[cX]; if (LOSSY) xR = (d.Rzz + k0)[cX];
+        }
+    }
+    // velocity stage lags two planes: own new-stress queue (q-1..q+2), own Vx,Vy of planes p-2, p-1, accumulators of q
+    float nSm1 = 0, nS0 = 0, nSp1 = 0, nSp2 = 0;
+    float vxA = 0, vxB = 0, vyA = 0, vyB = 0;           // A = plane p-2, B = plane p-1
+    float av = 0, pv = 0;
+
+    for (int p = pFirst; p < pEnd; p++) {
+        const int b = (p - pFirst) & 1;
+        const long ko = (long)p * pl;
+        float *tVx = sVx + b * FVX_N, *tVy = sVy + b * FVY_N;
+        tVx[tid] = tx0; if (hx1) tVx[ex1] = tx1;
+        tVy[tid] = ty0; tVy[ey1] = ty1; if (hy2) tVy[ey2] = ty2;
+        __syncthreads();
+
+        // loads of plane p+1
+        float ntx0 = 0, ntx1 = 0, nty0 = 0, nty1 = 0, nty2 = 0, noz = 0, nxz = 0, noS = 0, noR = 0, nxS = 0, nxR = 0, nav = 0, npv = 0;
+        if (p + 1 < pEnd) {
+            ntx0 = (d.Vx + ko + pl)[gx0]; if (hx1) ntx1 = (d.Vx + ko + pl)[gx1];
+            nty0 = (d.Vy + ko + pl)[gy0]; nty1 = (d.Vy + ko + pl)[gy1]; if (hy2) nty2 = (d.Vy + ko + pl)[gy2];
+            noz = (d.Vz + ko + 2 * pl)[cOwn];
+            noS = (d.Szz + ko + pl)[cOwn]; if (LOSSY) noR = (d.Rzz + ko + pl)[cOwn];
+            if (hasX) { nxz = (d.Vz + ko + 2 * pl)[cX]; nxS = (d.Szz + ko + pl)[cX]; if (LOSSY) nxR = (d.Rzz + ko + pl)[cX]; }
+        }
+        const int q = p - 2;                             // velocity plane of this iteration
+        if (ACC && q + 1 >= kbeg && q + 1 < kend) {
+            if (accA) nav = (accP + ko - pl)[cOwn];
+            if (accK) npv = (pkP + ko - pl)[cOwn];
+        }
+
+        // ---- stress of plane p on the grown region (own cell, then the ring cell) ----
+        float *rS = sS + ((p - pFirst) % 3) * FR_N;
+        float vxOwn, vyOwn;
+        {
+            const float *sx = tVx + (ty + 2) * FVX_W + tx + 4, *sy = tVy + (ty + 4) * FR_W + tx + 2;
+            vxOwn = sx[0]; vyOwn = sy[0];
+            const float dxVx = dminus4(sx[-2], sx[-1], vxOwn, sx[1]);
+            const float dyVy = dminus4(sy[-2 * FR_W], sy[-FR_W], vyOwn, sy[FR_W]);
+            const float dzVz = dminus4(ozm2, ozm1, oz0, ozp1);
+            const float div = (dxVx + dyVy) + dzVz;
+            float val, rn = 0.f;
+            if (LOSSY) { rn = c1 * oR - BP * div; val = oS + (AP * div + 0.5f * (oR + rn)); }
+            else val = oS + AP * div;
+            rS[rOwn] = val;
+            if (p >= kbeg && p < kend) {
+                (d.SzzW + ko)[cOwn] = val;
+                if (LOSSY) (d.RzzW + ko)[cOwn] = rn;
+            }
+            nSm1 = nS0; nS0 = nSp1; nSp1 = nSp2; nSp2 = val;
+        }
+        if (hasX) {
+            const float *sx = tVx + lyX * FVX_W + lxX + 2, *sy = tVy + (lyX + 2) * FR_W + lxX;
+            const float dxVx = dminus4(sx[-2], sx[-1], sx[0], sx[1]);
+            const float dyVy = dminus4(sy[-2 * FR_W], sy[-FR_W], sy[0], sy[FR_W]);
+            const float dzVz = dminus4(xzm2, xzm1, xz0, xzp1);
+            const float div = (dxVx + dyVy) + dzVz;
+            float val;
+            if (LOSSY) { const float rn = c1 * xR - BP * div; val = xS + (AP * div + 0.5f * (xR + rn)); }
+            else val = xS + AP * div;
+            rS[rX] = val;
+        }
+        __syncthreads();
+
+        // ---- velocity of plane q = p-2 on the tile: new stress of planes q-1 .. q+2 is in the queue ----
+        if (q >= kbeg && q < kend) {
+            const long kq = ko - 2 * pl;
+            const float *ps = sS + ((q - pFirst) % 3) * FR_N + rOwn;
+            const float s0 = nS0;
+            if (ACC) {
+                const float s = (s0 + s0) + s0;
+                const float pr = -s * (1.0f / 3.0f);
+                if (accA) (accP + kq)[cOwn] = av + pr * pr;
+                if (accK) { const float ap = fabsf(pr); if (ap > pv) (pkP + kq)[cOwn] = ap; }
+            }
+            const float dx = dplus4(ps[-1], s0, ps[1], ps[2]);
+            const float dy = dplus4(ps[-FR_W], s0, ps[FR_W], ps[2 * FR_W]);
+            const float dz = dplus4(nSm1, nS0, nSp1, nSp2);
+            const float rr = 0.5f * (ru + ru);
+            (d.VxW + kq)[cOwn] = vxA + rr * dx;
+            (d.VyW + kq)[cOwn] = vyA + rr * dy;
+            (d.VzW + kq)[cOwn] = ozm2 + rr * dz;
+        }
+        // rotate
+        vxA = vxB; vxB = vxOwn; vyA = vyB; vyB = vyOwn;
+        ozm2 = ozm1; ozm1 = oz0; oz0 = ozp1; ozp1 = noz;
+        xzm2 = xzm1; xzm1 = xz0; xz0 = xzp1; xzp1 = nxz;
+        oS = noS; oR = noR; xS = nxS; xR = nxR;
+        tx0 = ntx0; tx1 = ntx1; ty0 = nty0; ty1 = nty1; ty2 = nty2;
+        av = nav; pv = npv;
+    }
+}
+
+template <bool ACC>
+__global__ __launch_bounds__(NTHREADS, FUSED_WAVES_PER_SIMD) void fused_fluid(bfd_dev d, int tilesX, int nblocks,
+                                                                               const int4 *__restrict__ runs,
+                                                                               float *__restrict__ accP, float *__restrict__ pkP)
+{
+    __shared__ float sVx[2 * FVX_N], sVy[2 * FVY_N], sS[3 * FR_N];
+    const int4 run = runs[remap_block(blockIdx.x, nblocks)];
+    const int bx = run.x % tilesX, by = run.x / tilesX, kbeg = run.y & 0xFFFF, kend = run.y >> 16, tm = run.w;
+    if (run.z & 2) fused_fluid_body<true, ACC>(d, bx, by, kbeg, kend, tm, sVx, sVy, sS, accP, pkP);
+    else fused_fluid_body<false, ACC>(d, bx, by, kbeg, kend, tm, sVx, sVy, sS, accP, pkP);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -864,8 +1039,8 @@ __global__ __launch_bounds__(NTHREADS, 4) void stress_normal_solid(bfd_dev d, in
             float dyVy = dminus4(sy[-2 * LW], sy[-LW], vy0, sy[LW]);
             float dzVz = dminus4(vzm2, vzm1, vz0, vzp1);
             if (mraw & BFD_REFLECTOR_BIT) {
-                (d.Sxx + ko)[cij] = 0.f; (d.Syy + ko)[cij] = 0.f; (d.Szz + ko)[cij] = 0.f;
-                (d.Rxx + ko)[cij] = 0.f; (d.Ryy + ko)[cij] = 0.f; (d.Rzz + ko)[cij] = 0.f;
+                (d.Sxx + ko)[cij] = 0.f; (d.Syy + ko)[cij] = 0.f; (d.SzzW + ko)[cij] = 0.f;
+                (d.Rxx + ko)[cij] = 0.f; (d.Ryy + ko)[cij] = 0.f; (d.RzzW + ko)[cij] = 0.f;
                 (d.Sxy + ko)[cij] = 0.f; (d.Sxz + ko)[cij] = 0.f; (d.Syz + ko)[cij] = 0.f;
                 (d.Rxy + ko)[cij] = 0.f; (d.Rxz + ko)[cij] = 0.f; (d.Ryz + ko)[cij] = 0.f;
             } else {
@@ -884,9 +1059,9 @@ __global__ __launch_bounds__(NTHREADS, 4) void stress_normal_solid(bfd_dev d, in
                     else {
                         const float rn = c1 * rzz - BP * div;
                         val = szz + (AP * div + 0.5f * (rzz + rn));
-                        (d.Rxx + ko)[cij] = rn; (d.Ryy + ko)[cij] = rn; (d.Rzz + ko)[cij] = rn;
+                        (d.Rxx + ko)[cij] = rn; (d.Ryy + ko)[cij] = rn; (d.RzzW + ko)[cij] = rn;
                     }
-                    (d.Sxx + ko)[cij] = val; (d.Syy + ko)[cij] = val; (d.Szz + ko)[cij] = val;
+                    (d.Sxx + ko)[cij] = val; (d.Syy + ko)[cij] = val; (d.SzzW + ko)[cij] = val;
                 } else {
                     const float sYZ = dyVy + dzVz, sXZ = dxVx + dzVz;
                     float rn;
@@ -895,7 +1070,7 @@ __global__ __launch_bounds__(NTHREADS, 4) void stress_normal_solid(bfd_dev d, in
                     rn = c1 * ryy - (BP * div - BS2 * sXZ);
                     (d.Syy + ko)[cij] = syy + ((AP * div - AS2 * sXZ) + 0.5f * (ryy + rn)); (d.Ryy + ko)[cij] = rn;
                     rn = c1 * rzz - (BP * div - BS2 * sXY);
-                    (d.Szz + ko)[cij] = szz + ((AP * div - AS2 * sXY) + 0.5f * (rzz + rn)); (d.Rzz + ko)[cij] = rn;
+                    (d.SzzW + ko)[cij] = szz + ((AP * div - AS2 * sXY) + 0.5f * (rzz + rn)); (d.RzzW + ko)[cij] = rn;
                 }
             }
         }
@@ -1125,7 +1300,10 @@ __global__ void classify_tiles(bfd_dev d, int tilesX, int tilesY, int *__restric
         const int xa = bx * TX, xb = min(xa + TX, d.N1), ya = by * TY, yb = min(ya + TY, d.N2);
         const int za = d.k0 + bz * SUBZ, zb = za + nzOwn;
         const bool pml = xa < P || xb > d.N1 - P || ya < P || yb > d.N2 - P || za < P || zb > d.N3 - P;
-        flags[tile] = solid | (lossy << 1) | (mixed ? 0 : 4) | (pml ? 8 : 0);
+        // bit6: an absorbing-layer cell (or the domain edge) within the sub-tile grown by 2 cells, or a ragged tile
+        const bool pmlGrown = xa - 2 < P || xb + 2 > d.N1 - P || ya - 2 < P || yb + 2 > d.N2 - P || za - 2 < P || zb + 2 > d.N3 - P ||
+                              xb - xa < TX || yb - ya < TY;
+        flags[tile] = solid | (lossy << 1) | (mixed ? 0 : 4) | (pml ? 8 : 0) | (pmlGrown ? 64 : 0);
         tileMat[tile] = (int)(first & BFD_MAT_MASK);
     }
 }
@@ -1195,6 +1373,17 @@ void bfd_launch_stress_v2(const bfd_dev &d, hipStream_t s, const bfd_tiles *t, i
         if (e0 > b0) hipLaunchKernelGGL(stress_shear_sparse, dim3((unsigned)((e0 - b0 + 255) / 256)), dim3(256), 0, s, d, t->shearCells + b0, t->shearCoef + 6 * b0, e0 - b0);
         if (e1 > b1) hipLaunchKernelGGL(stress_shear_sparse, dim3((unsigned)((e1 - b1 + 255) / 256)), dim3(256), 0, s, d, t->shearCells + b1, t->shearCoef + 6 * b1, e1 - b1);
     }
+}
+
+// fused time step of the eligible fluid runs (variant 4; whole half-steps only); d = stress-side view of the fields
+void bfd_launch_fused(const bfd_dev &d, hipStream_t s, float *accP, float *pkP, const bfd_tiles *t)
+{
+    const int tilesX = (d.N1 + TX - 1) / TX;
+    const int n = t->nFused;
+    if (!n) return;
+    const int4 *runs = t->runs + t->nFluid + t->nSolid;
+    if (accP || pkP) BFD_LAUNCH((fused_fluid<true>), n, runs, accP, pkP);
+    else BFD_LAUNCH((fused_fluid<false>), n, runs, accP, pkP);
 }
 
 void bfd_launch_velocity_v2(const bfd_dev &d, hipStream_t s, float *accP, float *pkP, const bfd_tiles *t, int part)

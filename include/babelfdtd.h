@@ -68,7 +68,7 @@ typedef struct bfd_config {
     uint32_t selMapsSensors;   /* SelMapsSensorsList as BFD_MAP_* bits (BASE:2356)                */
     int32_t qfactorCorrection; /* QfactorCorrection (BASE:2361)                                   */
     int32_t device;            /* HIP device ordinal                                              */
-    int32_t kernelVariant;     /* 0 = default (= 3), 1 = simple one-thread-per-voxel kernels, 2 = LDS-tiled dense, 3 = LDS-tiled with fluid/solid tile classes */
+    int32_t kernelVariant;     /* 0 = default (= 3), 1 = simple one-thread-per-voxel kernels, 2 = LDS-tiled dense, 3 = LDS-tiled with fluid/solid tile classes, 4 = 3 + fused stress/velocity pass over eligible fluid tiles (whole domains only: keeps two copies of V, Szz, Rzz; on a Z-slab it is 3) */
     int32_t reserved0;
     double h;                  /* SpatialStep, m (BASE:2344)                                      */
     double dt;                 /* DT, s (BASE:2351)                                               */
@@ -173,6 +173,8 @@ int bfd_tile_counts(bfd_sim *sim, int32_t *nLossless, int32_t *nLossy, int32_t *
 /* fluid sub-tiles that keep a single copy of their three identical normal stresses: all of them in an all-fluid
  * slab, those without a solid sub-tile beside them in x or y otherwise; 0 when a Sigma** output is selected */
 int bfd_tile_count_lean(bfd_sim *sim, int32_t *nLean);
+/* fluid sub-tiles advanced by the fused time-step kernel (kernelVariant 4 on a whole domain; 0 otherwise) */
+int bfd_tile_count_fused(bfd_sim *sim, int32_t *nFused);
 /* device memory this sim holds, bytes */
 int64_t bfd_device_bytes(bfd_sim *sim);
 

@@ -288,3 +288,45 @@ def test_graph_replay_equals_direct_launches(monkeypatch):
                 assert np.array_equal(x, y)
             for x, y in zip(ref[1], scaled):
                 assert np.array_equal(x, y)
+
+
+@pytest.mark.parametrize('config', ['C1', 'C1-lossy', 'C2', 'C3'])
+def test_fused_fluid_step_variant4(config):
+    """kernelVariant 4: eligible fluid runs advance both half-steps in one pass over two copies of V, Szz, Rzz
+    (fused_fluid_body); everything else runs the variant-3 kernels out of place. Outputs and raw fields must equal
+    the oracle's like every other variant."""
+    from babelbrain_amd import _engine
+    from babelbrain_amd.PropagationModel import compact_sources
+    N = (150, 62, 80)
+    a, k, info = H.make_problem(config.split('-')[0], N=N, steps=170, stable_dt_fn=oracle_dt)
+    if config == 'C1-lossy':                                   # one attenuating fluid everywhere: the LOSSY flavour of the fused body
+        a = list(a); a[1] = np.array([[1041.0, 1562.0, 0.0, 30.0, 0.0]]); a = tuple(a)
+        assert k['DT'] <= oracle_dt(a[1], a[2], a[5], 0.95)
+    k['SelMapsRMSPeakList'] = ['Pressure', 'Vx', 'Vz']
+    k['SelMapsSensorsList'] = ['Pressure', 'Vy']
+    k['SelRMSorPeak'] = 3
+    oh, orf = run_both(a, k, 4)
+    compare_runs(oh, orf, TOL, both=True)
+    assert orf[2]['Pressure'].max() > 0
+    mm, ml, f, smap, pulse, h, T, sensor = a
+    N1, N2, N3 = mm.shape
+    eng = _engine.Engine(N1, N2, N3, len(ml), h, k['DT'], f, info['nt'], sensorSub=k['SensorSubSampling'],
+                         sensorStart=k['SensorStart'], selMapsRMS=['Pressure'], selMapsSensors=['Pressure'], kernelVariant=4)
+    eng.set_materials(ml, k['QCorrection'])
+    eng.set_material_map(mm, 0, 0)
+    eng.set_sources(*compact_sources(smap, k['Ox'], k['Oy'], k['Oz']), pulse)
+    eng.set_sensor_map(sensor)
+    tc = eng.tile_counts()
+    print(config, tc)
+    assert tc['fused_fluid'] > 0 or config in ('C2', 'C3'), tc   # the small shells leave no eligible run; their ping-pong path is still covered
+    if config == 'C1-lossy':
+        assert tc['lossy_fluid'] > 0 and tc['lossless_fluid'] == 0
+    eng.run(info['nt'] - 1)
+    eng.half_step_stress(); eng.half_step_velocity()         # odd and even numbers of swaps both leave the right copy current
+    k2 = dict(k); k2['SelMapsRMSPeakList'] = ['Sigmaxx', 'Sigmazz', 'Vx', 'Vy', 'Vz']; k2['SelRMSorPeak'] = 1
+    ref = O.StaggeredFDTD_3D_with_relaxation(*a, **k2)
+    for name, key in (('Szz', 'Sigmazz'), ('Sxx', 'Sigmaxx'), ('Vx', 'Vx'), ('Vy', 'Vy'), ('Vz', 'Vz')):
+        assert rel_l2(eng.get_field(name), ref[1][key]) <= TOL, name
+    with pytest.raises(_engine.EngineError):
+        eng.half_step_stress(1)                                # split half-steps belong to Z-slabs (which stay in place)
+    eng.close()
