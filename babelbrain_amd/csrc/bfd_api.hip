@@ -831,14 +831,21 @@ static int build_tile_lists(bfd_sim *s)
             }
         }
     }
+    // fused runs may be longer than a z-chunk (their 3 extra stress planes and 5 extra velocity planes are pure
+    // overhead): up to fusedSub sub-tiles, crossing chunk boundaries; sub-tiles taken that way are skipped later
+    int fusedSub = 32 / SUB;
+    if (const char *ev = getenv("BFD_FUSED_ZRUN")) { const int z = atoi(ev); if (z >= SUB && z % SUB == 0 && z <= 0x7000) fusedSub = z / SUB; }
+    std::vector<char> taken((size_t)n, 0);
     for (const auto &pc : seq) {
         const int txy = pc.first, c = pc.second;
-            const int sb = c * perChunk, se = std::min(sb + perChunk, nsub);
+            const int sb = c * perChunk, se0 = std::min(sb + perChunk, nsub);
             int q = sb;
-            while (q < se) {
+            while (q < se0) {
+                if (taken[(size_t)q * tx * ty + txy]) { q++; continue; }
                 const int f = flags[(size_t)q * tx * ty + txy], m = mats[(size_t)q * tx * ty + txy];
                 const bool solid = f & 1;
                 const bool bnd = subBnd(q);
+                const int se = (!solid && (f & 32)) ? std::min(q + fusedSub, nsub) : se0;
                 int r = q + 1;
                 while (r < se) {
                     const int f2 = flags[(size_t)r * tx * ty + txy], m2 = mats[(size_t)r * tx * ty + txy];
@@ -850,6 +857,7 @@ static int build_tile_lists(bfd_sim *s)
                 int4 run; run.x = txy; run.y = kbeg | (kend << 16); run.z = solid ? 1 : f; run.w = m;
                 lists[(!solid && (f & 32)) ? 4 : (solid ? 2 : 0) + (bnd ? 0 : 1)].push_back(run);
                 for (int u = q; u < r; u++) {
+                    taken[(size_t)u * tx * ty + txy] = 1;
                     if (solid) T.nSolidSub++;
                     else { if (f & 2) T.nLossy++; else T.nLossless++; if (f & 4) T.nUni++; if (f & 8) T.nPml++; if (f & 16) T.nLean++; if (f & 32) T.nFusedSub++; }
                 }

@@ -36,8 +36,8 @@ BYTES_STEP = BYTES_STRESS + BYTES_VELOCITY + BYTES_RMS   # 172
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=60)
-    ap.add_argument('--warmup', type=int, default=6)
+    ap.add_argument('--steps', type=int, default=600)
+    ap.add_argument('--warmup', type=int, default=300)
     ap.add_argument('--config', default='C3')
     ap.add_argument('--size', type=int, nargs=3, default=None, help='override per-GPU grid N1 N2 N3')
     ap.add_argument('--variant', type=int, default=0, help='kernel variant (0 default, 1 simple, 2 LDS-tiled)')
