@@ -35,7 +35,7 @@ class Config(C.Structure):
                 ('nMat', C.c_int32), ('NDelta', C.c_int32), ('typeSource', C.c_int32), ('sensorSub', C.c_int32),
                 ('sensorStart', C.c_int32), ('nt', C.c_int32), ('selRMSorPeak', C.c_int32),
                 ('selMapsRMS', C.c_uint32), ('selMapsSensors', C.c_uint32), ('qfactorCorrection', C.c_int32),
-                ('device', C.c_int32), ('kernelVariant', C.c_int32), ('reserved0', C.c_int32),
+                ('device', C.c_int32), ('kernelVariant', C.c_int32), ('rmsFirstStep', C.c_int32),
                 ('h', C.c_double), ('dt', C.c_double), ('freq', C.c_double), ('reflectionLimit', C.c_double)]
 
 
@@ -213,7 +213,7 @@ class Engine:
 
     def __init__(self, N1, N2, N3, nMat, h, dt, freq, nt, k0=0, nk=None, NDelta=12, reflectionLimit=1e-5,
                  typeSource=0, sensorSub=1, sensorStart=0, selRMSorPeak=1, selMapsRMS=('Pressure',),
-                 selMapsSensors=('Pressure',), qfactorCorrection=True, device=0, kernelVariant=0):
+                 selMapsSensors=('Pressure',), qfactorCorrection=True, device=0, kernelVariant=0, rmsFirstStep=0):
         self.lib = load_library()
         if self.lib.bfd_device_count() <= 0:
             raise EngineError('no HIP device visible: the MI355X engine has no CPU fallback')
@@ -223,7 +223,7 @@ class Engine:
         self.cfg = Config(N1=N1, N2=N2, N3=N3, k0=k0, nk=nk, nMat=nMat, NDelta=NDelta, typeSource=typeSource,
                           sensorSub=sensorSub, sensorStart=sensorStart, nt=nt, selRMSorPeak=selRMSorPeak,
                           selMapsRMS=mask_of(self.selR), selMapsSensors=mask_of(self.selS),
-                          qfactorCorrection=int(bool(qfactorCorrection)), device=device, kernelVariant=kernelVariant,
+                          qfactorCorrection=int(bool(qfactorCorrection)), device=device, kernelVariant=kernelVariant, rmsFirstStep=rmsFirstStep,
                           h=h, dt=dt, freq=freq, reflectionLimit=reflectionLimit)
         self.h = C.c_void_p()
         _check(self.lib.bfd_create(C.byref(self.cfg), C.byref(self.h)), 'bfd_create')

@@ -438,6 +438,7 @@ int bfd_create(const bfd_config *cfg, bfd_sim **out)
     if (cfg->sensorSub <= 0 || cfg->sensorStart < 0 || cfg->nt < 0) BFD_FAIL(-2, "bfd_create: bad sensor sampling / nt");
     if (cfg->typeSource < 0 || cfg->typeSource > 3) BFD_FAIL(-2, "bfd_create: TypeSource must be 0..3");
     if (cfg->kernelVariant < 0 || cfg->kernelVariant > 4) BFD_FAIL(-2, "bfd_create: kernelVariant must be 0..4");
+    if (cfg->rmsFirstStep < 0) BFD_FAIL(-2, "bfd_create: rmsFirstStep must be >= 0");
     if (cfg->selRMSorPeak < 0 || cfg->selRMSorPeak > 3) BFD_FAIL(-2, "bfd_create: SelRMSorPeak must be 0..3");
     if ((long)cfg->N1 * cfg->N2 * (cfg->nk + 4) >= (1L << 31)) BFD_FAIL(-2, "bfd_create: slab exceeds 2^31 voxels (split it into Z-slabs)");
     if (!(cfg->h > 0) || !(cfg->dt > 0) || !(cfg->freq > 0) || !(cfg->reflectionLimit > 0 && cfg->reflectionLimit < 1))
@@ -503,7 +504,7 @@ int bfd_create(const bfd_config *cfg, bfd_sim **out)
     s->nSelS = sel_list(cfg->selMapsSensors, s->selS);
     if (!rc && (cfg->selRMSorPeak & 1) && s->nSelR) rc = dev_alloc(s, &s->acc, (size_t)s->nSelR * s->nloc);
     if (!rc && (cfg->selRMSorPeak & 2) && s->nSelR) rc = dev_alloc(s, &s->pk, (size_t)s->nSelR * s->nloc);
-    s->accStart = cfg->sensorStart * cfg->sensorSub;
+    s->accStart = cfg->rmsFirstStep > 0 ? cfg->rmsFirstStep - 1 : cfg->sensorStart * cfg->sensorSub;
     s->nTs = 0;
     for (int n = 0; n < cfg->nt; n++) if (n % cfg->sensorSub == 0 && n / cfg->sensorSub >= cfg->sensorStart) s->nTs++;
     if (rc) { bfd_destroy(s); return rc; }

@@ -171,7 +171,7 @@ class SlabRunner:
             self.step()
 
 
-def create_hip_slab(args, kwargs, rank, world, device, kernelVariant=0, local=None, host_staging=False):
+def create_hip_slab(args, kwargs, rank, world, device, kernelVariant=0, local=None, host_staging=False, rmsFirstStep=0):
     """Build the engine for this rank's slab from the same arguments the reference passes to
     StaggeredFDTD_3D_with_relaxation (BASE:2338-2365). Returns (HipSlab, info).
     local=(N3, k0, nk, gl, gh): the volumes in `args` are already this rank's slab (MaterialMap with
@@ -196,7 +196,7 @@ def create_hip_slab(args, kwargs, rank, world, device, kernelVariant=0, local=No
                          selMapsRMS=kwargs.get('SelMapsRMSPeakList', ('Pressure',)),
                          selMapsSensors=kwargs.get('SelMapsSensorsList', ('Pressure',)),
                          qfactorCorrection=kwargs.get('QfactorCorrection', True), device=device,
-                         kernelVariant=kernelVariant)
+                         kernelVariant=kernelVariant, rmsFirstStep=rmsFirstStep)
     eng.set_materials(ml, kwargs.get('QCorrection', 1.0))
     if local is None:
         view, gl, gh = material_slab(np.asarray(MaterialMap), k0, nk)

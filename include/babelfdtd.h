@@ -69,7 +69,8 @@ typedef struct bfd_config {
     int32_t qfactorCorrection; /* QfactorCorrection (BASE:2361)                                   */
     int32_t device;            /* HIP device ordinal                                              */
     int32_t kernelVariant;     /* 0 = default (= 3), 1 = simple one-thread-per-voxel kernels, 2 = LDS-tiled dense, 3 = LDS-tiled with fluid/solid tile classes, 4 = 3 + fused stress/velocity pass over eligible fluid tiles (whole domains only: keeps two copies of V, Szz, Rzz; on a Z-slab it is 3) */
-    int32_t reserved0;
+    int32_t rmsFirstStep;      /* 0 = RMS/peak accumulation starts at step SensorStart*SensorSubSampling (the reference's last-cycles
+                                * window, BASE:2108-2109); n > 0 = it starts at step n-1 (bench: every timed step accumulates) */
     double h;                  /* SpatialStep, m (BASE:2344)                                      */
     double dt;                 /* DT, s (BASE:2351)                                               */
     double freq;               /* Frequency, Hz (BASE:2341)                                       */
