@@ -193,7 +193,7 @@ def main():
             'ms_per_step': wall / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': '%s: %dx%dx%d per GPU (%dx%dx%d total), %s medium, %s source, PML 12, %d materials, '
-                                   'Pressure RMS + sensors on' % (args.config, n1, n2, n3, N[0], N[1], N[2], info['medium'], info['tx'], info['n_mat']),
+                                   'Pressure RMS accumulated in every step, sensors over the last 2 periods' % (args.config, n1, n2, n3, N[0], N[1], N[2], info['medium'], info['tx'], info['n_mat']),
                        'parallelism': 'z-slab x%d' % world, 'kernel_variant': args.variant, 'dt': info['dt'], 'ppp': info['ppp'],
                        'n_sources': info['n_sources'], 'n_sensors_rank0': int(eng.num_sensors), 'tiles_rank0': eng.tile_counts(),
                        'halo_exchange': 'overlapped' if runner.overlap else ('none' if world == 1 else 'blocking')},
