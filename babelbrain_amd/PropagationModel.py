@@ -103,6 +103,13 @@ class PropagationModel:
             DT = _engine.stable_dt(ml, Frequency, QfactorCorrection, SpatialStep, AlphaCFL, QCorrection)
         nt = n_steps(DurationSimulation, DT)
         device = self._device if DefaultGPUDeviceNumber is None else DefaultGPUDeviceNumber
+        if DefaultGPUDeviceNumber is None and DefaultGPUDeviceName:
+            # the reference selects the device by a substring of its name (BASE:2358, 918-925); an unknown name keeps
+            # this object's device, like the reference's backends keep their default when nothing matches
+            for d, name in _engine.list_devices():
+                if str(DefaultGPUDeviceName).lower() in name.lower():
+                    device = d
+                    break
         eng = Engine(N1, N2, N3, ml.shape[0], SpatialStep, DT, Frequency, nt, NDelta=NDelta,
                      reflectionLimit=ReflectionLimit, typeSource=TypeSource, sensorSub=SensorSubSampling,
                      sensorStart=SensorStart, selRMSorPeak=SelRMSorPeak, selMapsRMS=SelMapsRMSPeakList,
