@@ -63,7 +63,7 @@ def material_slab(MaterialMap, k0, nk):
 
 
 class PropagationModel:
-    def __init__(self, device=0, kernelVariant=0):
+    def __init__(self, device=None, kernelVariant=0):
         self._device = device
         self._kernelVariant = kernelVariant
         self.last_timing = None
@@ -102,11 +102,12 @@ class PropagationModel:
         if DT is None:
             DT = _engine.stable_dt(ml, Frequency, QfactorCorrection, SpatialStep, AlphaCFL, QCorrection)
         nt = n_steps(DurationSimulation, DT)
-        device = self._device if DefaultGPUDeviceNumber is None else DefaultGPUDeviceNumber
-        if DefaultGPUDeviceNumber is None and DefaultGPUDeviceName:
-            # the reference selects the device by a substring of its name (BASE:2358, 918-925); an unknown name keeps
-            # this object's device, like the reference's backends keep their default when nothing matches
-            for d, name in _engine.list_devices():
+        # device: explicit ordinal of the call, else the one this object was built with, else the first device whose
+        # name contains DefaultGPUDeviceName (the reference selects by name substring, BASE:2358, 918-925), else 0
+        device = DefaultGPUDeviceNumber if DefaultGPUDeviceNumber is not None else self._device
+        if device is None:
+            device = 0
+            for d, name in _engine.list_devices() if DefaultGPUDeviceName else []:
                 if str(DefaultGPUDeviceName).lower() in name.lower():
                     device = d
                     break
