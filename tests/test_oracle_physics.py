@@ -18,12 +18,12 @@ F0 = 500e3
 ND = 12
 
 
-def _run(mm, ml, h, dt, nt, smap, pulse, sensor, qcorr=1.0, sub=1, start=0, maps=('Pressure',), **kw):
+def _run(mm, ml, h, dt, nt, smap, pulse, sensor, qcorr=1.0, sub=1, start=0, maps=('Pressure',), field='Pressure', **kw):
     rho_c = ml[0][0] * ml[0][1]
     Ox = kw.pop('Ox', np.zeros(mm.shape)); Oy = np.zeros(mm.shape); Oz = np.ones(mm.shape) / rho_c
     return O.StaggeredFDTD_3D_with_relaxation(mm, np.asarray(ml, float), F0, smap, pulse, h, nt * dt, sensor, Ox=Ox, Oy=Oy, Oz=Oz,
                                               NDelta=ND, DT=dt, SensorSubSampling=sub, SensorStart=start, QCorrection=qcorr,
-                                              SelMapsRMSPeakList=list(maps), SelMapsSensorsList=['Pressure'], **kw)
+                                              SelMapsRMSPeakList=list(maps), SelMapsSensorsList=[field], **kw)
 
 
 def _cw(nt, dt, ramp_cycles=4):
@@ -34,14 +34,14 @@ def _cw(nt, dt, ramp_cycles=4):
     return p[None, :]
 
 
-def _axis_amplitude(S, dt_s):
-    p = S['Pressure'].astype(np.float64)
+def _axis_amplitude(S, dt_s, field='Pressure'):
+    p = S[field].astype(np.float64)
     n = p.shape[1]
     k = np.argmin(np.abs(np.fft.fftfreq(n, dt_s) - F0))
     return np.fft.fft(p, axis=1)[:, k] * 2 / n
 
 
-def _piston_case(ml, mm_fn=None, N=(56, 56, 132), ppp=25, cycles=36, qcorr=1.0):
+def _piston_case(ml, mm_fn=None, N=(56, 56, 132), ppp=25, cycles=36, qcorr=1.0, field='Pressure', full_plane=False):
     """Square piston radiating along +z; complex amplitude of the plane-wave component per z plane,
     from the last 2 periods."""
     h = 1500.0 / F0 / 6
@@ -52,13 +52,15 @@ def _piston_case(ml, mm_fn=None, N=(56, 56, 132), ppp=25, cycles=36, qcorr=1.0):
         mm_fn(mm)
     smap = np.zeros(N, np.uint32)
     smap[ND:-ND, ND:-ND, ND + 1] = 1
+    if full_plane:          # uniform in x and y: a 1-D plane wave, on which the lateral absorbing layers do not act
+        smap[:, :, ND + 1] = 1
     nt = ppp * cycles
     sensor = np.zeros(N, np.uint32)
     sensor[ND:-ND, ND:-ND, ND + 2:-ND] = 1
-    S, L, R, I = _run(mm, ml, h, dt, nt, smap, _cw(nt, dt), sensor, qcorr=qcorr, sub=1, start=nt - 2 * ppp)
+    S, L, R, I = _run(mm, ml, h, dt, nt, smap, _cw(nt, dt), sensor, qcorr=qcorr, sub=1, start=nt - 2 * ppp, field=field)
     # cross-section mean = the (kx,ky)=(0,0) plane-wave component, which advances exactly as exp(-ikz)
     # whatever the diffraction of the finite piston does on the axis (sensors are x-fastest ordered)
-    A = _axis_amplitude(S, dt).reshape(N3 - 2 * ND - 2, N2 - 2 * ND, N1 - 2 * ND)
+    A = _axis_amplitude(S, dt, field).reshape(N3 - 2 * ND - 2, N2 - 2 * ND, N1 - 2 * ND)
     return A.mean(axis=(1, 2)), h, dt
 
 
@@ -102,6 +104,51 @@ def test_K3_density_interface_transmission():
     ratio = np.abs(A1[kk] / A0[kk])
     assert abs(ratio.mean() / T - 1) < 0.01, (ratio.mean(), T)
     assert ratio.std() / T < 0.01
+
+
+def test_K3b_water_to_bone_normal_incidence():
+    """Water onto a lossless bone half-space with shear (rho 1896.5, cL 2476, cS 1542). The source fills the whole
+    plane, so the field is a 1-D plane wave (laterally uniform: the side layers see no gradient). A 10-cycle tone burst
+    is time-gated against the echo of the far absorbing layer (1.2 wavelengths thick in bone: its CW reflection is
+    about 2 %): the normal traction -sigma_zz is transmitted with T = 2 Z2/(Z1+Z2), reflected with R = (Z2-Z1)/(Z2+Z1),
+    Z = rho cL, and the two carry the incident energy."""
+    from scipy.signal import hilbert
+    bone = [1896.5, 2476.0, 1542.0, 0.0, 0.0]
+    h = 1500.0 / F0 / 6
+    ppp = 25
+    dt = 1 / F0 / ppp
+    N = (36, 36, 200)
+    kint = 70
+    nt = int(56e-6 / dt)
+    smap = np.zeros(N, np.uint32)
+    smap[:, :, ND + 1] = 1
+    nb, r = 10 * ppp, 3 * ppp
+    env = np.ones(nb)
+    env[:r] = 0.5 * (1 - np.cos(np.pi * np.arange(r) / r))
+    env[-r:] = env[:r][::-1]
+    pulse = np.zeros((1, nt + 1))
+    pulse[0, :nb] = np.sin(2 * np.pi * F0 * np.arange(nb) * dt) * env
+    sensor = np.zeros(N, np.uint32)
+    for kz in (ND + 18, kint + 20):                                   # 40 cells in front of the interface, 20 cells inside the bone
+        sensor[18, 18, kz] = 1
+
+    def envelopes(two):
+        mm = np.zeros(N, np.uint32)
+        if two:
+            mm[:, :, kint:] = 1
+        S, L, R, I = _run(mm, [WATER, bone], h, dt, nt, smap, pulse, sensor, sub=1, start=0, field='Sigmazz')
+        return np.abs(hilbert(S['Sigmazz'].astype(np.float64), axis=1))
+    ew, eb = envelopes(False), envelopes(True)
+    p0 = ew[0].max()
+    assert abs(ew[1].max() / p0 - 1) < 0.03                           # accuracy of the burst-envelope measurement itself
+    Z1, Z2 = 1000.0 * 1500.0, bone[0] * bone[1]
+    T, R = 2 * Z2 / (Z1 + Z2), (Z2 - Z1) / (Z2 + Z1)
+    t_num = eb[1].max() / p0
+    r_num = eb[0][int(np.argmax(ew[0])) + 8 * ppp:].max() / p0        # the echo at the front sensor, after the direct burst
+    print('K3b: T %.4f (exact %.4f), R %.4f (exact %.4f), energy %.4f' % (t_num, T, r_num, R, t_num ** 2 * Z1 / Z2 + r_num ** 2))
+    assert abs(t_num / T - 1) < 0.03, (t_num, T)
+    assert abs(r_num / R - 1) < 0.06, (r_num, R)
+    assert abs(t_num ** 2 * Z1 / Z2 + r_num ** 2 - 1) < 0.03
 
 
 def test_K4_absorbing_layer():
