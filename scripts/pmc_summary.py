@@ -9,7 +9,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(root + '/p*/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
         name = r['Kernel_Name']
-        if 'stress' in name or 'velocity' in name or 'accumulate' in name or 'record_sensors' in name:
+        if 'stress' in name or 'velocity' in name or 'fused' in name or 'accumulate' in name or 'record_sensors' in name:
             short = name.split('(')[1].split(')')[-1] if False else name.replace('(anonymous namespace)::', '').split('(')[0]
             agg[short][r['Counter_Name']].append(float(r['Counter_Value']))
             agg[short]['VGPR'].append(float(r['VGPR_Count'])); agg[short]['SGPR'].append(float(r['SGPR_Count']))

@@ -3,7 +3,7 @@ export TMPDIR=/tmp
 tag=$1; shift
 mkdir -p gpurun_out/pmc_$tag
 i=0
-for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum"; do
+for grp in "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
   timeout 300 rocprofv3 --pmc $grp --output-format csv -d gpurun_out/pmc_$tag/p$i -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-dense-reference "$@" > gpurun_out/pmc_$tag/p$i.log 2>&1
 done
