@@ -24,7 +24,7 @@ ABI_SYMBOLS = [
     'bfd_abi_version', 'bfd_last_error', 'bfd_device_count', 'bfd_device_name', 'bfd_stable_dt',
     'bfd_material_tables', 'bfd_create', 'bfd_destroy', 'bfd_set_stream', 'bfd_use_private_stream', 'bfd_set_materials',
     'bfd_set_material_map', 'bfd_set_reflector', 'bfd_set_sources', 'bfd_set_sensor_map', 'bfd_run',
-    'bfd_half_step_stress', 'bfd_half_step_velocity', 'bfd_half_step_stress_part', 'bfd_half_step_velocity_part', 'bfd_sync', 'bfd_current_step', 'bfd_halo_region',
+    'bfd_half_step_stress', 'bfd_half_step_velocity', 'bfd_half_step_stress_part', 'bfd_half_step_velocity_part', 'bfd_half_step_stress_part_on', 'bfd_half_step_velocity_part_on', 'bfd_sync', 'bfd_current_step', 'bfd_halo_region',
     'bfd_timing_begin', 'bfd_timing_end', 'bfd_num_sensors', 'bfd_num_sensor_steps', 'bfd_get_sensor_index',
     'bfd_get_sensors', 'bfd_get_map', 'bfd_get_field', 'bfd_tile_counts', 'bfd_tile_count_lean', 'bfd_tile_count_fused', 'bfd_device_bytes', 'bfd_rayleigh_forward', 'bfd_get_sensor_dft', 'bfd_dft_series', 'bfd_bhte_run', 'bfd_bhte_run_fields',
 ]
@@ -101,6 +101,8 @@ def load_library():
     lib.bfd_half_step_velocity.argtypes = [C.c_void_p]
     lib.bfd_half_step_stress_part.argtypes = [C.c_void_p, C.c_int32]
     lib.bfd_half_step_velocity_part.argtypes = [C.c_void_p, C.c_int32]
+    lib.bfd_half_step_stress_part_on.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+    lib.bfd_half_step_velocity_part_on.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
     lib.bfd_sync.argtypes = [C.c_void_p]
     lib.bfd_current_step.argtypes = [C.c_void_p]
     lib.bfd_halo_region.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p),
@@ -299,11 +301,18 @@ class Engine:
     def run(self, nSteps):
         _check(self.lib.bfd_run(self.h, int(nSteps)), 'bfd_run')
 
-    def half_step_stress(self, part=0):
-        _check(self.lib.bfd_half_step_stress_part(self.h, part), 'bfd_half_step_stress_part')
+    def half_step_stress(self, part=0, stream=None):
+        """stream: raw HIP stream handle (int) to launch this part on, without synchronisation; None = the engine's stream."""
+        if stream is None:
+            _check(self.lib.bfd_half_step_stress_part(self.h, part), 'bfd_half_step_stress_part')
+        else:
+            _check(self.lib.bfd_half_step_stress_part_on(self.h, part, C.c_void_p(stream)), 'bfd_half_step_stress_part_on')
 
-    def half_step_velocity(self, part=0):
-        _check(self.lib.bfd_half_step_velocity_part(self.h, part), 'bfd_half_step_velocity_part')
+    def half_step_velocity(self, part=0, stream=None):
+        if stream is None:
+            _check(self.lib.bfd_half_step_velocity_part(self.h, part), 'bfd_half_step_velocity_part')
+        else:
+            _check(self.lib.bfd_half_step_velocity_part_on(self.h, part, C.c_void_p(stream)), 'bfd_half_step_velocity_part_on')
 
     def halo_fields(self):
         """Which fields of each halo group this slab reads from its Z-neighbours' planes:

@@ -1033,6 +1033,25 @@ int bfd_half_step_stress(bfd_sim *s) { return stress_part(s, 0); }
 int bfd_half_step_velocity(bfd_sim *s) { return velocity_part(s, 0); }
 int bfd_half_step_stress_part(bfd_sim *s, int32_t part) { return stress_part(s, part); }
 int bfd_half_step_velocity_part(bfd_sim *s, int32_t part) { return velocity_part(s, part); }
+// the same on a caller-chosen stream (no synchronisation here: the caller orders the streams with events)
+int bfd_half_step_stress_part_on(bfd_sim *s, int32_t part, void *hipStream)
+{
+    if (!s) BFD_FAIL(-1, "null sim");
+    hipStream_t keep = s->stream;
+    s->stream = (hipStream_t)hipStream;
+    const int rc = stress_part(s, part);
+    s->stream = keep;
+    return rc;
+}
+int bfd_half_step_velocity_part_on(bfd_sim *s, int32_t part, void *hipStream)
+{
+    if (!s) BFD_FAIL(-1, "null sim");
+    hipStream_t keep = s->stream;
+    s->stream = (hipStream_t)hipStream;
+    const int rc = velocity_part(s, part);
+    s->stream = keep;
+    return rc;
+}
 
 // One plain time step recorded into the capture stream: same launches as stress_part / velocity_part (part 0),
 // sources indexed by the device step counter, which the last node advances.

@@ -6,6 +6,9 @@ SURVEY.md 2.2); this is the new capability BASELINE.json asks for. In the solver
 order i is fastest and k slowest (BabelIntegrationBASE.py:2508-2511), so a Z-slab is one
 contiguous block and every halo plane is one contiguous N1*N2 run.
 
+Launch with TORCH_NCCL_HIGH_PRIORITY=1 (bench.py sets it before creating the process group): the exchange kernel then
+runs beside the interior kernels instead of queueing behind their workgroups.
+
 Per time step and interface:
     exchange Vx,Vy,Vz boundary planes (2 per side)  -> stress half-step
     exchange Sxz,Syz,Szz boundary planes            -> velocity half-step
@@ -83,11 +86,22 @@ class HipSlab:
                 for side in sides:
                     self._t[(group, f, side, 0)].copy_(self._h[(group, f, side, 0)])
 
-    def half_step_stress(self, part=0):
-        self.eng.half_step_stress(part)
+    def half_step_stress(self, part=0, stream=None):
+        self.eng.half_step_stress(part, None if stream is None else stream.cuda_stream)
 
-    def half_step_velocity(self, part=0):
-        self.eng.half_step_velocity(part)
+    def half_step_velocity(self, part=0, stream=None):
+        self.eng.half_step_velocity(part, None if stream is None else stream.cuda_stream)
+
+    def streams(self):
+        """(main, side) torch streams for the overlapped step: the main one is the stream the engine runs on; the side
+        stream carries the boundary part of a half-step and the halo exchange that waits for it. None with host staging."""
+        if self.host_staging:
+            return None
+        if getattr(self, '_streams', None) is None:
+            torch = self.torch
+            # high priority: the small boundary kernels and the exchange must not queue behind the interior's workgroups
+            self._streams = (torch.cuda.current_stream(self.device), torch.cuda.Stream(self.device, priority=-1))
+        return self._streams
 
     def sync(self):
         self.torch.cuda.synchronize(self.device)
@@ -148,9 +162,33 @@ class SlabRunner:
     def exchange(self, halo_group):
         self.exchange_finish(self.exchange_start(halo_group), halo_group)
 
+    # --- overlapped half-step, device tensors (HipSlab): two streams -----------------------------------------------
+    # main M: interior part (+ end-of-step work); side B: boundary part, then the exchange, which therefore waits for the
+    # boundary part only. The host queues the interior (most of a millisecond of GPU work) BEFORE it spends ~0.1 ms
+    # building the RCCL group, so neither that host time nor the transfer is exposed:
+    #   B waits for M (everything before) -> part 1 on B -> M waits for part 1 -> part 2 on M
+    #   -> on B: isend/irecv + wait -> M waits for B (the next half-step needs the received planes).
+    def launch_parts(self, half, M, B):
+        fn = self.slab.half_step_stress if half == HALO_STRESS else self.slab.half_step_velocity
+        B.wait_stream(M)
+        fn(1, stream=B)
+        M.wait_event(B.record_event())
+        fn(2, stream=M)
+
+    def exchange_on(self, half, B):
+        with self.slab.torch.cuda.stream(B):
+            self.exchange_finish(self.exchange_start(half), half)
+
     def step(self):
         s = self.slab
-        if self.overlap:
+        st = s.streams() if (self.overlap and hasattr(s, 'streams')) else None
+        if st is not None:
+            M, B = st
+            for half in (HALO_STRESS, HALO_VELOCITY):      # the stress half-step produces the STRESS halo group, etc.
+                self.launch_parts(half, M, B)
+                self.exchange_on(half, B)
+                M.wait_stream(B)
+        elif self.overlap:
             # ghosts of V are current on entry (zero before the first step, exchanged at the end of every step)
             s.half_step_stress(1)
             w = self.exchange_start(HALO_STRESS)

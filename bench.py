@@ -123,6 +123,9 @@ def main():
         if shared:
             dist.init_process_group('gloo', rank=rank, world_size=world)
         else:
+            # RCCL's stream at high priority: its small send/recv kernel must not queue behind the 16k workgroups of the
+            # interior half-step (rocprofv3 timeline: it otherwise starts only when the interior kernel has drained)
+            os.environ.setdefault('TORCH_NCCL_HIGH_PRIORITY', '1')
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
 
     def dt_fn(ml, f, h, acfl):

@@ -133,6 +133,12 @@ int bfd_half_step_velocity(bfd_sim *sim);   /* also accumulates, records sensors
  * part 1 then part 2. (kernelVariant 1: part 1 is empty.) */
 int bfd_half_step_stress_part(bfd_sim *sim, int32_t part);
 int bfd_half_step_velocity_part(bfd_sim *sim, int32_t part);
+/* The same launched on a stream of the caller (NULL = the default stream) without any synchronisation: the boundary part
+ * can run on a side stream that a halo exchange waits on while the interior part keeps the main stream busy. The caller
+ * orders the two streams (events); parts of one half-step are independent of each other, the end-of-step work of
+ * velocity part 2 (sensors, non-Pressure accumulators) reads the whole slab. */
+int bfd_half_step_stress_part_on(bfd_sim *sim, int32_t part, void *hipStream);
+int bfd_half_step_velocity_part_on(bfd_sim *sim, int32_t part, void *hipStream);
 int bfd_sync(bfd_sim *sim);
 int bfd_current_step(bfd_sim *sim);
 

@@ -8,6 +8,7 @@ import torch.distributed as dist
 from babelbrain_amd import harness as H, slab, _engine, RayleighAndBHTE
 from babelbrain_amd._engine import HALO_STRESS, HALO_VELOCITY
 
+os.environ.setdefault('TORCH_NCCL_HIGH_PRIORITY', '1')
 os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29534')
 torch.cuda.set_device(0)
 dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
@@ -32,11 +33,20 @@ def step(mode):
         s.half_step_stress(); s.half_step_velocity()
     elif mode == 'blocking':
         finish(start(HALO_VELOCITY)); s.half_step_stress(); finish(start(HALO_STRESS)); s.half_step_velocity()
-    else:
+    elif mode == 'overlap':
         s.half_step_stress(1); w = start(HALO_STRESS); s.half_step_stress(2); finish(w)
         s.half_step_velocity(1); w = start(HALO_VELOCITY); s.half_step_velocity(2); finish(w)
+    else:               # 'streams': SlabRunner's two-stream choreography
+        for half in (HALO_STRESS, HALO_VELOCITY):
+            runner.launch_parts(half, M, B)
+            with torch.cuda.stream(B):
+                finish(start(half))
+            M.wait_stream(B)
 
-for mode in ('none', 'blocking', 'overlap', 'none', 'blocking', 'overlap'):
+runner = slab.SlabRunner(s, 0, 1)
+M, B = s.streams()
+modes = sys.argv[1:] or ['none', 'blocking', 'overlap', 'streams', 'none', 'blocking', 'overlap', 'streams']
+for mode in modes:
     for _ in range(10): step(mode)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(50): step(mode)
