@@ -166,13 +166,16 @@ class SlabRunner:
     # main M: interior part (+ end-of-step work); side B: boundary part, then the exchange, which therefore waits for the
     # boundary part only. The host queues the interior (most of a millisecond of GPU work) BEFORE it spends ~0.1 ms
     # building the RCCL group, so neither that host time nor the transfer is exposed:
-    #   B waits for M (everything before) -> part 1 on B -> M waits for part 1 -> part 2 on M
+    #   B waits for M (everything before) -> part 1 on B -> (velocity only: M waits for part 1) -> part 2 on M
     #   -> on B: isend/irecv + wait -> M waits for B (the next half-step needs the received planes).
     def launch_parts(self, half, M, B):
         fn = self.slab.half_step_stress if half == HALO_STRESS else self.slab.half_step_velocity
         B.wait_stream(M)
         fn(1, stream=B)
-        M.wait_event(B.record_event())
+        if half == HALO_VELOCITY:
+            # the end-of-step work queued with velocity part 2 (sensors, non-Pressure accumulators) reads the whole slab,
+            # boundary tiles included. The two parts of the stress half-step touch disjoint tiles and may run together.
+            M.wait_event(B.record_event())
         fn(2, stream=M)
 
     def exchange_on(self, half, B):
