@@ -362,6 +362,16 @@ int dev_alloc(bfd_sim *s, T **p, size_t count, bool zero = true)
     return 0;
 }
 
+// frees an array obtained from dev_alloc before the sim is destroyed (inputs that are set again)
+template <typename T>
+void dev_release(bfd_sim *s, T **p)
+{
+    if (!*p) return;
+    auto it = std::find(s->allocs.begin(), s->allocs.end(), (void *)*p);
+    if (it != s->allocs.end()) { hipFree(*it); s->allocs.erase(it); }
+    *p = nullptr;
+}
+
 inline size_t span_elems(int N1, int N2, int nk, int64_t s1, int64_t s2, int64_t s3)
 {
     return (size_t)((N1 - 1) * s1 + (N2 - 1) * s2 + (nk - 1) * s3 + 1);
@@ -654,6 +664,9 @@ int bfd_set_sources(bfd_sim *s, int64_t nVox, const uint32_t *localIndex, const 
         if (localIndex[v] >= s->nloc) BFD_FAIL(-2, "bfd_set_sources: voxel index outside the slab");
         if ((int)row[v] >= nSources) BFD_FAIL(-2, "bfd_set_sources: SourceMap id exceeds PulseSource rows");
     }
+    BFD_HIP(hipStreamSynchronize(s->stream));
+    dev_release(s, &s->srcLin); dev_release(s, &s->srcRow); dev_release(s, &s->pulseT);
+    for (int a = 0; a < 3; a++) dev_release(s, &s->srcW[a]);
     s->nSrcVox = nVox; s->nSources = nSources; s->lengthSource = lengthSource;
     s->srcLowEnd = 0; s->srcHighBeg = nVox; s->tilesReady = false; drop_step_graph(s);
     if (nVox == 0) return 0;
@@ -717,6 +730,7 @@ int bfd_set_sensor_map(bfd_sim *s, const uint32_t *map, int64_t s1, int64_t s2, 
     int rc = 0;
     if (e == hipSuccess) {
         s->nSensors = count;
+        dev_release(s, &s->sensLin); dev_release(s, &s->sensOut);
         rc = dev_alloc(s, &s->sensLin, (size_t)count, false);
         if (!rc && count) e = hipMemcpyAsync(s->sensLin, sel, (size_t)count * sizeof(uint32_t), hipMemcpyDeviceToDevice, s->stream);
         if (!rc && s->nSelS && s->nTs > 0) rc = dev_alloc(s, &s->sensOut, (size_t)s->nSelS * s->nTs * (size_t)count);
@@ -736,6 +750,11 @@ static int build_tile_lists(bfd_sim *s)
 {
     int tx, ty, nsub; bfd_tile_grid(s->d, &tx, &ty, &nsub);
     const int n = tx * ty * nsub;
+    {   // lists of an earlier build (inputs were set again)
+        unsigned char *oldLean = const_cast<unsigned char *>(s->d.lean);
+        dev_release(s, &oldLean); s->d.lean = nullptr;
+        dev_release(s, &s->tiles.runs); dev_release(s, &s->tiles.rowFlags); dev_release(s, &s->tiles.shearCells); dev_release(s, &s->tiles.shearCoef);
+    }
     const int SUB = bfd_tile_subz();
     // longest run one workgroup marches: 16 planes; 8 on small grids so that the launch still has a few thousand
     // workgroups (measured: 256^3 49 -> 58, 128^3 29 -> 46 Gvoxel-steps/s). 32 was best at 512^3 while the z-chunks of
