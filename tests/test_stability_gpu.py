@@ -43,3 +43,21 @@ def test_cw_run_settles_and_stays_bounded(config):
     rms = eng.get_map(_engine.KIND_RMS, 'Pressure')
     assert np.isfinite(rms).all() and rms.max() > 0
     eng.close()
+
+
+def test_parity_holds_over_a_production_length_run():
+    """The other parity cases run 60-230 steps; a production call runs thousands. Both sides follow the same
+    canonical float32 arithmetic, so the agreement must not drift: 1500 steps of C2 (solid skull with shear, CPML,
+    attenuation) against the oracle, every output."""
+    from babelbrain_amd import PropagationModel
+    from oracle import oracle as O
+    from tests.util import compare_runs, oracle_dt
+    a, k, info = H.make_problem('C2', N=(96, 88, 120), steps=1500, stable_dt_fn=oracle_dt)
+    k['SelMapsRMSPeakList'] = ['Pressure', 'Vz', 'Sigmaxy']
+    k['SelMapsSensorsList'] = ['Pressure', 'Vx']
+    k['SelRMSorPeak'] = 3
+    out_h = PropagationModel().StaggeredFDTD_3D_with_relaxation(*a, SILENT=True, **k)
+    out_r = O.StaggeredFDTD_3D_with_relaxation(*a, **k)
+    worst = compare_runs(out_h, out_r, 1e-5, both=True)
+    print('worst rel L2 after 1500 steps', worst)
+    assert np.abs(out_r[1]['Sigmaxy']).max() > 0 and out_r[2]['Pressure'].max() > 0
