@@ -330,3 +330,17 @@ def test_fused_fluid_step_variant4(config):
     with pytest.raises(_engine.EngineError):
         eng.half_step_stress(1)                                # split half-steps belong to Z-slabs (which stay in place)
     eng.close()
+
+
+@pytest.mark.parametrize('variant', [1, 3])
+@pytest.mark.parametrize('nd,rl', [(8, 1e-4), (16, 1e-6)])
+def test_other_absorbing_layer_settings(variant, nd, rl):
+    """NDelta and ReflectionLimit are arguments of the call (BASE:2350, 2352); the tile classes and the compact
+    CPML storage follow the layer width."""
+    a, k, info = H.make_problem('C2', N=(72, 64, 80), steps=160, stable_dt_fn=oracle_dt)
+    k['NDelta'] = nd
+    k['ReflectionLimit'] = rl
+    k['SelMapsRMSPeakList'] = ['Pressure', 'Vx', 'Sigmaxz']
+    oh, orf = run_both(a, k, variant)
+    compare_runs(oh, orf, TOL)
+    assert orf[2]['Pressure'].max() > 0
