@@ -1,0 +1,84 @@
+"""Host-side helpers of the drop-in (no GPU): slab partition, source compaction, sensor bookkeeping, BHTE schedule."""
+import numpy as np
+import pytest
+from hypothesis import given, settings, strategies as st
+
+from babelbrain_amd import slab
+from babelbrain_amd.PropagationModel import compact_sources, material_slab, n_steps, sensor_steps
+from babelbrain_amd.RayleighAndBHTE import field_schedule
+
+
+@given(st.integers(4, 4000), st.integers(1, 16))
+@settings(max_examples=200, deadline=None)
+def test_partition_is_a_balanced_cover(N3, world):
+    if N3 < slab.MIN_PLANES * world:
+        with pytest.raises(ValueError):
+            slab.partition(N3, world)
+        return
+    parts = slab.partition(N3, world)
+    assert parts[0][0] == 0 and sum(nk for _, nk in parts) == N3
+    assert all(parts[r][0] + parts[r][1] == parts[r + 1][0] for r in range(world - 1))
+    sizes = [nk for _, nk in parts]
+    assert max(sizes) - min(sizes) <= 1 and min(sizes) >= slab.MIN_PLANES
+
+
+@given(st.integers(0, 10 ** 6), st.integers(1, 12), st.integers(0, 200))
+@settings(max_examples=200, deadline=None)
+def test_sensor_steps_follow_the_sampling_rule(nt, sub, start):
+    steps = sensor_steps(nt, sub, start)
+    assert np.all(steps % sub == 0) and np.all(steps // sub >= start) and np.all(steps < max(nt, 0) + (nt == 0))
+    assert len(steps) == max(0, (nt + sub - 1) // sub - start)
+
+
+def test_n_steps_matches_the_callers_time_plan():
+    dt = 1 / 500e3 / 35
+    for nt in (1, 2, 70, 6755, 6760):
+        assert n_steps(nt * dt, dt) == nt                         # TimeSimulation = nt*dt (BASE:2089)
+
+
+@given(st.integers(0, 2 ** 32 - 1))
+@settings(max_examples=50, deadline=None)
+def test_compact_sources_per_slab_union_is_the_whole(seed):
+    rng = np.random.default_rng(seed)
+    N = (int(rng.integers(3, 9)), int(rng.integers(3, 9)), int(rng.integers(8, 20)))
+    smap = (rng.uniform(size=N) < 0.1) * rng.integers(1, 5, size=N)
+    smap = smap.astype(np.uint32)
+    Oz = rng.uniform(0.5, 1.5, N)
+    whole = compact_sources(smap, np.array([0.0]), np.array([1]), Oz)
+    lin, row, wx, wy, wz = whole
+    assert np.all(np.diff(lin.astype(np.int64)) > 0)               # sorted by x-fastest voxel index
+    i, j, k = lin % N[0], (lin // N[0]) % N[1], lin // (N[0] * N[1])
+    assert np.array_equal(row, smap[i, j, k] - 1) and wy is None and np.all(wx == 0) and np.allclose(wz, Oz[i, j, k].astype(np.float32))
+    seen = []
+    for k0, nk in slab.partition(N[2], 2):
+        l2, r2, _, _, _ = compact_sources(smap, np.array([0.0]), np.array([1]), Oz, k0, nk)
+        assert np.all(l2 < N[0] * N[1] * nk)
+        seen += list(l2.astype(np.int64) + k0 * N[0] * N[1])
+    assert seen == list(lin.astype(np.int64))
+
+
+def test_material_slab_ghost_planes():
+    mm = np.arange(4 * 3 * 10).reshape(4, 3, 10)
+    v, gl, gh = material_slab(mm, 0, 5)
+    assert (gl, gh) == (0, 2) and v.shape[2] == 7
+    v, gl, gh = material_slab(mm, 5, 5)
+    assert (gl, gh) == (2, 0) and np.array_equal(v[:, :, 0], mm[:, :, 3])
+    v, gl, gh = material_slab(mm, 1, 8)
+    assert (gl, gh) == (1, 1) and v.shape[2] == 10
+
+
+@given(st.lists(st.tuples(st.integers(0, 6), st.integers(0, 6)), min_size=1, max_size=5), st.integers(0, 80))
+@settings(max_examples=200, deadline=None)
+def test_field_schedule_properties(onoff, total):
+    if sum(a + b for a, b in onoff) == 0:
+        with pytest.raises(ValueError):
+            field_schedule(onoff, total)
+        return
+    s = field_schedule(onoff, total)
+    assert len(s) == total and set(np.unique(s)) <= set(range(-1, len(onoff)))
+    period = sum(a + b for a, b in onoff)
+    if total > period:
+        assert np.array_equal(s[period:], s[:total - period])       # periodic
+    first = s[:period]
+    for n, (on, off) in enumerate(onoff):
+        assert np.count_nonzero(first == n) == (on if total >= period else np.count_nonzero(first == n))
