@@ -388,7 +388,7 @@ hipEvent_t get_event(bfd_sim *s)
 {
     hipEvent_t e;
     if (!s->evPool.empty()) { e = s->evPool.back(); s->evPool.pop_back(); return e; }
-    hipEventCreate(&e);
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;      // callers skip the timing pair
     return e;
 }
 
@@ -469,7 +469,8 @@ int bfd_create(const bfd_config *cfg, bfd_sim **out)
     s->tables = nullptr; s->profiles = nullptr; s->cmax = 0;
     if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) { delete s; BFD_FAIL(-10, "hipStreamCreate failed"); }
     s->ownStream = true;
-    hipEventCreate(&s->evBegin); hipEventCreate(&s->evEnd);
+    if (hipEventCreate(&s->evBegin) != hipSuccess) { hipStreamDestroy(s->stream); delete s; BFD_FAIL(-10, "hipEventCreate failed"); }
+    if (hipEventCreate(&s->evEnd) != hipSuccess) { hipEventDestroy(s->evBegin); hipStreamDestroy(s->stream); delete s; BFD_FAIL(-10, "hipEventCreate failed"); }
 
     bfd_dev &d = s->d;
     memset(&d, 0, sizeof d);
@@ -965,7 +966,7 @@ static void swap_fields(bfd_dev &d)
     std::swap(d.Vx, d.VxW); std::swap(d.Vy, d.VyW); std::swap(d.Vz, d.VzW); std::swap(d.Szz, d.SzzW); std::swap(d.Rzz, d.RzzW);
 }
 
-static void inject_part(bfd_sim *s, int part, const bfd_dev &view)
+static void inject_part(bfd_sim *s, int part, const bfd_dev &view, hipStream_t st)
 {
     const int64_t n = s->nSrcVox;
     int64_t beg[2] = {0, 0}, end[2] = {0, 0};
@@ -976,7 +977,7 @@ static void inject_part(bfd_sim *s, int part, const bfd_dev &view)
     for (int r = 0; r < 2; r++) {
         const int64_t c = end[r] - beg[r];
         if (c <= 0) continue;
-        hipLaunchKernelGGL(inject_sources, dim3(grid_for(c)), dim3(256), 0, s->stream, view, s->cfg.typeSource,
+        hipLaunchKernelGGL(inject_sources, dim3(grid_for(c)), dim3(256), 0, st, view, s->cfg.typeSource,
                            s->srcLin + beg[r], s->srcRow + beg[r], s->srcW[0] ? s->srcW[0] + beg[r] : nullptr,
                            s->srcW[1] ? s->srcW[1] + beg[r] : nullptr, s->srcW[2] ? s->srcW[2] + beg[r] : nullptr, pulse, (long)c);
     }
@@ -984,47 +985,55 @@ static void inject_part(bfd_sim *s, int part, const bfd_dev &view)
 
 // part 0 = whole half-step; 1 = boundary tiles (first/last z-chunk: what a Z-neighbour reads) with their
 // sources; 2 = interior tiles with theirs. Variant 1 has no tiles: part 1 is empty, part 2 is everything.
-static int stress_part(bfd_sim *s, int part)
+static int stress_part(bfd_sim *s, int part, hipStream_t st)
 {
     int rc = check_ready(s); if (rc) return rc;
     if (part < 0 || part > 2) BFD_FAIL(-2, "half-step part must be 0, 1 or 2");
     BFD_HIP(hipSetDevice(s->cfg.device));
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (s->timing && s->perKernel) { e0 = get_event(s); e1 = get_event(s); hipEventRecord(e0, s->stream); }
+    if (s->timing && s->perKernel) {
+        e0 = get_event(s); e1 = get_event(s);
+        if (!e0 || !e1) { if (e0) s->evPool.push_back(e0); if (e1) s->evPool.push_back(e1); e0 = e1 = nullptr; }
+        else hipEventRecord(e0, st);
+    }
     if (s->pingpong && part != 0) BFD_FAIL(-2, "split half-steps are not available with kernelVariant 4 on a whole domain");
-    if (s->cfg.kernelVariant == 1) { if (part != 1) bfd_launch_stress_v1(s->d, s->stream); }
-    else bfd_launch_stress_v2(s->d, s->stream, &s->tiles, part);
-    if (e0) { hipEventRecord(e1, s->stream); s->evStress.push_back(e0); s->evStress.push_back(e1); }
-    if (s->nSrcVox && s->cfg.typeSource >= 2 && s->step < s->lengthSource) inject_part(s, part, new_stress_view(s->d));
+    if (s->cfg.kernelVariant == 1) { if (part != 1) bfd_launch_stress_v1(s->d, st); }
+    else bfd_launch_stress_v2(s->d, st, &s->tiles, part);
+    if (e0) { hipEventRecord(e1, st); s->evStress.push_back(e0); s->evStress.push_back(e1); }
+    if (s->nSrcVox && s->cfg.typeSource >= 2 && s->step < s->lengthSource) inject_part(s, part, new_stress_view(s->d), st);
     BFD_HIP(hipGetLastError());
     return 0;
 }
 
-static int velocity_part(bfd_sim *s, int part)
+static int velocity_part(bfd_sim *s, int part, hipStream_t st)
 {
     int rc = check_ready(s); if (rc) return rc;
     if (part < 0 || part > 2) BFD_FAIL(-2, "half-step part must be 0, 1 or 2");
     BFD_HIP(hipSetDevice(s->cfg.device));
     const bfd_dev &d = s->d;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (s->timing && s->perKernel) { e0 = get_event(s); e1 = get_event(s); hipEventRecord(e0, s->stream); }
+    if (s->timing && s->perKernel) {
+        e0 = get_event(s); e1 = get_event(s);
+        if (!e0 || !e1) { if (e0) s->evPool.push_back(e0); if (e1) s->evPool.push_back(e1); e0 = e1 = nullptr; }
+        else hipEventRecord(e0, st);
+    }
     const int n = s->step;
     const bool accNow = (s->acc || s->pk) && n >= s->accStart;
     int qP = -1;   // Pressure is accumulated inside the tiled velocity kernels
     if (accNow && s->cfg.kernelVariant != 1)
         for (int q = 0; q < s->nSelR; q++) if (s->selR[q] == BFD_MAP_PRESSURE) qP = q;
-    if (s->cfg.kernelVariant == 1) { if (part != 1) bfd_launch_velocity_v1(d, s->stream); }
+    if (s->cfg.kernelVariant == 1) { if (part != 1) bfd_launch_velocity_v1(d, st); }
     else {
         float *accP = (qP >= 0 && s->acc) ? s->acc + (size_t)qP * s->nloc : nullptr;
         float *pkP = (qP >= 0 && s->pk) ? s->pk + (size_t)qP * s->nloc : nullptr;
         if (s->pingpong) {
             if (part != 0) BFD_FAIL(-2, "split half-steps are not available with kernelVariant 4 on a whole domain");
-            bfd_launch_fused(d, s->stream, accP, pkP, &s->tiles);        // both half-steps of its runs: old fields -> W copies
+            bfd_launch_fused(d, st, accP, pkP, &s->tiles);        // both half-steps of its runs: old fields -> W copies
         }
-        bfd_launch_velocity_v2(new_stress_view(d), s->stream, accP, pkP, &s->tiles, part);
+        bfd_launch_velocity_v2(new_stress_view(d), st, accP, pkP, &s->tiles, part);
     }
-    if (e0) { hipEventRecord(e1, s->stream); s->evVelocity.push_back(e0); s->evVelocity.push_back(e1); }
-    if (s->nSrcVox && s->cfg.typeSource < 2 && s->step < s->lengthSource) inject_part(s, part, new_velocity_view(d));
+    if (e0) { hipEventRecord(e1, st); s->evVelocity.push_back(e0); s->evVelocity.push_back(e1); }
+    if (s->nSrcVox && s->cfg.typeSource < 2 && s->step < s->lengthSource) inject_part(s, part, new_velocity_view(d), st);
     if (part == 1) { BFD_HIP(hipGetLastError()); return 0; }
     if (s->pingpong) swap_fields(s->d);
     // end of the time step: remaining accumulators, sensors
@@ -1032,13 +1041,13 @@ static int velocity_part(bfd_sim *s, int part)
         SelList L; L.n = s->nSelR; memcpy(L.sel, s->selR, sizeof L.sel);
         for (int q = 0; q < BFD_MAP_COUNT; q++) L.skip[q] = (q == qP);
         dim3 block(64, 4, 1), grid((d.N1 + 63) / 64, (d.N2 + 3) / 4, d.nk);
-        hipLaunchKernelGGL(accumulate_maps, grid, block, 0, s->stream, d, L, s->acc, s->pk, (long)s->nloc);
+        hipLaunchKernelGGL(accumulate_maps, grid, block, 0, st, d, L, s->acc, s->pk, (long)s->nloc);
     }
     if (s->nSensors && s->sensOut && n % s->cfg.sensorSub == 0 && n / s->cfg.sensorSub >= s->cfg.sensorStart) {
         const int col = n / s->cfg.sensorSub - s->cfg.sensorStart;
         if (col < s->nTs) {
             SelList L; L.n = s->nSelS; memcpy(L.sel, s->selS, sizeof L.sel); memset(L.skip, 0, sizeof L.skip);
-            hipLaunchKernelGGL(record_sensors, dim3(grid_for(s->nSensors)), dim3(256), 0, s->stream, d, L, s->sensLin,
+            hipLaunchKernelGGL(record_sensors, dim3(grid_for(s->nSensors)), dim3(256), 0, st, d, L, s->sensLin,
                                (long)s->nSensors, s->sensOut, col, s->nTs);
         }
     }
@@ -1048,28 +1057,21 @@ static int velocity_part(bfd_sim *s, int part)
     return 0;
 }
 
-int bfd_half_step_stress(bfd_sim *s) { return stress_part(s, 0); }
-int bfd_half_step_velocity(bfd_sim *s) { return velocity_part(s, 0); }
-int bfd_half_step_stress_part(bfd_sim *s, int32_t part) { return stress_part(s, part); }
-int bfd_half_step_velocity_part(bfd_sim *s, int32_t part) { return velocity_part(s, part); }
-// the same on a caller-chosen stream (no synchronisation here: the caller orders the streams with events)
+int bfd_half_step_stress(bfd_sim *s) { return s ? stress_part(s, 0, s->stream) : check_ready(s); }
+int bfd_half_step_velocity(bfd_sim *s) { return s ? velocity_part(s, 0, s->stream) : check_ready(s); }
+int bfd_half_step_stress_part(bfd_sim *s, int32_t part) { return s ? stress_part(s, part, s->stream) : check_ready(s); }
+int bfd_half_step_velocity_part(bfd_sim *s, int32_t part) { return s ? velocity_part(s, part, s->stream) : check_ready(s); }
+// the same on a caller-chosen stream (no synchronisation here: the caller orders the streams with events); the
+// engine's own stream is left untouched, so parts may be queued on different streams back to back
 int bfd_half_step_stress_part_on(bfd_sim *s, int32_t part, void *hipStream)
 {
     if (!s) BFD_FAIL(-1, "null sim");
-    hipStream_t keep = s->stream;
-    s->stream = (hipStream_t)hipStream;
-    const int rc = stress_part(s, part);
-    s->stream = keep;
-    return rc;
+    return stress_part(s, part, (hipStream_t)hipStream);
 }
 int bfd_half_step_velocity_part_on(bfd_sim *s, int32_t part, void *hipStream)
 {
     if (!s) BFD_FAIL(-1, "null sim");
-    hipStream_t keep = s->stream;
-    s->stream = (hipStream_t)hipStream;
-    const int rc = velocity_part(s, part);
-    s->stream = keep;
-    return rc;
+    return velocity_part(s, part, (hipStream_t)hipStream);
 }
 
 // One plain time step recorded into the capture stream: same launches as stress_part / velocity_part (part 0),

@@ -17,39 +17,62 @@ import numpy as np
 from . import harness as H
 
 
+def _clear_layer(plane, width):
+    """Zero the absorbing-layer frame of a source plane (nothing is injected inside the layer)."""
+    out = np.array(plane, copy=True)
+    frame = np.ones(out.shape, bool)
+    frame[width:out.shape[0] - width, width:out.shape[1] - width] = False
+    out[frame] = 0
+    return out
+
+
+def element_drive(field_at_elements, n_elems, subsources_per_elem, amplitude):
+    """Time-reversal programming of the array: every element is driven with the conjugate phase of the field that
+    reached its centre; all sub-sources of an element share the element's drive. Returns (programming (nElem,),
+    per-sub-source drive (nElem*subsources_per_elem, 1)), both complex64."""
+    conj = np.conjugate(np.asarray(field_at_elements).reshape(-1)[:n_elems])
+    unit = np.exp(1j * np.angle(conj))        # in the precision the Rayleigh sum returned
+    drive = np.repeat(amplitude * unit, subsources_per_elem).astype(np.complex64).reshape(-1, 1)
+    return conj.astype(np.complex64), drive
+
+
 def back_propagation_rayleigh(SourceMapRayleigh, PressMapFourierBack, XDim, YDim, ZDim, ZSourceLocation, SpatialStep,
                               Frequency, Tx, SourceAmpPa, PMLThickness, forward, c_water=1500.0, weights=1.0):
-    """CONCAVE:407-454. Returns (SourceMapRayleighRefocus (N1,N2) complex, programming (nElem,) complex64).
-    forward: ForwardSimple-compatible callable."""
-    assert np.all(np.array(SourceMapRayleigh.shape) == np.array(PressMapFourierBack.shape))
-    sel = np.abs(SourceMapRayleigh) > 0
-    ypp, xpp = np.meshgrid(YDim, XDim)
-    center = np.zeros((int(sel.sum()), 3), np.float32)
-    center[:, 0] = xpp[sel].flatten()
-    center[:, 1] = ypp[sel].flatten()
-    center[:, 2] = ZDim[ZSourceLocation]
-    ds = np.ones(center.shape[0]) * SpatialStep ** 2
-    u0 = PressMapFourierBack[sel]
-    k = np.array(2 * np.pi * Frequency / c_water + 1j * 0).astype(np.complex64)
-    u2back = np.asarray(forward(k, center.astype(np.float32), ds.astype(np.float32), u0, Tx['elemcenter'].astype(np.float32)))
-    nElem, edims = int(Tx['NumberElems']), int(Tx['elemdims'])
-    prog = np.zeros(nElem, np.complex64)
-    u0n = np.zeros((Tx['center'].shape[0], 1), np.complex64)
-    for n in range(nElem):
-        phi = np.angle(np.conjugate(u2back[n]))
-        prog[n] = np.conjugate(u2back[n])
-        u0n[n * edims:(n + 1) * edims] = (SourceAmpPa * np.exp(1j * phi)).astype(np.complex64)
-    u0n = u0n * weights
-    yp, xp, zp = np.meshgrid(YDim, XDim, ZDim[ZSourceLocation:ZSourceLocation + 1])      # only the source plane is kept
-    rf = np.hstack((xp.reshape(-1, 1), yp.reshape(-1, 1), zp.reshape(-1, 1))).astype(np.float32)
-    u2 = np.asarray(forward(k, Tx['center'].astype(np.float32), Tx['ds'].astype(np.float32), u0n, rf)).reshape(xp.shape)[:, :, 0]
-    plane = u2.copy()
-    p = PMLThickness
-    plane[:p, :] = 0
-    plane[-p:, :] = 0
-    plane[:, :p] = 0
-    plane[:, -p:] = 0
-    return plane, prog
+    """What BackPropagationRayleigh computes (BabelIntegrationCONCAVE_PHASEDARRAY.py:407-454), organised as two
+    Rayleigh sums around `element_drive`:
+      plane voxels (each a dx*dx piston carrying the plane spectrum of call 2) -> element centres,
+      re-phased sub-sources of the array -> the source plane only (the reference evaluates the whole volume and keeps
+      this one plane).
+    Returns (SourceMapRayleighRefocus (N1,N2) complex, programming (nElem,) complex64). The outputs are held to the
+    reference's own by tests/test_golden_harness.py::test_refocusing_orchestration.
+    forward: ForwardSimple-compatible callable (the device kernel in production)."""
+    plane_in = np.asarray(SourceMapRayleigh)
+    spectrum = np.asarray(PressMapFourierBack)
+    if plane_in.shape != spectrum.shape:
+        raise ValueError('source plane and plane spectrum must have the same shape')
+    XDim, YDim, ZDim = (np.asarray(v, np.float64) for v in (XDim, YDim, ZDim))
+    z_plane = ZDim[ZSourceLocation]
+    wavenumber = np.complex64(2 * np.pi * Frequency / c_water)
+    wavenumber = np.array(wavenumber)
+
+    # 1) pistons of the active plane voxels, in the row-major order boolean indexing gives
+    ii, jj = np.nonzero(np.abs(plane_in) > 0)
+    pistons = np.column_stack([XDim[ii], YDim[jj], np.full(ii.size, z_plane)]).astype(np.float32)
+    areas = np.full(ii.size, SpatialStep ** 2, np.float32)
+    at_elements = np.asarray(forward(wavenumber, pistons, areas, spectrum[ii, jj], np.asarray(Tx['elemcenter'], np.float32)))
+
+    # 2) conjugate phases per element, spread over the element's sub-sources, optional amplitude weights
+    programming, drive = element_drive(at_elements, int(Tx['NumberElems']), int(Tx['elemdims']), SourceAmpPa)
+    n_sub = np.asarray(Tx['center']).shape[0]
+    full = np.zeros((n_sub, 1), np.complex64)
+    full[:drive.shape[0]] = drive[:n_sub]
+    full = full * weights
+
+    # 3) the re-phased array radiates onto the source plane
+    gx, gy = np.meshgrid(XDim, YDim, indexing='ij')
+    targets = np.column_stack([gx.ravel(), gy.ravel(), np.full(gx.size, z_plane)]).astype(np.float32)
+    on_plane = np.asarray(forward(wavenumber, np.asarray(Tx['center'], np.float32), np.asarray(Tx['ds'], np.float32), full, targets))
+    return _clear_layer(on_plane.reshape(gx.shape), PMLThickness), programming
 
 
 def refocus_sources(SourceMapRayleigh, SourceMapRayleighRefocus, freq, dt, T, ramp_length=4):

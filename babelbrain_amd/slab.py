@@ -106,6 +106,13 @@ class HipSlab:
     def sync(self):
         self.torch.cuda.synchronize(self.device)
 
+    def close(self):
+        """Release the engine; the halo tensors alias its device memory, so they go first."""
+        self._t = {}
+        self._h = None
+        self._streams = None
+        self.eng.close()
+
 
 ALL_FIELDS = {HALO_VELOCITY: [0, 1, 2], HALO_STRESS: [0, 1, 2]}
 

@@ -1,6 +1,6 @@
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 for m in streams; do
-rocprofv3 --kernel-trace --output-format csv -d gpurun_out/ovl_$m -o t -- python3 scripts/nccl_overlap_test.py $m > gpurun_out/ovl_$m.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d gpurun_out/ovl_$m -o t -- python3 scripts/nccl_overlap_check.py $m > gpurun_out/ovl_$m.log 2>&1
 python3 - $m <<'PY'
 import csv, glob, sys
 m = sys.argv[1]

@@ -6,10 +6,9 @@ import os
 
 import numpy as np
 import pytest
-import torch.multiprocessing as mp
 
 from babelbrain_amd import harness as H
-from tests.util import oracle_dt
+from tests.util import oracle_dt, run_ranks
 
 pytestmark = pytest.mark.gpu
 
@@ -48,15 +47,7 @@ def _worker(rank, world, port, q):
 @pytest.mark.parametrize('world', [2, 3])
 def test_multiprocess_slabs_match_single_domain(world):
     from babelbrain_amd import PropagationModel
-    ctx = mp.get_context('spawn')
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, 29650 + world, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    merged = q.get(timeout=800)
-    for p in procs:
-        p.join(120)
-        assert p.exitcode == 0
+    merged = run_ranks(_worker, world, timeout=800)
     a, k, info = _problem()
     Sensor, Last, RMS, Peak, Inp = PropagationModel(kernelVariant=3).StaggeredFDTD_3D_with_relaxation(*a, SILENT=True, **k)
     assert np.array_equal(merged['IndexSensorMap'], Inp['IndexSensorMap'])

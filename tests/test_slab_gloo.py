@@ -12,7 +12,7 @@ import torch.multiprocessing as mp
 from babelbrain_amd import harness as H
 from babelbrain_amd import slab
 from oracle import oracle as O
-from tests.util import oracle_dt
+from tests.util import oracle_dt, run_ranks
 
 
 def _problem():
@@ -48,16 +48,7 @@ def _worker(rank, world, port, q):
 @pytest.mark.timeout(600)
 @pytest.mark.parametrize('world', [2, 3])
 def test_slab_decomposition_matches_single_domain(world):
-    ctx = mp.get_context('spawn')
-    q = ctx.Queue()
-    port = 29610 + world
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    merged, sent = q.get(timeout=500)
-    for p in procs:
-        p.join(60)
-        assert p.exitcode == 0
+    merged, sent = run_ranks(_worker, world, timeout=500)
     a, k, info = _problem()
     ref = O.StaggeredFDTD_3D_with_relaxation(*a, **k)
     Sensor, Last, RMS, Peak, Inp = ref

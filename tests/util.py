@@ -12,6 +12,48 @@ def rel_l2(a, b):
     return float(np.sqrt(np.sum((a - b) ** 2)) / den)
 
 
+def free_port():
+    """A TCP port nobody listens on (rendezvous of spawned ranks on 127.0.0.1)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        return sk.getsockname()[1]
+
+
+def run_ranks(worker, world, timeout=800, extra=()):
+    """Spawn `world` processes running worker(rank, world, port, queue, *extra), return what rank 0 put on the queue.
+    Polls the children while waiting (a crashed rank fails the test at once instead of stalling it) and never leaves
+    orphans behind."""
+    import queue
+    import time
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=worker, args=(r, world, port, q) + tuple(extra)) for r in range(world)]
+    for p in procs:
+        p.start()
+    result = None
+    try:
+        deadline = time.time() + timeout
+        while result is None:
+            try:
+                result = q.get(timeout=2)
+            except queue.Empty:
+                dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+                assert not dead, 'a rank died (exit codes %s)' % dead
+                assert time.time() < deadline, 'ranks timed out'
+        for p in procs:
+            p.join(120)
+            assert p.exitcode == 0
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+            p.join(10)
+    return result
+
+
 def oracle_dt(ml, f, h, acfl):
     return O.stable_dt(ml, f, True, h, acfl)
 
