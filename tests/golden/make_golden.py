@@ -216,6 +216,24 @@ def main():
     out['refocus_plane'] = slf._SourceMapRayleighRefocus
     out['refocus_pulse'] = slf._PulseSourceRefocus
 
+    # (8b) CreateSources of the phased-array integration (CONCAVE:358-404): besides the plane sources it builds the
+    #      point source of the back-propagation call (row a5 of SURVEY 8a): PunctualSource (sine, ramped up AND down)
+    #      and SourceMapPunctual (one voxel at the focal spot)
+    for tag, nsteps in (('a', 360), ('b', 150)):
+        slf2 = SimpleNamespace(_SourceMapRayleigh=smr, _N1=N1, _N2=N2, _N3=N3, _ZSourceLocation=zsrc, _Frequency=500e3,
+                               _TemporalStep=1 / 500e3 / 30, _TimeSimulation=nsteps / 500e3 / 30,
+                               _FocalSpotLocation=np.array([N1 // 2 + 1, N2 // 2 - 2, 25]),
+                               _XSteering=0.0, _YSteering=0.0, _ZSteering=0.0, _SpatialStep=h)
+        CC.SimulationConditions.CreateSources(slf2)
+        out['punctual_%s_args' % tag] = np.array([500e3, slf2._TemporalStep, slf2._TimeSimulation])
+        out['punctual_%s_source' % tag] = slf2._PunctualSource
+        out['punctual_%s_voxel' % tag] = np.array(np.nonzero(slf2._SourceMapPunctual)).reshape(-1)
+        out['punctual_%s_value' % tag] = np.array([slf2._SourceMapPunctual.max(), slf2._SourceMapPunctual.sum()])
+        out['punctual_%s_focal' % tag] = slf2._FocalSpotLocation
+        if tag == 'a':
+            out['concave_sources_map_plane'] = slf2._SourceMap[:, :, zsrc]
+            out['concave_sources_pulse'] = slf2._PulseSource
+
     # (9) ReturnResults, BASE:2729-2896: crop of the absorbing layer, zeroing up to the source plane, Z flip,
     #     DataForSim dictionary (what Step 3 and the GUI read back from *DataForSim.h5)
     rng = np.random.default_rng(23)

@@ -5,6 +5,7 @@ fixture (parity unpinned)."""
 import inspect
 
 import numpy as np
+import pytest
 
 from babelbrain_amd import harness as H
 from babelbrain_amd.PropagationModel import PropagationModel, compact_sources, n_steps, sensor_steps
@@ -121,6 +122,33 @@ def test_refocusing_orchestration(golden):
     pulse = refocus.refocus_sources(g['refocus_source_plane'], plane, f, dt, T)
     assert pulse.shape == g['refocus_pulse'].shape
     np.testing.assert_allclose(pulse, g['refocus_pulse'], rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize('tag', ['a', 'b'])
+def test_punctual_source(golden, tag):
+    """Row a5: PunctualSource / SourceMapPunctual as the phased-array CreateSources builds them (CONCAVE:395-404);
+    case b is shorter than two ramps (they overlap in the middle)."""
+    g, _ = golden
+    f, dt, T = g['punctual_%s_args' % tag]
+    p = H.punctual_source(f, dt, T)
+    ref = g['punctual_%s_source' % tag]
+    assert p.shape == ref.shape and p.dtype == ref.dtype
+    np.testing.assert_allclose(p, ref, rtol=0, atol=1e-15)
+    N1, N2 = g['refocus_source_plane'].shape
+    N3 = int(g['refocus_args'][2])
+    m = H.punctual_source_map(N1, N2, N3, g['punctual_%s_focal' % tag])
+    assert m.dtype == np.uint32 and np.array_equal(np.array(np.nonzero(m)).reshape(-1), g['punctual_%s_voxel' % tag])
+    assert [m.max(), m.sum()] == list(g['punctual_%s_value' % tag])
+
+
+def test_phased_array_create_sources(golden):
+    """CreateSources of the phased-array integration (CONCAVE:358-391) builds the same plane sources as the Single one."""
+    g, _ = golden
+    f, dt, T = g['punctual_a_args']
+    zsrc, N3 = int(g['refocus_args'][4]), int(g['refocus_args'][2])
+    smap, pulse = H.pulse_sources(g['refocus_source_plane'], f, dt, T, N3, zsrc)
+    assert np.array_equal(smap[:, :, zsrc], g['concave_sources_map_plane']) and smap.sum() == smap[:, :, zsrc].sum()
+    np.testing.assert_allclose(pulse, g['concave_sources_pulse'], rtol=1e-12, atol=1e-12)
 
 
 def test_return_results_and_data_for_sim(golden):
