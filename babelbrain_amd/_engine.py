@@ -17,6 +17,7 @@ MAP_BITS = {'Vx': 0, 'Vy': 1, 'Vz': 2, 'Sigmaxx': 3, 'Sigmayy': 4, 'Sigmazz': 5,
             'Sigmaxy': 6, 'Sigmaxz': 7, 'Sigmayz': 8, 'Pressure': 9, 'ALLV': 10}
 KIND_RMS, KIND_PEAK, KIND_LAST = 0, 1, 2
 HALO_VELOCITY, HALO_STRESS = 0, 1
+KERNEL_CLASSES = ['stress_fluid', 'stress_normal_solid', 'stress_shear_sparse', 'velocity_fluid', 'velocity_solid', 'fused_fluid']
 FIELD_NAMES = ['Vx', 'Vy', 'Vz', 'Sxx', 'Syy', 'Szz', 'Sxy', 'Sxz', 'Syz', 'Rxx', 'Ryy', 'Rzz', 'Rxy', 'Rxz', 'Ryz']
 
 # every symbol include/babelfdtd.h declares (tests check that the library exports all of them)
@@ -25,7 +26,7 @@ ABI_SYMBOLS = [
     'bfd_material_tables', 'bfd_create', 'bfd_destroy', 'bfd_set_stream', 'bfd_use_private_stream', 'bfd_set_materials',
     'bfd_set_material_map', 'bfd_set_reflector', 'bfd_set_sources', 'bfd_set_sensor_map', 'bfd_run',
     'bfd_half_step_stress', 'bfd_half_step_velocity', 'bfd_half_step_stress_part', 'bfd_half_step_velocity_part', 'bfd_half_step_stress_part_on', 'bfd_half_step_velocity_part_on', 'bfd_sync', 'bfd_current_step', 'bfd_halo_region',
-    'bfd_timing_begin', 'bfd_timing_end', 'bfd_num_sensors', 'bfd_num_sensor_steps', 'bfd_get_sensor_index',
+    'bfd_timing_begin', 'bfd_timing_end', 'bfd_timing_kernels', 'bfd_algorithmic_bytes', 'bfd_reset', 'bfd_num_sensors', 'bfd_num_sensor_steps', 'bfd_get_sensor_index',
     'bfd_get_sensors', 'bfd_get_map', 'bfd_get_field', 'bfd_tile_counts', 'bfd_tile_count_lean', 'bfd_tile_count_fused', 'bfd_device_bytes', 'bfd_rayleigh_forward', 'bfd_get_sensor_dft', 'bfd_dft_series', 'bfd_bhte_run', 'bfd_bhte_run_fields',
 ]
 
@@ -109,6 +110,9 @@ def load_library():
                                     C.POINTER(C.c_size_t)]
     lib.bfd_timing_begin.argtypes = [C.c_void_p, C.c_int32]
     lib.bfd_timing_end.argtypes = [C.c_void_p] + [C.POINTER(C.c_double)] * 4 + [C.POINTER(C.c_int64)] * 2
+    lib.bfd_timing_kernels.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.bfd_algorithmic_bytes.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+    lib.bfd_reset.argtypes = [C.c_void_p]
     lib.bfd_num_sensors.argtypes = [C.c_void_p]
     lib.bfd_num_sensors.restype = C.c_int64
     lib.bfd_num_sensor_steps.argtypes = [C.c_void_p]
@@ -335,6 +339,7 @@ class Engine:
         return p.value, n.value
 
     def timing_begin(self, perKernel=False):
+        """perKernel: False/0 whole window only, True/1 + per half-step, 2 + per kernel class (timing_kernels)."""
         _check(self.lib.bfd_timing_begin(self.h, int(perKernel)), 'bfd_timing_begin')
 
     def timing_end(self):
@@ -343,6 +348,22 @@ class Engine:
         _check(self.lib.bfd_timing_end(self.h, *[C.byref(x) for x in d], *[C.byref(x) for x in n]), 'bfd_timing_end')
         return {'total_ms': d[0].value, 'stress_ms': d[1].value, 'velocity_ms': d[2].value, 'other_ms': d[3].value,
                 'n_stress': n[0].value, 'n_velocity': n[1].value}
+
+    def timing_kernels(self):
+        """After timing_begin(2) ... timing_end(): {class: (total ms, launches)} per kernel class."""
+        ms = np.zeros(len(KERNEL_CLASSES), np.float64)
+        n = np.zeros(len(KERNEL_CLASSES), np.int64)
+        _check(self.lib.bfd_timing_kernels(self.h, _ptr(ms), _ptr(n)), 'bfd_timing_kernels')
+        return {c: (float(ms[i]), int(n[i])) for i, c in enumerate(KERNEL_CLASSES)}
+
+    def algorithmic_bytes(self, accumulating=True):
+        """Algorithmic bytes per launch of each kernel class (bfd_algorithmic_bytes)."""
+        b = np.zeros(len(KERNEL_CLASSES), np.float64)
+        _check(self.lib.bfd_algorithmic_bytes(self.h, int(bool(accumulating)), _ptr(b)), 'bfd_algorithmic_bytes')
+        return {c: float(b[i]) for i, c in enumerate(KERNEL_CLASSES)}
+
+    def reset(self):
+        _check(self.lib.bfd_reset(self.h), 'bfd_reset')
 
     # ---- outputs ----
     @property

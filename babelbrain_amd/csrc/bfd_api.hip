@@ -392,7 +392,26 @@ hipEvent_t get_event(bfd_sim *s)
     return e;
 }
 
+// number of non-zero edge coefficients A (active shear updates) in the sparse shear list
+__global__ void count_active_edges(const float *__restrict__ coef, long n, unsigned long long *__restrict__ out)
+{
+    unsigned c = 0;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x)
+        c += (coef[6 * t] != 0.f) + (coef[6 * t + 2] != 0.f) + (coef[6 * t + 4] != 0.f);
+    if (c) atomicAdd(out, (unsigned long long)c);
+}
+
 }  // namespace
+
+void bfd_kmark(bfd_sim *s, int cls, int end, hipStream_t st)
+{
+    hipEvent_t e = get_event(s);
+    if (!e) return;
+    if (!end && (s->evK[cls].size() & 1)) { s->evPool.push_back(e); return; }    // unmatched begin: keep pairs intact
+    if (end && !(s->evK[cls].size() & 1)) { s->evPool.push_back(e); return; }
+    hipEventRecord(e, st);
+    s->evK[cls].push_back(e);
+}
 
 // ------------------------------------------------------------------------------------------------
 extern "C" {
@@ -467,6 +486,7 @@ int bfd_create(const bfd_config *cfg, bfd_sim **out)
     s->nSensors = 0; s->sensLin = nullptr; s->sensOut = nullptr;
     s->acc = s->pk = nullptr; s->timing = s->perKernel = false;
     s->tables = nullptr; s->profiles = nullptr; s->cmax = 0;
+    memset(s->algBytes, 0, sizeof s->algBytes); s->tiles.ktimer = nullptr;
     if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) { delete s; BFD_FAIL(-10, "hipStreamCreate failed"); }
     s->ownStream = true;
     if (hipEventCreate(&s->evBegin) != hipSuccess) { hipStreamDestroy(s->stream); delete s; BFD_FAIL(-10, "hipEventCreate failed"); }
@@ -535,6 +555,7 @@ void bfd_destroy(bfd_sim *s)
     for (hipEvent_t e : s->evPool) hipEventDestroy(e);
     for (hipEvent_t e : s->evStress) hipEventDestroy(e);
     for (hipEvent_t e : s->evVelocity) hipEventDestroy(e);
+    for (auto &v : s->evK) for (hipEvent_t e : v) hipEventDestroy(e);
     hipEventDestroy(s->evBegin); hipEventDestroy(s->evEnd);
     if (s->ownStream) hipStreamDestroy(s->stream);
     delete s;
@@ -940,6 +961,61 @@ static int build_tile_lists(bfd_sim *s)
         s->srcLowEnd = std::lower_bound(lin.begin(), lin.end(), (uint32_t)lowPlanes * (uint32_t)s->d.plane) - lin.begin();
         s->srcHighBeg = std::lower_bound(lin.begin(), lin.end(), (uint32_t)hiStart * (uint32_t)s->d.plane) - lin.begin();
     }
+    {   // algorithmic bytes per launch and kernel class (DESIGN.md "Kernels": per-cell byte tables of the tile classes):
+        // what each kernel has to move once per half-step if every value were fetched exactly once -- float32 fields 4 B,
+        // material ids 2 B; absorbing-layer memory variables, tables and halo re-reads excluded
+        double (*B)[BFD_K_COUNT] = s->algBytes;
+        memset(s->algBytes, 0, sizeof s->algBytes);
+        const int N1 = s->d.N1, N2 = s->d.N2, N3 = s->d.N3, ND = s->d.ND, k0g = s->d.k0;
+        const int ZC = bfd_tile_zchunk();
+        std::vector<unsigned short> rowF;
+        if (s->tiles.rowFlags && T.nSolid) {
+            rowF.resize((size_t)T.nSolid * ZC);
+            BFD_HIP(hipMemcpy(rowF.data(), s->tiles.rowFlags, rowF.size() * sizeof(unsigned short), hipMemcpyDeviceToHost));
+        }
+        auto overlap = [](int a, int b, int lo, int hi) { return (double)std::max(0, std::min(b, hi) - std::max(a, lo)); };
+        for (size_t r = 0; r < all.size(); r++) {
+            const int4 &run = all[r];
+            const int bx = run.x % tx, by = run.x / tx, kb = run.y & 0xFFFF, ke = run.y >> 16, f = run.z;
+            const int xa = bx * 64, xb = std::min(xa + 64, N1), ya = by * 8, yb = std::min(ya + 8, N2);
+            const double cells = (double)(xb - xa) * (yb - ya) * (ke - kb);
+            const double inner = overlap(xa, xb, ND, N1 - ND) * overlap(ya, yb, ND, N2 - ND) * overlap(k0g + kb, k0g + ke, ND, N3 - ND);
+            const bool fusedRun = r >= (size_t)(T.nFluid + T.nSolid);
+            if (fusedRun) {          // V, Szz (Rzz) read and written once per step
+                const double b = 32.0 + ((f & 2) ? 8.0 : 0.0);
+                B[0][BFD_K_FUSED] += b * cells; B[1][BFD_K_FUSED] += b * cells + 8.0 * inner;
+            } else if (r < (size_t)T.nFluid) {
+                const bool lossy = f & 2, uni = f & 4, single = s->d.collapsed || (f & 16);
+                double bs = 12.0 + 8.0 + (lossy ? 8.0 : 0.0) + (uni ? 0.0 : 2.0);
+                if (!single) bs += 8.0 + (lossy ? 8.0 : 0.0);
+                const double bv = 4.0 + 24.0 + (uni ? 0.0 : 2.0);
+                for (int a = 0; a < 2; a++) { B[a][BFD_K_STRESS_FLUID] += bs * cells; B[a][BFD_K_VELOCITY_FLUID] += bv * cells + (a ? 8.0 * inner : 0.0); }
+            } else {
+                double bs = 0;
+                if (rowF.empty()) bs = (s->cfg.kernelVariant == 2 ? 110.0 : 62.0) * cells;      // dense: V + 6 S + 6 R read, 6 S + 6 R written, id
+                else {
+                    const size_t ri = r - (size_t)T.nFluid;
+                    for (int kl = kb; kl < ke; kl++)
+                        for (int y = 0; y < yb - ya; y++) {
+                            const unsigned rc = (rowF[ri * ZC + (kl - kb)] >> (2 * y)) & 3u;
+                            bs += (rc & 1u ? (rc & 2u ? 30.0 : 46.0) : 62.0) * (xb - xa);
+                        }
+                }
+                for (int a = 0; a < 2; a++) { B[a][BFD_K_STRESS_SOLID] += bs; B[a][BFD_K_VELOCITY_SOLID] += 50.0 * cells + (a ? 8.0 * inner : 0.0); }
+            }
+        }
+        if (s->tiles.nShear) {       // sparse shear: cell index + 6 coefficients + V of the cell + read-modify-write of S and R per active edge
+            unsigned long long *dc = nullptr, hc = 0;
+            BFD_HIP(hipMalloc((void **)&dc, sizeof hc));
+            hipMemsetAsync(dc, 0, sizeof hc, s->stream);
+            hipLaunchKernelGGL(count_active_edges, dim3(grid_for(s->tiles.nShear)), dim3(256), 0, s->stream, s->tiles.shearCoef, s->tiles.nShear, dc);
+            hipMemcpyAsync(&hc, dc, sizeof hc, hipMemcpyDeviceToHost, s->stream);
+            const hipError_t e = hipStreamSynchronize(s->stream);
+            hipFree(dc);
+            if (e != hipSuccess) BFD_FAIL(-10, std::string("shear edge count: ") + hipGetErrorString(e));
+            for (int a = 0; a < 2; a++) B[a][BFD_K_STRESS_SHEAR] = 40.0 * (double)s->tiles.nShear + 16.0 * (double)hc;
+        }
+    }
     s->tilesReady = true;
     return 0;
 }
@@ -1179,7 +1255,9 @@ int bfd_timing_begin(bfd_sim *s, int32_t perKernel)
     for (hipEvent_t e : s->evStress) s->evPool.push_back(e);
     for (hipEvent_t e : s->evVelocity) s->evPool.push_back(e);
     s->evStress.clear(); s->evVelocity.clear();
+    for (auto &v : s->evK) { for (hipEvent_t e : v) s->evPool.push_back(e); v.clear(); }
     s->timing = true; s->perKernel = perKernel != 0;
+    s->tiles.ktimer = perKernel == 2 ? s : nullptr;      // 2: additionally one event pair around every kernel launch
     BFD_HIP(hipEventRecord(s->evBegin, s->stream));
     return 0;
 }
@@ -1204,6 +1282,55 @@ int bfd_timing_end(bfd_sim *s, double *totalMs, double *stressMs, double *veloci
     if (nStress) *nStress = (int64_t)s->evStress.size() / 2;
     if (nVelocity) *nVelocity = (int64_t)s->evVelocity.size() / 2;
     s->timing = false;
+    s->tiles.ktimer = nullptr;
+    return 0;
+}
+
+int bfd_timing_kernels(bfd_sim *s, double *msPerClass, int64_t *launchesPerClass)
+{
+    if (!s || !msPerClass) BFD_FAIL(-1, "bfd_timing_kernels: null argument");
+    BFD_HIP(hipSetDevice(s->cfg.device));
+    for (int c = 0; c < BFD_K_COUNT; c++) {
+        double sum = 0;
+        const std::vector<hipEvent_t> &v = s->evK[c];
+        for (size_t a = 0; a + 1 < v.size(); a += 2) {
+            BFD_HIP(hipEventSynchronize(v[a + 1]));
+            float t; BFD_HIP(hipEventElapsedTime(&t, v[a], v[a + 1])); sum += t;
+        }
+        msPerClass[c] = sum;
+        if (launchesPerClass) launchesPerClass[c] = (int64_t)v.size() / 2;
+    }
+    return 0;
+}
+
+int bfd_algorithmic_bytes(bfd_sim *s, int32_t accumulating, double *bytesPerClass)
+{
+    int rc = check_ready(s); if (rc) return rc;
+    if (!bytesPerClass) BFD_FAIL(-1, "bfd_algorithmic_bytes: null argument");
+    if (s->cfg.kernelVariant == 1) BFD_FAIL(-2, "bfd_algorithmic_bytes: kernelVariant 1 has no tile classes");
+    for (int c = 0; c < BFD_K_COUNT; c++) bytesPerClass[c] = s->algBytes[accumulating ? 1 : 0][c];
+    return 0;
+}
+
+int bfd_reset(bfd_sim *s)
+{
+    if (!s) BFD_FAIL(-1, "null sim");
+    BFD_HIP(hipSetDevice(s->cfg.device));
+    const bfd_dev &d = s->d;
+    for (int a = 0; a < 15; a++) BFD_HIP(hipMemsetAsync(s->stateBase[a], 0, s->nalloc * sizeof(float), s->stream));
+    if (s->pingpong) for (int a = 0; a < 5; a++) BFD_HIP(hipMemsetAsync(s->ppBase[a], 0, s->nalloc * sizeof(float), s->stream));
+    const int P = d.P;
+    const bool zTouch = (d.k0 < P) || (d.k0 + d.nk > d.N3 - P);
+    static const int dirOf[18] = {0, 1, 2, 1, 0, 2, 0, 2, 1, 0, 1, 2, 0, 1, 2, 0, 1, 2};
+    for (int a = 0; a < 18; a++) {
+        size_t n = dirOf[a] == 0 ? (size_t)d.nk * d.N2 * 2 * P : (dirOf[a] == 1 ? (size_t)d.nk * 2 * P * d.N1 : (zTouch ? (size_t)2 * P * d.plane : 0));
+        if (n) BFD_HIP(hipMemsetAsync(d.psi[a], 0, n * sizeof(float), s->stream));
+    }
+    if (s->acc) BFD_HIP(hipMemsetAsync(s->acc, 0, (size_t)s->nSelR * s->nloc * sizeof(float), s->stream));
+    if (s->pk) BFD_HIP(hipMemsetAsync(s->pk, 0, (size_t)s->nSelR * s->nloc * sizeof(float), s->stream));
+    if (s->sensOut) BFD_HIP(hipMemsetAsync(s->sensOut, 0, (size_t)s->nSelS * s->nTs * (size_t)s->nSensors * sizeof(float), s->stream));
+    s->step = 0; s->stepDevValid = false;
+    BFD_HIP(hipStreamSynchronize(s->stream));
     return 0;
 }
 

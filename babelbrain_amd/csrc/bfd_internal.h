@@ -55,7 +55,14 @@ struct bfd_dev {
 // runs [fluid boundary | fluid interior | solid boundary | solid interior] (boundary = inside the first/last
 // 32 planes); run = (bx + tilesX*by, kbeg | kend<<16, flags: bit0 solid, bit1 lossy, bit2 UNI, bit3 PML, bit4 LEAN, material
 // id of UNI runs). n* counters after nSolidB are in 64x8x8 sub-tiles, for reporting.
-struct bfd_tiles { int4 *runs; unsigned short *rowFlags /* per solid run x 32 planes, see stress_normal_solid */;
+// kernel classes of the per-kernel timing / byte accounting (bfd_timing_kernels, bfd_algorithmic_bytes)
+enum { BFD_K_STRESS_FLUID = 0, BFD_K_STRESS_SOLID = 1, BFD_K_STRESS_SHEAR = 2, BFD_K_VELOCITY_FLUID = 3, BFD_K_VELOCITY_SOLID = 4,
+       BFD_K_FUSED = 5, BFD_K_COUNT = 6 };
+struct bfd_sim;
+// records an event before (end = 0) / after (end = 1) a launch of class cls (bfd_api.hip); t->ktimer != null while class timing is on
+void bfd_kmark(bfd_sim *sim, int cls, int end, hipStream_t st);
+
+struct bfd_tiles { bfd_sim *ktimer; int4 *runs; unsigned short *rowFlags /* per solid run x 32 planes, see stress_normal_solid */;
                    unsigned *shearCells; float *shearCoef; long nShear, shearLowEnd, shearHighBeg;   /* sparse shear list */
                    int nFluid, nFluidB, nSolid, nSolidB, nFused /* runs of the fused kernel, after the solid runs */;
                    int nLossless, nLossy, nSolidSub, nUni, nPml, nLean, nFusedSub; };
@@ -91,6 +98,8 @@ struct bfd_sim {
     bool timing, perKernel;
     hipEvent_t evBegin, evEnd;
     std::vector<hipEvent_t> evStress, evVelocity;  // pairs
+    std::vector<hipEvent_t> evK[BFD_K_COUNT];      // pairs per kernel class (perKernel == 2)
+    double algBytes[2][BFD_K_COUNT];               // algorithmic bytes per launch and class: [0] no accumulation, [1] Pressure RMS accumulated
     std::vector<hipEvent_t> evPool;
     // optional hipGraph replay of "plain" time steps (no accumulation, no sensor sample, no per-kernel timing) in
     // bfd_run, BFD_USE_GRAPH=1; measured slower than direct launches on ROCm 7.2, so off by default (see bfd_run)

@@ -1339,6 +1339,7 @@ void bfd_launch_classify(const bfd_dev &d, hipStream_t s, int *flagsDev, int *ti
 }
 
 #define BFD_LAUNCH(K, n, ...) hipLaunchKernelGGL(K, dim3(n), dim3(TX, TY, 1), 0, s, d, tilesX, n, __VA_ARGS__)
+#define BFD_KT(cls, end) do { if (t->ktimer) bfd_kmark(t->ktimer, cls, end, s); } while (0)
 
 // run list layout: [fluid boundary | fluid interior | solid boundary | solid interior]; "boundary" = runs
 // inside the first and the last ZCHUNK planes of the slab (the planes a Z-neighbour reads).
@@ -1356,22 +1357,28 @@ void bfd_launch_stress_v2(const bfd_dev &d, hipStream_t s, const bfd_tiles *t, i
     int off, n;
     part_range(t->nFluid, t->nFluidB, part, &off, &n);
     if (n) {
+        BFD_KT(BFD_K_STRESS_FLUID, 0);
         if (d.collapsed) BFD_LAUNCH((stress_fluid<true>), n, t->runs + off);
         else BFD_LAUNCH((stress_fluid<false>), n, t->runs + off);
+        BFD_KT(BFD_K_STRESS_FLUID, 1);
     }
     part_range(t->nSolid, t->nSolidB, part, &off, &n);
     if (n) {
+        BFD_KT(BFD_K_STRESS_SOLID, 0);
         if (t->shearCells || !t->rowFlags) {
             if (t->rowFlags) BFD_LAUNCH(stress_normal_solid, n, t->runs + t->nFluid + off, t->rowFlags + (size_t)off * ZCHUNK);
             else BFD_LAUNCH(stress_v2, n, t->runs + t->nFluid + off, (const unsigned short *)nullptr);     // variant 2: monolithic
         } else BFD_LAUNCH(stress_v2, n, t->runs + t->nFluid + off, t->rowFlags + (size_t)off * ZCHUNK);
+        BFD_KT(BFD_K_STRESS_SOLID, 1);
     }
     if (t->shearCells && t->nShear) {     // sparse shear: cells sorted by index; [0,lowEnd) and [highBeg,n) are the boundary chunks
         long b0 = 0, e0 = t->nShear, b1 = 0, e1 = 0;
         if (part == 1) { e0 = t->shearLowEnd; b1 = t->shearHighBeg; e1 = t->nShear; }
         else if (part == 2) { b0 = t->shearLowEnd; e0 = t->shearHighBeg; }
+        BFD_KT(BFD_K_STRESS_SHEAR, 0);
         if (e0 > b0) hipLaunchKernelGGL(stress_shear_sparse, dim3((unsigned)((e0 - b0 + 255) / 256)), dim3(256), 0, s, d, t->shearCells + b0, t->shearCoef + 6 * b0, e0 - b0);
         if (e1 > b1) hipLaunchKernelGGL(stress_shear_sparse, dim3((unsigned)((e1 - b1 + 255) / 256)), dim3(256), 0, s, d, t->shearCells + b1, t->shearCoef + 6 * b1, e1 - b1);
+        BFD_KT(BFD_K_STRESS_SHEAR, 1);
     }
 }
 
@@ -1382,8 +1389,10 @@ void bfd_launch_fused(const bfd_dev &d, hipStream_t s, float *accP, float *pkP, 
     const int n = t->nFused;
     if (!n) return;
     const int4 *runs = t->runs + t->nFluid + t->nSolid;
+    BFD_KT(BFD_K_FUSED, 0);
     if (accP || pkP) BFD_LAUNCH((fused_fluid<true>), n, runs, accP, pkP);
     else BFD_LAUNCH((fused_fluid<false>), n, runs, accP, pkP);
+    BFD_KT(BFD_K_FUSED, 1);
 }
 
 void bfd_launch_velocity_v2(const bfd_dev &d, hipStream_t s, float *accP, float *pkP, const bfd_tiles *t, int part)
@@ -1393,12 +1402,16 @@ void bfd_launch_velocity_v2(const bfd_dev &d, hipStream_t s, float *accP, float 
     int off, n;
     part_range(t->nFluid, t->nFluidB, part, &off, &n);
     if (n) {
+        BFD_KT(BFD_K_VELOCITY_FLUID, 0);
         if (acc) BFD_LAUNCH((velocity_fluid<true>), n, t->runs + off, accP, pkP);
         else BFD_LAUNCH((velocity_fluid<false>), n, t->runs + off, accP, pkP);
+        BFD_KT(BFD_K_VELOCITY_FLUID, 1);
     }
     part_range(t->nSolid, t->nSolidB, part, &off, &n);
     if (n) {
+        BFD_KT(BFD_K_VELOCITY_SOLID, 0);
         if (acc) BFD_LAUNCH((velocity_v2<true>), n, accP, pkP, t->runs + t->nFluid + off);
         else BFD_LAUNCH((velocity_v2<false>), n, accP, pkP, t->runs + t->nFluid + off);
+        BFD_KT(BFD_K_VELOCITY_SOLID, 1);
     }
 }

@@ -1,21 +1,30 @@
 #!/usr/bin/env python3
 """Benchmark of the Step-2 FDTD hot path on MI355X (BASELINE.json metric).
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W [--config C3] [--scaling weak|strong]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
-A "step" is one full time step (stress half-step + velocity half-step + RMS accumulation
-+ sensor capture when due) over the whole domain. Workload at N=1: BASELINE.json configs[2]
-("512^3 CT-derived heterogeneous skull, CTX500 transducer, PML on"), the configuration the metric
-is quoted on. At N>1 every rank owns a 512x512x512 Z-slab of a 512x512x(512 N) domain (weak
-scaling), with neighbour halo exchange over RCCL.
+A "step" is one full time step (stress half-step + velocity half-step + RMS accumulation + sensor capture when due)
+over the whole domain. Workload at N=1: BASELINE.json configs[2] ("512^3 CT-derived heterogeneous skull, CTX500
+transducer, PML on"), the configuration the metric is quoted on.
 
-Prints ONE JSON line on rank 0. `value` = voxel-steps of all ranks / max-over-ranks wall time of
-the K timed steps (inputs resident in HBM), in Mvoxel-steps/s.
+  --scaling weak   (default) every rank owns one full grid of the config as a Z-slab of an N-times longer domain
+  --scaling strong ONE volume of the config (C4 = 512x512x1024 H317 700 kHz, C5 = 1024^3 1 MHz, ...) is split into N
+                   Z-slabs; N=1 runs the whole volume on one GPU
+Neighbour slabs exchange 2+2 halo planes per half-step over RCCL (babelbrain_amd/slab.py); there is no collective on
+the step path.
+
+Prints ONE JSON line on rank 0. `value` = voxel-steps of all ranks / max-over-ranks wall time of the K timed steps
+(inputs resident in HBM), in Mvoxel-steps/s. `roofline` describes the kernel with the longest average launch:
+achieved = ALGORITHMIC bytes of one launch (per-cell byte tables of the tile classes the engine built, DESIGN.md
+section 6; bfd_algorithmic_bytes) / average launch duration from HIP events on the engine's stream. At N=1 the line also
+carries `shear_workload` (the C2 medium -- cortical bone with shear -- on the same 512^3 grid: the viscoelastic kernels)
+and `cpu_baseline` (the oracle on this host's cores).
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -27,10 +36,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
-BYTES_STRESS = 112.0           # algorithmic bytes per voxel, stress half-step   
-BYTES_VELOCITY = 52.0          # velocity half-step
-BYTES_RMS = 8.0                # Pressure RMS accumulate
-BYTES_STEP = BYTES_STRESS + BYTES_VELOCITY + BYTES_RMS   # 172
+BYTES_STEP_DENSE = 172.0       # every array of every voxel, full viscoelastic everywhere (secondary figure)
+STEADY_SECONDS = 0.35          # GPU load before the timed window (clocks settle; short bursts read a few % high)
 
 
 def parse():
@@ -39,12 +46,16 @@ def parse():
     ap.add_argument('--steps', type=int, default=300)
     ap.add_argument('--warmup', type=int, default=50)
     ap.add_argument('--config', default='C3')
-    ap.add_argument('--size', type=int, nargs=3, default=None, help='override per-GPU grid N1 N2 N3')
-    ap.add_argument('--variant', type=int, default=0, help='kernel variant (0 default, 1 simple, 2 LDS-tiled)')
+    ap.add_argument('--scaling', choices=['weak', 'strong'], default='weak')
+    ap.add_argument('--size', type=int, nargs=3, default=None, help='override the grid N1 N2 N3 (per GPU if weak, total if strong)')
+    ap.add_argument('--variant', type=int, default=0, help='kernel variant (0 default, 1 simple, 2 LDS-tiled dense, 4 fused fluid step)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-dense-reference', action='store_true', help='skip the extra timing of the dense kernels (variant 2) at N=1')
+    ap.add_argument('--no-shear-workload', action='store_true', help='skip the C2-medium (viscoelastic) block at N=1')
+    ap.add_argument('--no-kernel-pass', action='store_true', help='skip the per-kernel timing pass (roofline then covers half-steps only)')
+    ap.add_argument('--dense-reference', action='store_true', help='also time the dense kernels (variant 2) at N=1')
+    ap.add_argument('--no-steady-warmup', action='store_true', help='do exactly W warm-up steps (default: at least W, and enough for %.2f s of load)' % STEADY_SECONDS)
     ap.add_argument('--debug-gloo-shared-gpu', action='store_true', help='debug only: N ranks on GPU 0, gloo backend, halos staged through the host (validates the multi-rank code path on a 1-GPU box)')
-    ap.add_argument('--lean-host', action='store_true', help='build the inputs slab-style (size-1 Ox/Oy/Oz) also at N=1: for 1024^3 on one GPU')
+    ap.add_argument('--lean-host', action='store_true', help='build the inputs slab-style (size-1 Ox/Oy/Oz) also at N=1')
     ap.add_argument('--cpu-sample', type=int, nargs=4, default=[384, 384, 256, 64], help='N1 N2 N3 steps of the oracle sample')
     return ap.parse_args()
 
@@ -89,15 +100,159 @@ def cpu_baseline(args, dt_fn):
             'cpu_model': model, 'host_cores': cores}
 
 
-def measured_traffic(args, n1, n2, n3):
-    """HBM bytes per half-step from the committed rocprofv3 PMC profile of this workload, if one exists
-    (profiles/traffic.json, written from the PMC passes of scripts/pmc_passes.sh)."""
+def profile_traffic(config, n1, n2, n3, variant):
+    """HBM bytes per launch and kernel from the committed rocprofv3 PMC profile of this workload, if one exists
+    (profiles/traffic.json, written from the PMC passes of scripts/pmc_passes.sh). A constant from the repository,
+    not a measurement of this run."""
     try:
         t = json.load(open(os.path.join(ROOT, 'profiles', 'traffic.json')))
-        key = '%s_%dx%dx%d_variant%d' % (args.config, n1, n2, n3, args.variant)
-        return t.get(key, {})
+        return t.get('%s_%dx%dx%d_variant%d' % (config, n1, n2, n3, variant), {})
     except Exception:
         return {}
+
+
+class Workload:
+    """One slab engine per rank for a config, with the two timing passes of the bench."""
+
+    def __init__(self, args, config, dims, scaling, rank, world, local_rank, dist, dt_fn, steps, warmup, variant, full_sensors=True):
+        import torch
+        from babelbrain_amd import harness as H, slab, RayleighAndBHTE
+        self.torch, self.dist, self.rank, self.world = torch, dist, rank, world
+        n1, n2, n3 = dims
+        self.N = (n1, n2, n3 * world) if scaling == 'weak' else (n1, n2, n3)
+        self.config, self.scaling, self.variant = config, scaling, variant
+        nvox_rank_est = float(self.N[0]) * self.N[1] * self.N[2] / world
+        extra = 0
+        if not args.no_steady_warmup:
+            est_step = nvox_rank_est / 55e9 + 25e-6            # rough: only sizes the untimed load
+            extra = max(int(math.ceil(STEADY_SECONDS / est_step)) - warmup, 0)
+        self.steps, self.warmup, self.extra_warmup = steps, warmup, min(extra, 2000)
+        nt = steps + warmup + self.extra_warmup
+        shared = args.debug_gloo_shared_gpu
+        t0 = time.time()
+        lean = world > 1 or args.lean_host or nvox_rank_est > 300e6
+        RayleighAndBHTE._device = local_rank
+        if not lean:
+            a, k, info = H.make_problem(config, N=self.N, steps=nt, stable_dt_fn=dt_fn, forward=RayleighAndBHTE.ForwardSimple, full_sensors=full_sensors)
+            local = None
+        else:   # every rank builds only its own Z-slab of the domain
+            k0, nk = slab.partition(self.N[2], world)[rank]
+            a, k, info = H.make_problem(config, N=self.N, steps=nt, stable_dt_fn=dt_fn, zslab=(k0, nk), forward=RayleighAndBHTE.ForwardSimple, full_sensors=full_sensors)
+            local = (self.N[2], k0, nk) + tuple(info['ghost'])
+        self.host_build_s = time.time() - t0
+        self.a, self.k, self.info, self.local = a, k, info, local
+        # rmsFirstStep=1: the Pressure RMS accumulates in EVERY step (warm-up included); a production call accumulates
+        # only over the last 2 periods (the sensors keep that window here)
+        self.slab, self.sinfo = slab.create_hip_slab(a, k, rank, world, local_rank, kernelVariant=variant, local=local,
+                                                     host_staging=shared, rmsFirstStep=1)
+        self.eng = self.slab.eng
+        self.runner = slab.SlabRunner(self.slab, rank, world, dist, overlap=False if shared else None)
+        self.nvox_rank = float(n1) * n2 * self.sinfo['nk']
+        self.total_vox = float(self.N[0]) * self.N[1] * self.N[2]
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def check_exchange(self, nsteps=6):
+        """world > 1: the overlapped two-stream step must reproduce the blocking single-stream order exactly on this
+        slab (outside any timed window). Falls back to the blocking order if it does not."""
+        from babelbrain_amd._engine import KIND_RMS
+        r = self.runner
+        if self.world == 1 or not r.overlap:
+            return None
+        r.run(nsteps)
+        self.barrier()
+        a = self.eng.get_map(KIND_RMS, 'Pressure')
+        self.eng.reset()
+        self.barrier()
+        r.overlap = False
+        r.run(nsteps)
+        self.barrier()
+        b = self.eng.get_map(KIND_RMS, 'Pressure')
+        self.eng.reset()
+        ok = bool(np.array_equal(a, b)) and float(b.max()) > 0 if self.rank == 0 else bool(np.array_equal(a, b))
+        flag = self.torch.tensor([1 if ok else 0], dtype=self.torch.int32, device='cuda')
+        self.dist.all_reduce(flag, op=self.dist.ReduceOp.MIN)
+        ok_all = bool(flag.item())
+        r.overlap = ok_all
+        self.barrier()
+        return {'steps': nsteps, 'overlapped_equals_blocking': ok_all, 'order_used': 'overlapped' if ok_all else 'blocking'}
+
+    def timed(self):
+        """W (+ steady-state) untimed steps, then exactly K timed steps between barrier + synchronize; max over ranks."""
+        torch, dist = self.torch, self.dist
+        self.runner.run(self.warmup + self.extra_warmup)
+        self.barrier()
+        self.eng.timing_begin(False)       # one event pair around the whole window; the per-kernel split comes from kernel_pass
+        t0 = time.perf_counter()
+        self.runner.run(self.steps)
+        torch.cuda.synchronize()
+        self.barrier()
+        wall = time.perf_counter() - t0
+        tm = self.eng.timing_end()
+        if self.world > 1:
+            dev = 'cpu' if dist.get_backend() == 'gloo' else 'cuda'
+            w = torch.tensor([wall], dtype=torch.float64, device=dev)
+            dist.all_reduce(w, op=dist.ReduceOp.MAX)
+            wall = float(w.item())
+        self.wall, self.tm = wall, tm
+        return wall, tm
+
+    def kernel_pass(self, nsteps):
+        """A separate short pass with one HIP event pair around every kernel launch (engine's stream)."""
+        self.eng.timing_begin(2)
+        self.runner.run(nsteps)
+        self.torch.cuda.synchronize()
+        tm = self.eng.timing_end()
+        kt = self.eng.timing_kernels()
+        self.barrier()
+        return tm, kt
+
+    def roofline(self, kt, traffic):
+        """Per kernel class: algorithmic bytes per launch / average launch duration."""
+        alg = self.eng.algorithmic_bytes(True)
+        rows = {}
+        for c, (ms, n) in kt.items():
+            if n == 0:
+                continue
+            avg = ms / n * 1e-3
+            ach = alg[c] / avg / 1e9
+            rows[c] = {'achieved': ach, 'frac': ach / HBM_PEAK_GBS, 'algorithmic_bytes_per_launch': alg[c], 'avg_launch_ms': avg * 1e3,
+                       'launches': n, 'traffic_from_profile': traffic.get(c)}
+            if traffic.get(c):
+                rows[c]['frac_of_peak_by_profile_traffic'] = traffic[c] / avg / 1e9 / HBM_PEAK_GBS
+        return rows, alg
+
+    def close(self):
+        self.slab.close()
+
+
+def measure(w, args, traffic):
+    """Runs the passes of one workload; returns the fields of its JSON block (rank 0 uses them)."""
+    check = w.check_exchange()
+    wall, tm = w.timed()
+    value = w.total_vox * w.steps / wall / 1e6
+    out = {'value': value, 'ms_per_step': wall / w.steps * 1e3, 'exchange_check': check,
+           'device_ms_per_step': tm['total_ms'] / w.steps, 'half_steps': None}
+    if w.variant != 1:
+        alg = w.eng.algorithmic_bytes(True)
+        step_bytes = sum(alg.values())
+        ach = step_bytes / (tm['total_ms'] / w.steps * 1e-3) / 1e9
+        out['roofline_step'] = {'achieved': ach, 'frac': ach / HBM_PEAK_GBS, 'unit': 'GB/s', 'algorithmic_bytes_per_step': step_bytes,
+                                'algorithmic_bytes_per_voxel_step': step_bytes / w.nvox_rank,
+                                'dense_accounting': {'bytes_per_voxel_step': BYTES_STEP_DENSE,
+                                                     'achieved': BYTES_STEP_DENSE * w.nvox_rank / (tm['total_ms'] / w.steps * 1e-3) / 1e9,
+                                                     'note': 'SURVEY 8d figure (all 15 arrays of every voxel); the tiled kernels move fewer bytes, so this is not a roofline fraction'}}
+        if not args.no_kernel_pass:
+            nk = min(w.steps, 60)
+            tk, kt = w.kernel_pass(nk)
+            out['half_steps'] = {'stress_ms': tk['stress_ms'] / nk, 'velocity_ms': tk['velocity_ms'] / nk, 'other_ms': tk['other_ms'] / nk,
+                                 'note': 'from the per-kernel pass (%d steps with an event pair around every launch)' % nk}
+            rows, _ = w.roofline(kt, traffic)
+            out['roofline_kernels'] = rows
+    return out
 
 
 def main():
@@ -110,7 +265,7 @@ def main():
             raise SystemExit('launch with torch.distributed.run --nproc-per-node %d for --gpus %d' % (args.gpus, args.gpus))
         args.gpus = world
     import torch
-    from babelbrain_amd import _engine, harness as H, slab, RayleighAndBHTE
+    from babelbrain_amd import _engine, harness as H
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (the HIP engine has no CPU fallback)')
     shared = args.debug_gloo_shared_gpu
@@ -132,109 +287,74 @@ def main():
         return _engine.stable_dt(ml, f, True, h, acfl)
 
     cfg = H.CONFIGS[args.config]
-    n1, n2, n3 = args.size if args.size else cfg['N']
-    N = (n1, n2, n3 * world)                       # weak scaling: one full grid per GPU
-    nt = args.steps + args.warmup
-    t0 = time.time()
-    if world == 1 and not args.lean_host:
-        a, k, info = H.make_problem(args.config, N=N, steps=nt, stable_dt_fn=dt_fn, forward=RayleighAndBHTE.ForwardSimple)
-        local = None
-    else:   # every rank builds only its own Z-slab of the domain
-        k0, nk = slab.partition(N[2], world)[rank]
-        RayleighAndBHTE._device = local_rank
-        a, k, info = H.make_problem(args.config, N=N, steps=nt, stable_dt_fn=dt_fn, zslab=(k0, nk), forward=RayleighAndBHTE.ForwardSimple)
-        local = (N[2], k0, nk) + tuple(info['ghost'])
-    t_build = time.time() - t0
-    # rmsFirstStep=1: the Pressure RMS accumulates in EVERY step (warm-up included), as the 172 B/voxel-step accounting
-    # assumes; a production call accumulates only over the last 2 periods (the sensors keep that window here)
-    s, sinfo = slab.create_hip_slab(a, k, rank, world, local_rank, kernelVariant=args.variant, local=local, host_staging=shared,
-                                    rmsFirstStep=1)
-    eng = s.eng
-    runner = slab.SlabRunner(s, rank, world, dist, overlap=False if shared else None)
-    nvox_rank = float(n1) * n2 * sinfo['nk']
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    runner.run(args.warmup)
-    barrier()
-    eng.timing_begin(True)
-    t0 = time.perf_counter()
-    runner.run(args.steps)
-    torch.cuda.synchronize()
-    barrier()
-    wall = time.perf_counter() - t0
-    tm = eng.timing_end()
-    if world > 1:
-        w = torch.tensor([wall], dtype=torch.float64, device='cpu' if shared else 'cuda')
-        dist.all_reduce(w, op=dist.ReduceOp.MAX)
-        wall = float(w.item())
-    total_vox = float(n1) * n2 * n3 * world
-    value = total_vox * args.steps / wall / 1e6
-
+    dims = tuple(args.size) if args.size else cfg['N']
+    w = Workload(args, args.config, dims, args.scaling, rank, world, local_rank, dist, dt_fn, args.steps, args.warmup, args.variant)
+    traffic = profile_traffic(args.config, dims[0], dims[1], w.sinfo['nk'], args.variant)
+    res = measure(w, args, traffic)
+    info, eng = w.info, w.eng
+    line = None
     if rank == 0:
-        st = tm['stress_ms'] / args.steps * 1e-3          # all launches of one stress half-step
-        ve = tm['velocity_ms'] / args.steps * 1e-3        # all launches of one velocity half-step (+ fused Pressure RMS)
-        step_dev = tm['total_ms'] / args.steps * 1e-3
-        ach_stress = BYTES_STRESS * nvox_rank / st / 1e9
-        ach_vel = (BYTES_VELOCITY + BYTES_RMS) * nvox_rank / ve / 1e9
-        ach_step = BYTES_STEP * nvox_rank / step_dev / 1e9
-        traffic = measured_traffic(args, n1, n2, n3)
-        # `roofline` describes the half-step that takes longer; the other one is in `roofline_other`
-        halves = {'stress half-step': dict(achieved=ach_stress, frac=ach_stress / HBM_PEAK_GBS, algorithmic_bytes_per_voxel=BYTES_STRESS,
-                                           avg_launch_ms=st * 1e3, traffic=traffic.get('stress')),
-                  'velocity half-step (+ fused Pressure RMS)': dict(achieved=ach_vel, frac=ach_vel / HBM_PEAK_GBS,
-                                                                    algorithmic_bytes_per_voxel=BYTES_VELOCITY + BYTES_RMS,
-                                                                    avg_launch_ms=ve * 1e3, traffic=traffic.get('velocity'))}
-        dom = max(halves, key=lambda n: halves[n]['avg_launch_ms'])
-        oth = [n for n in halves if n != dom][0]
         line = {
             'metric': 'Mvoxel-steps/sec, 512^3 skull FDTD (achieved HBM GB/s in roofline)',
-            'value': value, 'unit': 'Mvoxel-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': wall / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'value': res['value'], 'unit': 'Mvoxel-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': res['ms_per_step'], 'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': '%s: %dx%dx%d per GPU (%dx%dx%d total), %s medium, %s source, PML 12, %d materials, '
-                                   'Pressure RMS accumulated in every step, sensors over the last 2 periods' % (args.config, n1, n2, n3, N[0], N[1], N[2], info['medium'], info['tx'], info['n_mat']),
+            'config': {'workload': '%s, %s scaling: %dx%dx%d total, %dx%dx%d on rank 0, %s medium, %s source, PML 12, %d materials, '
+                                   'Pressure RMS accumulated in every step, sensors over the last 2 periods'
+                                   % (args.config, args.scaling, w.N[0], w.N[1], w.N[2], dims[0], dims[1], w.sinfo['nk'], info['medium'], info['tx'], info['n_mat']),
                        'parallelism': 'z-slab x%d' % world, 'kernel_variant': args.variant, 'dt': info['dt'], 'ppp': info['ppp'],
-                       'n_sources': info['n_sources'], 'n_sensors_rank0': int(eng.num_sensors), 'tiles_rank0': eng.tile_counts(),
-                       'halo_exchange': 'overlapped' if runner.overlap else ('none' if world == 1 else 'blocking')},
-            'roofline': dict(bound='hbm', kernel=dom, peak=HBM_PEAK_GBS, unit='GB/s',
-                             note='achieved = algorithmic bytes (SURVEY 8d) / measured time; the tiled kernels move fewer bytes than '
-                                  'the algorithmic count (exact fluid-tile shortcuts), so frac can exceed 1; traffic = HBM bytes per '
-                                  'launch from rocprofv3 PMC (profiles/), null if no profile matches this grid',
-                             **halves[dom]),
-            'roofline_other': dict(kernel=oth, **halves[oth]),
-            'roofline_step': {'achieved': ach_step, 'frac': ach_step / HBM_PEAK_GBS, 'algorithmic_bytes_per_voxel_step': BYTES_STEP,
-                              'device_ms_per_step': step_dev * 1e3, 'other_ms_per_step': tm['other_ms'] / args.steps},
-            'device_bytes': int(eng.device_bytes), 'host_build_s': t_build,
+                       'n_sources': info['n_sources'], 'n_sensors_rank0': int(eng.num_sensors), 'tiles_rank0': eng.tile_counts() if args.variant != 1 else None,
+                       'halo_exchange': 'overlapped' if w.runner.overlap else ('none' if world == 1 else 'blocking'),
+                       'halo_exchange_check': res['exchange_check'], 'untimed_steps_before_window': args.warmup + w.extra_warmup},
+            'device_ms_per_step': res['device_ms_per_step'], 'half_steps_ms': res['half_steps'],
+            'device_bytes': int(eng.device_bytes), 'host_build_s': w.host_build_s,
         }
-        if world == 1 and not args.no_dense_reference and args.variant in (0, 3):
-            # the same workload on the dense LDS-tiled kernels (variant 2: every array of every voxel is read and
-            # written, no fluid-tile shortcuts) -- the like-for-like figure against the 172 B algorithmic count
-            try:
-                eng.close()
-                s2, _ = slab.create_hip_slab(a, k, 0, 1, local_rank, kernelVariant=2, local=local, rmsFirstStep=1)
-                r2 = slab.SlabRunner(s2, 0, 1, None)
-                r2.run(args.warmup)
-                torch.cuda.synchronize()
-                s2.eng.timing_begin(False)
-                r2.run(args.steps)
-                t2 = s2.eng.timing_end()
-                ms2 = t2['total_ms'] / args.steps
-                ach2 = BYTES_STEP * nvox_rank / (ms2 * 1e-3) / 1e9
-                line['dense_reference'] = {'kernel_variant': 2, 'value': total_vox / (ms2 * 1e-3) / 1e6, 'unit': 'Mvoxel-steps/s',
-                                           'device_ms_per_step': ms2, 'roofline_step': {'achieved': ach2, 'frac': ach2 / HBM_PEAK_GBS,
-                                                                                        'algorithmic_bytes_per_voxel_step': BYTES_STEP}}
-                s2.eng.close()
-            except Exception as e:
-                line['dense_reference'] = {'value': None, 'error': repr(e)}
-        if not args.no_cpu_baseline and world == 1:
-            try:
-                line['cpu_baseline'] = cpu_baseline(args, dt_fn)
-            except Exception as e:   # the baseline is a reported extra; never lose the GPU line over it
-                line['cpu_baseline'] = {'value': None, 'unit': 'Mvoxel-steps/s', 'cores': 0, 'kind': 'port', 'sample': 'failed: %r' % (e,)}
+        rows = res.get('roofline_kernels')
+        note = ('achieved = algorithmic bytes of one launch (per-cell byte tables of the tile classes, bfd_algorithmic_bytes / DESIGN.md 6) '
+                '/ average launch duration (HIP events on the engine stream, separate short pass); traffic_from_profile = HBM bytes per launch '
+                'from the committed rocprofv3 PMC profile of this workload (profiles/traffic.json), null if none matches')
+        if rows:
+            dom = max(rows, key=lambda c: rows[c]['avg_launch_ms'])
+            r = rows[dom]
+            line['roofline'] = dict(bound='hbm', kernel=dom, achieved=r['achieved'], peak=HBM_PEAK_GBS, unit='GB/s', frac=r['frac'],
+                                    traffic=r['traffic_from_profile'], traffic_from_profile=r['traffic_from_profile'],
+                                    algorithmic_bytes_per_launch=r['algorithmic_bytes_per_launch'], avg_launch_ms=r['avg_launch_ms'], note=note)
+            line['roofline_kernels'] = rows
+        elif 'roofline_step' in res:
+            s = res['roofline_step']
+            line['roofline'] = dict(bound='hbm', kernel='whole time step', achieved=s['achieved'], peak=HBM_PEAK_GBS, unit='GB/s', frac=s['frac'],
+                                    traffic=None, note=note)
+        if 'roofline_step' in res:
+            line['roofline_step'] = res['roofline_step']
+    w.close()
+
+    if world == 1 and not args.no_shear_workload and args.variant in (0, 3) and args.config == 'C3' and not args.size:
+        # the viscoelastic kernels: C2's medium (water / cortical bone with shear / brain) on the same 512^3 grid, same K/W
+        try:
+            ws = Workload(args, 'C2', dims, 'weak', 0, 1, local_rank, None, dt_fn, args.steps, args.warmup, args.variant, full_sensors=True)
+            rs = measure(ws, args, profile_traffic('C2', dims[0], dims[1], dims[2], args.variant))
+            line['shear_workload'] = {'workload': 'C2 medium (3 materials: water, cortical bone cS=%g m/s, brain) on %dx%dx%d, single source, same K/W' % (ws.a[1][1][2], *dims),
+                                      'value': rs['value'], 'unit': 'Mvoxel-steps/s', 'ms_per_step': rs['ms_per_step'], 'device_ms_per_step': rs['device_ms_per_step'],
+                                      'half_steps_ms': rs['half_steps'], 'tiles': ws.eng.tile_counts(), 'roofline_step': rs.get('roofline_step'),
+                                      'roofline_kernels': rs.get('roofline_kernels')}
+            ws.close()
+        except Exception as e:
+            line['shear_workload'] = {'value': None, 'error': repr(e)}
+    if world == 1 and args.dense_reference and args.variant in (0, 3):
+        try:
+            wd = Workload(args, args.config, dims, args.scaling, 0, 1, local_rank, None, dt_fn, args.steps, args.warmup, 2)
+            wall, tm = wd.timed()
+            line['dense_reference'] = {'kernel_variant': 2, 'value': wd.total_vox * wd.steps / wall / 1e6, 'unit': 'Mvoxel-steps/s',
+                                       'device_ms_per_step': tm['total_ms'] / wd.steps}
+            wd.close()
+        except Exception as e:
+            line['dense_reference'] = {'value': None, 'error': repr(e)}
+    if world == 1 and not args.no_cpu_baseline:
+        try:
+            line['cpu_baseline'] = cpu_baseline(args, dt_fn)
+        except Exception as e:   # the baseline is a reported extra; never lose the GPU line over it
+            line['cpu_baseline'] = {'value': None, 'unit': 'Mvoxel-steps/s', 'cores': 0, 'kind': 'port', 'sample': 'failed: %r' % (e,)}
+    if rank == 0:
         print(json.dumps(line))
     if world > 1:
         dist.barrier()

@@ -153,6 +153,18 @@ int bfd_timing_begin(bfd_sim *sim, int32_t perKernel);
 int bfd_timing_end(bfd_sim *sim, double *totalMs, double *stressMs, double *velocityMs,
                    double *otherMs, int64_t *nStressLaunches, int64_t *nVelocityLaunches);
 
+/* Finer timing (bfd_timing_begin(sim, 2)): device ms and launch count per kernel class over the timed window, classes
+ * 0 stress fluid tiles, 1 normal stresses of solid tiles, 2 sparse shear stresses, 3 velocity fluid tiles,
+ * 4 velocity solid tiles, 5 fused fluid time step. Call after bfd_timing_end. Arrays of 6. */
+int bfd_timing_kernels(bfd_sim *sim, double *msPerClass, int64_t *launchesPerClass);
+/* ALGORITHMIC bytes one launch of each kernel class has to move (same class order), from the tile-class counts: every
+ * field value of the class's per-cell byte table fetched / stored exactly once (float32 4 B, material id 2 B; absorbing-
+ * layer memory variables, coefficient tables and halo re-reads excluded). accumulating != 0 adds the
+ * Pressure RMS accumulator (8 B per cell outside the absorbing layer) to the velocity classes. DESIGN.md section 6. */
+int bfd_algorithmic_bytes(bfd_sim *sim, int32_t accumulating, double *bytesPerClass);
+/* back to step 0: fields, absorbing-layer memory, accumulators and the sensor block zeroed; inputs are kept */
+int bfd_reset(bfd_sim *sim);
+
 /* results */
 int64_t bfd_num_sensors(bfd_sim *sim);
 int32_t bfd_num_sensor_steps(bfd_sim *sim);

@@ -16,11 +16,20 @@ for f in glob.glob(root + '/p*/**/*counter_collection.csv', recursive=True):
             agg[short]['LDS'].append(float(r['LDS_Block_Size']))
             agg[short]['dur_us'].append((float(r['End_Timestamp']) - float(r['Start_Timestamp'])) / 1e3)
 import json
+# bench.py's kernel classes (babelbrain_amd/_engine.py KERNEL_CLASSES) by kernel name
+CLASS_OF = {'stress_fluid': 'stress_fluid', 'stress_normal_solid': 'stress_normal_solid', 'stress_solid': 'stress_normal_solid', 'stress_v2': 'stress_normal_solid',
+            'stress_shear_sparse': 'stress_shear_sparse', 'velocity_fluid': 'velocity_fluid', 'velocity_v2': 'velocity_solid', 'velocity_solid': 'velocity_solid',
+            'fused_fluid': 'fused_fluid'}
 traffic = {'stress': 0.0, 'velocity': 0.0}
 for k, d in agg.items():
-    if 'FETCH_SIZE' in d and 'WRITE_SIZE' in d and ('stress' in k or 'velocity' in k):
+    if 'FETCH_SIZE' in d and 'WRITE_SIZE' in d and ('stress' in k or 'velocity' in k or 'fused' in k):
         f = sum(d['FETCH_SIZE']) / len(d['FETCH_SIZE']); w = sum(d['WRITE_SIZE']) / len(d['WRITE_SIZE'])
-        traffic['stress' if 'stress' in k else 'velocity'] += (2 * f + w) * 1024     # gfx950: FETCH_SIZE counts half the read bytes
+        b = (2 * f + w) * 1024     # gfx950: FETCH_SIZE counts half the read bytes
+        if 'fused' not in k:
+            traffic['stress' if 'stress' in k else 'velocity'] += b
+        base = k.split('<')[0]
+        if base in CLASS_OF:
+            traffic[CLASS_OF[base]] = traffic.get(CLASS_OF[base], 0.0) + b
 if len(sys.argv) > 2:
     json.dump({sys.argv[2]: traffic}, open(root + '/traffic.json', 'w'))
 for k, d in sorted(agg.items()):
