@@ -1092,7 +1092,9 @@ __device__ __forceinline__ float ldv(const float *__restrict__ a, int N1, int N2
 __global__ __launch_bounds__(256) void stress_shear_sparse(bfd_dev d, const unsigned *__restrict__ cells,
                                                            const float *__restrict__ coef, long n)
 {
-    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    // XCD e works through the e-th contiguous eighth of the (index-sorted) list: the V values a cell gathers from its
+    // row / plane neighbours were fetched by blocks just before it on the SAME XCD (its own L2)
+    const long t = (long)remap_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
     if (t >= n) return;
     const int N1 = d.N1, N2 = d.N2, P = d.P;
     const long pl = d.plane;
