@@ -166,15 +166,10 @@ __global__ void transpose_pulse(const double *__restrict__ in, float *__restrict
     }
 }
 
-// does cell c (local linear index) hold only the Szz/Rzz copy of its normal stresses?
+// does cell c (local linear index) hold only the Szz/Rzz copy of its normal stresses? (every fluid cell: bfd_dev::cls)
 __device__ __forceinline__ bool normal_collapsed(const bfd_dev &d, long c)
 {
-    if (d.collapsed) return true;
-    if (!d.lean) return false;
-    const int kl = (int)(c / d.plane);
-    const int r = (int)(c - (long)kl * d.plane);
-    const int j = r / d.N1, i = r - j * d.N1;
-    return d.lean[((long)(kl / BFD_SUBZ) * d.tilesY + j / BFD_TILE_Y) * d.tilesX + i / BFD_TILE_X] != 0;
+    return (d.cls[c] & BFD_CLS_FLUID) != 0;
 }
 
 __device__ __forceinline__ float map_value(const bfd_dev &d, int sel, long c)
@@ -183,8 +178,8 @@ __device__ __forceinline__ float map_value(const bfd_dev &d, int sel, long c)
     case BFD_MAP_VX: return d.Vx[c];
     case BFD_MAP_VY: return d.Vy[c];
     case BFD_MAP_VZ: return d.Vz[c];
-    case BFD_MAP_SIGMAXX: return d.Sxx[c];
-    case BFD_MAP_SIGMAYY: return d.Syy[c];
+    case BFD_MAP_SIGMAXX: return normal_collapsed(d, c) ? d.Szz[c] : d.Sxx[c];     // a fluid cell keeps one copy of its normal stresses
+    case BFD_MAP_SIGMAYY: return normal_collapsed(d, c) ? d.Szz[c] : d.Syy[c];
     case BFD_MAP_SIGMAZZ: return d.Szz[c];
     case BFD_MAP_SIGMAXY: return d.Sxy[c];
     case BFD_MAP_SIGMAXZ: return d.Sxz[c];
@@ -197,7 +192,7 @@ __device__ __forceinline__ float map_value(const bfd_dev &d, int sel, long c)
     default: return 0.0f;
     }
 }
-// collapsed slabs keep only Szz/Rzz of the identical normal stresses: restore the other copies
+// fluid cells keep only Szz/Rzz of their identical normal stresses: restore the other copies
 __global__ void expand_normal(bfd_dev d, long n)
 {
     for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (long)gridDim.x * blockDim.x) {
@@ -508,6 +503,9 @@ int bfd_create(const bfd_config *cfg, bfd_sim **out)
     }
     if (!rc) rc = dev_alloc(s, &s->matBase, s->nalloc);
     if (!rc) d.mat = s->matBase + 2 * (size_t)d.plane;
+    if (!rc) rc = dev_alloc(s, &s->clsBase, s->nalloc);
+    if (!rc) d.cls = s->clsBase + 2 * (size_t)d.plane;
+    s->classesReady = false;
     d.VxW = d.Vx; d.VyW = d.Vy; d.VzW = d.Vz; d.SzzW = d.Szz; d.RzzW = d.Rzz;
     // variant 4 (fused fluid time step) needs the old fields to survive the step: second copies of V, Szz, Rzz. A
     // Z-slab keeps the in-place update (its neighbours alias the halo planes once), i.e. behaves like variant 3.
@@ -616,7 +614,7 @@ int bfd_set_materials(bfd_sim *s, const double *matlist, const double *qcorr)
     d.axI = bx; d.bxI = bx + d.N1; d.axH = bx + 2 * d.N1; d.bxH = bx + 3 * d.N1;
     d.ayI = by; d.byI = by + d.N2; d.ayH = by + 2 * d.N2; d.byH = by + 3 * d.N2;
     d.azI = bz; d.bzI = bz + d.N3; d.azH = bz + 2 * d.N3; d.bzH = bz + 3 * d.N3;
-    s->haveMaterials = true; s->tilesReady = false; drop_step_graph(s);
+    s->haveMaterials = true; s->tilesReady = false; s->classesReady = false; drop_step_graph(s);
     return 0;
 }
 
@@ -650,7 +648,7 @@ int bfd_set_material_map(bfd_sim *s, const uint32_t *map, int64_t s1, int64_t s2
     hipFree(tmp); if (flag) hipFree(flag);
     if (e != hipSuccess) BFD_FAIL(-10, std::string("bfd_set_material_map: ") + hipGetErrorString(e));
     if (hflag) BFD_FAIL(-5, "bfd_set_material_map: MaterialMap holds an id >= number of MaterialList rows");
-    s->haveMap = true; s->tilesReady = false; drop_step_graph(s);
+    s->haveMap = true; s->tilesReady = false; s->classesReady = false; drop_step_graph(s);
     return 0;
 }
 
@@ -670,7 +668,7 @@ int bfd_set_reflector(bfd_sim *s, const uint32_t *mask, int64_t s1, int64_t s2, 
                        s->matBase + 2 * (size_t)d.plane, d.N1, d.N2, d.nk, mask ? 0 : 1);
     BFD_HIP(hipStreamSynchronize(s->stream));
     if (tmp) hipFree(tmp);
-    s->tilesReady = false; drop_step_graph(s);      // reflector cells end the UNI class of their tiles
+    s->tilesReady = false; s->classesReady = false; drop_step_graph(s);      // reflector cells end the UNI class of their tiles
     return 0;
 }
 
@@ -772,11 +770,7 @@ static int build_tile_lists(bfd_sim *s)
 {
     int tx, ty, nsub; bfd_tile_grid(s->d, &tx, &ty, &nsub);
     const int n = tx * ty * nsub;
-    {   // lists of an earlier build (inputs were set again)
-        unsigned char *oldLean = const_cast<unsigned char *>(s->d.lean);
-        dev_release(s, &oldLean); s->d.lean = nullptr;
-        dev_release(s, &s->tiles.runs); dev_release(s, &s->tiles.rowFlags); dev_release(s, &s->tiles.shearCells); dev_release(s, &s->tiles.shearCoef);
-    }
+    dev_release(s, &s->tiles.runs); dev_release(s, &s->tiles.shearCells); dev_release(s, &s->tiles.shearCoef);    // lists of an earlier build
     const int SUB = bfd_tile_subz();
     // longest run one workgroup marches: 16 planes; 8 on small grids so that the launch still has a few thousand
     // workgroups (measured: 256^3 49 -> 58, 128^3 29 -> 46 Gvoxel-steps/s). 32 was best at 512^3 while the z-chunks of
@@ -802,34 +796,11 @@ static int build_tile_lists(bfd_sim *s)
         if (e != hipSuccess) BFD_FAIL(-10, std::string("classify tiles: ") + hipGetErrorString(e));
     }
     bfd_tiles &T = s->tiles;
-    T.nFluid = T.nFluidB = T.nSolid = T.nSolidB = T.nFused = T.nLossless = T.nLossy = T.nSolidSub = T.nUni = T.nPml = T.nLean = T.nFusedSub = 0;
-    // per-component normal stresses are needed only by solid tiles or by a Sigma** output selection
-    const uint32_t sig = (1u << BFD_MAP_SIGMAXX) | (1u << BFD_MAP_SIGMAYY) | (1u << BFD_MAP_SIGMAZZ);
-    const bool sigmaOut = ((s->cfg.selMapsRMS | s->cfg.selMapsSensors) & sig) != 0;
-    // LEAN fluid sub-tiles of a slab that has solid ones: Sxx/Syy of a cell are read only by the x / y derivative
-    // of the velocity update of a cell at most 2 cells away in the same plane, and a FLUID tile reads Szz instead,
-    // so a fluid sub-tile without a solid sub-tile beside it in x or y keeps just Szz/Rzz (bit4)
-    s->d.lean = nullptr; s->d.tilesX = tx; s->d.tilesY = ty;
-    if (s->cfg.kernelVariant != 2 && !sigmaOut) {
-        std::vector<unsigned char> lean((size_t)n, 0);
-        bool anySolid = false, anyLean = false;
-        for (int q = 0; q < nsub; q++)
-            for (int by = 0; by < ty; by++)
-                for (int bx = 0; bx < tx; bx++) {
-                    const size_t id = ((size_t)q * ty + by) * tx + bx;
-                    if (flags[id] & 1) { anySolid = true; continue; }
-                    auto solidAt = [&](int x, int y) { return x >= 0 && x < tx && y >= 0 && y < ty && (flags[((size_t)q * ty + y) * tx + x] & 1); };
-                    if (!solidAt(bx - 1, by) && !solidAt(bx + 1, by) && !solidAt(bx, by - 1) && !solidAt(bx, by + 1)) { lean[id] = 1; anyLean = true; }
-                }
-        if (anySolid && anyLean) {
-            unsigned char *dl = nullptr;
-            int rcl = dev_alloc(s, &dl, (size_t)n, false);
-            if (rcl) return rcl;
-            BFD_HIP(hipMemcpy(dl, lean.data(), (size_t)n, hipMemcpyHostToDevice));
-            s->d.lean = dl;
-            for (int id = 0; id < n; id++) if (lean[id]) flags[id] |= 16;
-        }
-    }
+    T.nFluid = T.nFluidB = T.nSolid = T.nSolidB = T.nSolidBP = T.nSolidIP = T.nFused = T.nLossless = T.nLossy = T.nSolidSub = T.nUni = T.nPml = T.nLean = T.nFusedSub = 0;
+    s->d.tilesX = tx; s->d.tilesY = ty;
+    // Every fluid sub-tile is LEAN (bit4): fluid cells keep a single copy of their identical normal stresses, whatever
+    // tile they sit in and whatever reads them (bfd_dev::cls)
+    if (s->cfg.kernelVariant != 2) for (int id = 0; id < n; id++) if (!(flags[id] & 1)) flags[id] |= 16;
     // "boundary" sub-tiles hold the 2 first / 2 last planes of the slab (what a Z-neighbour reads): they form the
     // small part 1 of a split half-step; everything else is part 2. lowPlanes / hiStart delimit them in planes.
     const int nkl = s->d.nk;
@@ -839,14 +810,12 @@ static int build_tile_lists(bfd_sim *s)
     std::vector<int4> lists[5];      // fluid boundary, fluid interior, solid boundary, solid interior, fused fluid
     // runs of the fused kernel (variant 4, see fused_fluid_body): fluid + UNI + single-copy normal stresses, nothing of
     // the absorbing layer within 2 cells, not a boundary sub-tile, sources of velocity type (bit5)
-    if (s->pingpong && s->cfg.typeSource < 2 && !sigmaOut) {
-        bool anySolid = false;
-        for (int id = 0; id < n; id++) anySolid = anySolid || (flags[id] & 1);
+    if (s->pingpong && s->cfg.typeSource < 2) {
         for (int q = 0; q < nsub; q++) {
             if (subBnd(q)) continue;
             for (int txy = 0; txy < tx * ty; txy++) {
                 int &f = flags[(size_t)q * tx * ty + txy];
-                if (!(f & 1) && (f & 4) && !(f & 64) && (!anySolid || (f & 16))) f |= 32;
+                if (!(f & 1) && (f & 4) && !(f & 64)) f |= 32;
             }
         }
     }
@@ -888,15 +857,17 @@ static int build_tile_lists(bfd_sim *s)
                 const bool solid = f & 1;
                 const bool bnd = subBnd(q);
                 const int se = (!solid && (f & 32)) ? std::min(q + fusedSub, nsub) : se0;
-                int r = q + 1;
+                int r = q + 1, pmlAny = f & 8;
                 while (r < se) {
                     const int f2 = flags[(size_t)r * tx * ty + txy], m2 = mats[(size_t)r * tx * ty + txy];
                     if (subBnd(r) != bnd) break;
                     if (solid ? !(f2 & 1) : (f2 != f || ((f & 4) && m2 != m))) break;
+                    pmlAny |= f2 & 8;
                     r++;
                 }
                 const int kbeg = q * SUB, kend = std::min(r * SUB, s->d.nk);
-                int4 run; run.x = txy; run.y = kbeg | (kend << 16); run.z = solid ? 1 : f; run.w = m;
+                // solid runs: bit0 + bit3 (a sub-tile of the run touches the absorbing layer)
+                int4 run; run.x = txy; run.y = kbeg | (kend << 16); run.z = solid ? (1 | pmlAny) : f; run.w = m;
                 lists[(!solid && (f & 32)) ? 4 : (solid ? 2 : 0) + (bnd ? 0 : 1)].push_back(run);
                 for (int u = q; u < r; u++) {
                     taken[(size_t)u * tx * ty + txy] = 1;
@@ -906,6 +877,14 @@ static int build_tile_lists(bfd_sim *s)
                 q = r;
             }
         }
+    // solid runs that touch the absorbing layer go to the two ends of the solid list: [boundary: PML | plain][interior: plain | PML]
+    {
+        auto isPml = [](const int4 &r) { return (r.z & 8) != 0; };
+        auto mid = std::stable_partition(lists[2].begin(), lists[2].end(), isPml);
+        T.nSolidBP = (int)(mid - lists[2].begin());
+        auto mid2 = std::stable_partition(lists[3].begin(), lists[3].end(), [&](const int4 &r) { return !isPml(r); });
+        T.nSolidIP = (int)(lists[3].end() - mid2);
+    }
     T.nFluidB = (int)lists[0].size(); T.nFluid = T.nFluidB + (int)lists[1].size();
     T.nSolidB = (int)lists[2].size(); T.nSolid = T.nSolidB + (int)lists[3].size();
     T.nFused = (int)lists[4].size();
@@ -914,13 +893,9 @@ static int build_tile_lists(bfd_sim *s)
     int rc = dev_alloc(s, &s->tiles.runs, all.size(), false);
     if (rc) return rc;
     BFD_HIP(hipMemcpy(s->tiles.runs, all.data(), all.size() * sizeof(int4), hipMemcpyHostToDevice));
-    s->tiles.rowFlags = nullptr; s->tiles.shearCells = nullptr; s->tiles.shearCoef = nullptr;
+    s->tiles.shearCells = nullptr; s->tiles.shearCoef = nullptr;
     s->tiles.nShear = s->tiles.shearLowEnd = s->tiles.shearHighBeg = 0;
     if (T.nSolid && s->cfg.kernelVariant != 2) {     // variant 2 stays monolithic and fully dense
-        // row classes inside solid runs
-        rc = dev_alloc(s, &s->tiles.rowFlags, (size_t)T.nSolid * bfd_tile_zchunk(), true);
-        if (rc) return rc;
-        bfd_launch_classify_rows(s->d, s->stream, s->tiles.runs + T.nFluid, T.nSolid, s->tiles.rowFlags);
         // sparse shear list: cells with a solid centre, ascending index, + their edge coefficients
         unsigned char *flag = nullptr; unsigned *sel = nullptr; int *dcount = nullptr; void *work = nullptr;
         hipError_t e = hipMalloc((void **)&flag, s->nloc);
@@ -953,8 +928,6 @@ static int build_tile_lists(bfd_sim *s)
         s->tiles.shearLowEnd = std::lower_bound(hostCells.begin(), hostCells.end(), (unsigned)lowPlanes * (unsigned)s->d.plane) - hostCells.begin();
         s->tiles.shearHighBeg = std::lower_bound(hostCells.begin(), hostCells.end(), (unsigned)hiStart * (unsigned)s->d.plane) - hostCells.begin();
     }
-    const int nC = T.nSolid;
-    s->d.collapsed = (nC == 0 && !sigmaOut) ? 1 : 0;
     {   // sources of the first / last z-chunk (bfd_set_sources sorted them by voxel)
         std::vector<uint32_t> lin((size_t)s->nSrcVox);
         if (s->nSrcVox) BFD_HIP(hipMemcpy(lin.data(), s->srcLin, lin.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
@@ -967,11 +940,17 @@ static int build_tile_lists(bfd_sim *s)
         double (*B)[BFD_K_COUNT] = s->algBytes;
         memset(s->algBytes, 0, sizeof s->algBytes);
         const int N1 = s->d.N1, N2 = s->d.N2, N3 = s->d.N3, ND = s->d.ND, k0g = s->d.k0;
-        const int ZC = bfd_tile_zchunk();
-        std::vector<unsigned short> rowF;
-        if (s->tiles.rowFlags && T.nSolid) {
-            rowF.resize((size_t)T.nSolid * ZC);
-            BFD_HIP(hipMemcpy(rowF.data(), s->tiles.rowFlags, rowF.size() * sizeof(unsigned short), hipMemcpyDeviceToHost));
+        // class counts over the cells of the solid runs (fluid / solid centre, with / without memory variables, active edges)
+        unsigned long long cnt[6] = {0, 0, 0, 0, 0, 0};
+        if (T.nSolid && s->cfg.kernelVariant != 2) {
+            unsigned long long *dc = nullptr;
+            BFD_HIP(hipMalloc((void **)&dc, sizeof cnt));
+            hipMemsetAsync(dc, 0, sizeof cnt, s->stream);
+            bfd_launch_count_solid_cells(s->d, s->stream, s->tiles.runs + T.nFluid, T.nSolid, dc);
+            hipMemcpyAsync(cnt, dc, sizeof cnt, hipMemcpyDeviceToHost, s->stream);
+            const hipError_t e = hipStreamSynchronize(s->stream);
+            hipFree(dc);
+            if (e != hipSuccess) BFD_FAIL(-10, std::string("solid cell counts: ") + hipGetErrorString(e));
         }
         auto overlap = [](int a, int b, int lo, int hi) { return (double)std::max(0, std::min(b, hi) - std::max(a, lo)); };
         for (size_t r = 0; r < all.size(); r++) {
@@ -985,24 +964,26 @@ static int build_tile_lists(bfd_sim *s)
                 const double b = 32.0 + ((f & 2) ? 8.0 : 0.0);
                 B[0][BFD_K_FUSED] += b * cells; B[1][BFD_K_FUSED] += b * cells + 8.0 * inner;
             } else if (r < (size_t)T.nFluid) {
-                const bool lossy = f & 2, uni = f & 4, single = s->d.collapsed || (f & 16);
+                const bool lossy = f & 2, uni = f & 4, single = (f & 16) != 0;
                 double bs = 12.0 + 8.0 + (lossy ? 8.0 : 0.0) + (uni ? 0.0 : 2.0);
                 if (!single) bs += 8.0 + (lossy ? 8.0 : 0.0);
                 const double bv = 4.0 + 24.0 + (uni ? 0.0 : 2.0);
                 for (int a = 0; a < 2; a++) { B[a][BFD_K_STRESS_FLUID] += bs * cells; B[a][BFD_K_VELOCITY_FLUID] += bv * cells + (a ? 8.0 * inner : 0.0); }
-            } else {
-                double bs = 0;
-                if (rowF.empty()) bs = (s->cfg.kernelVariant == 2 ? 110.0 : 62.0) * cells;      // dense: V + 6 S + 6 R read, 6 S + 6 R written, id
-                else {
-                    const size_t ri = r - (size_t)T.nFluid;
-                    for (int kl = kb; kl < ke; kl++)
-                        for (int y = 0; y < yb - ya; y++) {
-                            const unsigned rc = (rowF[ri * ZC + (kl - kb)] >> (2 * y)) & 3u;
-                            bs += (rc & 1u ? (rc & 2u ? 30.0 : 46.0) : 62.0) * (xb - xa);
-                        }
-                }
-                for (int a = 0; a < 2; a++) { B[a][BFD_K_STRESS_SOLID] += bs; B[a][BFD_K_VELOCITY_SOLID] += 50.0 * cells + (a ? 8.0 * inner : 0.0); }
+            } else if (s->cfg.kernelVariant == 2) {     // dense: V + 6 S + 6 R read, 6 S + 6 R written, id; 6 S + V read, V written, id
+                for (int a = 0; a < 2; a++) { B[a][BFD_K_STRESS_SOLID] += 110.0 * cells; B[a][BFD_K_VELOCITY_SOLID] += 50.0 * cells + (a ? 8.0 * inner : 0.0); }
+            } else {                                    // class-predicated solid kernels: per-cell terms come from the class counts below
+                for (int a = 0; a < 2; a++) B[a][BFD_K_VELOCITY_SOLID] += (a ? 8.0 * inner : 0.0);
             }
+        }
+        if (T.nSolid && s->cfg.kernelVariant != 2) {
+            // stress: V 12 + id 2 + class 1, + Szz r/w 8 (+ Rzz r/w 8) at a fluid cell, + 3 S r/w 24 + 3 R r/w 24 at a solid one
+            // (a reflector cell: 48 B of zero stores); velocity: V r/w 24 + ids 2 + class 1 + Szz 4, + Sxx, Syy 8 at a solid cell,
+            // + 4 per active shear edge
+            const double nF0 = (double)cnt[0], nF1 = (double)cnt[1], nS = (double)cnt[2] + (double)cnt[3], nE = (double)cnt[4], nR = (double)cnt[5];
+            const double all = nF0 + nF1 + nS + nR;
+            const double bs = 15.0 * all + 8.0 * nF0 + 16.0 * nF1 + 48.0 * nS + 48.0 * nR;
+            const double bv = 31.0 * all + 8.0 * (nS + nR) + 4.0 * nE;
+            for (int a = 0; a < 2; a++) { B[a][BFD_K_STRESS_SOLID] += bs; B[a][BFD_K_VELOCITY_SOLID] += bv; }
         }
         if (s->tiles.nShear) {       // sparse shear: cell index + 6 coefficients + V of the cell + read-modify-write of S and R per active edge
             unsigned long long *dc = nullptr, hc = 0;
@@ -1024,6 +1005,13 @@ static int check_ready(bfd_sim *s)
 {
     if (!s) BFD_FAIL(-1, "null sim");
     if (!s->haveMaterials || !s->haveMap) BFD_FAIL(-6, "materials and material map must be set before stepping");
+    if (!s->classesReady) {      // per-cell class bytes (every variant: the output kernels consult them too)
+        BFD_HIP(hipSetDevice(s->cfg.device));
+        bfd_launch_cell_classes(s->d, s->stream, s->clsBase, (long)s->nalloc);
+        BFD_HIP(hipGetLastError());
+        BFD_HIP(hipStreamSynchronize(s->stream));
+        s->classesReady = true;
+    }
     if (!s->tilesReady && s->cfg.kernelVariant != 1) {
         BFD_HIP(hipSetDevice(s->cfg.device));
         return build_tile_lists(s);
@@ -1423,7 +1411,7 @@ int bfd_get_map(bfd_sim *s, int32_t kind, int32_t map, float *out, int64_t s1, i
 
 static void expand_if_collapsed(bfd_sim *s)
 {
-    if (s->d.collapsed || s->d.lean)
+    if (s->classesReady)
         hipLaunchKernelGGL(expand_normal, dim3(grid_for((long)s->nloc)), dim3(256), 0, s->stream, s->d, (long)s->nloc);
 }
 
@@ -1515,7 +1503,7 @@ int bfd_tile_counts(bfd_sim *s, int32_t *nLossless, int32_t *nLossy, int32_t *nS
 int bfd_tile_count_lean(bfd_sim *s, int32_t *nLean)
 {
     int rc = check_ready(s); if (rc) return rc;
-    if (nLean) *nLean = !s->tilesReady ? 0 : (s->d.collapsed ? s->tiles.nLossless + s->tiles.nLossy : s->tiles.nLean);
+    if (nLean) *nLean = !s->tilesReady ? 0 : s->tiles.nLean;
     return 0;
 }
 

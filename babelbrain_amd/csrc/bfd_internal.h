@@ -8,6 +8,13 @@
 
 #define BFD_REFLECTOR_BIT 0x8000u   // bit 15 of the device material id marks a reflector voxel
 #define BFD_MAT_MASK 0x7FFFu
+// class byte of a cell (bfd_dev::cls)
+#define BFD_CLS_FLUID 1u    // fluid centre (cS = 0), no reflector: Sxx == Syy == Szz, only Szz/Rzz is kept
+#define BFD_CLS_NOMEM 2u    // BP == 0 and BS2 == 0: the normal stresses have no memory variable
+#define BFD_CLS_EXY 4u      // the xy / xz / yz shear edge of this cell is updated (centre and the 3 other cells solid)
+#define BFD_CLS_EXZ 8u
+#define BFD_CLS_EYZ 16u
+#define BFD_CLS_REFL 32u    // reflector voxel
 
 // CA, CB of the O(4) staggered first derivative
 #define BFD_CA 1.125f
@@ -30,6 +37,11 @@ struct bfd_dev {
     // state, each (nk+4) planes; pointer addresses local plane 0 (ghost planes at -2,-1,nk,nk+1)
     float *Vx, *Vy, *Vz, *Sxx, *Syy, *Szz, *Sxy, *Sxz, *Syz, *Rxx, *Ryy, *Rzz, *Rxy, *Rxz, *Ryz;
     const uint16_t *mat;   // same ghosting; bit 15 = reflector
+    // per-cell class byte (same ghosting), computed at setup from ids, tables and the reflector mask (BFD_CLS_*).
+    // Invariant of the tiled kernels (variants 0/3/4): at a cell with BFD_CLS_FLUID only Szz/Rzz of the three identical
+    // normal stresses (and memory variables) is maintained -- every reader takes Szz there; a shear stress entry is
+    // read only where its edge bit is set (elsewhere it is never updated and stays exactly 0).
+    const uint8_t *cls;
     // per-material tables
     const float *AP, *BP, *AS2, *BS2, *invMu, *tauS, *invRho;
     float c1, k2;
@@ -40,11 +52,6 @@ struct bfd_dev {
     // stress half-step: 0 dxVx 1 dyVy 2 dzVz 3 dyVx 4 dxVy 5 dzVx 6 dxVz 7 dzVy 8 dyVz
     // velocity half-step: 9 dxSxx 10 dySxy 11 dzSxz 12 dxSxy 13 dySyy 14 dzSyz 15 dxSxz 16 dySyz 17 dzSzz
     float *psi[18];
-    // 1: every tile of the slab is FLUID and only Szz/Rzz of the (identical) normal stresses are kept
-    int collapsed;
-    // slab with solid tiles: per 64x8x8 sub-tile, 1 = LEAN fluid sub-tile (keeps only Szz/Rzz like a collapsed slab:
-    // no solid sub-tile beside it in x or y, the only places its Sxx/Syy would be read from). null = none.
-    const unsigned char *lean;
     int tilesX, tilesY;
     // write targets of the fields that variant 4 keeps in two copies (V, Szz, Rzz); equal to the read pointers in
     // every other variant (in-place update). Kernels read d.X and write d.XW.
@@ -62,9 +69,9 @@ struct bfd_sim;
 // records an event before (end = 0) / after (end = 1) a launch of class cls (bfd_api.hip); t->ktimer != null while class timing is on
 void bfd_kmark(bfd_sim *sim, int cls, int end, hipStream_t st);
 
-struct bfd_tiles { bfd_sim *ktimer; int4 *runs; unsigned short *rowFlags /* per solid run x 32 planes, see stress_normal_solid */;
+struct bfd_tiles { bfd_sim *ktimer; int4 *runs;
                    unsigned *shearCells; float *shearCoef; long nShear, shearLowEnd, shearHighBeg;   /* sparse shear list */
-                   int nFluid, nFluidB, nSolid, nSolidB, nFused /* runs of the fused kernel, after the solid runs */;
+                   int nFluid, nFluidB, nSolid, nSolidB, nSolidBP /* leading boundary runs that touch the absorbing layer */, nSolidIP /* trailing interior ones */, nFused /* runs of the fused kernel, after the solid runs */;
                    int nLossless, nLossy, nSolidSub, nUni, nPml, nLean, nFusedSub; };
 
 struct bfd_sim {
@@ -76,6 +83,7 @@ struct bfd_sim {
     size_t nloc, nalloc;            // owned voxels, allocated voxels per state array
     float *stateBase[15];           // allocation bases
     uint16_t *matBase;
+    uint8_t *clsBase; bool classesReady;
     float *tables;                  // 7*nMat
     float *profiles;                // 4*(N1+N2+N3)
     std::vector<void *> allocs;     // everything to free
@@ -130,7 +138,10 @@ int bfd_tile_subz(void);
 void bfd_launch_classify(const bfd_dev &d, hipStream_t s, int *flagsDev, int *tileMatDev);
 void bfd_launch_mark_solid(const bfd_dev &d, hipStream_t s, unsigned char *flag, long n);
 void bfd_launch_shear_coefficients(const bfd_dev &d, hipStream_t s, const unsigned *cells, float *coef, long n);
-void bfd_launch_classify_rows(const bfd_dev &d, hipStream_t s, const int4 *solidRuns, int nSolid, unsigned short *rowFlags);
+void bfd_launch_cell_classes(const bfd_dev &d, hipStream_t s, uint8_t *clsBase, long nalloc);
+// counts over the cells of the solid runs: [0] fluid no-memory, [1] fluid with memory, [2] solid no-memory, [3] solid with memory,
+// [4] active shear edges, [5] reflector cells
+void bfd_launch_count_solid_cells(const bfd_dev &d, hipStream_t s, const int4 *solidRuns, int nSolid, unsigned long long *counts6);
 int bfd_tile_zchunk(void);
 // part: 0 = every tile, 1 = boundary tiles, 2 = interior tiles (variant 2 lists every tile as solid)
 void bfd_launch_stress_v2(const bfd_dev &d, hipStream_t s, const bfd_tiles *t, int part);

@@ -936,20 +936,27 @@ __global__ __launch_bounds__(NTHREADS, FUSED_WAVES_PER_SIMD) void fused_fluid(bf
 }
 
 // ------------------------------------------------------------------------------------------------
-// SOLID runs in the tiled path (variant 3): normal stresses by a pipelined marching kernel
-// (stress_normal_solid), shear stresses by a sparse per-cell kernel (stress_shear_sparse) over the list of
-// cells with a solid centre. Each kernel is lean (no long dependent chains behind a workgroup barrier),
-// which the monolithic stress_v2 is not. Values equal stress_v2's; CPML memory variables of the cross
-// derivatives are advanced only at listed cells (they feed nothing else).
+// SOLID runs in the tiled path (variant 3): normal stresses by a pipelined marching kernel (stress_solid), shear
+// stresses by a sparse per-cell kernel (stress_shear_sparse) over the list of cells with a solid centre. Each
+// kernel is lean (no long dependent chains behind a workgroup barrier), which the monolithic stress_v2 is not.
+// Values equal stress_v2's; CPML memory variables of the cross derivatives are advanced only at listed cells
+// (they feed nothing else).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NTHREADS, 4) void stress_normal_solid(bfd_dev d, int tilesX, int nblocks,
-                                                                   const int4 *__restrict__ runs,
-                                                                   const unsigned short *__restrict__ rowFlags)
+// ------------------------------------------------------------------------------------------------
+// SOLID runs, class-predicated kernels (variants 0/3/4). A solid run is a 64 x 8 x (8..16) block that has a solid cell
+// within 2 cells, but typically two thirds of its cells are fluid (a thin curved shell cuts through it). Every lane
+// therefore works by the class byte of ITS cell (bfd_dev::cls, computed at setup):
+//   * fluid cell: the three normal stresses are identical -> only Szz/Rzz is read and written (nobody reads Sxx/Syy of a
+//     fluid cell: every reader substitutes Szz there, also across tile borders);
+//   * a shear stress entry is loaded only where its edge bit says it is ever updated (elsewhere it is exactly 0).
+// Loads are per-lane predicated, so only the lines of the cells that need an array are fetched; the arithmetic is the
+// canonical sequence for every lane (zeros / substituted values make it equal to the dense kernels' bit for bit, up
+// to the sign of an exact zero). Class bytes run two planes ahead of the state loads they steer.
+// ------------------------------------------------------------------------------------------------
+template <bool PML>
+__device__ __forceinline__ void stress_solid_body(const bfd_dev &d, const int4 &run, int tilesX, float (*sV)[2][LH * LW])
 {
-    __shared__ float sV[2][2][LH * LW];
     const int N1 = d.N1, N2 = d.N2;
-    const int pos = remap_block(blockIdx.x, nblocks);
-    const int4 run = runs[pos];
     const int bx = run.x % tilesX, by = run.x / tilesX, kbeg = run.y & 0xFFFF, kend = run.y >> 16;
     const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * TX + tx;
     const int i0 = bx * TX, j0 = by * TY;
@@ -959,7 +966,6 @@ __global__ __launch_bounds__(NTHREADS, 4) void stress_normal_solid(bfd_dev d, in
     const int P = d.P;
     const int own = (ty + 2) * LW + tx + 2;
     const unsigned cij = valid ? (unsigned)(j * N1 + i) : 0u;
-    const int wrow = __builtin_amdgcn_readfirstlane(ty);
 
     HaloTask t; t.lofs = -1; t.ok = false; t.arr = 0; t.gofs = 0;
     if (tid < YT) ytask(tid, 1, i0, j0, N1, N2, t);
@@ -969,33 +975,31 @@ __global__ __launch_bounds__(NTHREADS, 4) void stress_normal_solid(bfd_dev d, in
     float *lh = &sV[0][t.arr][has ? t.lofs : 0];
     const float c1 = d.c1;
 
-    const bool zi = valid && (i < P || i >= N1 - P);
-    const bool zj = valid && (j < P || j >= N2 - P);
+    const bool zi = PML && valid && (i < P || i >= N1 - P);
+    const bool zj = PML && valid && (j < P || j >= N2 - P);
     float ax = 0, bxc = 0, ay = 0, byc = 0, px = 0, py = 0, pz = 0;
     unsigned qx = 0, qy = 0;
     const unsigned dqx = (unsigned)(N2 * 2 * P), dqy = (unsigned)(2 * P * N1);
     if (zi) { ax = d.axI[i]; bxc = d.bxI[i]; qx = (unsigned)((kbeg * N2 + j) * (2 * P) + (i < P ? i : i - (N1 - 2 * P))); px = d.psi[0][qx]; }
     if (zj) { ay = d.ayI[j]; byc = d.byI[j]; qy = (unsigned)((kbeg * (2 * P) + (j < P ? j : j - (N2 - 2 * P))) * N1 + i); py = d.psi[1][qy]; }
-    {
+    if (PML) {
         const int kg = d.k0 + kbeg;
         if (valid && (kg < P || kg >= d.N3 - P)) pz = d.psi[2][(unsigned)((kg < P ? kg : kg - (d.N3 - 2 * P)) * d.plane) + cij];
     }
 
-    // row class of a plane: bit0 fluid row (one normal stress is read), bit1 lossless row (no memory variable)
-    auto rowClass = [&](int kl) -> unsigned { return (rowFlags[pos * ZCHUNK + (kl - kbeg)] >> (2 * wrow)) & 3u; };
-
     float vx0 = 0, vy0 = 0, vzm2 = 0, vzm1 = 0, vz0 = 0, vzp1 = 0;
     float sxx = 0, syy = 0, szz = 0, rxx = 0, ryy = 0, rzz = 0;
-    unsigned mraw = 0;
-    unsigned rc = rowClass(kbeg);
+    unsigned mraw = 0, cl = BFD_CLS_FLUID | BFD_CLS_NOMEM, cl1 = BFD_CLS_FLUID | BFD_CLS_NOMEM;
     if (valid) {
         const float *bVz = d.Vz + kbeg * pl;
+        cl = (d.cls + kbeg * pl)[cij]; cl1 = (d.cls + kbeg * pl + pl)[cij];
         vx0 = (d.Vx + kbeg * pl)[cij]; vy0 = (d.Vy + kbeg * pl)[cij];
         vzm2 = (bVz - 2 * pl)[cij]; vzm1 = (bVz - pl)[cij]; vz0 = bVz[cij]; vzp1 = (bVz + pl)[cij];
         mraw = (d.mat + kbeg * pl)[cij];
         szz = (d.Szz + kbeg * pl)[cij];
-        if (!(rc & 2u)) rzz = (d.Rzz + kbeg * pl)[cij];
-        if (!(rc & 1u)) {
+        const bool fl = cl & BFD_CLS_FLUID, mem = !(cl & BFD_CLS_NOMEM) || !fl;
+        if (mem) rzz = (d.Rzz + kbeg * pl)[cij];
+        if (!fl) {
             sxx = (d.Sxx + kbeg * pl)[cij]; syy = (d.Syy + kbeg * pl)[cij];
             rxx = (d.Rxx + kbeg * pl)[cij]; ryy = (d.Ryy + kbeg * pl)[cij];
         }
@@ -1009,20 +1013,22 @@ __global__ __launch_bounds__(NTHREADS, 4) void stress_normal_solid(bfd_dev d, in
         sV[b][0][own] = vx0; sV[b][1][own] = vy0;
         if (has) lh[b * (2 * LH * LW)] = hv;
         const int m = mraw & BFD_MAT_MASK;
+        const bool fl = cl & BFD_CLS_FLUID, mem = !(cl & BFD_CLS_NOMEM) || !fl;
         float AP = 0, BP = 0, AS2 = 0, BS2 = 0;
-        if (valid) { AP = d.AP[m]; BP = d.BP[m]; if (!(rc & 1u)) { AS2 = d.AS2[m]; BS2 = d.BS2[m]; } }
+        if (valid) { AP = d.AP[m]; if (mem) BP = d.BP[m]; if (!fl) { AS2 = d.AS2[m]; BS2 = d.BS2[m]; } }
         __syncthreads();
 
         float nvx = 0, nvy = 0, nvz = 0, nh = 0, nsxx = 0, nsyy = 0, nszz = 0, nrxx = 0, nryy = 0, nrzz = 0, npx = 0, npy = 0, npz = 0;
-        unsigned nmraw = 0, nrc = 3u;
+        unsigned nmraw = 0, ncl2 = BFD_CLS_FLUID | BFD_CLS_NOMEM;
+        if (valid) ncl2 = (d.cls + ko + 2 * pl)[cij];           // ghost planes make kl+2 addressable
         if (kl + 1 < kend) {
-            nrc = rowClass(kl + 1);
             if (valid) {
+                const bool nfl = cl1 & BFD_CLS_FLUID, nmem = !(cl1 & BFD_CLS_NOMEM) || !nfl;
                 nvx = (d.Vx + ko + pl)[cij]; nvy = (d.Vy + ko + pl)[cij]; nvz = (d.Vz + ko + 2 * pl)[cij];
                 nmraw = (d.mat + ko + pl)[cij];
                 nszz = (d.Szz + ko + pl)[cij];
-                if (!(nrc & 2u)) nrzz = (d.Rzz + ko + pl)[cij];
-                if (!(nrc & 1u)) {
+                if (nmem) nrzz = (d.Rzz + ko + pl)[cij];
+                if (!nfl) {
                     nsxx = (d.Sxx + ko + pl)[cij]; nsyy = (d.Syy + ko + pl)[cij];
                     nrxx = (d.Rxx + ko + pl)[cij]; nryy = (d.Ryy + ko + pl)[cij];
                 }
@@ -1031,14 +1037,14 @@ __global__ __launch_bounds__(NTHREADS, 4) void stress_normal_solid(bfd_dev d, in
             if (zi) npx = d.psi[0][qx + dqx];
             if (zj) npy = d.psi[1][qy + dqy];
             const int kn = k + 1;
-            if (valid && (kn < P || kn >= d.N3 - P)) npz = d.psi[2][(unsigned)((kn < P ? kn : kn - (d.N3 - 2 * P)) * d.plane) + cij];
+            if (PML && valid && (kn < P || kn >= d.N3 - P)) npz = d.psi[2][(unsigned)((kn < P ? kn : kn - (d.N3 - 2 * P)) * d.plane) + cij];
         }
         if (valid) {
             const float *sx = &sV[b][0][own], *sy = &sV[b][1][own];
             float dxVx = dminus4(sx[-2], sx[-1], vx0, sx[1]);
             float dyVy = dminus4(sy[-2 * LW], sy[-LW], vy0, sy[LW]);
             float dzVz = dminus4(vzm2, vzm1, vz0, vzp1);
-            if (mraw & BFD_REFLECTOR_BIT) {
+            if (cl & BFD_CLS_REFL) {
                 (d.Sxx + ko)[cij] = 0.f; (d.Syy + ko)[cij] = 0.f; (d.SzzW + ko)[cij] = 0.f;
                 (d.Rxx + ko)[cij] = 0.f; (d.Ryy + ko)[cij] = 0.f; (d.RzzW + ko)[cij] = 0.f;
                 (d.Sxy + ko)[cij] = 0.f; (d.Sxz + ko)[cij] = 0.f; (d.Syz + ko)[cij] = 0.f;
@@ -1046,22 +1052,22 @@ __global__ __launch_bounds__(NTHREADS, 4) void stress_normal_solid(bfd_dev d, in
             } else {
                 if (zi) { const float pn = bxc * px + ax * dxVx; d.psi[0][qx] = pn; dxVx = dxVx + pn; }
                 if (zj) { const float pn = byc * py + ay * dyVy; d.psi[1][qy] = pn; dyVy = dyVy + pn; }
-                if (k < P || k >= d.N3 - P) {
+                if (PML && (k < P || k >= d.N3 - P)) {
                     const float pn = d.bzI[k] * pz + d.azI[k] * dzVz;
                     d.psi[2][(unsigned)((k < P ? k : k - (d.N3 - 2 * P)) * d.plane) + cij] = pn;
                     dzVz = dzVz + pn;
                 }
                 const float sXY = dxVx + dyVy;
                 const float div = sXY + dzVz;
-                if (rc & 1u) {          // fluid row: the three normal stresses are identical
+                if (fl) {               // fluid cell: one copy of the identical normal stresses
                     float val;
-                    if (rc & 2u) val = szz + AP * div;
+                    if (!mem) val = szz + AP * div;
                     else {
                         const float rn = c1 * rzz - BP * div;
                         val = szz + (AP * div + 0.5f * (rzz + rn));
-                        (d.Rxx + ko)[cij] = rn; (d.Ryy + ko)[cij] = rn; (d.RzzW + ko)[cij] = rn;
+                        (d.RzzW + ko)[cij] = rn;
                     }
-                    (d.Sxx + ko)[cij] = val; (d.Syy + ko)[cij] = val; (d.SzzW + ko)[cij] = val;
+                    (d.SzzW + ko)[cij] = val;
                 } else {
                     const float sYZ = dyVy + dzVz, sXZ = dxVx + dzVz;
                     float rn;
@@ -1076,9 +1082,281 @@ __global__ __launch_bounds__(NTHREADS, 4) void stress_normal_solid(bfd_dev d, in
         }
         vx0 = nvx; vy0 = nvy;
         vzm2 = vzm1; vzm1 = vz0; vz0 = vzp1; vzp1 = nvz;
-        hv = nh; mraw = nmraw; rc = nrc;
+        hv = nh; mraw = nmraw; cl = cl1; cl1 = ncl2;
         sxx = nsxx; syy = nsyy; szz = nszz; rxx = nrxx; ryy = nryy; rzz = nrzz;
         px = npx; py = npy; pz = npz; qx += dqx; qy += dqy;
+    }
+}
+
+__global__ __launch_bounds__(NTHREADS, 4) void stress_solid(bfd_dev d, int tilesX, int nblocks, const int4 *__restrict__ runs)
+{
+    __shared__ float sV[2][2][LH * LW];
+    const int4 run = runs[remap_block(blockIdx.x, nblocks)];
+    if (run.z & 8) stress_solid_body<true>(d, run, tilesX, sV);
+    else stress_solid_body<false>(d, run, tilesX, sV);
+}
+
+// one halo value of the solid velocity kernel: SUBST (Sxx / Syy halos): Szz where the halo cell is fluid; otherwise a
+// shear array, loaded only where its edge bit is set. base / alt are wave-uniform (SGPR) plane bases.
+__device__ __forceinline__ float halo_value(const float *__restrict__ base, const float *__restrict__ alt, bool subst, unsigned bit,
+                                            unsigned hc, unsigned off)
+{
+    if (subst) return ((hc & BFD_CLS_FLUID) ? alt : base)[off];
+    return (hc & bit) ? base[off] : 0.0f;
+}
+
+// LDS set: 0 Sxx (x halo), 1 Syy (y halo), 2 Sxy (x and y halo), 3 Sxz (x halo), 4 Syz (y halo)
+// PML: the run touches an absorbing-layer zone (otherwise no CPML code, pointers or registers)
+template <bool ACC, bool PML>
+__device__ __forceinline__ void velocity_solid_body(const bfd_dev &d, const int4 &run, int tilesX, float (*sS)[5][LH * LW],
+                                                    float *__restrict__ accP, float *__restrict__ pkP)
+{
+    const int N1 = d.N1, N2 = d.N2;
+    const int bx = run.x % tilesX, by = run.x / tilesX;
+    const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * TX + tx;
+    const int wv = __builtin_amdgcn_readfirstlane(ty);      // wave index = tile row (uniform)
+    const int i0 = bx * TX, j0 = by * TY;
+    const int i = i0 + tx, j = j0 + ty;
+    const bool valid = (i < N1) && (j < N2);
+    const long pl = d.plane;
+    const int kbeg = run.y & 0xFFFF, kend = run.y >> 16;
+    const int P = d.P;
+    const int own = (ty + 2) * LW + tx + 2;
+    const unsigned cij = valid ? (unsigned)(j * N1 + i) : 0u;
+    const unsigned cx = valid ? (unsigned)(j * N1 + min(i + 1, N1 - 1)) : 0u;      // (i+1, j)
+    const unsigned cy = valid ? (unsigned)(min(j + 1, N2 - 1) * N1 + i) : 0u;      // (i, j+1)
+    const bool accA = ACC && accP != nullptr, accK = ACC && pkP != nullptr;
+
+    // halo tasks, the array of a task is uniform per wave (its plane base stays in SGPRs):
+    //   A: waves 0-3 the 4 halo rows of Syy, waves 4-7 those of Sxy
+    //   B: waves 0-3 the 4 halo rows of Syz; lanes 0..31 of wave 4 / 5 / 6 the halo columns of Sxx / Sxy / Sxz
+    HaloTask ta, tb;
+    const int arrA = wv < 4 ? 1 : 2;
+    ytask(tid & 255, arrA, i0, j0, N1, N2, ta);
+    const int arrB = wv < 4 ? 4 : (wv == 4 ? 0 : (wv == 5 ? 2 : 3));
+    if (wv < 4) ytask(tid, 4, i0, j0, N1, N2, tb);
+    else if (wv < 7 && tx < XT) xtask(tx, arrB, i0, j0, N1, N2, tb);
+    else { tb.lofs = -1; tb.ok = false; tb.arr = arrB; tb.gofs = 0; }
+    const float *baseA = arrA == 1 ? d.Syy : d.Sxy;
+    const float *baseB = arrB == 4 ? d.Syz : (arrB == 0 ? d.Sxx : (arrB == 2 ? d.Sxy : d.Sxz));
+    const bool substA = arrA == 1, substB = arrB == 0;
+    const unsigned bitA = BFD_CLS_EXY, bitB = arrB == 4 ? BFD_CLS_EYZ : (arrB == 2 ? BFD_CLS_EXY : BFD_CLS_EXZ);
+    const unsigned offA = ta.ok ? (unsigned)ta.gofs : 0u, offB = tb.ok ? (unsigned)tb.gofs : 0u;
+    float *la = &sS[0][ta.arr][ta.lofs];
+    float *lb = &sS[0][tb.arr][tb.lofs < 0 ? 0 : tb.lofs];
+    const bool hasB = tb.lofs >= 0;
+    const int bufStride = 5 * LH * LW;
+
+    const bool zi = PML && valid && (i < P || i >= N1 - P);
+    const bool zj = PML && valid && (j < P || j >= N2 - P);
+    const bool inner = valid && i >= d.ND && i < N1 - d.ND && j >= d.ND && j < N2 - d.ND;
+
+    // z queues: Szz k-1..k+2 ; Sxz, Syz k-2..k+1 ; in-plane arrays one plane ahead. Class bytes of the own column:
+    // cB = plane kl+1, cC = plane kl+2 (they steer the loads of the coming iterations)
+    float zzm1 = 0, zz0 = 0, zzp1 = 0, zzp2 = 0, xzm2 = 0, xzm1 = 0, xz0 = 0, xzp1 = 0, yzm2 = 0, yzm1 = 0, yz0 = 0, yzp1 = 0;
+    unsigned cB = BFD_CLS_FLUID, cC = BFD_CLS_FLUID;
+    {
+    float sxx = 0, syy = 0, sxy = 0;
+    if (valid) {
+        const float *bzz = d.Szz + kbeg * pl, *bxz = d.Sxz + kbeg * pl, *byz = d.Syz + kbeg * pl;
+        const uint8_t *bc = d.cls + kbeg * pl;
+        const unsigned cm2 = (bc - 2 * pl)[cij], cm1 = (bc - pl)[cij], c0 = bc[cij];
+        cB = (bc + pl)[cij]; cC = (bc + 2 * pl)[cij];
+        zzm1 = (bzz - pl)[cij]; zz0 = bzz[cij]; zzp1 = (bzz + pl)[cij]; zzp2 = (bzz + 2 * pl)[cij];
+        if (cm2 & BFD_CLS_EXZ) xzm2 = (bxz - 2 * pl)[cij];
+        if (cm1 & BFD_CLS_EXZ) xzm1 = (bxz - pl)[cij];
+        if (c0 & BFD_CLS_EXZ) xz0 = bxz[cij];
+        if (cB & BFD_CLS_EXZ) xzp1 = (bxz + pl)[cij];
+        if (cm2 & BFD_CLS_EYZ) yzm2 = (byz - 2 * pl)[cij];
+        if (cm1 & BFD_CLS_EYZ) yzm1 = (byz - pl)[cij];
+        if (c0 & BFD_CLS_EYZ) yz0 = byz[cij];
+        if (cB & BFD_CLS_EYZ) yzp1 = (byz + pl)[cij];
+        if (c0 & BFD_CLS_FLUID) { sxx = zz0; syy = zz0; }
+        else { sxx = (d.Sxx + kbeg * pl)[cij]; syy = (d.Syy + kbeg * pl)[cij]; }
+        if (c0 & BFD_CLS_EXY) sxy = (d.Sxy + kbeg * pl)[cij];
+    }
+    // the values of a plane are staged in LDS at the end of the iteration before it (here: plane kbeg into buffer kbeg & 1)
+    const int bo0 = (kbeg & 1) * bufStride;
+    sS[0][0][bo0 + own] = sxx; sS[0][1][bo0 + own] = syy; sS[0][2][bo0 + own] = sxy; sS[0][3][bo0 + own] = xz0; sS[0][4][bo0 + own] = yz0;
+    }
+    // V and the accumulators are loaded in the iteration that uses them (their latency hides behind the barrier and the
+    // other waves; prefetching them one plane ahead costs 5 registers this kernel does not have)
+    float r0 = 0;
+    unsigned mraw = 0, mraw1 = 0, mx = 0, my = 0;
+    if (valid) {
+        const uint16_t *bM = d.mat + kbeg * pl;
+        mraw = bM[cij]; mraw1 = (bM + pl)[cij]; mx = bM[cx]; my = bM[cy];
+        r0 = d.invRho[mraw & BFD_MAT_MASK];
+    }
+    // halo values of plane kbeg and the class bytes of the halo cells one plane ahead
+    unsigned hcA = 0, hcB = 0;
+    {
+        float ha = 0.f, hb = 0.f;
+        if (ta.ok) { ha = halo_value(baseA + kbeg * pl, d.Szz + kbeg * pl, substA, bitA, (d.cls + kbeg * pl)[offA], offA); hcA = (d.cls + kbeg * pl + pl)[offA]; }
+        if (tb.ok) { hb = halo_value(baseB + kbeg * pl, d.Szz + kbeg * pl, substB, bitB, (d.cls + kbeg * pl)[offB], offB); hcB = (d.cls + kbeg * pl + pl)[offB]; }
+        la[(kbeg & 1) * bufStride] = ha;
+        if (hasB) lb[(kbeg & 1) * bufStride] = hb;
+    }
+
+    for (int kl = kbeg; kl < kend; kl++) {
+        const int b = kl & 1;
+        const long ko = (long)kl * pl;
+        const int k = d.k0 + kl;
+        const int bn = (b ^ 1) * bufStride;     // buffer of plane kl+1 (free: every thread is past the barrier of iteration kl-1's reads)
+        float r1 = 0, rx = 0, ry = 0, vx = 0, vy = 0, vz = 0, av = 0, pv = 0;
+        if (valid) {
+            r1 = d.invRho[mraw1 & BFD_MAT_MASK];       // plane kl+1, becomes r0 of the next iteration
+            rx = d.invRho[mx & BFD_MAT_MASK];
+            ry = d.invRho[my & BFD_MAT_MASK];
+            vx = (d.Vx + ko)[cij]; vy = (d.Vy + ko)[cij]; vz = (d.Vz + ko)[cij];
+            if (accA) av = (accP + ko)[cij];
+            if (accK) pv = (pkP + ko)[cij];
+        }
+        __syncthreads();
+
+        float *wVx = d.VxW + ko, *wVy = d.VyW + ko, *wVz = d.VzW + ko;
+        float nzz = 0, nxz = 0, nyz = 0, nxx = 0, nyy = 0, nxy = 0, nha = 0, nhb = 0;
+        unsigned nm2 = 0, nmx = 0, nmy = 0, nc3 = BFD_CLS_FLUID, nhcA = 0, nhcB = 0;
+        if (valid) { nm2 = (d.mat + ko + 2 * pl)[cij]; nc3 = (d.cls + ko + 3 * pl)[cij]; }       // kl+3 <= nk+1: ghost planes exist
+        if (kl + 1 < kend) {
+            if (valid) {
+                nzz = (d.Szz + ko + 3 * pl)[cij];
+                if (cC & BFD_CLS_EXZ) nxz = (d.Sxz + ko + 2 * pl)[cij];
+                if (cC & BFD_CLS_EYZ) nyz = (d.Syz + ko + 2 * pl)[cij];
+                if (cB & BFD_CLS_FLUID) { nxx = zzp1; nyy = zzp1; }
+                else { nxx = (d.Sxx + ko + pl)[cij]; nyy = (d.Syy + ko + pl)[cij]; }
+                if (cB & BFD_CLS_EXY) nxy = (d.Sxy + ko + pl)[cij];
+                nmx = (d.mat + ko + pl)[cx]; nmy = (d.mat + ko + pl)[cy];
+            }
+            if (ta.ok) { nha = halo_value(baseA + ko + pl, d.Szz + ko + pl, substA, bitA, hcA, offA); nhcA = (d.cls + ko + 2 * pl)[offA]; }
+            if (tb.ok) { nhb = halo_value(baseB + ko + pl, d.Szz + ko + pl, substB, bitB, hcB, offB); nhcB = (d.cls + ko + 2 * pl)[offB]; }
+        }
+
+        if (valid) {
+            const float sxx = sS[b][0][own], syy = sS[b][1][own], sxy = sS[b][2][own];
+            if (ACC) {
+                if (inner && k >= d.ND && k < d.N3 - d.ND) {
+                    const float s = (sxx + syy) + zz0;
+                    const float p = -s * (1.0f / 3.0f);
+                    if (accA) (accP + ko)[cij] = av + p * p;
+                    if (accK) { const float ap = fabsf(p); if (ap > pv) (pkP + ko)[cij] = ap; }
+                }
+            }
+            if (mraw & BFD_REFLECTOR_BIT) {
+                wVx[cij] = 0.f; wVy[cij] = 0.f; wVz[cij] = 0.f;
+            } else {
+                const float *pxx = &sS[b][0][own], *pyy = &sS[b][1][own], *pxy = &sS[b][2][own];
+                const float *pxz = &sS[b][3][own], *pyz = &sS[b][4][own];
+                float dxSxx = dplus4(pxx[-1], sxx, pxx[1], pxx[2]);
+                float dySxy = dminus4(pxy[-2 * LW], pxy[-LW], sxy, pxy[LW]);
+                float dzSxz = dminus4(xzm2, xzm1, xz0, xzp1);
+                float dxSxy = dminus4(pxy[-2], pxy[-1], sxy, pxy[1]);
+                float dySyy = dplus4(pyy[-LW], syy, pyy[LW], pyy[2 * LW]);
+                float dzSyz = dminus4(yzm2, yzm1, yz0, yzp1);
+                float dxSxz = dminus4(pxz[-2], pxz[-1], xz0, pxz[1]);
+                float dySyz = dminus4(pyz[-2 * LW], pyz[-LW], yz0, pyz[LW]);
+                float dzSzz = dplus4(zzm1, zz0, zzp1, zzp2);
+                if (zi) {
+                    const int xi = i < P ? i : i - (N1 - 2 * P);
+                    const unsigned q = (unsigned)((kl * N2 + j) * (2 * P) + xi);
+                    dxSxx = cpml(d.psi[9], q, d.axH[i], d.bxH[i], dxSxx);
+                    dxSxy = cpml(d.psi[12], q, d.axI[i], d.bxI[i], dxSxy);
+                    dxSxz = cpml(d.psi[15], q, d.axI[i], d.bxI[i], dxSxz);
+                }
+                if (zj) {
+                    const int yj = j < P ? j : j - (N2 - 2 * P);
+                    const unsigned q = (unsigned)((kl * (2 * P) + yj) * N1 + i);
+                    dySxy = cpml(d.psi[10], q, d.ayI[j], d.byI[j], dySxy);
+                    dySyy = cpml(d.psi[13], q, d.ayH[j], d.byH[j], dySyy);
+                    dySyz = cpml(d.psi[16], q, d.ayI[j], d.byI[j], dySyz);
+                }
+                if (PML && (k < P || k >= d.N3 - P)) {
+                    const int zk = k < P ? k : k - (d.N3 - 2 * P);
+                    const unsigned q = (unsigned)(zk * d.plane) + cij;
+                    dzSxz = cpml(d.psi[11], q, d.azI[k], d.bzI[k], dzSxz);
+                    dzSyz = cpml(d.psi[14], q, d.azI[k], d.bzI[k], dzSyz);
+                    dzSzz = cpml(d.psi[17], q, d.azH[k], d.bzH[k], dzSzz);
+                }
+                const float bxv = 0.5f * (r0 + rx), byv = 0.5f * (r0 + ry), bzv = 0.5f * (r0 + r1);
+                wVx[cij] = vx + bxv * ((dxSxx + dySxy) + dzSxz);
+                wVy[cij] = vy + byv * ((dxSxy + dySyy) + dzSyz);
+                wVz[cij] = vz + bzv * ((dxSxz + dySyz) + dzSzz);
+            }
+        }
+        zzm1 = zz0; zz0 = zzp1; zzp1 = zzp2; zzp2 = nzz;
+        xzm2 = xzm1; xzm1 = xz0; xz0 = xzp1; xzp1 = nxz;
+        yzm2 = yzm1; yzm1 = yz0; yz0 = yzp1; yzp1 = nyz;
+        // stage plane kl+1 (the loads were issued before this plane's arithmetic)
+        sS[0][0][bn + own] = nxx; sS[0][1][bn + own] = nyy; sS[0][2][bn + own] = nxy; sS[0][3][bn + own] = xz0; sS[0][4][bn + own] = yz0;
+        la[bn] = nha;
+        if (hasB) lb[bn] = nhb;
+        hcA = nhcA; hcB = nhcB;
+        r0 = r1; mraw = mraw1; mraw1 = nm2; mx = nmx; my = nmy;
+        cB = cC; cC = nc3;
+    }
+}
+
+// two kernels (the absorbing-layer flavour needs ~18 registers more and would spill inside a common one); the solid run
+// list keeps the runs that touch the layer at its two ends (bfd_tiles::nSolidBP / nSolidIP)
+template <bool ACC, bool PML>
+__global__ __launch_bounds__(NTHREADS, VELOCITY_WAVES_PER_SIMD) void velocity_solid(bfd_dev d, int tilesX, int nblocks,
+                                                        float *__restrict__ accP, float *__restrict__ pkP,
+                                                        const int4 *__restrict__ runs)
+{
+    __shared__ float sS[2][5][LH * LW];
+    const int4 run = runs[remap_block(blockIdx.x, nblocks)];
+    velocity_solid_body<ACC, PML>(d, run, tilesX, sS, accP, pkP);
+}
+
+// setup: class byte of every allocated cell (local planes -2 .. nk+1). base pointers address allocation plane 0.
+__global__ void cell_classes(bfd_dev d, const uint16_t *__restrict__ matBase, uint8_t *__restrict__ clsBase, long nalloc, int nplanes)
+{
+    const int N1 = d.N1, N2 = d.N2;
+    const long pl = d.plane;
+    for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < nalloc; v += (long)gridDim.x * blockDim.x) {
+        const int kk = (int)(v / pl);
+        const int r = (int)(v - (long)kk * pl);
+        const int j = r / N1, i = r - j * N1;
+        const unsigned raw = matBase[v];
+        const int m = raw & BFD_MAT_MASK;
+        const bool refl = raw & BFD_REFLECTOR_BIT;
+        const float iv0 = d.invMu[m];
+        unsigned c = 0;
+        if (refl) c |= BFD_CLS_REFL;
+        else if (!(iv0 > 0.f)) c |= BFD_CLS_FLUID;
+        if (d.BP[m] == 0.f && d.BS2[m] == 0.f) c |= BFD_CLS_NOMEM;
+        if (!refl && iv0 > 0.f) {
+            const int i1 = min(i + 1, N1 - 1), j1 = min(j + 1, N2 - 1), k1 = min(kk + 1, nplanes - 1);
+            const long r0 = (long)kk * pl + (long)j * N1, r1 = (long)kk * pl + (long)j1 * N1;
+            const long z0 = (long)k1 * pl + (long)j * N1, z1 = (long)k1 * pl + (long)j1 * N1;
+            const bool sx = d.invMu[matBase[r0 + i1] & BFD_MAT_MASK] > 0.f, sy = d.invMu[matBase[r1 + i] & BFD_MAT_MASK] > 0.f;
+            const bool sz = d.invMu[matBase[z0 + i] & BFD_MAT_MASK] > 0.f;
+            if (sx && sy && d.invMu[matBase[r1 + i1] & BFD_MAT_MASK] > 0.f) c |= BFD_CLS_EXY;
+            if (sx && sz && d.invMu[matBase[z0 + i1] & BFD_MAT_MASK] > 0.f) c |= BFD_CLS_EXZ;
+            if (sy && sz && d.invMu[matBase[z1 + i] & BFD_MAT_MASK] > 0.f) c |= BFD_CLS_EYZ;
+        }
+        clsBase[v] = (uint8_t)c;
+    }
+}
+
+// class counts over the cells of the solid runs (byte accounting): one workgroup per run
+__global__ __launch_bounds__(NTHREADS) void count_solid_cells(bfd_dev d, int tilesX, const int4 *__restrict__ runs, unsigned long long *__restrict__ out)
+{
+    const int4 run = runs[blockIdx.x];
+    const int bx = run.x % tilesX, by = run.x / tilesX, kbeg = run.y & 0xFFFF, kend = run.y >> 16;
+    const int i = bx * TX + threadIdx.x, j = by * TY + threadIdx.y;
+    unsigned n[6] = {0, 0, 0, 0, 0, 0};
+    if (i < d.N1 && j < d.N2)
+        for (int kl = kbeg; kl < kend; kl++) {
+            const unsigned c = d.cls[(long)kl * d.plane + (long)j * d.N1 + i];
+            if (c & BFD_CLS_REFL) n[5]++;
+            else n[((c & BFD_CLS_FLUID) ? 0 : 2) + ((c & BFD_CLS_NOMEM) && (c & BFD_CLS_FLUID) ? 0 : 1)]++;
+            n[4] += ((c & BFD_CLS_EXY) ? 1 : 0) + ((c & BFD_CLS_EXZ) ? 1 : 0) + ((c & BFD_CLS_EYZ) ? 1 : 0);
+        }
+    for (int q = 0; q < 6; q++) {
+        unsigned v = n[q];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+        if (threadIdx.x == 0 && v) atomicAdd(&out[q], (unsigned long long)v);
     }
 }
 
@@ -1245,33 +1523,6 @@ __global__ __launch_bounds__(NTHREADS, FLUID_WAVES_PER_SIMD) void velocity_fluid
     }
 }
 
-// one workgroup (64 x 8) per solid run: 2 bits per row and plane for stress_v2 (see there)
-__global__ __launch_bounds__(NTHREADS) void classify_rows(bfd_dev d, int tilesX, const int4 *__restrict__ runs,
-                                                          unsigned short *__restrict__ rowFlags)
-{
-    __shared__ unsigned bits;
-    const int4 run = runs[blockIdx.x];
-    const int bx = run.x % tilesX, by = run.x / tilesX, kbeg = run.y & 0xFFFF, kend = run.y >> 16;
-    const int i = bx * TX + threadIdx.x, j = by * TY + threadIdx.y;
-    const bool valid = i < d.N1 && j < d.N2;
-    for (int kl = kbeg; kl < kend; kl++) {
-        if (threadIdx.x == 0 && threadIdx.y == 0) bits = 0u;
-        __syncthreads();
-        bool solidish = false, lossy = false;
-        if (valid) {
-            const unsigned raw = d.mat[(long)kl * d.plane + (long)j * d.N1 + i];
-            const int m = raw & BFD_MAT_MASK;
-            solidish = (raw & BFD_REFLECTOR_BIT) || d.invMu[m] > 0.f;
-            lossy = d.BP[m] != 0.f;
-        }
-        const bool rowFluid = __ballot(solidish) == 0ull, rowLossless = rowFluid && __ballot(lossy) == 0ull;
-        if (threadIdx.x == 0) atomicOr(&bits, ((rowFluid ? 1u : 0u) | (rowLossless ? 2u : 0u)) << (2 * threadIdx.y));
-        __syncthreads();
-        if (threadIdx.x == 0 && threadIdx.y == 0) rowFlags[blockIdx.x * ZCHUNK + (kl - kbeg)] = (unsigned short)bits;
-        __syncthreads();
-    }
-}
-
 // one workgroup per 64 x 8 x SUBZ sub-tile. flags: bit0 = a solid cell within the sub-tile grown by 2 cells;
 // bit1 = a cell of the sub-tile relaxes (BP != 0); bit2 = UNI: one material and no reflector in the grown
 // region; bit3 = PML: a cell of the sub-tile lies inside an absorbing-layer zone. mat = id at its first cell.
@@ -1320,9 +1571,14 @@ void bfd_tile_grid(const bfd_dev &d, int *tilesX, int *tilesY, int *subZ)
 int bfd_tile_zchunk(void) { return ZCHUNK; }
 int bfd_tile_subz(void) { return SUBZ; }
 
-void bfd_launch_classify_rows(const bfd_dev &d, hipStream_t s, const int4 *solidRuns, int nSolid, unsigned short *rowFlags)
+void bfd_launch_cell_classes(const bfd_dev &d, hipStream_t s, uint8_t *clsBase, long nalloc)
 {
-    if (nSolid) hipLaunchKernelGGL(classify_rows, dim3(nSolid), dim3(TX, TY, 1), 0, s, d, (d.N1 + TX - 1) / TX, solidRuns, rowFlags);
+    const uint16_t *matBase = d.mat - 2 * (long)d.plane;
+    hipLaunchKernelGGL(cell_classes, dim3((unsigned)std::min<long>((nalloc + 255) / 256, 16384)), dim3(256), 0, s, d, matBase, clsBase, nalloc, d.nk + 4);
+}
+void bfd_launch_count_solid_cells(const bfd_dev &d, hipStream_t s, const int4 *solidRuns, int nSolid, unsigned long long *counts6)
+{
+    if (nSolid) hipLaunchKernelGGL(count_solid_cells, dim3(nSolid), dim3(TX, TY, 1), 0, s, d, (d.N1 + TX - 1) / TX, solidRuns, counts6);
 }
 
 void bfd_launch_mark_solid(const bfd_dev &d, hipStream_t s, unsigned char *flag, long n)
@@ -1360,17 +1616,14 @@ void bfd_launch_stress_v2(const bfd_dev &d, hipStream_t s, const bfd_tiles *t, i
     part_range(t->nFluid, t->nFluidB, part, &off, &n);
     if (n) {
         BFD_KT(BFD_K_STRESS_FLUID, 0);
-        if (d.collapsed) BFD_LAUNCH((stress_fluid<true>), n, t->runs + off);
-        else BFD_LAUNCH((stress_fluid<false>), n, t->runs + off);
+        BFD_LAUNCH((stress_fluid<true>), n, t->runs + off);      // fluid cells keep one copy of their normal stresses (bfd_dev::cls)
         BFD_KT(BFD_K_STRESS_FLUID, 1);
     }
     part_range(t->nSolid, t->nSolidB, part, &off, &n);
     if (n) {
         BFD_KT(BFD_K_STRESS_SOLID, 0);
-        if (t->shearCells || !t->rowFlags) {
-            if (t->rowFlags) BFD_LAUNCH(stress_normal_solid, n, t->runs + t->nFluid + off, t->rowFlags + (size_t)off * ZCHUNK);
-            else BFD_LAUNCH(stress_v2, n, t->runs + t->nFluid + off, (const unsigned short *)nullptr);     // variant 2: monolithic
-        } else BFD_LAUNCH(stress_v2, n, t->runs + t->nFluid + off, t->rowFlags + (size_t)off * ZCHUNK);
+        if (t->shearCells) BFD_LAUNCH(stress_solid, n, t->runs + t->nFluid + off);
+        else BFD_LAUNCH(stress_v2, n, t->runs + t->nFluid + off, (const unsigned short *)nullptr);     // variant 2: monolithic, dense
         BFD_KT(BFD_K_STRESS_SOLID, 1);
     }
     if (t->shearCells && t->nShear) {     // sparse shear: cells sorted by index; [0,lowEnd) and [highBeg,n) are the boundary chunks
@@ -1412,8 +1665,24 @@ void bfd_launch_velocity_v2(const bfd_dev &d, hipStream_t s, float *accP, float 
     part_range(t->nSolid, t->nSolidB, part, &off, &n);
     if (n) {
         BFD_KT(BFD_K_VELOCITY_SOLID, 0);
-        if (acc) BFD_LAUNCH((velocity_v2<true>), n, accP, pkP, t->runs + t->nFluid + off);
-        else BFD_LAUNCH((velocity_v2<false>), n, accP, pkP, t->runs + t->nFluid + off);
+        if (t->shearCells) {
+            // solid list = [boundary: PML | plain][interior: plain | PML]: the plain runs of the requested part are contiguous
+            const int4 *base = t->runs + t->nFluid;
+            int pb = 0, pe = 0, qb = 0, qe = 0;                 // PML pieces [pb,pe) and [qb,qe); plain piece between / around
+            if (part != 2) { pb = 0; pe = t->nSolidBP; }
+            if (part != 1) { qb = t->nSolid - t->nSolidIP; qe = t->nSolid; }
+            const int nb = part == 2 ? t->nSolidB : t->nSolidBP, ne = part == 1 ? t->nSolidB : t->nSolid - t->nSolidIP;
+            auto go = [&](bool pml, int a0, int a1) {
+                const int cnt = a1 - a0;
+                if (cnt <= 0) return;
+                if (pml) { if (acc) BFD_LAUNCH((velocity_solid<true, true>), cnt, accP, pkP, base + a0); else BFD_LAUNCH((velocity_solid<false, true>), cnt, accP, pkP, base + a0); }
+                else { if (acc) BFD_LAUNCH((velocity_solid<true, false>), cnt, accP, pkP, base + a0); else BFD_LAUNCH((velocity_solid<false, false>), cnt, accP, pkP, base + a0); }
+            };
+            go(false, nb, ne); go(true, pb, pe); go(true, qb, qe);
+        } else {                                                     // variant 2: dense
+            if (acc) BFD_LAUNCH((velocity_v2<true>), n, accP, pkP, t->runs + t->nFluid + off);
+            else BFD_LAUNCH((velocity_v2<false>), n, accP, pkP, t->runs + t->nFluid + off);
+        }
         BFD_KT(BFD_K_VELOCITY_SOLID, 1);
     }
 }

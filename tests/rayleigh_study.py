@@ -1,0 +1,137 @@
+"""Re-creation of the reference's own acceptance study of its solver (test infrastructure).
+
+/root/reference/OfflineBatchExamples/CompareRayleightWithFDTD compares, for 309 water-only cases, the field of
+"Rayleigh source plane + BabelViscoFDTD" with the Rayleigh integral alone, and stores per-case metrics in
+SummaryAnalysis.xlsx (parsed into tests/golden/rayleigh_study.json by tests/golden/make_rayleigh_study.py). Those are the
+only numbers in the reference tree that its solver produced. This module rebuilds the Single-transducer cases the way
+the reference's driver builds them and computes the notebook's metrics, so the engine can be held to the workbook row by
+row:
+
+  * domain, PART_1 cell 8 + BASE:1853-2068 (bTightNarrowBeamDomain): laterally the voxels within RadiusFace = 1.1 * Aperture/2
+    of the axis, axially from the source plane to zLengthBeyonFocalPointWhenNarrow = 80 mm past the target, 12-cell
+    absorbing layer around; water only (bWaterOnly: the material list is [Water], BASE:1306-1377);
+  * time step: CalculateMatricesForPropagation(AlphaCFL = 0.5) snapped by the PPP rule (BASE:1799-1828); duration and
+    sensor window from BASE:2082-2109;
+  * source: Rayleigh integral of the bowl on the plane k = 12 (Single:250-304), sources per Single:313-346; the rim of
+    the bowl sits in the source plane for ZAdj = 0 and 10 mm above it for ZAdj = -10 (PART_1 cell 8: TxMechanicalAdjustmentZ);
+  * result: RMS map * sqrt(2) * dispersion Correction (BASE:2433-2440), zeroed up to the source plane, cropped like the
+    `_Sub` volumes (BASE:1459-1512); metrics of PART_2 cell 5 (`qcheck`).
+
+What the reference tree does not tell is the depth of the study's target under the top of its mask (it comes from a
+patient dataset); it only sets how far the domain extends in z (target depth + 80 mm). DEPTH_TARGET is an assumption.
+"""
+import numpy as np
+from scipy import ndimage
+
+from babelbrain_amd import harness as H
+
+DEPTH_TARGET = 65e-3          # assumed distance source plane -> target voxel (unknown, see above)
+Z_BEYOND = 80e-3              # zLengthBeyonFocalPointWhenNarrow of the Single runs (PART_1 cell 12)
+C_WATER = 1500.0              # Material['Water'][1]
+
+
+def build_case(freq, ppw, focal, diam, zadj, stable_dt_fn, forward, depth_target=DEPTH_TARGET):
+    """-> dict with the solver arguments of one Single-Tx water case and the Rayleigh field on the whole domain."""
+    pml = H.PML_THICKNESS
+    h = H.SSOS_AT_WATER_DENSITY / freq / ppw                       # GetSmallestSOS(f, bShear=True) is its floor at every study frequency
+    water = np.array([H.MATERIALS[500e3]['Water']], np.float64)
+    dt_ideal = stable_dt_fn(water, freq, h, H.ALPHA_CFL)
+    dt_water = stable_dt_fn(water, freq, h, 1.0)
+    ppp, dt = H.ppp_rule(dt_ideal, freq)
+    dout = np.sqrt(focal ** 2 - (diam / 2) ** 2)
+    if zadj > 0:
+        raise NotImplementedError('ZAdj > 0 moves the source plane into the domain (ZIntoSkin); not rebuilt here')
+    radius_face = 1.1 * diam / 2                                   # BASE:1938-1944 (capped at Aperture/2, then * 1.1)
+    n_half = int(np.floor(radius_face / h + 1e-9))
+    n_lat = 2 * n_half + 1
+    nz = int(np.round(depth_target / h)) + int(Z_BEYOND / h) + 1
+    N1 = N2 = n_lat + 2 * pml
+    N3 = nz + 2 * pml
+    zsrc = pml
+    xs = (np.arange(N1) - (pml + n_half)) * h
+    # z measured from the source plane; the rim of the bowl is `gap` above it (one voxel for ZAdj = 0: the reference moves
+    # the transducer back by whole voxels until its sub-sources are behind the plane, Single:268-274)
+    gap = h if zadj == 0 else -zadj
+    zs = (np.arange(N3) - zsrc) * h
+    lam = 1482.0 / freq                                            # SpeedofSoundWater(20.0) ~ 1482 m/s sets the sub-source size
+    alpha = np.arcsin(diam / 2 / focal)
+    n_rings = max(int(np.ceil(alpha * focal / (lam / 5))), 4)      # GenerateFocusTx: PPWSurface = 5 (Single:132-137)
+    pts, ds = H._bowl_points(focal, diam, n_rings, 0.0)            # apex at z = 0, focus at z = focal, rim at focal - dout
+    pts = pts.copy()
+    pts[:, 2] += -(focal - dout) - gap                             # rim plane at z = -gap
+    k = np.array(2 * np.pi * freq / C_WATER + 0j).astype(np.complex64)
+    X, Y, Z = np.meshgrid(xs, xs, zs, indexing='ij')
+    rf = np.stack([X.ravel(), Y.ravel(), Z.ravel()], 1).astype(np.float32)
+    del X, Y, Z
+    u2 = np.asarray(forward(k, pts.astype(np.float32), ds.astype(np.float32), np.ones(len(ds), np.complex64), rf)).reshape(N1, N2, N3)
+    plane = u2[:, :, zsrc].copy()
+    plane[:pml, :] = 0; plane[-pml:, :] = 0; plane[:, :pml] = 0; plane[:, -pml:] = 0
+    T, nt, sub, start = H.time_plan(N1, N2, N3, h, dt, ppp, C_WATER)
+    smap, pulse = H.pulse_sources(plane, freq, dt, T, N3, zsrc)
+    sensor = np.zeros((N1, N2, N3), np.uint32)
+    sensor[N1 // 2, N2 // 2, zsrc + 1:-pml] = 1                    # the full sensor volume is not needed for the RMS map
+    rho_c = water[0, 0] * water[0, 1]
+    args = (np.zeros((N1, N2, N3), np.uint32), water, freq, smap, pulse, h, T, sensor)
+    kwargs = dict(Ox=np.array([0.0]), Oy=np.array([0.0]), Oz=np.array([1.0 / rho_c]), NDelta=pml, DT=dt,
+                  ReflectionLimit=H.REFLECTION_LIMIT, USE_SINGLE=True, SelMapsRMSPeakList=['Pressure'],
+                  SelMapsSensorsList=['Pressure'], SelRMSorPeak=1, AlphaCFL=1.0, TypeSource=0, QfactorCorrection=True,
+                  QCorrection=1.0, SensorSubSampling=sub, SensorStart=start, ReflectorMask=None)
+    return dict(args=args, kwargs=kwargs, u2=u2, h=h, dt=dt, dt_water=dt_water, ppp=ppp, nt=nt, zsrc=zsrc, N=(N1, N2, N3),
+                n_sources=pulse.shape[0], focus_plane=zsrc + (dout + gap) / h)
+
+
+def result_volumes(case, rms_pressure):
+    """FDTD and Rayleigh amplitude volumes as the study compares them: Correction * sqrt(2) (BASE:2433-2440), zero up to the
+    source plane (BASE:2746, 2767-2769), the `_Sub` crop (interior without its last row / column and without the source
+    plane, BASE:1488-1512 after the Z flip is undone)."""
+    pml, zsrc = H.PML_THICKNESS, case['zsrc']
+    corr = H.dispersion_correction(case['dt'], case['dt_water'])
+    A = np.array(rms_pressure, np.float64) * corr * np.sqrt(2.0)
+    B = np.abs(case['u2']).astype(np.float64)
+    out = []
+    for v in (A, B):
+        v[:, :, :zsrc + 1] = 0
+        c = v[pml:-pml, pml:-pml, pml:-pml]
+        out.append(c[:-1, :-1, 1:])
+    return out[0], out[1]
+
+
+def _focal_region(data, voxel):
+    """CalcVolumetricMetrics of PART_2 cell 5: largest connected region at >= half of the maximum."""
+    lab, n = ndimage.label(data / data.max() >= 0.5)
+    if n > 1:
+        sizes = ndimage.sum(np.ones_like(lab), lab, index=np.arange(1, n + 1))
+        sel = lab == (1 + int(np.argmax(sizes)))
+    else:
+        sel = lab == 1
+    idx = np.array(np.nonzero(sel), np.float64)
+    return idx.mean(axis=1) * voxel, sel.sum() * voxel ** 3
+
+
+def qcheck(A, B, voxel_mm):
+    """The notebook's metrics (PART_2 cell 5) for FDTD volume A against Rayleigh volume B."""
+    line = A[A.shape[0] // 2, A.shape[1] // 2, :]
+    first = int(np.nonzero(line != 0.0)[0][0])
+    A, B = A[:, :, first + 1:], B[:, :, first + 1:]
+    ca, va = _focal_region(A, voxel_mm)
+    cb, vb = _focal_region(B, voxel_mm)
+    linf = 100.0 * np.abs(A - B) / B.max()
+    loc = np.unravel_index(int(np.argmax(linf)), linf.shape)
+    return {'Distance focal centroid': float(np.linalg.norm(ca - cb)),
+            'Distance focal max': float(np.linalg.norm((np.array(np.unravel_index(int(np.argmax(A)), A.shape)) -
+                                                        np.array(np.unravel_index(int(np.argmax(B)), B.shape))) * voxel_mm)),
+            'Difference amplitude': float(100 * (A.max() - B.max()) / B.max()),
+            'Difference volume': float(100 * (va - vb) / vb),
+            'L Inf': float(linf.max()), 'L Inf location': [int(x) for x in loc],
+            'L2': float(100.0 * np.sqrt(np.sum((A - B) ** 2) / np.sum(B ** 2)))}
+
+
+def run_case(row, solver, stable_dt_fn, forward, depth_target=DEPTH_TARGET):
+    """row: an entry of rayleigh_study.json (tx == 'Single'). solver(*args, **kwargs) -> the solver tuple."""
+    case = build_case(row['freq_khz'] * 1e3, row['ppw'], row['focal_mm'] * 1e-3, row['diam_mm'] * 1e-3, row['zadj_mm'] * 1e-3,
+                      stable_dt_fn, forward, depth_target)
+    out = solver(*case['args'], **case['kwargs'])
+    A, B = result_volumes(case, out[2]['Pressure'])
+    m = qcheck(A, B, case['h'] * 1e3)
+    m.update(N=case['N'], nt=case['nt'], ppp=case['ppp'], cfl_water=case['dt'] / case['dt_water'], n_sources=case['n_sources'])
+    return m
