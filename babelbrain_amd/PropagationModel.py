@@ -88,7 +88,11 @@ class PropagationModel:
                                          SelMapsRMSPeakList=('ALLV',), SelMapsSensorsList=('Vx', 'Vy', 'Vz'),
                                          SensorSubSampling=2, SensorStart=0, DefaultGPUDeviceName='MI355X',
                                          DefaultGPUDeviceNumber=None, ReflectorMask=None, SILENT=False,
-                                         ReturnSensorDFT=False, **unused):
+                                         ReturnSensorDFT=False, ReturnSensorSeries=True, **unused):
+        """Extensions beyond the reference's keyword set: ReturnSensorDFT=True adds the single-frequency
+        content of the sensor series (what CalculatePhaseData extracts, BASE:2498-2520) to InputParam; with
+        ReturnSensorSeries=False as well, the series themselves are never stored -- re/im/peak are accumulated per sensor
+        while the samples are taken (20 B per sensor instead of 4*nTs) and Sensor holds only 'time'."""
         if not USE_SINGLE:
             raise NotImplementedError('the MI355X engine computes in float32 (USE_SINGLE=True, BASE:2354)')
         MaterialMap = np.asarray(MaterialMap)
@@ -115,7 +119,10 @@ class PropagationModel:
                      reflectionLimit=ReflectionLimit, typeSource=TypeSource, sensorSub=SensorSubSampling,
                      sensorStart=SensorStart, selRMSorPeak=SelRMSorPeak, selMapsRMS=SelMapsRMSPeakList,
                      selMapsSensors=SelMapsSensorsList, qfactorCorrection=QfactorCorrection, device=device,
-                     kernelVariant=self._kernelVariant)
+                     kernelVariant=self._kernelVariant, sensorMode=1 if (ReturnSensorDFT and not ReturnSensorSeries) else 0)
+        if not ReturnSensorSeries and not ReturnSensorDFT:
+            eng.close()
+            raise ValueError('ReturnSensorSeries=False needs ReturnSensorDFT=True')
         try:
             eng.set_materials(ml, QCorrection)
             eng.set_material_map(MaterialMap, 0, 0)
@@ -129,9 +136,10 @@ class PropagationModel:
             self.last_timing = eng.timing_end()
             self.last_timing['voxel_steps'] = float(N1) * N2 * N3 * nt
             Sensor = {'time': sensor_steps(nt, SensorSubSampling, SensorStart) * DT}
-            sens = eng.sensors()
-            for q, name in enumerate(eng.selS):
-                Sensor[name] = sens[q]
+            if ReturnSensorSeries:
+                sens = eng.sensors()
+                for q, name in enumerate(eng.selS):
+                    Sensor[name] = sens[q]
             InputParam = {'IndexSensorMap': eng.sensor_index(), 'DT': DT, 'nt': nt,
                           'device_bytes': eng.device_bytes, 'timing': self.last_timing}
             if ReturnSensorDFT:

@@ -36,7 +36,7 @@ class Config(C.Structure):
                 ('nMat', C.c_int32), ('NDelta', C.c_int32), ('typeSource', C.c_int32), ('sensorSub', C.c_int32),
                 ('sensorStart', C.c_int32), ('nt', C.c_int32), ('selRMSorPeak', C.c_int32),
                 ('selMapsRMS', C.c_uint32), ('selMapsSensors', C.c_uint32), ('qfactorCorrection', C.c_int32),
-                ('device', C.c_int32), ('kernelVariant', C.c_int32), ('rmsFirstStep', C.c_int32),
+                ('device', C.c_int32), ('kernelVariant', C.c_int32), ('rmsFirstStep', C.c_int32), ('sensorMode', C.c_int32),
                 ('h', C.c_double), ('dt', C.c_double), ('freq', C.c_double), ('reflectionLimit', C.c_double)]
 
 
@@ -136,7 +136,7 @@ def load_library():
     lib.bfd_dft_series.argtypes = [C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_double, C.c_double, C.c_void_p, C.c_void_p]
     lib.bfd_rayleigh_forward.argtypes = [C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double,
                                          C.c_int64, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
-    if lib.bfd_abi_version() != 1:
+    if lib.bfd_abi_version() != 2:
         raise EngineError('libbabelfdtd_hip.so ABI version mismatch')
     _lib = lib
     return lib
@@ -219,7 +219,7 @@ class Engine:
 
     def __init__(self, N1, N2, N3, nMat, h, dt, freq, nt, k0=0, nk=None, NDelta=12, reflectionLimit=1e-5,
                  typeSource=0, sensorSub=1, sensorStart=0, selRMSorPeak=1, selMapsRMS=('Pressure',),
-                 selMapsSensors=('Pressure',), qfactorCorrection=True, device=0, kernelVariant=0, rmsFirstStep=0):
+                 selMapsSensors=('Pressure',), qfactorCorrection=True, device=0, kernelVariant=0, rmsFirstStep=0, sensorMode=0):
         self.lib = load_library()
         if self.lib.bfd_device_count() <= 0:
             raise EngineError('no HIP device visible: the MI355X engine has no CPU fallback')
@@ -229,7 +229,7 @@ class Engine:
         self.cfg = Config(N1=N1, N2=N2, N3=N3, k0=k0, nk=nk, nMat=nMat, NDelta=NDelta, typeSource=typeSource,
                           sensorSub=sensorSub, sensorStart=sensorStart, nt=nt, selRMSorPeak=selRMSorPeak,
                           selMapsRMS=mask_of(self.selR), selMapsSensors=mask_of(self.selS),
-                          qfactorCorrection=int(bool(qfactorCorrection)), device=device, kernelVariant=kernelVariant, rmsFirstStep=rmsFirstStep,
+                          qfactorCorrection=int(bool(qfactorCorrection)), device=device, kernelVariant=kernelVariant, rmsFirstStep=rmsFirstStep, sensorMode=sensorMode,
                           h=h, dt=dt, freq=freq, reflectionLimit=reflectionLimit)
         self.h = C.c_void_p()
         _check(self.lib.bfd_create(C.byref(self.cfg), C.byref(self.h)), 'bfd_create')
@@ -289,6 +289,7 @@ class Engine:
 
     def set_sources(self, localIndex, row, wx, wy, wz, PulseSource):
         pulse = np.ascontiguousarray(np.atleast_2d(PulseSource), np.float64)
+        self._pulse = pulse     # a large table is streamed from here in time tiles during the run: keep it alive with the engine
         li = np.ascontiguousarray(localIndex, np.uint32)
         rw = np.ascontiguousarray(row, np.uint32)
         ws = [None if w is None else np.ascontiguousarray(w, np.float32) for w in (wx, wy, wz)]

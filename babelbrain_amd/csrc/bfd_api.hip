@@ -10,6 +10,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <thread>
 #include <hipcub/hipcub.hpp>
 
 static thread_local std::string g_err;
@@ -254,6 +255,34 @@ __global__ void record_sensors(bfd_dev d, SelList L, const uint32_t *__restrict_
         }
     }
 }
+// sensorMode 1: the sample of this step goes straight into the running single-bin DFT sums and peaks of its sensor
+// (same arithmetic, sample by sample, as dft_series applies to a stored series)
+__global__ void accumulate_sensor_dft(bfd_dev d, SelList L, const uint32_t *__restrict__ lin, long nSens, double *__restrict__ acc,
+                                      float *__restrict__ pk, int col, int nTs, int bin)
+{
+    const int r = (int)(((long)bin * col) % nTs);                 // exact phase index
+    double sn, cs;
+    sincospi(2.0 * (double)r / (double)nTs, &sn, &cs);
+    for (long s = (long)blockIdx.x * blockDim.x + threadIdx.x; s < nSens; s += (long)gridDim.x * blockDim.x) {
+        const long c = lin[s];
+        for (int q = 0; q < L.n; q++) {
+            const float x = (L.sel[q] == BFD_MAP_ALLV) ? sqrtf(map_sq(d, BFD_MAP_ALLV, c)) : map_value(d, L.sel[q], c);
+            double *a = acc + 2 * ((long)q * nSens + s);
+            a[0] += (double)x * cs; a[1] -= (double)x * sn;
+            float *p = pk + (long)q * nSens + s;
+            *p = fmaxf(*p, x);
+        }
+    }
+}
+__global__ void fill_float(float *__restrict__ p, long n, float v)
+{
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = v;
+}
+__global__ void finalize_sensor_dft(const double *__restrict__ acc, float *__restrict__ out, long n2, double sc)
+{
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (long)gridDim.x * blockDim.x) out[i] = (float)(acc[i] * sc);
+}
+
 // [q][nTs][nSens] -> [q][nSens][nTs]
 __global__ void transpose_sensors(const float *__restrict__ in, float *__restrict__ out, long nSens, int nTs, int nq)
 {
@@ -396,7 +425,94 @@ __global__ void count_active_edges(const float *__restrict__ coef, long n, unsig
     if (c) atomicAdd(out, (unsigned long long)c);
 }
 
+
+// ---- streamed source table -------------------------------------------------------------------------------------------
+// tile t = steps [t*TS, min((t+1)*TS, L)) of the caller's [nSources][L] float64 table -> pinned [steps][nSources] float32
+// (the same float64 -> float32 rounding the resident path applies on the device). Row blocks keep reads and writes in cache.
+void pack_tile_rows(const double *pulse, int nSources, int L, int t0, int len, float *out, int r0, int r1)
+{
+    const int RB = 64;
+    for (int rb = r0; rb < r1; rb += RB) {
+        const int re = std::min(rb + RB, r1);
+        for (int q = 0; q < len; q++) {
+            float *o = out + (size_t)q * nSources;
+            for (int r = rb; r < re; r++) o[r] = (float)pulse[(size_t)r * L + t0 + q];
+        }
+    }
+}
+void pack_tile(const double *pulse, int nSources, int L, int TS, int t, float *out)
+{
+    const int t0 = t * TS, len = std::min(TS, L - t0);
+    const int nth = (size_t)nSources * len > (1u << 20) ? 4 : 1;
+    if (nth == 1) { pack_tile_rows(pulse, nSources, L, t0, len, out, 0, nSources); return; }
+    std::vector<std::thread> th;
+    for (int a = 0; a < nth; a++) {
+        const int r0 = (int)((long)nSources * a / nth) / 64 * 64, r1 = a + 1 == nth ? nSources : (int)((long)nSources * (a + 1) / nth) / 64 * 64;
+        th.emplace_back(pack_tile_rows, pulse, nSources, L, t0, len, out, r0, r1);
+    }
+    for (auto &x : th) x.join();
+}
+
+void drain_pack_jobs(bfd_sim *s)
+{
+    for (int b = 0; b < 2; b++) if (s->packJob[b].valid()) s->packJob[b].wait();
+}
+
+void release_streaming(bfd_sim *s)
+{
+    drain_pack_jobs(s);
+    for (int b = 0; b < 2; b++) {
+        if (s->packJob[b].valid()) s->packJob[b].get();
+        dev_release(s, &s->tileDev[b]);
+        if (s->tilePinned[b]) { hipHostFree(s->tilePinned[b]); s->tilePinned[b] = nullptr; }
+        s->tileLoaded[b] = s->tilePacked[b] = -1; s->evTileUsed[b] = false;
+    }
+    s->pulseHost = nullptr; s->tileSteps = s->nTiles = 0;
+}
+
+// the float32 [nSources] row of source values for time step `step`, resident on the device when the kernels of stream st
+// run: either a row of the resident table or of the time tile that holds the step (uploaded here when the run enters it)
+int pulse_row(bfd_sim *s, int step, hipStream_t st, const float **row)
+{
+    if (!s->pulseHost) { *row = s->pulseT + (size_t)step * s->nSources; return 0; }
+    const int TS = s->tileSteps, t = step / TS, b = t & 1;
+    if (s->tileLoaded[b] != t) {
+        if (s->tilePacked[b] == t && s->packJob[b].valid()) s->packJob[b].get();
+        else {           // first tile, or the run jumped (bfd_reset): pack it here
+            if (s->packJob[b].valid()) s->packJob[b].get();
+            if (s->evTileUsed[b]) BFD_HIP(hipEventSynchronize(s->evTile[b]));
+            pack_tile(s->pulseHost, s->nSources, s->lengthSource, TS, t, s->tilePinned[b]);
+            s->tilePacked[b] = t;
+        }
+        const int len = std::min(TS, s->lengthSource - t * TS);
+        // stream order puts this copy behind the kernels that read the tile this buffer held two tiles ago
+        BFD_HIP(hipMemcpyAsync(s->tileDev[b], s->tilePinned[b], (size_t)len * s->nSources * sizeof(float), hipMemcpyHostToDevice, st));
+        BFD_HIP(hipEventRecord(s->evTile[b], st));
+        s->evTileUsed[b] = true; s->tileLoaded[b] = t;
+        // the next tile is packed beside the GPU's work on this one (the pinned buffer is free once its last upload is done)
+        const int nb = b ^ 1, nt = t + 1;
+        if (nt < s->nTiles && s->tilePacked[nb] != nt) {
+            if (s->packJob[nb].valid()) s->packJob[nb].get();
+            s->tilePacked[nb] = nt;
+            const bool waitEv = s->evTileUsed[nb];
+            hipEvent_t ev = s->evTile[nb];
+            const int dev = s->cfg.device;
+            const double *ph = s->pulseHost; const int nS = s->nSources, L = s->lengthSource; float *dst = s->tilePinned[nb];
+            s->packJob[nb] = std::async(std::launch::async, [=]() {
+                if (waitEv) { hipSetDevice(dev); hipEventSynchronize(ev); }
+                pack_tile(ph, nS, L, TS, nt, dst);
+            });
+        }
+    } else {
+        BFD_HIP(hipStreamWaitEvent(st, s->evTile[b], 0));      // a part launched on another stream than the upload
+    }
+    *row = s->tileDev[b] + (size_t)(step - t * TS) * s->nSources;
+    return 0;
+}
+
 }  // namespace
+
+static int dft_bin(int n, double d, double freq);
 
 void bfd_kmark(bfd_sim *s, int cls, int end, hipStream_t st)
 {
@@ -435,7 +551,7 @@ double bfd_stable_dt(int32_t nMat, const double *matlist, const double *qcorr, d
     HostTables T;
     make_tables(nMat, matlist, qcorr, freq, qfactorCorrection != 0, h, 1.0, T);
     // O(2,4) staggered leapfrog: dt <= (6/7) h / (sqrt(3) cmax)
-    return alphaCFL * (6.0 / 7.0) * h / (sqrt(3.0) * T.cmax);
+    return alphaCFL * BFD_STAB * h / (sqrt(3.0) * T.cmax);
 }
 
 int bfd_material_tables(int32_t nMat, const double *matlist, const double *qcorr, double freq,
@@ -464,6 +580,7 @@ int bfd_create(const bfd_config *cfg, bfd_sim **out)
     if (cfg->kernelVariant < 0 || cfg->kernelVariant > 4) BFD_FAIL(-2, "bfd_create: kernelVariant must be 0..4");
     if (cfg->rmsFirstStep < 0) BFD_FAIL(-2, "bfd_create: rmsFirstStep must be >= 0");
     if (cfg->selRMSorPeak < 0 || cfg->selRMSorPeak > 3) BFD_FAIL(-2, "bfd_create: SelRMSorPeak must be 0..3");
+    if (cfg->sensorMode < 0 || cfg->sensorMode > 1) BFD_FAIL(-2, "bfd_create: sensorMode must be 0 or 1");
     if ((long)cfg->N1 * cfg->N2 * (cfg->nk + 4) >= (1L << 31)) BFD_FAIL(-2, "bfd_create: slab exceeds 2^31 voxels (split it into Z-slabs)");
     if (!(cfg->h > 0) || !(cfg->dt > 0) || !(cfg->freq > 0) || !(cfg->reflectionLimit > 0 && cfg->reflectionLimit < 1))
         BFD_FAIL(-2, "bfd_create: h, dt, freq must be > 0 and 0 < reflectionLimit < 1");
@@ -478,10 +595,22 @@ int bfd_create(const bfd_config *cfg, bfd_sim **out)
     s->step = 0; s->devBytes = 0; s->haveMaterials = s->haveMap = false; s->tilesReady = false;
     s->nSrcVox = 0; s->srcLin = s->srcRow = nullptr; s->srcW[0] = s->srcW[1] = s->srcW[2] = nullptr; s->pulseT = nullptr;
     s->nSources = s->lengthSource = 0;
-    s->nSensors = 0; s->sensLin = nullptr; s->sensOut = nullptr;
+    s->pulseHost = nullptr; s->tileSteps = s->nTiles = 0;
+    for (int b = 0; b < 2; b++) { s->tileDev[b] = s->tilePinned[b] = nullptr; s->tileLoaded[b] = s->tilePacked[b] = -1; s->evTile[b] = nullptr; s->evTileUsed[b] = false; }
+    s->nSensors = 0; s->sensLin = nullptr; s->sensOut = nullptr; s->dftAcc = nullptr; s->dftPk = nullptr; s->dftBin = 0;
     s->acc = s->pk = nullptr; s->timing = s->perKernel = false;
     s->tables = nullptr; s->profiles = nullptr; s->cmax = 0;
     memset(s->algBytes, 0, sizeof s->algBytes); s->tiles.ktimer = nullptr;
+    s->tiles.side = nullptr; s->tiles.evFork = s->tiles.evJoin = nullptr;
+    if (const char *ev = getenv("BFD_CONCURRENT")) {       // experiment: solid-run kernels on a second stream beside the fluid-run kernel
+        const int mode = atoi(ev);
+        if (mode) {
+            int lo = 0, hi = 0; hipDeviceGetStreamPriorityRange(&lo, &hi);
+            if (hipStreamCreateWithPriority(&s->tiles.side, hipStreamNonBlocking, mode == 2 ? hi : (mode == 3 ? lo : 0)) != hipSuccess) s->tiles.side = nullptr;
+            if (s->tiles.side && (hipEventCreateWithFlags(&s->tiles.evFork, hipEventDisableTiming) != hipSuccess ||
+                                  hipEventCreateWithFlags(&s->tiles.evJoin, hipEventDisableTiming) != hipSuccess)) { hipStreamDestroy(s->tiles.side); s->tiles.side = nullptr; }
+        }
+    }
     if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) { delete s; BFD_FAIL(-10, "hipStreamCreate failed"); }
     s->ownStream = true;
     if (hipEventCreate(&s->evBegin) != hipSuccess) { hipStreamDestroy(s->stream); delete s; BFD_FAIL(-10, "hipEventCreate failed"); }
@@ -549,12 +678,15 @@ void bfd_destroy(bfd_sim *s)
     hipDeviceSynchronize();
     if (s->stepGraph) hipGraphExecDestroy(s->stepGraph);
     if (s->captureStream) hipStreamDestroy(s->captureStream);
+    release_streaming(s);
+    for (int b = 0; b < 2; b++) if (s->evTile[b]) hipEventDestroy(s->evTile[b]);
     for (void *p : s->allocs) hipFree(p);
     for (hipEvent_t e : s->evPool) hipEventDestroy(e);
     for (hipEvent_t e : s->evStress) hipEventDestroy(e);
     for (hipEvent_t e : s->evVelocity) hipEventDestroy(e);
     for (auto &v : s->evK) for (hipEvent_t e : v) hipEventDestroy(e);
     hipEventDestroy(s->evBegin); hipEventDestroy(s->evEnd);
+    if (s->tiles.side) { hipStreamDestroy(s->tiles.side); hipEventDestroy(s->tiles.evFork); hipEventDestroy(s->tiles.evJoin); }
     if (s->ownStream) hipStreamDestroy(s->stream);
     delete s;
 }
@@ -594,7 +726,7 @@ int bfd_set_materials(bfd_sim *s, const double *matlist, const double *qcorr)
     HostTables T;
     make_tables(c.nMat, matlist, qcorr, c.freq, c.qfactorCorrection != 0, c.h, c.dt, T);
     const double cfl = T.cmax * c.dt / c.h;
-    if (cfl > (6.0 / 7.0) / sqrt(3.0) * 1.0000001)
+    if (cfl > BFD_STAB / sqrt(3.0) * 1.0000001)
         BFD_FAIL(-4, "bfd_set_materials: DT violates the stability limit dt <= (6/7) h / (sqrt(3) cmax)");
     s->cmax = T.cmax;
     BFD_HIP(hipMemcpyAsync(s->tables, T.t.data(), T.t.size() * sizeof(float), hipMemcpyHostToDevice, s->stream));
@@ -686,6 +818,7 @@ int bfd_set_sources(bfd_sim *s, int64_t nVox, const uint32_t *localIndex, const 
     }
     BFD_HIP(hipStreamSynchronize(s->stream));
     dev_release(s, &s->srcLin); dev_release(s, &s->srcRow); dev_release(s, &s->pulseT);
+    release_streaming(s);
     for (int a = 0; a < 3; a++) dev_release(s, &s->srcW[a]);
     s->nSrcVox = nVox; s->nSources = nSources; s->lengthSource = lengthSource;
     s->srcLowEnd = 0; s->srcHighBeg = nVox; s->tilesReady = false; drop_step_graph(s);
@@ -713,6 +846,23 @@ int bfd_set_sources(bfd_sim *s, int64_t nVox, const uint32_t *localIndex, const 
         }
     }
     const size_t np = (size_t)nSources * lengthSource;
+    // Large tables are streamed: the float64 table stays where the caller built it (it must stay valid until the run is
+    // over, as it does inside the solver call of the drop-in) and the device holds two time tiles. BFD_SOURCE_TILE=<steps>
+    // forces streaming with that tile length (tests).
+    int tile = 0;
+    if (const char *ev = getenv("BFD_SOURCE_TILE")) tile = atoi(ev);
+    if (tile <= 0 && np * sizeof(float) > ((size_t)1 << 30)) tile = 64;
+    if (tile > 0 && lengthSource > 0 && nSources > 0) {
+        tile = std::min(tile, (int)lengthSource);
+        s->pulseHost = pulse; s->tileSteps = tile; s->nTiles = (lengthSource + tile - 1) / tile;
+        for (int b = 0; b < 2; b++) {
+            if ((rc = dev_alloc(s, &s->tileDev[b], (size_t)tile * nSources, false))) return rc;
+            BFD_HIP(hipHostMalloc((void **)&s->tilePinned[b], (size_t)tile * nSources * sizeof(float), hipHostMallocDefault));
+            if (!s->evTile[b]) BFD_HIP(hipEventCreateWithFlags(&s->evTile[b], hipEventDisableTiming));
+        }
+        s->graphState = -1;        // the recorded step graph indexes a resident table
+        return 0;
+    }
     if ((rc = dev_alloc(s, &s->pulseT, np, false))) return rc;
     double *tmp = nullptr;
     BFD_HIP(hipMalloc((void **)&tmp, std::max<size_t>(np, 1) * sizeof(double)));
@@ -750,10 +900,18 @@ int bfd_set_sensor_map(bfd_sim *s, const uint32_t *map, int64_t s1, int64_t s2, 
     int rc = 0;
     if (e == hipSuccess) {
         s->nSensors = count;
-        dev_release(s, &s->sensLin); dev_release(s, &s->sensOut);
+        dev_release(s, &s->sensLin); dev_release(s, &s->sensOut); dev_release(s, &s->dftAcc); dev_release(s, &s->dftPk);
         rc = dev_alloc(s, &s->sensLin, (size_t)count, false);
         if (!rc && count) e = hipMemcpyAsync(s->sensLin, sel, (size_t)count * sizeof(uint32_t), hipMemcpyDeviceToDevice, s->stream);
-        if (!rc && s->nSelS && s->nTs > 0) rc = dev_alloc(s, &s->sensOut, (size_t)s->nSelS * s->nTs * (size_t)count);
+        if (!rc && s->nSelS && s->nTs > 0) {
+            if (s->cfg.sensorMode == 0) rc = dev_alloc(s, &s->sensOut, (size_t)s->nSelS * s->nTs * (size_t)count);
+            else {
+                rc = dev_alloc(s, &s->dftAcc, 2 * (size_t)s->nSelS * (size_t)count);
+                if (!rc) rc = dev_alloc(s, &s->dftPk, (size_t)s->nSelS * (size_t)std::max(count, 1), false);
+                if (!rc) hipLaunchKernelGGL(fill_float, dim3(grid_for((long)s->nSelS * count)), dim3(256), 0, s->stream, s->dftPk, (long)s->nSelS * count, -INFINITY);
+                s->dftBin = dft_bin(s->nTs, s->cfg.dt * s->cfg.sensorSub, s->cfg.freq);
+            }
+        }
         if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
     }
     hipFree(tmp); hipFree(flags); hipFree(sel); hipFree(dcount); if (work) hipFree(work);
@@ -1030,14 +1188,15 @@ static void swap_fields(bfd_dev &d)
     std::swap(d.Vx, d.VxW); std::swap(d.Vy, d.VyW); std::swap(d.Vz, d.VzW); std::swap(d.Szz, d.SzzW); std::swap(d.Rzz, d.RzzW);
 }
 
-static void inject_part(bfd_sim *s, int part, const bfd_dev &view, hipStream_t st)
+static int inject_part(bfd_sim *s, int part, const bfd_dev &view, hipStream_t st)
 {
     const int64_t n = s->nSrcVox;
     int64_t beg[2] = {0, 0}, end[2] = {0, 0};
-    if (part == 0 || s->cfg.kernelVariant == 1) { if (part == 1) return; end[0] = n; }
+    if (part == 0 || s->cfg.kernelVariant == 1) { if (part == 1) return 0; end[0] = n; }
     else if (part == 1) { end[0] = s->srcLowEnd; beg[1] = s->srcHighBeg; end[1] = n; }
     else { beg[0] = s->srcLowEnd; end[0] = s->srcHighBeg; }
-    const float *pulse = s->pulseT + (size_t)s->step * s->nSources;
+    const float *pulse = nullptr;
+    { const int rc = pulse_row(s, s->step, st, &pulse); if (rc) return rc; }
     for (int r = 0; r < 2; r++) {
         const int64_t c = end[r] - beg[r];
         if (c <= 0) continue;
@@ -1045,6 +1204,7 @@ static void inject_part(bfd_sim *s, int part, const bfd_dev &view, hipStream_t s
                            s->srcLin + beg[r], s->srcRow + beg[r], s->srcW[0] ? s->srcW[0] + beg[r] : nullptr,
                            s->srcW[1] ? s->srcW[1] + beg[r] : nullptr, s->srcW[2] ? s->srcW[2] + beg[r] : nullptr, pulse, (long)c);
     }
+    return 0;
 }
 
 // part 0 = whole half-step; 1 = boundary tiles (first/last z-chunk: what a Z-neighbour reads) with their
@@ -1064,7 +1224,7 @@ static int stress_part(bfd_sim *s, int part, hipStream_t st)
     if (s->cfg.kernelVariant == 1) { if (part != 1) bfd_launch_stress_v1(s->d, st); }
     else bfd_launch_stress_v2(s->d, st, &s->tiles, part);
     if (e0) { hipEventRecord(e1, st); s->evStress.push_back(e0); s->evStress.push_back(e1); }
-    if (s->nSrcVox && s->cfg.typeSource >= 2 && s->step < s->lengthSource) inject_part(s, part, new_stress_view(s->d), st);
+    if (s->nSrcVox && s->cfg.typeSource >= 2 && s->step < s->lengthSource) { rc = inject_part(s, part, new_stress_view(s->d), st); if (rc) return rc; }
     BFD_HIP(hipGetLastError());
     return 0;
 }
@@ -1097,7 +1257,7 @@ static int velocity_part(bfd_sim *s, int part, hipStream_t st)
         bfd_launch_velocity_v2(new_stress_view(d), st, accP, pkP, &s->tiles, part);
     }
     if (e0) { hipEventRecord(e1, st); s->evVelocity.push_back(e0); s->evVelocity.push_back(e1); }
-    if (s->nSrcVox && s->cfg.typeSource < 2 && s->step < s->lengthSource) inject_part(s, part, new_velocity_view(d), st);
+    if (s->nSrcVox && s->cfg.typeSource < 2 && s->step < s->lengthSource) { rc = inject_part(s, part, new_velocity_view(d), st); if (rc) return rc; }
     if (part == 1) { BFD_HIP(hipGetLastError()); return 0; }
     if (s->pingpong) swap_fields(s->d);
     // end of the time step: remaining accumulators, sensors
@@ -1107,12 +1267,16 @@ static int velocity_part(bfd_sim *s, int part, hipStream_t st)
         dim3 block(64, 4, 1), grid((d.N1 + 63) / 64, (d.N2 + 3) / 4, d.nk);
         hipLaunchKernelGGL(accumulate_maps, grid, block, 0, st, d, L, s->acc, s->pk, (long)s->nloc);
     }
-    if (s->nSensors && s->sensOut && n % s->cfg.sensorSub == 0 && n / s->cfg.sensorSub >= s->cfg.sensorStart) {
+    if (s->nSensors && (s->sensOut || s->dftAcc) && n % s->cfg.sensorSub == 0 && n / s->cfg.sensorSub >= s->cfg.sensorStart) {
         const int col = n / s->cfg.sensorSub - s->cfg.sensorStart;
         if (col < s->nTs) {
             SelList L; L.n = s->nSelS; memcpy(L.sel, s->selS, sizeof L.sel); memset(L.skip, 0, sizeof L.skip);
-            hipLaunchKernelGGL(record_sensors, dim3(grid_for(s->nSensors)), dim3(256), 0, st, d, L, s->sensLin,
-                               (long)s->nSensors, s->sensOut, col, s->nTs);
+            if (s->sensOut)
+                hipLaunchKernelGGL(record_sensors, dim3(grid_for(s->nSensors)), dim3(256), 0, st, d, L, s->sensLin,
+                                   (long)s->nSensors, s->sensOut, col, s->nTs);
+            else
+                hipLaunchKernelGGL(accumulate_sensor_dft, dim3(grid_for(s->nSensors)), dim3(256), 0, st, d, L, s->sensLin,
+                                   (long)s->nSensors, s->dftAcc, s->dftPk, col, s->nTs, s->dftBin);
         }
     }
     BFD_HIP(hipGetLastError());
@@ -1175,7 +1339,7 @@ static bool plain_steps(const bfd_sim *s, int n, int G)
 {
     if ((s->timing && s->perKernel) || s->pingpong) return false;
     if ((s->acc || s->pk) && n + G > s->accStart) return false;
-    if (s->nSensors && s->sensOut) {
+    if (s->nSensors && (s->sensOut || s->dftAcc)) {
         const int sub = s->cfg.sensorSub;
         const int last = n + G - 1;
         // a sample is taken at step m when m % sub == 0 and m / sub in [sensorStart, sensorStart + nTs)
@@ -1317,8 +1481,14 @@ int bfd_reset(bfd_sim *s)
     if (s->acc) BFD_HIP(hipMemsetAsync(s->acc, 0, (size_t)s->nSelR * s->nloc * sizeof(float), s->stream));
     if (s->pk) BFD_HIP(hipMemsetAsync(s->pk, 0, (size_t)s->nSelR * s->nloc * sizeof(float), s->stream));
     if (s->sensOut) BFD_HIP(hipMemsetAsync(s->sensOut, 0, (size_t)s->nSelS * s->nTs * (size_t)s->nSensors * sizeof(float), s->stream));
+    if (s->dftAcc) {
+        BFD_HIP(hipMemsetAsync(s->dftAcc, 0, 2 * (size_t)s->nSelS * (size_t)s->nSensors * sizeof(double), s->stream));
+        hipLaunchKernelGGL(fill_float, dim3(grid_for((long)s->nSelS * s->nSensors)), dim3(256), 0, s->stream, s->dftPk, (long)s->nSelS * s->nSensors, -INFINITY);
+    }
     s->step = 0; s->stepDevValid = false;
     BFD_HIP(hipStreamSynchronize(s->stream));
+    drain_pack_jobs(s);
+    for (int b = 0; b < 2; b++) s->tileLoaded[b] = -1;        // the streamed source table starts over (tiles are re-packed on demand)
     return 0;
 }
 
@@ -1342,6 +1512,7 @@ int bfd_get_sensors(bfd_sim *s, float *out)
     if (!s) BFD_FAIL(-1, "null sim");
     const size_t n = (size_t)s->nSelS * s->nTs * (size_t)s->nSensors;
     if (!n) return 0;
+    if (s->cfg.sensorMode != 0) BFD_FAIL(-6, "bfd_get_sensors: the series are not stored with sensorMode 1 (use bfd_get_sensor_dft)");
     if (!out || !s->sensOut) BFD_FAIL(-1, "bfd_get_sensors: null argument");
     BFD_HIP(hipSetDevice(s->cfg.device));
     float *tmp = nullptr;
@@ -1443,9 +1614,21 @@ int bfd_get_sensor_dft(bfd_sim *s, double freq, float *outReIm, float *outPeak)
     if (!s) BFD_FAIL(-1, "null sim");
     const size_t n = (size_t)s->nSelS * (size_t)s->nSensors;
     if (!n || s->nTs <= 0) return 0;
-    if (!outReIm || !s->sensOut) BFD_FAIL(-1, "bfd_get_sensor_dft: null argument");
+    if (!outReIm || !(s->sensOut || s->dftAcc)) BFD_FAIL(-1, "bfd_get_sensor_dft: null argument");
     BFD_HIP(hipSetDevice(s->cfg.device));
     const int bin = dft_bin(s->nTs, s->cfg.dt * s->cfg.sensorSub, freq);
+    if (s->dftAcc) {         // accumulated in the loop
+        if (bin != s->dftBin) BFD_FAIL(-2, "bfd_get_sensor_dft: with sensorMode 1 the bin is the one of the sim's own frequency");
+        float *dre = nullptr;
+        BFD_HIP(hipMalloc((void **)&dre, 2 * n * sizeof(float)));
+        hipLaunchKernelGGL(finalize_sensor_dft, dim3(grid_for((long)(2 * n))), dim3(256), 0, s->stream, s->dftAcc, dre, (long)(2 * n), 2.0 / (double)s->nTs);
+        hipError_t e = hipMemcpyAsync(outReIm, dre, 2 * n * sizeof(float), hipMemcpyDeviceToHost, s->stream);
+        if (e == hipSuccess && outPeak) e = hipMemcpyAsync(outPeak, s->dftPk, n * sizeof(float), hipMemcpyDeviceToHost, s->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+        hipFree(dre);
+        if (e != hipSuccess) BFD_FAIL(-10, std::string("bfd_get_sensor_dft: ") + hipGetErrorString(e));
+        return 0;
+    }
     float *dre = nullptr, *dpk = nullptr;
     BFD_HIP(hipMalloc((void **)&dre, 2 * n * sizeof(float)));
     hipError_t e = hipMalloc((void **)&dpk, n * sizeof(float));

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <future>
 #include <string>
 #include <vector>
 #include "../../include/babelfdtd.h"
@@ -16,9 +17,16 @@
 #define BFD_CLS_EYZ 16u
 #define BFD_CLS_REFL 32u    // reflector voxel
 
-// CA, CB of the O(4) staggered first derivative
+// CA, CB of the O(4) staggered first derivative (Taylor coefficients) and the matching stability constant
+// 1/(CA+CB) of dt <= BFD_STAB h / (sqrt(3) cmax). Overridable for scheme experiments (tests/rayleigh_study.py):
+// make TAG=holberg EXTRA='-DBFD_CA=1.1382f -DBFD_CB=0.046414f -DBFD_STAB=(1.0/1.184614)'
+#ifndef BFD_CA
 #define BFD_CA 1.125f
 #define BFD_CB (1.0f / 24.0f)
+#endif
+#ifndef BFD_STAB
+#define BFD_STAB (6.0 / 7.0)
+#endif
 
 // tile geometry of the class-specialised kernels (bfd_kernels_v2.hip): 64 x 8 cells per workgroup plane,
 // classification in sub-tiles of BFD_SUBZ planes
@@ -69,7 +77,10 @@ struct bfd_sim;
 // records an event before (end = 0) / after (end = 1) a launch of class cls (bfd_api.hip); t->ktimer != null while class timing is on
 void bfd_kmark(bfd_sim *sim, int cls, int end, hipStream_t st);
 
-struct bfd_tiles { bfd_sim *ktimer; int4 *runs;
+struct bfd_tiles { bfd_sim *ktimer;
+                   // optional second stream: the solid-run kernels of a half-step run beside the fluid-run kernel (disjoint tiles)
+                   hipStream_t side; hipEvent_t evFork, evJoin;
+                   int4 *runs;
                    unsigned *shearCells; float *shearCoef; long nShear, shearLowEnd, shearHighBeg;   /* sparse shear list */
                    int nFluid, nFluidB, nSolid, nSolidB, nSolidBP /* leading boundary runs that touch the absorbing layer */, nSolidIP /* trailing interior ones */, nFused /* runs of the fused kernel, after the solid runs */;
                    int nLossless, nLossy, nSolidSub, nUni, nPml, nLean, nFusedSub; };
@@ -97,8 +108,15 @@ struct bfd_sim {
     // sources
     int64_t nSrcVox, srcLowEnd, srcHighBeg;   // sources sorted by voxel: [0,lowEnd) first z-chunk, [highBeg,n) last z-chunk
     uint32_t *srcLin, *srcRow; float *srcW[3]; float *pulseT; int nSources, lengthSource;
+    // streamed source table (large PulseSource): the caller's float64 table stays on the host, time tiles of
+    // tileSteps steps are converted to float32 [step][source] by a packer job and uploaded double-buffered
+    const double *pulseHost; int tileSteps, nTiles;
+    float *tileDev[2], *tilePinned[2]; int tileLoaded[2], tilePacked[2];
+    hipEvent_t evTile[2]; bool evTileUsed[2];
+    std::future<void> packJob[2];
     // sensors
     int64_t nSensors; uint32_t *sensLin; float *sensOut; int nTs; int nSelS; int selS[BFD_MAP_COUNT];
+    double *dftAcc; float *dftPk; int dftBin;      // sensorMode 1: [nSelS][nSensors][2] running DFT sums, [nSelS][nSensors] running peaks
     // accumulators
     int nSelR; int selR[BFD_MAP_COUNT]; float *acc, *pk;
     int accStart;

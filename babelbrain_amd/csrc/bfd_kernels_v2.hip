@@ -1010,6 +1010,32 @@ __device__ __forceinline__ void stress_solid_body(const bfd_dev &d, const int4 &
         const int b = kl & 1;
         const long ko = (long)kl * pl;
         const int k = d.k0 + kl;
+        float nvx = 0, nvy = 0, nvz = 0, nh = 0, nsxx = 0, nsyy = 0, nszz = 0, nrxx = 0, nryy = 0, nrzz = 0, npx = 0, npy = 0, npz = 0;
+        unsigned nmraw = 0, ncl2 = BFD_CLS_FLUID | BFD_CLS_NOMEM;
+        auto prefetch_next = [&]() {
+        if (valid) ncl2 = (d.cls + ko + 2 * pl)[cij];           // ghost planes make kl+2 addressable
+            if (kl + 1 < kend) {
+                if (valid) {
+                    const bool nfl = cl1 & BFD_CLS_FLUID, nmem = !(cl1 & BFD_CLS_NOMEM) || !nfl;
+                    nvx = (d.Vx + ko + pl)[cij]; nvy = (d.Vy + ko + pl)[cij]; nvz = (d.Vz + ko + 2 * pl)[cij];
+                    nmraw = (d.mat + ko + pl)[cij];
+                    nszz = (d.Szz + ko + pl)[cij];
+                    if (nmem) nrzz = (d.Rzz + ko + pl)[cij];
+                    if (!nfl) {
+                        nsxx = (d.Sxx + ko + pl)[cij]; nsyy = (d.Syy + ko + pl)[cij];
+                        nrxx = (d.Rxx + ko + pl)[cij]; nryy = (d.Ryy + ko + pl)[cij];
+                    }
+                }
+                if (t.ok) nh = ph[ko + pl];
+                if (zi) npx = d.psi[0][qx + dqx];
+                if (zj) npy = d.psi[1][qy + dqy];
+                const int kn = k + 1;
+                if (PML && valid && (kn < P || kn >= d.N3 - P)) npz = d.psi[2][(unsigned)((kn < P ? kn : kn - (d.N3 - 2 * P)) * d.plane) + cij];
+            }
+        };
+#ifdef BFD_EARLY_PREFETCH
+        prefetch_next();        // the loads of plane kl+1 are in flight across the staging, the barrier and this plane's arithmetic
+#endif
         sV[b][0][own] = vx0; sV[b][1][own] = vy0;
         if (has) lh[b * (2 * LH * LW)] = hv;
         const int m = mraw & BFD_MAT_MASK;
@@ -1018,27 +1044,9 @@ __device__ __forceinline__ void stress_solid_body(const bfd_dev &d, const int4 &
         if (valid) { AP = d.AP[m]; if (mem) BP = d.BP[m]; if (!fl) { AS2 = d.AS2[m]; BS2 = d.BS2[m]; } }
         __syncthreads();
 
-        float nvx = 0, nvy = 0, nvz = 0, nh = 0, nsxx = 0, nsyy = 0, nszz = 0, nrxx = 0, nryy = 0, nrzz = 0, npx = 0, npy = 0, npz = 0;
-        unsigned nmraw = 0, ncl2 = BFD_CLS_FLUID | BFD_CLS_NOMEM;
-        if (valid) ncl2 = (d.cls + ko + 2 * pl)[cij];           // ghost planes make kl+2 addressable
-        if (kl + 1 < kend) {
-            if (valid) {
-                const bool nfl = cl1 & BFD_CLS_FLUID, nmem = !(cl1 & BFD_CLS_NOMEM) || !nfl;
-                nvx = (d.Vx + ko + pl)[cij]; nvy = (d.Vy + ko + pl)[cij]; nvz = (d.Vz + ko + 2 * pl)[cij];
-                nmraw = (d.mat + ko + pl)[cij];
-                nszz = (d.Szz + ko + pl)[cij];
-                if (nmem) nrzz = (d.Rzz + ko + pl)[cij];
-                if (!nfl) {
-                    nsxx = (d.Sxx + ko + pl)[cij]; nsyy = (d.Syy + ko + pl)[cij];
-                    nrxx = (d.Rxx + ko + pl)[cij]; nryy = (d.Ryy + ko + pl)[cij];
-                }
-            }
-            if (t.ok) nh = ph[ko + pl];
-            if (zi) npx = d.psi[0][qx + dqx];
-            if (zj) npy = d.psi[1][qy + dqy];
-            const int kn = k + 1;
-            if (PML && valid && (kn < P || kn >= d.N3 - P)) npz = d.psi[2][(unsigned)((kn < P ? kn : kn - (d.N3 - 2 * P)) * d.plane) + cij];
-        }
+#ifndef BFD_EARLY_PREFETCH
+        prefetch_next();
+#endif
         if (valid) {
             const float *sx = &sV[b][0][own], *sy = &sV[b][1][own];
             float dxVx = dminus4(sx[-2], sx[-1], vx0, sx[1]);
@@ -1203,6 +1211,27 @@ __device__ __forceinline__ void velocity_solid_body(const bfd_dev &d, const int4
         const long ko = (long)kl * pl;
         const int k = d.k0 + kl;
         const int bn = (b ^ 1) * bufStride;     // buffer of plane kl+1 (free: every thread is past the barrier of iteration kl-1's reads)
+        float nzz = 0, nxz = 0, nyz = 0, nxx = 0, nyy = 0, nxy = 0, nha = 0, nhb = 0;
+        unsigned nm2 = 0, nmx = 0, nmy = 0, nc3 = BFD_CLS_FLUID, nhcA = 0, nhcB = 0;
+        auto prefetch_next = [&]() {
+        if (valid) { nm2 = (d.mat + ko + 2 * pl)[cij]; nc3 = (d.cls + ko + 3 * pl)[cij]; }       // kl+3 <= nk+1: ghost planes exist
+            if (kl + 1 < kend) {
+                if (valid) {
+                    nzz = (d.Szz + ko + 3 * pl)[cij];
+                    if (cC & BFD_CLS_EXZ) nxz = (d.Sxz + ko + 2 * pl)[cij];
+                    if (cC & BFD_CLS_EYZ) nyz = (d.Syz + ko + 2 * pl)[cij];
+                    if (cB & BFD_CLS_FLUID) { nxx = zzp1; nyy = zzp1; }
+                    else { nxx = (d.Sxx + ko + pl)[cij]; nyy = (d.Syy + ko + pl)[cij]; }
+                    if (cB & BFD_CLS_EXY) nxy = (d.Sxy + ko + pl)[cij];
+                    nmx = (d.mat + ko + pl)[cx]; nmy = (d.mat + ko + pl)[cy];
+                }
+                if (ta.ok) { nha = halo_value(baseA + ko + pl, d.Szz + ko + pl, substA, bitA, hcA, offA); nhcA = (d.cls + ko + 2 * pl)[offA]; }
+                if (tb.ok) { nhb = halo_value(baseB + ko + pl, d.Szz + ko + pl, substB, bitB, hcB, offB); nhcB = (d.cls + ko + 2 * pl)[offB]; }
+            }
+        };
+#ifdef BFD_EARLY_PREFETCH
+        prefetch_next();        // in flight across the table look-ups, the barrier and this plane's arithmetic
+#endif
         float r1 = 0, rx = 0, ry = 0, vx = 0, vy = 0, vz = 0, av = 0, pv = 0;
         if (valid) {
             r1 = d.invRho[mraw1 & BFD_MAT_MASK];       // plane kl+1, becomes r0 of the next iteration
@@ -1215,23 +1244,9 @@ __device__ __forceinline__ void velocity_solid_body(const bfd_dev &d, const int4
         __syncthreads();
 
         float *wVx = d.VxW + ko, *wVy = d.VyW + ko, *wVz = d.VzW + ko;
-        float nzz = 0, nxz = 0, nyz = 0, nxx = 0, nyy = 0, nxy = 0, nha = 0, nhb = 0;
-        unsigned nm2 = 0, nmx = 0, nmy = 0, nc3 = BFD_CLS_FLUID, nhcA = 0, nhcB = 0;
-        if (valid) { nm2 = (d.mat + ko + 2 * pl)[cij]; nc3 = (d.cls + ko + 3 * pl)[cij]; }       // kl+3 <= nk+1: ghost planes exist
-        if (kl + 1 < kend) {
-            if (valid) {
-                nzz = (d.Szz + ko + 3 * pl)[cij];
-                if (cC & BFD_CLS_EXZ) nxz = (d.Sxz + ko + 2 * pl)[cij];
-                if (cC & BFD_CLS_EYZ) nyz = (d.Syz + ko + 2 * pl)[cij];
-                if (cB & BFD_CLS_FLUID) { nxx = zzp1; nyy = zzp1; }
-                else { nxx = (d.Sxx + ko + pl)[cij]; nyy = (d.Syy + ko + pl)[cij]; }
-                if (cB & BFD_CLS_EXY) nxy = (d.Sxy + ko + pl)[cij];
-                nmx = (d.mat + ko + pl)[cx]; nmy = (d.mat + ko + pl)[cy];
-            }
-            if (ta.ok) { nha = halo_value(baseA + ko + pl, d.Szz + ko + pl, substA, bitA, hcA, offA); nhcA = (d.cls + ko + 2 * pl)[offA]; }
-            if (tb.ok) { nhb = halo_value(baseB + ko + pl, d.Szz + ko + pl, substB, bitB, hcB, offB); nhcB = (d.cls + ko + 2 * pl)[offB]; }
-        }
-
+#ifndef BFD_EARLY_PREFETCH
+        prefetch_next();
+#endif
         if (valid) {
             const float sxx = sS[b][0][own], syy = sS[b][1][own], sxy = sS[b][2][own];
             if (ACC) {
@@ -1609,21 +1624,20 @@ static inline void part_range(int n, int nB, int part, int *off, int *cnt)
     else { *off = 0; *cnt = n; }
 }
 
-void bfd_launch_stress_v2(const bfd_dev &d, hipStream_t s, const bfd_tiles *t, int part)
+void bfd_launch_stress_v2(const bfd_dev &d, hipStream_t s0, const bfd_tiles *t, int part)
 {
     const int tilesX = (d.N1 + TX - 1) / TX;
-    int off, n;
+    int off, n, offS, nS;
     part_range(t->nFluid, t->nFluidB, part, &off, &n);
-    if (n) {
-        BFD_KT(BFD_K_STRESS_FLUID, 0);
-        BFD_LAUNCH((stress_fluid<true>), n, t->runs + off);      // fluid cells keep one copy of their normal stresses (bfd_dev::cls)
-        BFD_KT(BFD_K_STRESS_FLUID, 1);
-    }
-    part_range(t->nSolid, t->nSolidB, part, &off, &n);
-    if (n) {
+    part_range(t->nSolid, t->nSolidB, part, &offS, &nS);
+    // solid-run kernels beside the fluid-run kernel (they touch disjoint cells and only read V): fork / join by events
+    const bool fork = t->side && n > 0 && nS > 0;
+    hipStream_t s = s0;
+    if (fork) { hipEventRecord(t->evFork, s0); hipStreamWaitEvent(t->side, t->evFork, 0); s = t->side; }
+    if (nS) {
         BFD_KT(BFD_K_STRESS_SOLID, 0);
-        if (t->shearCells) BFD_LAUNCH(stress_solid, n, t->runs + t->nFluid + off);
-        else BFD_LAUNCH(stress_v2, n, t->runs + t->nFluid + off, (const unsigned short *)nullptr);     // variant 2: monolithic, dense
+        if (t->shearCells) BFD_LAUNCH(stress_solid, nS, t->runs + t->nFluid + offS);
+        else BFD_LAUNCH(stress_v2, nS, t->runs + t->nFluid + offS, (const unsigned short *)nullptr);     // variant 2: monolithic, dense
         BFD_KT(BFD_K_STRESS_SOLID, 1);
     }
     if (t->shearCells && t->nShear) {     // sparse shear: cells sorted by index; [0,lowEnd) and [highBeg,n) are the boundary chunks
@@ -1635,6 +1649,13 @@ void bfd_launch_stress_v2(const bfd_dev &d, hipStream_t s, const bfd_tiles *t, i
         if (e1 > b1) hipLaunchKernelGGL(stress_shear_sparse, dim3((unsigned)((e1 - b1 + 255) / 256)), dim3(256), 0, s, d, t->shearCells + b1, t->shearCoef + 6 * b1, e1 - b1);
         BFD_KT(BFD_K_STRESS_SHEAR, 1);
     }
+    if (fork) { hipEventRecord(t->evJoin, t->side); s = s0; }
+    if (n) {
+        BFD_KT(BFD_K_STRESS_FLUID, 0);
+        BFD_LAUNCH((stress_fluid<true>), n, t->runs + off);      // fluid cells keep one copy of their normal stresses (bfd_dev::cls)
+        BFD_KT(BFD_K_STRESS_FLUID, 1);
+    }
+    if (fork) hipStreamWaitEvent(s0, t->evJoin, 0);
 }
 
 // fused time step of the eligible fluid runs (variant 4; whole half-steps only); d = stress-side view of the fields
@@ -1650,19 +1671,16 @@ void bfd_launch_fused(const bfd_dev &d, hipStream_t s, float *accP, float *pkP, 
     BFD_KT(BFD_K_FUSED, 1);
 }
 
-void bfd_launch_velocity_v2(const bfd_dev &d, hipStream_t s, float *accP, float *pkP, const bfd_tiles *t, int part)
+void bfd_launch_velocity_v2(const bfd_dev &d, hipStream_t s0, float *accP, float *pkP, const bfd_tiles *t, int part)
 {
     const int tilesX = (d.N1 + TX - 1) / TX;
     const bool acc = accP || pkP;
-    int off, n;
-    part_range(t->nFluid, t->nFluidB, part, &off, &n);
-    if (n) {
-        BFD_KT(BFD_K_VELOCITY_FLUID, 0);
-        if (acc) BFD_LAUNCH((velocity_fluid<true>), n, t->runs + off, accP, pkP);
-        else BFD_LAUNCH((velocity_fluid<false>), n, t->runs + off, accP, pkP);
-        BFD_KT(BFD_K_VELOCITY_FLUID, 1);
-    }
+    int offF, nF, off, n;
+    part_range(t->nFluid, t->nFluidB, part, &offF, &nF);
     part_range(t->nSolid, t->nSolidB, part, &off, &n);
+    const bool fork = t->side && nF > 0 && n > 0;
+    hipStream_t s = s0;
+    if (fork) { hipEventRecord(t->evFork, s0); hipStreamWaitEvent(t->side, t->evFork, 0); s = t->side; }
     if (n) {
         BFD_KT(BFD_K_VELOCITY_SOLID, 0);
         if (t->shearCells) {
@@ -1685,4 +1703,12 @@ void bfd_launch_velocity_v2(const bfd_dev &d, hipStream_t s, float *accP, float 
         }
         BFD_KT(BFD_K_VELOCITY_SOLID, 1);
     }
+    if (fork) { hipEventRecord(t->evJoin, t->side); s = s0; }
+    if (nF) {
+        BFD_KT(BFD_K_VELOCITY_FLUID, 0);
+        if (acc) BFD_LAUNCH((velocity_fluid<true>), nF, t->runs + offF, accP, pkP);
+        else BFD_LAUNCH((velocity_fluid<false>), nF, t->runs + offF, accP, pkP);
+        BFD_KT(BFD_K_VELOCITY_FLUID, 1);
+    }
+    if (fork) hipStreamWaitEvent(s0, t->evJoin, 0);
 }

@@ -133,31 +133,51 @@ class SlabRunner:
         self.low = rank - 1 if rank > 0 else None
         self.high = rank + 1 if rank < world - 1 else None
         self.bytes_sent = 0
-        self.overlap = (getattr(slab, 'supports_parts', False) if overlap is None else overlap) and world > 1
+        # Overlapped step (boundary part + exchange on a side stream beside the interior part) by default; a thin slab has
+        # too little interior work to hide anything behind and pays for the extra launches, so it takes the blocking order
+        # (BFD_OVERLAP_MIN_PLANES, default 64 planes; an explicit overlap= argument wins)
+        if overlap is None:
+            import os
+            thick = getattr(getattr(slab, 'eng', None), 'shape', (0, 0, 1 << 30))[2] >= int(os.environ.get('BFD_OVERLAP_MIN_PLANES', '64'))
+            overlap = getattr(slab, 'supports_parts', False) and thick
+            if world > 1 and dist is not None:      # the two orders exchange in a different sequence: every rank must take the same one
+                flags = [None] * world
+                dist.all_gather_object(flags, bool(overlap), group=group)
+                overlap = all(flags)
+        self.overlap = overlap and world > 1
         mine = slab.halo_fields() if hasattr(slab, 'halo_fields') else ALL_FIELDS
         self.needs = [mine]
         if world > 1:
             self.needs = [None] * world
             dist.all_gather_object(self.needs, mine, group=group)
 
+    def _ops(self, halo_group):
+        """The point-to-point operations of one exchange, built once per halo group (the tensors alias fixed device or
+        host buffers, so the same descriptors serve every step)."""
+        cache = self.__dict__.setdefault('_op_cache', {})
+        if halo_group not in cache:
+            dist, s = self.dist, self.slab
+            ops, nbytes = [], 0
+            # side 0 = my low face <-> peer's high ghosts, side 1 = my high face <-> peer's low ghosts
+            for side, peer in ((0, self.low), (1, self.high)):
+                if peer is None:
+                    continue
+                for f in self.needs[peer][halo_group]:          # what the peer reads from me
+                    t = s.halo(halo_group, f, side, True)
+                    ops.append(dist.P2POp(dist.isend, t, peer, self.group))
+                    nbytes += t.numel() * 4
+                for f in self.needs[self.rank][halo_group]:     # what I read from the peer
+                    ops.append(dist.P2POp(dist.irecv, s.halo(halo_group, f, side, False), peer, self.group))
+            cache[halo_group] = (ops, nbytes)
+        return cache[halo_group]
+
     def exchange_start(self, halo_group):
         if self.world == 1:
             return []
-        dist = self.dist
-        s = self.slab
-        s.before_send(halo_group)
-        ops = []
-        # side 0 = my low face <-> peer's high ghosts, side 1 = my high face <-> peer's low ghosts
-        for side, peer in ((0, self.low), (1, self.high)):
-            if peer is None:
-                continue
-            for f in self.needs[peer][halo_group]:          # what the peer reads from me
-                t = s.halo(halo_group, f, side, True)
-                ops.append(dist.P2POp(dist.isend, t, peer, self.group))
-                self.bytes_sent += t.numel() * 4
-            for f in self.needs[self.rank][halo_group]:     # what I read from the peer
-                ops.append(dist.P2POp(dist.irecv, s.halo(halo_group, f, side, False), peer, self.group))
-        return dist.batch_isend_irecv(ops) if ops else []
+        self.slab.before_send(halo_group)
+        ops, nbytes = self._ops(halo_group)
+        self.bytes_sent += nbytes
+        return self.dist.batch_isend_irecv(ops) if ops else []
 
     def exchange_finish(self, reqs, halo_group):
         if self.world == 1:

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define BFD_ABI_VERSION 1
+#define BFD_ABI_VERSION 2
 
 enum {
     BFD_MAP_VX = 0, BFD_MAP_VY = 1, BFD_MAP_VZ = 2,
@@ -71,6 +71,10 @@ typedef struct bfd_config {
     int32_t kernelVariant;     /* 0 = default (= 3), 1 = simple one-thread-per-voxel kernels, 2 = LDS-tiled dense, 3 = LDS-tiled with fluid/solid tile classes, 4 = 3 + fused stress/velocity pass over eligible fluid tiles (whole domains only: keeps two copies of V, Szz, Rzz; on a Z-slab it is 3) */
     int32_t rmsFirstStep;      /* 0 = RMS/peak accumulation starts at step SensorStart*SensorSubSampling (the reference's last-cycles
                                 * window, BASE:2108-2109); n > 0 = it starts at step n-1 (bench: every timed step accumulates) */
+    int32_t sensorMode;        /* 0 = the sensor series are stored ([nSensors][nTs] per selected map, what the reference returns);
+                                * 1 = only their single-frequency content is kept: re/im of the DFT bin nearest to `freq` and the peak
+                                * are accumulated per sensor while the samples are taken (what CalculatePhaseData extracts from the
+                                * series, BASE:2498-2520) -- 20 B per sensor instead of 4*nTs; bfd_get_sensors is then unavailable */
     double h;                  /* SpatialStep, m (BASE:2344)                                      */
     double dt;                 /* DT, s (BASE:2351)                                               */
     double freq;               /* Frequency, Hz (BASE:2341)                                       */
@@ -113,7 +117,12 @@ int bfd_set_material_map(bfd_sim *sim, const uint32_t *map, int64_t s1, int64_t 
 int bfd_set_reflector(bfd_sim *sim, const uint32_t *mask, int64_t s1, int64_t s2, int64_t s3);
 /* SourceMap/PulseSource/Ox,Oy,Oz (BASE:2342-2349) in compact form: nVox source voxels of this
  * slab, local x-fastest linear index, 0-based PulseSource row, per-voxel weights (NULL = 1),
- * pulse = [nSources][lengthSource] float64 exactly as the caller built it (Single:335-346). */
+ * pulse = [nSources][lengthSource] float64 exactly as the caller built it (Single:335-346).
+ * A table whose float32 form exceeds 1 GiB (238 k sources x 6.8 k steps at 512^3: 6.4 GB; 1 M x 7 k at 1024^3: 28 GB) is
+ * STREAMED: it stays in the caller's memory -- which must then remain valid and unchanged until the last time step has
+ * been issued, as it does inside the solver call -- and reaches the device in double-buffered time tiles of 64 steps
+ * (float64 -> float32 by a host packer that runs beside the GPU); the device holds 2 tiles instead of 12 bytes per
+ * table entry. Smaller tables are converted once and kept resident. Results are identical either way. */
 int bfd_set_sources(bfd_sim *sim, int64_t nVox, const uint32_t *localIndex, const uint32_t *row,
                     const float *wx, const float *wy, const float *wz,
                     const double *pulse, int32_t nSources, int32_t lengthSource);
@@ -176,7 +185,9 @@ int bfd_get_sensors(bfd_sim *sim, float *out);
  * FFT + bin pick of CalculatePhaseData (BASE:2498-2520) without moving the (nSensor x nTs) block.
  *   F[q][s] = (2/nTs) sum_n x[q][s][n] exp(-2 pi i bin n / nTs),  bin = argmin |fftfreq(nTs, DT*SensorSubSampling) - freq|
  *   peak[q][s] = max_n x[q][s][n]                                                   (BASE:2518)
- * outReIm: [nSelSensors][nSensors][2] float32, outPeak (may be NULL): [nSelSensors][nSensors]. */
+ * outReIm: [nSelSensors][nSensors][2] float32, outPeak (may be NULL): [nSelSensors][nSensors].
+ * With sensorMode 1 the values come from the in-loop accumulators (same arithmetic, sample by sample; freq must be the
+ * sim's own frequency). */
 int bfd_get_sensor_dft(bfd_sim *sim, double freq, float *outReIm, float *outPeak);
 /* the same transform for a host series [nSensors][nTs] (row-major), sampling period dtSensor */
 int bfd_dft_series(int32_t device, int64_t nSensors, int32_t nTs, const float *series, double dtSensor, double freq,

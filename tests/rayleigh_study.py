@@ -30,7 +30,7 @@ Z_BEYOND = 80e-3              # zLengthBeyonFocalPointWhenNarrow of the Single r
 C_WATER = 1500.0              # Material['Water'][1]
 
 
-def build_case(freq, ppw, focal, diam, zadj, stable_dt_fn, forward, depth_target=DEPTH_TARGET):
+def build_case(freq, ppw, focal, diam, zadj, stable_dt_fn, forward, depth_target=DEPTH_TARGET, gap_vox=1.0):
     """-> dict with the solver arguments of one Single-Tx water case and the Rayleigh field on the whole domain."""
     pml = H.PML_THICKNESS
     h = H.SSOS_AT_WATER_DENSITY / freq / ppw                       # GetSmallestSOS(f, bShear=True) is its floor at every study frequency
@@ -51,7 +51,7 @@ def build_case(freq, ppw, focal, diam, zadj, stable_dt_fn, forward, depth_target
     xs = (np.arange(N1) - (pml + n_half)) * h
     # z measured from the source plane; the rim of the bowl is `gap` above it (one voxel for ZAdj = 0: the reference moves
     # the transducer back by whole voxels until its sub-sources are behind the plane, Single:268-274)
-    gap = h if zadj == 0 else -zadj
+    gap = gap_vox * h if zadj == 0 else -zadj
     zs = (np.arange(N3) - zsrc) * h
     lam = 1482.0 / freq                                            # SpeedofSoundWater(20.0) ~ 1482 m/s sets the sub-source size
     alpha = np.arcsin(diam / 2 / focal)
@@ -126,10 +126,10 @@ def qcheck(A, B, voxel_mm):
             'L2': float(100.0 * np.sqrt(np.sum((A - B) ** 2) / np.sum(B ** 2)))}
 
 
-def run_case(row, solver, stable_dt_fn, forward, depth_target=DEPTH_TARGET):
+def run_case(row, solver, stable_dt_fn, forward, depth_target=DEPTH_TARGET, gap_vox=1.0):
     """row: an entry of rayleigh_study.json (tx == 'Single'). solver(*args, **kwargs) -> the solver tuple."""
     case = build_case(row['freq_khz'] * 1e3, row['ppw'], row['focal_mm'] * 1e-3, row['diam_mm'] * 1e-3, row['zadj_mm'] * 1e-3,
-                      stable_dt_fn, forward, depth_target)
+                      stable_dt_fn, forward, depth_target, gap_vox)
     out = solver(*case['args'], **case['kwargs'])
     A, B = result_volumes(case, out[2]['Pressure'])
     m = qcheck(A, B, case['h'] * 1e3)

@@ -38,6 +38,28 @@ def test_engine_sensor_dft_matches_host_fft():
         assert np.array_equal(Inp['SensorPeak'][name], S[name].max(axis=1))
 
 
+def test_in_loop_accumulation_equals_dft_of_stored_series():
+    """ReturnSensorSeries=False: re/im/peak are accumulated per sensor while the samples are taken and the series are
+    never stored; the result is the DFT of the stored series sample for sample (same arithmetic), device memory shrinks."""
+    from babelbrain_amd import PropagationModel
+    a, k, info = H.make_problem('C2', N=(56, 52, 80), steps=300, stable_dt_fn=oracle_dt)
+    k['SelMapsSensorsList'] = ['Pressure', 'Vz']
+    m = PropagationModel()
+    full = m.StaggeredFDTD_3D_with_relaxation(*a, SILENT=True, ReturnSensorDFT=True, **k)
+    lean = m.StaggeredFDTD_3D_with_relaxation(*a, SILENT=True, ReturnSensorDFT=True, ReturnSensorSeries=False, **k)
+    assert set(lean[0].keys()) == {'time'} and np.array_equal(lean[0]['time'], full[0]['time'])
+    assert np.array_equal(lean[-1]['IndexSensorMap'], full[-1]['IndexSensorMap'])
+    for name in ('Pressure', 'Vz'):
+        assert np.abs(full[-1]['SensorDFT'][name]).max() > 0
+        assert np.array_equal(lean[-1]['SensorDFT'][name], full[-1]['SensorDFT'][name])
+        assert np.array_equal(lean[-1]['SensorPeak'][name], full[-1]['SensorPeak'][name])
+    assert np.array_equal(lean[2]['Pressure'], full[2]['Pressure'])
+    nS, nTs = full[0]['Pressure'].shape
+    assert full[-1]['device_bytes'] - lean[-1]['device_bytes'] == 2 * nS * (4 * nTs - 20)
+    with pytest.raises(ValueError):
+        m.StaggeredFDTD_3D_with_relaxation(*a, SILENT=True, ReturnSensorSeries=False, **k)
+
+
 def test_solver_to_data_for_sim_file(tmp_path):
     """The acoustic step end to end on this package: solver call with on-device DFT -> volumes
     (CalculatePhaseData's outputs) -> caller scaling -> DataForSim (BASE:2812-2885) -> HDF5 -> read back."""

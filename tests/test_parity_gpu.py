@@ -343,3 +343,36 @@ def test_other_absorbing_layer_settings(variant, nd, rl):
     oh, orf = run_both(a, k, variant)
     compare_runs(oh, orf, TOL)
     assert orf[2]['Pressure'].max() > 0
+
+
+@pytest.mark.parametrize('tile,type_source', [(16, 0), (7, 2), (1000, 0)])
+def test_streamed_source_table_equals_resident(monkeypatch, tile, type_source):
+    """Large PulseSource tables stay on the host and reach the device in double-buffered time tiles (float64 -> float32
+    on the way); forced here with BFD_SOURCE_TILE. Every output equals the run with the resident table bit for bit --
+    also after a reset (the tiles start over) and for stress sources (injected after the stress half-step)."""
+    from babelbrain_amd import PropagationModel, _engine
+    from babelbrain_amd.PropagationModel import compact_sources
+    a, k, info = H.make_problem('C2', N=(48, 40, 56), steps=150, stable_dt_fn=oracle_dt)
+    k['TypeSource'] = type_source
+    k['SelMapsRMSPeakList'] = ['Pressure', 'Vz']
+    ref = PropagationModel().StaggeredFDTD_3D_with_relaxation(*a, SILENT=True, **k)
+    monkeypatch.setenv('BFD_SOURCE_TILE', str(tile))
+    got = PropagationModel().StaggeredFDTD_3D_with_relaxation(*a, SILENT=True, **k)
+    assert got[-1]['device_bytes'] != ref[-1]['device_bytes']
+    for name in ('Pressure', 'Vz'):
+        assert np.array_equal(got[2][name], ref[2][name]) and np.array_equal(got[1][name], ref[1][name])
+    assert np.array_equal(got[0]['Pressure'], ref[0]['Pressure'])
+    # engine level: run, reset, run again
+    mm, ml, f, smap, pulse, h, T, sensor = a
+    eng = _engine.Engine(*mm.shape, len(ml), h, k['DT'], f, info['nt'], typeSource=type_source, sensorSub=k['SensorSubSampling'],
+                         sensorStart=k['SensorStart'], selMapsRMS=['Pressure'], selMapsSensors=['Pressure'])
+    eng.set_materials(ml, k['QCorrection'])
+    eng.set_material_map(mm, 0, 0)
+    pulse64 = np.ascontiguousarray(pulse, np.float64)
+    eng.set_sources(*compact_sources(smap, k['Ox'], k['Oy'], k['Oz']), pulse64)
+    eng.set_sensor_map(sensor)
+    eng.run(60)
+    eng.reset()
+    eng.run(info['nt'])
+    assert np.array_equal(eng.get_map(_engine.KIND_RMS, 'Pressure'), ref[2]['Pressure'])
+    eng.close()
