@@ -601,16 +601,6 @@ int bfd_create(const bfd_config *cfg, bfd_sim **out)
     s->acc = s->pk = nullptr; s->timing = s->perKernel = false;
     s->tables = nullptr; s->profiles = nullptr; s->cmax = 0;
     memset(s->algBytes, 0, sizeof s->algBytes); s->tiles.ktimer = nullptr;
-    s->tiles.side = nullptr; s->tiles.evFork = s->tiles.evJoin = nullptr;
-    if (const char *ev = getenv("BFD_CONCURRENT")) {       // experiment: solid-run kernels on a second stream beside the fluid-run kernel
-        const int mode = atoi(ev);
-        if (mode) {
-            int lo = 0, hi = 0; hipDeviceGetStreamPriorityRange(&lo, &hi);
-            if (hipStreamCreateWithPriority(&s->tiles.side, hipStreamNonBlocking, mode == 2 ? hi : (mode == 3 ? lo : 0)) != hipSuccess) s->tiles.side = nullptr;
-            if (s->tiles.side && (hipEventCreateWithFlags(&s->tiles.evFork, hipEventDisableTiming) != hipSuccess ||
-                                  hipEventCreateWithFlags(&s->tiles.evJoin, hipEventDisableTiming) != hipSuccess)) { hipStreamDestroy(s->tiles.side); s->tiles.side = nullptr; }
-        }
-    }
     if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) { delete s; BFD_FAIL(-10, "hipStreamCreate failed"); }
     s->ownStream = true;
     if (hipEventCreate(&s->evBegin) != hipSuccess) { hipStreamDestroy(s->stream); delete s; BFD_FAIL(-10, "hipEventCreate failed"); }
@@ -686,7 +676,6 @@ void bfd_destroy(bfd_sim *s)
     for (hipEvent_t e : s->evVelocity) hipEventDestroy(e);
     for (auto &v : s->evK) for (hipEvent_t e : v) hipEventDestroy(e);
     hipEventDestroy(s->evBegin); hipEventDestroy(s->evEnd);
-    if (s->tiles.side) { hipStreamDestroy(s->tiles.side); hipEventDestroy(s->tiles.evFork); hipEventDestroy(s->tiles.evJoin); }
     if (s->ownStream) hipStreamDestroy(s->stream);
     delete s;
 }

@@ -77,10 +77,7 @@ struct bfd_sim;
 // records an event before (end = 0) / after (end = 1) a launch of class cls (bfd_api.hip); t->ktimer != null while class timing is on
 void bfd_kmark(bfd_sim *sim, int cls, int end, hipStream_t st);
 
-struct bfd_tiles { bfd_sim *ktimer;
-                   // optional second stream: the solid-run kernels of a half-step run beside the fluid-run kernel (disjoint tiles)
-                   hipStream_t side; hipEvent_t evFork, evJoin;
-                   int4 *runs;
+struct bfd_tiles { bfd_sim *ktimer; int4 *runs;
                    unsigned *shearCells; float *shearCoef; long nShear, shearLowEnd, shearHighBeg;   /* sparse shear list */
                    int nFluid, nFluidB, nSolid, nSolidB, nSolidBP /* leading boundary runs that touch the absorbing layer */, nSolidIP /* trailing interior ones */, nFused /* runs of the fused kernel, after the solid runs */;
                    int nLossless, nLossy, nSolidSub, nUni, nPml, nLean, nFusedSub; };

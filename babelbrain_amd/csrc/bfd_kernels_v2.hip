@@ -1033,9 +1033,6 @@ __device__ __forceinline__ void stress_solid_body(const bfd_dev &d, const int4 &
                 if (PML && valid && (kn < P || kn >= d.N3 - P)) npz = d.psi[2][(unsigned)((kn < P ? kn : kn - (d.N3 - 2 * P)) * d.plane) + cij];
             }
         };
-#ifdef BFD_EARLY_PREFETCH
-        prefetch_next();        // the loads of plane kl+1 are in flight across the staging, the barrier and this plane's arithmetic
-#endif
         sV[b][0][own] = vx0; sV[b][1][own] = vy0;
         if (has) lh[b * (2 * LH * LW)] = hv;
         const int m = mraw & BFD_MAT_MASK;
@@ -1044,9 +1041,7 @@ __device__ __forceinline__ void stress_solid_body(const bfd_dev &d, const int4 &
         if (valid) { AP = d.AP[m]; if (mem) BP = d.BP[m]; if (!fl) { AS2 = d.AS2[m]; BS2 = d.BS2[m]; } }
         __syncthreads();
 
-#ifndef BFD_EARLY_PREFETCH
-        prefetch_next();
-#endif
+        prefetch_next();        // after the barrier (issuing these loads before it was measured slower: 2.37 -> 2.52 ms per step at C2-medium 512^3)
         if (valid) {
             const float *sx = &sV[b][0][own], *sy = &sV[b][1][own];
             float dxVx = dminus4(sx[-2], sx[-1], vx0, sx[1]);
@@ -1214,7 +1209,8 @@ __device__ __forceinline__ void velocity_solid_body(const bfd_dev &d, const int4
         float nzz = 0, nxz = 0, nyz = 0, nxx = 0, nyy = 0, nxy = 0, nha = 0, nhb = 0;
         unsigned nm2 = 0, nmx = 0, nmy = 0, nc3 = BFD_CLS_FLUID, nhcA = 0, nhcB = 0;
         auto prefetch_next = [&]() {
-        if (valid) { nm2 = (d.mat + ko + 2 * pl)[cij]; nc3 = (d.cls + ko + 3 * pl)[cij]; }       // kl+3 <= nk+1: ghost planes exist
+        if (valid) nm2 = (d.mat + ko + 2 * pl)[cij];              // ghost planes make kl+2 addressable
+        if (valid && kl + 2 < kend) nc3 = (d.cls + ko + 3 * pl)[cij];       // steers the Sxz / Syz loads of iteration kl+1 (plane kl+3 <= nk+1)
             if (kl + 1 < kend) {
                 if (valid) {
                     nzz = (d.Szz + ko + 3 * pl)[cij];
@@ -1229,9 +1225,6 @@ __device__ __forceinline__ void velocity_solid_body(const bfd_dev &d, const int4
                 if (tb.ok) { nhb = halo_value(baseB + ko + pl, d.Szz + ko + pl, substB, bitB, hcB, offB); nhcB = (d.cls + ko + 2 * pl)[offB]; }
             }
         };
-#ifdef BFD_EARLY_PREFETCH
-        prefetch_next();        // in flight across the table look-ups, the barrier and this plane's arithmetic
-#endif
         float r1 = 0, rx = 0, ry = 0, vx = 0, vy = 0, vz = 0, av = 0, pv = 0;
         if (valid) {
             r1 = d.invRho[mraw1 & BFD_MAT_MASK];       // plane kl+1, becomes r0 of the next iteration
@@ -1244,9 +1237,7 @@ __device__ __forceinline__ void velocity_solid_body(const bfd_dev &d, const int4
         __syncthreads();
 
         float *wVx = d.VxW + ko, *wVy = d.VyW + ko, *wVz = d.VzW + ko;
-#ifndef BFD_EARLY_PREFETCH
-        prefetch_next();
-#endif
+        prefetch_next();        // after the barrier (issuing these loads before it was measured slower: 2.37 -> 2.52 ms per step at C2-medium 512^3)
         if (valid) {
             const float sxx = sS[b][0][own], syy = sS[b][1][own], sxy = sS[b][2][own];
             if (ACC) {
@@ -1630,10 +1621,7 @@ void bfd_launch_stress_v2(const bfd_dev &d, hipStream_t s0, const bfd_tiles *t, 
     int off, n, offS, nS;
     part_range(t->nFluid, t->nFluidB, part, &off, &n);
     part_range(t->nSolid, t->nSolidB, part, &offS, &nS);
-    // solid-run kernels beside the fluid-run kernel (they touch disjoint cells and only read V): fork / join by events
-    const bool fork = t->side && n > 0 && nS > 0;
     hipStream_t s = s0;
-    if (fork) { hipEventRecord(t->evFork, s0); hipStreamWaitEvent(t->side, t->evFork, 0); s = t->side; }
     if (nS) {
         BFD_KT(BFD_K_STRESS_SOLID, 0);
         if (t->shearCells) BFD_LAUNCH(stress_solid, nS, t->runs + t->nFluid + offS);
@@ -1649,13 +1637,11 @@ void bfd_launch_stress_v2(const bfd_dev &d, hipStream_t s0, const bfd_tiles *t, 
         if (e1 > b1) hipLaunchKernelGGL(stress_shear_sparse, dim3((unsigned)((e1 - b1 + 255) / 256)), dim3(256), 0, s, d, t->shearCells + b1, t->shearCoef + 6 * b1, e1 - b1);
         BFD_KT(BFD_K_STRESS_SHEAR, 1);
     }
-    if (fork) { hipEventRecord(t->evJoin, t->side); s = s0; }
     if (n) {
         BFD_KT(BFD_K_STRESS_FLUID, 0);
         BFD_LAUNCH((stress_fluid<true>), n, t->runs + off);      // fluid cells keep one copy of their normal stresses (bfd_dev::cls)
         BFD_KT(BFD_K_STRESS_FLUID, 1);
     }
-    if (fork) hipStreamWaitEvent(s0, t->evJoin, 0);
 }
 
 // fused time step of the eligible fluid runs (variant 4; whole half-steps only); d = stress-side view of the fields
@@ -1678,9 +1664,7 @@ void bfd_launch_velocity_v2(const bfd_dev &d, hipStream_t s0, float *accP, float
     int offF, nF, off, n;
     part_range(t->nFluid, t->nFluidB, part, &offF, &nF);
     part_range(t->nSolid, t->nSolidB, part, &off, &n);
-    const bool fork = t->side && nF > 0 && n > 0;
     hipStream_t s = s0;
-    if (fork) { hipEventRecord(t->evFork, s0); hipStreamWaitEvent(t->side, t->evFork, 0); s = t->side; }
     if (n) {
         BFD_KT(BFD_K_VELOCITY_SOLID, 0);
         if (t->shearCells) {
@@ -1703,12 +1687,10 @@ void bfd_launch_velocity_v2(const bfd_dev &d, hipStream_t s0, float *accP, float
         }
         BFD_KT(BFD_K_VELOCITY_SOLID, 1);
     }
-    if (fork) { hipEventRecord(t->evJoin, t->side); s = s0; }
     if (nF) {
         BFD_KT(BFD_K_VELOCITY_FLUID, 0);
         if (acc) BFD_LAUNCH((velocity_fluid<true>), nF, t->runs + offF, accP, pkP);
         else BFD_LAUNCH((velocity_fluid<false>), nF, t->runs + offF, accP, pkP);
         BFD_KT(BFD_K_VELOCITY_FLUID, 1);
     }
-    if (fork) hipStreamWaitEvent(s0, t->evJoin, 0);
 }

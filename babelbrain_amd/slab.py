@@ -145,6 +145,18 @@ class SlabRunner:
                 dist.all_gather_object(flags, bool(overlap), group=group)
                 overlap = all(flags)
         self.overlap = overlap and world > 1
+        if self.overlap and world > 1:
+            import os
+            import warnings
+            try:
+                nccl = dist.get_backend(group) == 'nccl'
+            except Exception:
+                nccl = False
+            if nccl and os.environ.get('TORCH_NCCL_HIGH_PRIORITY') != '1':
+                # measured (rocprofv3 timeline): at default priority RCCL's kernel starts only when the
+                # interior kernel has dispatched all of its workgroups, so the exchange is exposed
+                warnings.warn('SlabRunner: set TORCH_NCCL_HIGH_PRIORITY=1 before init_process_group, otherwise the halo '
+                              'exchange queues behind the interior kernels instead of running beside them')
         mine = slab.halo_fields() if hasattr(slab, 'halo_fields') else ALL_FIELDS
         self.needs = [mine]
         if world > 1:

@@ -17,11 +17,12 @@ sys.path.insert(0, ROOT)
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--zadj', type=float, nargs='*', default=[0.0, -10.0])
+    ap.add_argument('--zadj', type=float, nargs='*', default=[0.0, -10.0, 10.0])
     ap.add_argument('--every', type=int, default=1)
     ap.add_argument('--cases', type=int, nargs='*', default=None)
     ap.add_argument('--depth-mm', type=float, default=None)
     ap.add_argument('--gap-vox', type=float, default=1.0)
+    ap.add_argument('--pml', type=int, default=None, help='absorbing-layer thickness (sensitivity experiments; the reference uses 12)')
     ap.add_argument('--out', default=None)
     args = ap.parse_args()
     from babelbrain_amd import PropagationModel, RayleighAndBHTE as R, _engine
@@ -38,7 +39,7 @@ def main():
     out = []
     for r in rows:
         t = time.time()
-        m = RS.run_case(r, solver, dt_fn, R.ForwardSimple, depth, args.gap_vox)
+        m = RS.run_case(r, solver, dt_fn, R.ForwardSimple, depth, args.gap_vox, args.pml)
         m['case'] = r['case']; m['Description'] = r['Description']; m['seconds'] = time.time() - t
         m['ref'] = {k: r[k] for k in ('Difference amplitude', 'L2', 'L Inf', 'Distance focal centroid', 'L Inf location')}
         out.append(m)

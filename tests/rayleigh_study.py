@@ -12,8 +12,9 @@ row:
     absorbing layer around; water only (bWaterOnly: the material list is [Water], BASE:1306-1377);
   * time step: CalculateMatricesForPropagation(AlphaCFL = 0.5) snapped by the PPP rule (BASE:1799-1828); duration and
     sensor window from BASE:2082-2109;
-  * source: Rayleigh integral of the bowl on the plane k = 12 (Single:250-304), sources per Single:313-346; the rim of
-    the bowl sits in the source plane for ZAdj = 0 and 10 mm above it for ZAdj = -10 (PART_1 cell 8: TxMechanicalAdjustmentZ);
+  * source: Rayleigh integral of the bowl on the source plane (Single:250-304), sources per Single:313-346; the rim of
+    the bowl sits in the source plane for ZAdj = 0, 10 mm above it for ZAdj = -10, and for ZAdj = +10 the plane itself
+    moves 10 mm into the domain (PART_1 cell 8: TxMechanicalAdjustmentZ, ZIntoSkin);
   * result: RMS map * sqrt(2) * dispersion Correction (BASE:2433-2440), zeroed up to the source plane, cropped like the
     `_Sub` volumes (BASE:1459-1512); metrics of PART_2 cell 5 (`qcheck`).
 
@@ -30,28 +31,32 @@ Z_BEYOND = 80e-3              # zLengthBeyonFocalPointWhenNarrow of the Single r
 C_WATER = 1500.0              # Material['Water'][1]
 
 
-def build_case(freq, ppw, focal, diam, zadj, stable_dt_fn, forward, depth_target=DEPTH_TARGET, gap_vox=1.0):
+def build_case(freq, ppw, focal, diam, zadj, stable_dt_fn, forward, depth_target=DEPTH_TARGET, gap_vox=1.0, pml=None):
     """-> dict with the solver arguments of one Single-Tx water case and the Rayleigh field on the whole domain."""
-    pml = H.PML_THICKNESS
+    pml = H.PML_THICKNESS if pml is None else pml
     h = H.SSOS_AT_WATER_DENSITY / freq / ppw                       # GetSmallestSOS(f, bShear=True) is its floor at every study frequency
     water = np.array([H.MATERIALS[500e3]['Water']], np.float64)
     dt_ideal = stable_dt_fn(water, freq, h, H.ALPHA_CFL)
     dt_water = stable_dt_fn(water, freq, h, 1.0)
     ppp, dt = H.ppp_rule(dt_ideal, freq)
     dout = np.sqrt(focal ** 2 - (diam / 2) ** 2)
-    if zadj > 0:
-        raise NotImplementedError('ZAdj > 0 moves the source plane into the domain (ZIntoSkin); not rebuilt here')
-    radius_face = 1.1 * diam / 2                                   # BASE:1938-1944 (capped at Aperture/2, then * 1.1)
+    # BASE:1929-1944: the kept lateral region is the widest section of the beam cone, 1.1 * min(DistanceToFocus * tan(alpha),
+    # Aperture/2), DistanceToFocus = source plane -> geometric focus = DOut + ZAdj (a transducer pulled back by 10 mm has its
+    # focus 10 mm closer to the plane, and the cone is cut where it is narrower: the workbook's 'L Inf location' of those
+    # cases sits at the centre of exactly this many voxels)
+    alpha0 = np.arcsin(diam / 2 / focal)
+    radius_face = 1.1 * min((dout + min(zadj, 0.0)) * np.tan(alpha0), diam / 2)
     n_half = int(np.floor(radius_face / h + 1e-9))
     n_lat = 2 * n_half + 1
     nz = int(np.round(depth_target / h)) + int(Z_BEYOND / h) + 1
     N1 = N2 = n_lat + 2 * pml
     N3 = nz + 2 * pml
-    zsrc = pml
+    # ZAdj > 0 pushes the transducer "into the skin": the source plane moves ZIntoSkin deeper into the domain (BASE:1839-1841)
+    zsrc = pml + (int(np.round(zadj / h)) if zadj > 0 else 0)
     xs = (np.arange(N1) - (pml + n_half)) * h
     # z measured from the source plane; the rim of the bowl is `gap` above it (one voxel for ZAdj = 0: the reference moves
     # the transducer back by whole voxels until its sub-sources are behind the plane, Single:268-274)
-    gap = gap_vox * h if zadj == 0 else -zadj
+    gap = gap_vox * h if zadj >= 0 else -zadj
     zs = (np.arange(N3) - zsrc) * h
     lam = 1482.0 / freq                                            # SpeedofSoundWater(20.0) ~ 1482 m/s sets the sub-source size
     alpha = np.arcsin(diam / 2 / focal)
@@ -76,7 +81,7 @@ def build_case(freq, ppw, focal, diam, zadj, stable_dt_fn, forward, depth_target
                   ReflectionLimit=H.REFLECTION_LIMIT, USE_SINGLE=True, SelMapsRMSPeakList=['Pressure'],
                   SelMapsSensorsList=['Pressure'], SelRMSorPeak=1, AlphaCFL=1.0, TypeSource=0, QfactorCorrection=True,
                   QCorrection=1.0, SensorSubSampling=sub, SensorStart=start, ReflectorMask=None)
-    return dict(args=args, kwargs=kwargs, u2=u2, h=h, dt=dt, dt_water=dt_water, ppp=ppp, nt=nt, zsrc=zsrc, N=(N1, N2, N3),
+    return dict(args=args, kwargs=kwargs, u2=u2, pml=pml, h=h, dt=dt, dt_water=dt_water, ppp=ppp, nt=nt, zsrc=zsrc, N=(N1, N2, N3),
                 n_sources=pulse.shape[0], focus_plane=zsrc + (dout + gap) / h)
 
 
@@ -84,7 +89,7 @@ def result_volumes(case, rms_pressure):
     """FDTD and Rayleigh amplitude volumes as the study compares them: Correction * sqrt(2) (BASE:2433-2440), zero up to the
     source plane (BASE:2746, 2767-2769), the `_Sub` crop (interior without its last row / column and without the source
     plane, BASE:1488-1512 after the Z flip is undone)."""
-    pml, zsrc = H.PML_THICKNESS, case['zsrc']
+    pml, zsrc = case['pml'], case['zsrc']
     corr = H.dispersion_correction(case['dt'], case['dt_water'])
     A = np.array(rms_pressure, np.float64) * corr * np.sqrt(2.0)
     B = np.abs(case['u2']).astype(np.float64)
@@ -126,10 +131,10 @@ def qcheck(A, B, voxel_mm):
             'L2': float(100.0 * np.sqrt(np.sum((A - B) ** 2) / np.sum(B ** 2)))}
 
 
-def run_case(row, solver, stable_dt_fn, forward, depth_target=DEPTH_TARGET, gap_vox=1.0):
+def run_case(row, solver, stable_dt_fn, forward, depth_target=DEPTH_TARGET, gap_vox=1.0, pml=None):
     """row: an entry of rayleigh_study.json (tx == 'Single'). solver(*args, **kwargs) -> the solver tuple."""
     case = build_case(row['freq_khz'] * 1e3, row['ppw'], row['focal_mm'] * 1e-3, row['diam_mm'] * 1e-3, row['zadj_mm'] * 1e-3,
-                      stable_dt_fn, forward, depth_target, gap_vox)
+                      stable_dt_fn, forward, depth_target, gap_vox, pml)
     out = solver(*case['args'], **case['kwargs'])
     A, B = result_volumes(case, out[2]['Pressure'])
     m = qcheck(A, B, case['h'] * 1e3)
