@@ -86,15 +86,30 @@ def GenerateFocusTx(f, Foc, Diam, c, PPWSurface=4):
 # ------------------------------------------------------------------------------------------------
 # BHTE: Pennes bio-heat equation + CEM43 dose on the device (bfd_bhte_run)
 # ------------------------------------------------------------------------------------------------
-def bhte_coefficients(MaterialList, dx, dt, DutyCycle=1.0, blood_rho=1050.0, blood_ct=3617.0):
+# Heat source per voxel from the pressure amplitude. 'linear': Q = Absorption * alpha * p^2 / (rho c) (plane-wave intensity
+# times the local absorption); 'exponential': the energy a plane wave loses crossing the voxel,
+# Absorption * p^2 / (rho c) * (1 - exp(-2 h alpha)) / (2 h). They differ by about h*alpha (a few per cent in skull at
+# 0.3-0.5 mm voxels). Which one the absent package uses is unverified; module-level default, per call
+# through bhte_coefficients(source_form=...).
+BHTE_SOURCE_FORM = 'linear'
+
+
+def bhte_coefficients(MaterialList, dx, dt, DutyCycle=1.0, blood_rho=1050.0, blood_ct=3617.0, source_form=None):
     """Per-material float32 coefficients of the explicit scheme (documented in csrc/bfd_bhte.hip):
     cd = dt k/(rho c dx^2), cp = dt rho_b c_b w/(6e7 c) with w in mL/min/kg, and the factor qf that turns
-    p^2 into the temperature increment of one ON step: qf = dt DutyCycle Absorption Attenuation/(rho^2 c_s c)."""
+    p^2 into the temperature increment of one ON step: qf = dt DutyCycle Absorption A/(rho^2 c_s c), A = Attenuation
+    ('linear') or (1 - exp(-2 dx Attenuation))/(2 dx) ('exponential')."""
     rho = np.asarray(MaterialList['Density'], np.float64)
     ct = np.asarray(MaterialList['SpecificHeat'], np.float64)
     cd = dt * np.asarray(MaterialList['Conductivity'], np.float64) / (rho * ct * dx ** 2)
     cp = dt * blood_rho * blood_ct * np.asarray(MaterialList['Perfusion'], np.float64) / (6e7 * ct)
-    qf = (dt * DutyCycle * np.asarray(MaterialList['Absorption'], np.float64) * np.asarray(MaterialList['Attenuation'], np.float64)
+    att = np.asarray(MaterialList['Attenuation'], np.float64)
+    form = BHTE_SOURCE_FORM if source_form is None else source_form
+    if form == 'exponential':
+        att = -np.expm1(-2.0 * dx * att) / (2.0 * dx)
+    elif form != 'linear':
+        raise ValueError("source_form must be 'linear' or 'exponential'")
+    qf = (dt * DutyCycle * np.asarray(MaterialList['Absorption'], np.float64) * att
           / (rho * np.asarray(MaterialList['SoS'], np.float64)) / (rho * ct))
     if cd.max() > 1.0 / 6.0:
         raise ValueError('BHTE time step too large: dt k/(rho c dx^2) = %.3f > 1/6' % cd.max())

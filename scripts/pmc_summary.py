@@ -27,7 +27,7 @@ for k, d in agg.items():
         b = (2 * f + w) * 1024     # gfx950: FETCH_SIZE counts half the read bytes
         if 'fused' not in k:
             traffic['stress' if 'stress' in k else 'velocity'] += b
-        base = k.split('<')[0]
+        base = k.split('<')[0].replace('void ', '').strip()
         if base in CLASS_OF:
             traffic[CLASS_OF[base]] = traffic.get(CLASS_OF[base], 0.0) + b
 if len(sys.argv) > 2:

@@ -82,3 +82,22 @@ def test_field_schedule_properties(onoff, total):
     first = s[:period]
     for n, (on, off) in enumerate(onoff):
         assert np.count_nonzero(first == n) == (on if total >= period else np.count_nonzero(first == n))
+
+
+def test_bhte_source_forms():
+    """The finite-voxel (exponential) heat source tends to the linear one for h*alpha -> 0 and is smaller by about
+    h*alpha otherwise; everything else of the coefficient set is unchanged."""
+    from babelbrain_amd import RayleighAndBHTE as R
+    ml = {'Density': np.array([1000.0, 1896.5]), 'SoS': np.array([1500.0, 2476.0]), 'Attenuation': np.array([0.05, 81.0]),
+          'SpecificHeat': np.array([4178.0, 1313.0]), 'Conductivity': np.array([0.6, 0.32]), 'Perfusion': np.array([0.0, 10.0]),
+          'Absorption': np.array([0.85, 0.16])}
+    dx, dt = 0.4e-3, 0.01
+    cd, cp, q_lin = R.bhte_coefficients(ml, dx, dt, 0.5)
+    cd2, cp2, q_exp = R.bhte_coefficients(ml, dx, dt, 0.5, source_form='exponential')
+    assert np.array_equal(cd, cd2) and np.array_equal(cp, cp2)
+    ratio = q_exp.astype(np.float64) / q_lin
+    assert abs(ratio[0] - 1.0) < 1e-4                                     # water: h*alpha = 2e-5
+    ha = dx * 81.0
+    assert abs(ratio[1] - (1 - np.exp(-2 * ha)) / (2 * ha)) < 1e-6 and 0.95 < ratio[1] < 0.98
+    with pytest.raises(ValueError):
+        R.bhte_coefficients(ml, dx, dt, 0.5, source_form='other')
