@@ -36,7 +36,7 @@ constexpr int SUBZ = BFD_SUBZ;             // z granularity of the fluid/solid c
 #define STRESS_WAVES_PER_SIMD 4     // 2 workgroups of 8 waves per CU (<= 128 VGPRs); 6 or 8 spill and run 1.4-2.4x slower (measured)
 #endif
 #ifndef FLUID_WAVES_PER_SIMD
-#define FLUID_WAVES_PER_SIMD 6      // measured at 512^3: 6 -> 61 Gvoxel-steps/s, 8 (spills) -> 47, 5 -> 57, 4 -> 58
+#define FLUID_WAVES_PER_SIMD 8      // 57 / 64 VGPRs since the plane bases live in SGPRs (uni()); round 1, with 64-bit per-lane addresses: 6 -> 61 Gvoxel-steps/s, 8 (spills) -> 47
 #endif
 #ifndef VELOCITY_WAVES_PER_SIMD
 #define VELOCITY_WAVES_PER_SIMD 4
@@ -60,6 +60,25 @@ __device__ __forceinline__ float cpml(float *__restrict__ psi, unsigned idx, flo
     psi[idx] = pn;
     return D + pn;
 }
+
+
+// Element access as (wave-uniform plane base) + (32-bit BYTE offset in a VGPR): exactly the saddr form of global_load /
+// global_store (SGPR-pair base, 32-bit VGPR offset). Indexing a float* with a 32-bit cell index instead makes the compiler
+// build 64-bit addresses in VGPR pairs (it cannot prove that index*4 stays below 2^32): two registers and two VALU
+// instructions per access.
+// uni(): the plane base as an opaque wave-uniform value. Without it the compiler reassociates (array + plane) + lane offset
+// into (array + lane offset) + plane and hoists the first sum out of the z loop: a loop-invariant VGPR pair per array.
+template <typename T>
+__device__ __forceinline__ T *uni(T *p)
+{
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (T *)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ float &F4(float *base, unsigned byteOfs) { return *(float *)((char *)uni(base) + byteOfs); }
+__device__ __forceinline__ const float &F4(const float *base, unsigned byteOfs) { return *(const float *)((const char *)uni(base) + byteOfs); }
+__device__ __forceinline__ unsigned U2(const uint16_t *base, unsigned byteOfs) { return *(const uint16_t *)((const char *)uni(base) + byteOfs); }
+__device__ __forceinline__ unsigned U1(const uint8_t *base, unsigned byteOfs) { return uni(base)[byteOfs]; }
 
 // XCD-aware tile order: consecutive block ids land on different XCDs (round robin over 8), so give
 // XCD e the e-th contiguous run of tiles.
@@ -145,9 +164,9 @@ __global__ __launch_bounds__(NTHREADS, STRESS_WAVES_PER_SIMD) void stress_v2(bfd
     {
         const float *bVx = d.Vx + kbeg * pl, *bVy = d.Vy + kbeg * pl, *bVz = d.Vz + kbeg * pl;
         if (valid) {
-            vxm1 = (bVx - pl)[cij]; vx0 = bVx[cij]; vxp1 = (bVx + pl)[cij]; vxp2 = (bVx + 2 * pl)[cij];
-            vym1 = (bVy - pl)[cij]; vy0 = bVy[cij]; vyp1 = (bVy + pl)[cij]; vyp2 = (bVy + 2 * pl)[cij];
-            vzm2 = (bVz - 2 * pl)[cij]; vzm1 = (bVz - pl)[cij]; vz0 = bVz[cij]; vzp1 = (bVz + pl)[cij];
+            vxm1 = F4((bVx - pl), cij * 4u); vx0 = F4(bVx, cij * 4u); vxp1 = F4((bVx + pl), cij * 4u); vxp2 = F4((bVx + 2 * pl), cij * 4u);
+            vym1 = F4((bVy - pl), cij * 4u); vy0 = F4(bVy, cij * 4u); vyp1 = F4((bVy + pl), cij * 4u); vyp2 = F4((bVy + 2 * pl), cij * 4u);
+            vzm2 = F4((bVz - 2 * pl), cij * 4u); vzm1 = F4((bVz - pl), cij * 4u); vz0 = F4(bVz, cij * 4u); vzp1 = F4((bVz + pl), cij * 4u);
         }
     }
     float ha = ta.ok ? pa[kbeg * pl] : 0.0f;
@@ -173,14 +192,14 @@ __global__ __launch_bounds__(NTHREADS, STRESS_WAVES_PER_SIMD) void stress_v2(bfd
         unsigned mraw = 0;
         float sxx = 0, syy = 0, szz = 0, rxx = 0, ryy = 0, rzz = 0;
         if (valid) {
-            mraw = pM[cij];
-            szz = pSzz[cij];
-            if (!rowLossless) rzz = pRzz[cij];
-            if (!rowFluid) { sxx = pSxx[cij]; syy = pSyy[cij]; rxx = pRxx[cij]; ryy = pRyy[cij]; }
+            mraw = U2(pM, cij * 2u);
+            szz = F4(pSzz, cij * 4u);
+            if (!rowLossless) rzz = F4(pRzz, cij * 4u);
+            if (!rowFluid) { sxx = F4(pSxx, cij * 4u); syy = F4(pSyy, cij * 4u); rxx = F4(pRxx, cij * 4u); ryy = F4(pRyy, cij * 4u); }
         }
         float nvx = 0, nvy = 0, nvz = 0, nha = 0, nhb = 0;
         if (kl + 1 < kend) {
-            if (valid) { nvx = (d.Vx + ko + 3 * pl)[cij]; nvy = (d.Vy + ko + 3 * pl)[cij]; nvz = (d.Vz + ko + 2 * pl)[cij]; }
+            if (valid) { nvx = F4((d.Vx + ko + 3 * pl), cij * 4u); nvy = F4((d.Vy + ko + 3 * pl), cij * 4u); nvz = F4((d.Vz + ko + 2 * pl), cij * 4u); }
             if (ta.ok) nha = pa[ko + pl];
             if (tb.ok) nhb = pb[ko + pl];
         }
@@ -212,9 +231,9 @@ __global__ __launch_bounds__(NTHREADS, STRESS_WAVES_PER_SIMD) void stress_v2(bfd
             } else {
                 const float rn = c1 * rzz - d.BP[m] * div;
                 val = szz + (AP * div + 0.5f * (rzz + rn));
-                pRxx[cij] = rn; pRyy[cij] = rn; pRzz[cij] = rn;
+                F4(pRxx, cij * 4u) = rn; F4(pRyy, cij * 4u) = rn; F4(pRzz, cij * 4u) = rn;
             }
-            pSxx[cij] = val; pSyy[cij] = val; pSzz[cij] = val;
+            F4(pSxx, cij * 4u) = val; F4(pSyy, cij * 4u) = val; F4(pSzz, cij * 4u) = val;
         } else if (valid) {
             const float *sx = &sV[b][0][own], *sy = &sV[b][1][own], *sz = &sV[b][2][own];
             float dxVx = dminus4(sx[-2], sx[-1], vx0, sx[1]);
@@ -228,8 +247,8 @@ __global__ __launch_bounds__(NTHREADS, STRESS_WAVES_PER_SIMD) void stress_v2(bfd
             float dyVz = dplus4(sz[-LW], vz0, sz[LW], sz[2 * LW]);
 
             if (mraw & BFD_REFLECTOR_BIT) {
-                pSxx[cij] = 0.f; pSyy[cij] = 0.f; pSzz[cij] = 0.f; (d.Sxy + ko)[cij] = 0.f; (d.Sxz + ko)[cij] = 0.f; (d.Syz + ko)[cij] = 0.f;
-                pRxx[cij] = 0.f; pRyy[cij] = 0.f; pRzz[cij] = 0.f; (d.Rxy + ko)[cij] = 0.f; (d.Rxz + ko)[cij] = 0.f; (d.Ryz + ko)[cij] = 0.f;
+                F4(pSxx, cij * 4u) = 0.f; F4(pSyy, cij * 4u) = 0.f; F4(pSzz, cij * 4u) = 0.f; F4((d.Sxy + ko), cij * 4u) = 0.f; F4((d.Sxz + ko), cij * 4u) = 0.f; F4((d.Syz + ko), cij * 4u) = 0.f;
+                F4(pRxx, cij * 4u) = 0.f; F4(pRyy, cij * 4u) = 0.f; F4(pRzz, cij * 4u) = 0.f; F4((d.Rxy + ko), cij * 4u) = 0.f; F4((d.Rxz + ko), cij * 4u) = 0.f; F4((d.Ryz + ko), cij * 4u) = 0.f;
             } else {
                 const int m = mraw & BFD_MAT_MASK;
                 if (zi) {
@@ -260,11 +279,11 @@ __global__ __launch_bounds__(NTHREADS, STRESS_WAVES_PER_SIMD) void stress_v2(bfd
                     const float sYZ = dyVy + dzVz, sXZ = dxVx + dzVz;
                     float rn;
                     rn = c1 * rxx - (BP * div - BS2 * sYZ);
-                    pSxx[cij] = sxx + ((AP * div - AS2 * sYZ) + 0.5f * (rxx + rn)); pRxx[cij] = rn;
+                    F4(pSxx, cij * 4u) = sxx + ((AP * div - AS2 * sYZ) + 0.5f * (rxx + rn)); F4(pRxx, cij * 4u) = rn;
                     rn = c1 * ryy - (BP * div - BS2 * sXZ);
-                    pSyy[cij] = syy + ((AP * div - AS2 * sXZ) + 0.5f * (ryy + rn)); pRyy[cij] = rn;
+                    F4(pSyy, cij * 4u) = syy + ((AP * div - AS2 * sXZ) + 0.5f * (ryy + rn)); F4(pRyy, cij * 4u) = rn;
                     rn = c1 * rzz - (BP * div - BS2 * sXY);
-                    pSzz[cij] = szz + ((AP * div - AS2 * sXY) + 0.5f * (rzz + rn)); pRzz[cij] = rn;
+                    F4(pSzz, cij * 4u) = szz + ((AP * div - AS2 * sXY) + 0.5f * (rzz + rn)); F4(pRzz, cij * 4u) = rn;
                 }
                 const float iv0 = d.invMu[m];
                 if (iv0 > 0.f) {    // shear only where the centre cell is solid
@@ -284,8 +303,8 @@ __global__ __launch_bounds__(NTHREADS, STRESS_WAVES_PER_SIMD) void stress_v2(bfd
                             const float tau = 0.25f * ((t0 + d.tauS[mx]) + (d.tauS[my] + d.tauS[mxy]));
                             const float A = muH * (1.0f + tau), B = (muH * tau) * k2;
                             const float e = dyVx + dxVy;
-                            const float r = pR[cij], rn = c1 * r - B * e;
-                            pS[cij] = pS[cij] + (A * e + 0.5f * (r + rn)); pR[cij] = rn;
+                            const float r = F4(pR, cij * 4u), rn = c1 * r - B * e;
+                            F4(pS, cij * 4u) = F4(pS, cij * 4u) + (A * e + 0.5f * (r + rn)); F4(pR, cij * 4u) = rn;
                         }
                     }
                     {
@@ -296,8 +315,8 @@ __global__ __launch_bounds__(NTHREADS, STRESS_WAVES_PER_SIMD) void stress_v2(bfd
                             const float tau = 0.25f * ((t0 + d.tauS[mx]) + (d.tauS[mz] + d.tauS[mxz]));
                             const float A = muH * (1.0f + tau), B = (muH * tau) * k2;
                             const float e = dzVx + dxVz;
-                            const float r = pR[cij], rn = c1 * r - B * e;
-                            pS[cij] = pS[cij] + (A * e + 0.5f * (r + rn)); pR[cij] = rn;
+                            const float r = F4(pR, cij * 4u), rn = c1 * r - B * e;
+                            F4(pS, cij * 4u) = F4(pS, cij * 4u) + (A * e + 0.5f * (r + rn)); F4(pR, cij * 4u) = rn;
                         }
                     }
                     {
@@ -308,8 +327,8 @@ __global__ __launch_bounds__(NTHREADS, STRESS_WAVES_PER_SIMD) void stress_v2(bfd
                             const float tau = 0.25f * ((t0 + d.tauS[my]) + (d.tauS[mz] + d.tauS[myz]));
                             const float A = muH * (1.0f + tau), B = (muH * tau) * k2;
                             const float e = dzVy + dyVz;
-                            const float r = pR[cij], rn = c1 * r - B * e;
-                            pS[cij] = pS[cij] + (A * e + 0.5f * (r + rn)); pR[cij] = rn;
+                            const float r = F4(pR, cij * 4u), rn = c1 * r - B * e;
+                            F4(pS, cij * 4u) = F4(pS, cij * 4u) + (A * e + 0.5f * (r + rn)); F4(pR, cij * 4u) = rn;
                         }
                     }
                 }
@@ -376,10 +395,10 @@ __global__ __launch_bounds__(NTHREADS, VELOCITY_WAVES_PER_SIMD) void velocity_v2
     float sxx = 0, syy = 0, sxy = 0;
     if (valid) {
         const float *bzz = d.Szz + kbeg * pl, *bxz = d.Sxz + kbeg * pl, *byz = d.Syz + kbeg * pl;
-        zzm1 = (bzz - pl)[cij]; zz0 = bzz[cij]; zzp1 = (bzz + pl)[cij]; zzp2 = (bzz + 2 * pl)[cij];
-        xzm2 = (bxz - 2 * pl)[cij]; xzm1 = (bxz - pl)[cij]; xz0 = bxz[cij]; xzp1 = (bxz + pl)[cij];
-        yzm2 = (byz - 2 * pl)[cij]; yzm1 = (byz - pl)[cij]; yz0 = byz[cij]; yzp1 = (byz + pl)[cij];
-        sxx = (d.Sxx + kbeg * pl)[cij]; syy = (d.Syy + kbeg * pl)[cij]; sxy = (d.Sxy + kbeg * pl)[cij];
+        zzm1 = F4((bzz - pl), cij * 4u); zz0 = F4(bzz, cij * 4u); zzp1 = F4((bzz + pl), cij * 4u); zzp2 = F4((bzz + 2 * pl), cij * 4u);
+        xzm2 = F4((bxz - 2 * pl), cij * 4u); xzm1 = F4((bxz - pl), cij * 4u); xz0 = F4(bxz, cij * 4u); xzp1 = F4((bxz + pl), cij * 4u);
+        yzm2 = F4((byz - 2 * pl), cij * 4u); yzm1 = F4((byz - pl), cij * 4u); yz0 = F4(byz, cij * 4u); yzp1 = F4((byz + pl), cij * 4u);
+        sxx = F4((d.Sxx + kbeg * pl), cij * 4u); syy = F4((d.Syy + kbeg * pl), cij * 4u); sxy = F4((d.Sxy + kbeg * pl), cij * 4u);
     }
     // pipelined like the fluid bodies: V, accumulators and material ids of plane kl are in registers when its
     // iteration starts (own id two planes ahead: the z face needs 1/rho of plane kl+1)
@@ -387,10 +406,10 @@ __global__ __launch_bounds__(NTHREADS, VELOCITY_WAVES_PER_SIMD) void velocity_v2
     unsigned mraw = 0, mraw1 = 0, mx = 0, my = 0;
     if (valid) {
         const uint16_t *bM = d.mat + kbeg * pl;
-        vx = (d.Vx + kbeg * pl)[cij]; vy = (d.Vy + kbeg * pl)[cij]; vz = (d.Vz + kbeg * pl)[cij];
-        mraw = bM[cij]; mraw1 = (bM + pl)[cij]; mx = bM[cx]; my = bM[cy];
-        if (accA) av = (accP + kbeg * pl)[cij];
-        if (accK) pv = (pkP + kbeg * pl)[cij];
+        vx = F4((d.Vx + kbeg * pl), cij * 4u); vy = F4((d.Vy + kbeg * pl), cij * 4u); vz = F4((d.Vz + kbeg * pl), cij * 4u);
+        mraw = U2(bM, cij * 2u); mraw1 = U2((bM + pl), cij * 2u); mx = U2(bM, cx * 2u); my = U2(bM, cy * 2u);
+        if (accA) av = F4((accP + kbeg * pl), cij * 4u);
+        if (accK) pv = F4((pkP + kbeg * pl), cij * 4u);
         r0 = d.invRho[mraw & BFD_MAT_MASK];
     }
     float ha = ta.ok ? pa[kbeg * pl] : 0.0f;
@@ -417,15 +436,15 @@ __global__ __launch_bounds__(NTHREADS, VELOCITY_WAVES_PER_SIMD) void velocity_v2
         float nzz = 0, nxz = 0, nyz = 0, nxx = 0, nyy = 0, nxy = 0, nha = 0, nhb = 0;
         float nvx = 0, nvy = 0, nvz = 0, nav = 0, npv = 0;
         unsigned nm2 = 0, nmx = 0, nmy = 0;
-        if (valid) nm2 = (d.mat + ko + 2 * pl)[cij];              // ghost planes make kl+2 addressable
+        if (valid) nm2 = U2((d.mat + ko + 2 * pl), cij * 2u);              // ghost planes make kl+2 addressable
         if (kl + 1 < kend) {
             if (valid) {
-                nzz = (d.Szz + ko + 3 * pl)[cij]; nxz = (d.Sxz + ko + 2 * pl)[cij]; nyz = (d.Syz + ko + 2 * pl)[cij];
-                nxx = (d.Sxx + ko + pl)[cij]; nyy = (d.Syy + ko + pl)[cij]; nxy = (d.Sxy + ko + pl)[cij];
-                nvx = (pVx + pl)[cij]; nvy = (pVy + pl)[cij]; nvz = (pVz + pl)[cij];
-                nmx = (d.mat + ko + pl)[cx]; nmy = (d.mat + ko + pl)[cy];
-                if (accA) nav = (accP + ko + pl)[cij];
-                if (accK) npv = (pkP + ko + pl)[cij];
+                nzz = F4((d.Szz + ko + 3 * pl), cij * 4u); nxz = F4((d.Sxz + ko + 2 * pl), cij * 4u); nyz = F4((d.Syz + ko + 2 * pl), cij * 4u);
+                nxx = F4((d.Sxx + ko + pl), cij * 4u); nyy = F4((d.Syy + ko + pl), cij * 4u); nxy = F4((d.Sxy + ko + pl), cij * 4u);
+                nvx = F4((pVx + pl), cij * 4u); nvy = F4((pVy + pl), cij * 4u); nvz = F4((pVz + pl), cij * 4u);
+                nmx = U2((d.mat + ko + pl), cx * 2u); nmy = U2((d.mat + ko + pl), cy * 2u);
+                if (accA) nav = F4((accP + ko + pl), cij * 4u);
+                if (accK) npv = F4((pkP + ko + pl), cij * 4u);
             }
             if (ta.ok) nha = pa[ko + pl];
             if (tb.ok) nhb = pb[ko + pl];
@@ -438,12 +457,12 @@ __global__ __launch_bounds__(NTHREADS, VELOCITY_WAVES_PER_SIMD) void velocity_v2
                 if (inner && k >= d.ND && k < d.N3 - d.ND) {
                     const float s = (sxx + syy) + zz0;
                     const float p = -s * (1.0f / 3.0f);
-                    if (accA) (accP + ko)[cij] = av + p * p;
-                    if (accK) { const float ap = fabsf(p); if (ap > pv) (pkP + ko)[cij] = ap; }
+                    if (accA) F4((accP + ko), cij * 4u) = av + p * p;
+                    if (accK) { const float ap = fabsf(p); if (ap > pv) F4((pkP + ko), cij * 4u) = ap; }
                 }
             }
             if (mraw & BFD_REFLECTOR_BIT) {
-                wVx[cij] = 0.f; wVy[cij] = 0.f; wVz[cij] = 0.f;
+                F4(wVx, cij * 4u) = 0.f; F4(wVy, cij * 4u) = 0.f; F4(wVz, cij * 4u) = 0.f;
             } else {
                 const float *pxx = &sS[b][0][own], *pyy = &sS[b][1][own], *pxy = &sS[b][2][own];
                 const float *pxz = &sS[b][3][own], *pyz = &sS[b][4][own];
@@ -478,9 +497,9 @@ __global__ __launch_bounds__(NTHREADS, VELOCITY_WAVES_PER_SIMD) void velocity_v2
                     dzSzz = cpml(d.psi[17], q, d.azH[k], d.bzH[k], dzSzz);
                 }
                 const float bxv = 0.5f * (r0 + rx), byv = 0.5f * (r0 + ry), bzv = 0.5f * (r0 + r1);
-                wVx[cij] = vx + bxv * ((dxSxx + dySxy) + dzSxz);
-                wVy[cij] = vy + byv * ((dxSxy + dySyy) + dzSyz);
-                wVz[cij] = vz + bzv * ((dxSxz + dySyz) + dzSzz);
+                F4(wVx, cij * 4u) = vx + bxv * ((dxSxx + dySxy) + dzSxz);
+                F4(wVy, cij * 4u) = vy + byv * ((dxSxy + dySyy) + dzSyz);
+                F4(wVz, cij * 4u) = vz + bzv * ((dxSxz + dySyz) + dzSzz);
             }
         }
         zzm1 = zz0; zz0 = zzp1; zzp1 = zzp2; zzp2 = nzz;
@@ -532,7 +551,9 @@ __device__ __forceinline__ void stress_fluid_body(const bfd_dev &d, int bx, int 
     if (tid < YT) ytask(tid, 1, i0, j0, N1, N2, t);
     else if (tid < YT + XT) xtask(tid - YT, 0, i0, j0, N1, N2, t);
     const bool has = t.lofs >= 0;
-    const float *ph = (t.arr == 0 ? d.Vx : d.Vy) + (t.ok ? t.gofs : 0);
+    // the array of the task is uniform per wave (waves 0-3: Vy rows, wave 4: Vx columns): SGPR base + 32-bit byte offset
+    const float *ph = __builtin_amdgcn_readfirstlane(t.arr) == 0 ? d.Vx : d.Vy;
+    const unsigned hofs = t.ok ? (unsigned)t.gofs * 4u : 0u;
     float *lh = &sV[0][t.arr][has ? t.lofs : 0];
 
     const float c1 = d.c1;
@@ -546,23 +567,23 @@ __device__ __forceinline__ void stress_fluid_body(const bfd_dev &d, int bx, int 
     unsigned qx = 0, qy = 0;
     const unsigned dqx = (unsigned)(N2 * 2 * P), dqy = (unsigned)(2 * P * N1);
     if (PML) {
-        if (zi) { ax = d.axI[i]; bxc = d.bxI[i]; qx = (unsigned)((kbeg * N2 + j) * (2 * P) + (i < P ? i : i - (N1 - 2 * P))); px = d.psi[0][qx]; }
-        if (zj) { ay = d.ayI[j]; byc = d.byI[j]; qy = (unsigned)((kbeg * (2 * P) + (j < P ? j : j - (N2 - 2 * P))) * N1 + i); py = d.psi[1][qy]; }
+        if (zi) { ax = d.axI[i]; bxc = d.bxI[i]; qx = (unsigned)((kbeg * N2 + j) * (2 * P) + (i < P ? i : i - (N1 - 2 * P))); px = F4(d.psi[0], (unsigned)(qx) * 4u); }
+        if (zj) { ay = d.ayI[j]; byc = d.byI[j]; qy = (unsigned)((kbeg * (2 * P) + (j < P ? j : j - (N2 - 2 * P))) * N1 + i); py = F4(d.psi[1], (unsigned)(qy) * 4u); }
         const int kg = d.k0 + kbeg;
-        if (valid && (kg < P || kg >= d.N3 - P)) pz = d.psi[2][(long)(kg < P ? kg : kg - (d.N3 - 2 * P)) * pl + cij];
+        if (valid && (kg < P || kg >= d.N3 - P)) pz = F4(d.psi[2], (unsigned)((long)(kg < P ? kg : kg - (d.N3 - 2 * P)) * pl + cij) * 4u);
     }
 
     float vx0 = 0, vy0 = 0, vzm2 = 0, vzm1 = 0, vz0 = 0, vzp1 = 0, szz = 0, rzz = 0;
     unsigned mraw = 0;
     if (valid) {
         const float *bVz = d.Vz + kbeg * pl;
-        vx0 = (d.Vx + kbeg * pl)[cij]; vy0 = (d.Vy + kbeg * pl)[cij];
-        vzm2 = (bVz - 2 * pl)[cij]; vzm1 = (bVz - pl)[cij]; vz0 = bVz[cij]; vzp1 = (bVz + pl)[cij];
-        szz = (d.Szz + kbeg * pl)[cij];
-        if (LOSSY) rzz = (d.Rzz + kbeg * pl)[cij];
-        if (!UNI) mraw = (d.mat + kbeg * pl)[cij];
+        vx0 = F4((d.Vx + kbeg * pl), cij * 4u); vy0 = F4((d.Vy + kbeg * pl), cij * 4u);
+        vzm2 = F4((bVz - 2 * pl), cij * 4u); vzm1 = F4((bVz - pl), cij * 4u); vz0 = F4(bVz, cij * 4u); vzp1 = F4((bVz + pl), cij * 4u);
+        szz = F4((d.Szz + kbeg * pl), cij * 4u);
+        if (LOSSY) rzz = F4((d.Rzz + kbeg * pl), cij * 4u);
+        if (!UNI) mraw = U2((d.mat + kbeg * pl), cij * 2u);
     }
-    float hv = t.ok ? ph[kbeg * pl] : 0.0f;
+    float hv = t.ok ? F4(ph + kbeg * pl, hofs) : 0.0f;
 
     for (int kl = kbeg; kl < kend; kl++) {
         const int b = kl & 1;
@@ -579,17 +600,17 @@ __device__ __forceinline__ void stress_fluid_body(const bfd_dev &d, int bx, int 
         unsigned nmraw = 0;
         if (kl + 1 < kend) {
             if (valid) {
-                nvx = (d.Vx + ko + pl)[cij]; nvy = (d.Vy + ko + pl)[cij]; nvz = (d.Vz + ko + 2 * pl)[cij];
-                nszz = (d.Szz + ko + pl)[cij];
-                if (LOSSY) nrzz = (d.Rzz + ko + pl)[cij];
-                if (!UNI) nmraw = (d.mat + ko + pl)[cij];
+                nvx = F4((d.Vx + ko + pl), cij * 4u); nvy = F4((d.Vy + ko + pl), cij * 4u); nvz = F4((d.Vz + ko + 2 * pl), cij * 4u);
+                nszz = F4((d.Szz + ko + pl), cij * 4u);
+                if (LOSSY) nrzz = F4((d.Rzz + ko + pl), cij * 4u);
+                if (!UNI) nmraw = U2((d.mat + ko + pl), cij * 2u);
             }
-            if (t.ok) nh = ph[ko + pl];
+            if (t.ok) nh = F4(ph + ko + pl, hofs);
             if (PML) {
-                if (zi) npx = d.psi[0][qx + dqx];
-                if (zj) npy = d.psi[1][qy + dqy];
+                if (zi) npx = F4(d.psi[0], (unsigned)(qx + dqx) * 4u);
+                if (zj) npy = F4(d.psi[1], (unsigned)(qy + dqy) * 4u);
                 const int kn = k + 1;
-                if (valid && (kn < P || kn >= d.N3 - P)) npz = d.psi[2][(long)(kn < P ? kn : kn - (d.N3 - 2 * P)) * pl + cij];
+                if (valid && (kn < P || kn >= d.N3 - P)) npz = F4(d.psi[2], (unsigned)((long)(kn < P ? kn : kn - (d.N3 - 2 * P)) * pl + cij) * 4u);
             }
         }
         if (valid) {
@@ -600,11 +621,11 @@ __device__ __forceinline__ void stress_fluid_body(const bfd_dev &d, int bx, int 
             float val = 0.f, rn = 0.f;
             if (UNI || !(mraw & BFD_REFLECTOR_BIT)) {
                 if (PML) {
-                    if (zi) { const float pn = bxc * px + ax * dxVx; d.psi[0][qx] = pn; dxVx = dxVx + pn; }
-                    if (zj) { const float pn = byc * py + ay * dyVy; d.psi[1][qy] = pn; dyVy = dyVy + pn; }
+                    if (zi) { const float pn = bxc * px + ax * dxVx; F4(d.psi[0], (unsigned)(qx) * 4u) = pn; dxVx = dxVx + pn; }
+                    if (zj) { const float pn = byc * py + ay * dyVy; F4(d.psi[1], (unsigned)(qy) * 4u) = pn; dyVy = dyVy + pn; }
                     if (k < P || k >= d.N3 - P) {
                         const float pn = d.bzI[k] * pz + d.azI[k] * dzVz;
-                        d.psi[2][(long)(k < P ? k : k - (d.N3 - 2 * P)) * pl + cij] = pn;
+                        F4(d.psi[2], (unsigned)((long)(k < P ? k : k - (d.N3 - 2 * P)) * pl + cij) * 4u) = pn;
                         dzVz = dzVz + pn;
                     }
                 }
@@ -618,11 +639,11 @@ __device__ __forceinline__ void stress_fluid_body(const bfd_dev &d, int bx, int 
             }
             // COLLAPSED (no solid tile in the slab, no per-component stress output selected): nobody
             // reads Sxx/Syy/Rxx/Ryy, so only the Szz/Rzz copy is kept (expanded on demand, bfd_api.hip)
-            (d.SzzW + ko)[cij] = val;
-            if (!COLLAPSED) { (d.Sxx + ko)[cij] = val; (d.Syy + ko)[cij] = val; }
+            F4((d.SzzW + ko), cij * 4u) = val;
+            if (!COLLAPSED) { F4((d.Sxx + ko), cij * 4u) = val; F4((d.Syy + ko), cij * 4u) = val; }
             if (LOSSY) {
-                (d.RzzW + ko)[cij] = rn;
-                if (!COLLAPSED) { (d.Rxx + ko)[cij] = rn; (d.Ryy + ko)[cij] = rn; }
+                F4((d.RzzW + ko), cij * 4u) = rn;
+                if (!COLLAPSED) { F4((d.Rxx + ko), cij * 4u) = rn; F4((d.Ryy + ko), cij * 4u) = rn; }
             }
         }
         vx0 = nvx; vy0 = nvy;
@@ -653,7 +674,8 @@ __device__ __forceinline__ void velocity_fluid_body(const bfd_dev &d, int bx, in
     if (tid < YT) ytask(tid, 0, i0, j0, N1, N2, t);
     else if (tid < YT + XT) xtask(tid - YT, 0, i0, j0, N1, N2, t);
     const bool has = t.lofs >= 0;
-    const float *ph = d.Szz + (t.ok ? t.gofs : 0);
+    const float *ph = d.Szz;
+    const unsigned hofs = t.ok ? (unsigned)t.gofs * 4u : 0u;
     float *lh = &sS[0][has ? t.lofs : 0];
 
     const bool inner = valid && i >= d.ND && i < N1 - d.ND && j >= d.ND && j < N2 - d.ND;
@@ -667,10 +689,10 @@ __device__ __forceinline__ void velocity_fluid_body(const bfd_dev &d, int bx, in
     unsigned qx = 0, qy = 0;
     const unsigned dqx = (unsigned)(N2 * 2 * P), dqy = (unsigned)(2 * P * N1);
     if (PML) {
-        if (zi) { ax = d.axH[i]; bxc = d.bxH[i]; qx = (unsigned)((kbeg * N2 + j) * (2 * P) + (i < P ? i : i - (N1 - 2 * P))); px = d.psi[9][qx]; }
-        if (zj) { ay = d.ayH[j]; byc = d.byH[j]; qy = (unsigned)((kbeg * (2 * P) + (j < P ? j : j - (N2 - 2 * P))) * N1 + i); py = d.psi[13][qy]; }
+        if (zi) { ax = d.axH[i]; bxc = d.bxH[i]; qx = (unsigned)((kbeg * N2 + j) * (2 * P) + (i < P ? i : i - (N1 - 2 * P))); px = F4(d.psi[9], (unsigned)(qx) * 4u); }
+        if (zj) { ay = d.ayH[j]; byc = d.byH[j]; qy = (unsigned)((kbeg * (2 * P) + (j < P ? j : j - (N2 - 2 * P))) * N1 + i); py = F4(d.psi[13], (unsigned)(qy) * 4u); }
         const int kg = d.k0 + kbeg;
-        if (valid && (kg < P || kg >= d.N3 - P)) pz = d.psi[17][(long)(kg < P ? kg : kg - (d.N3 - 2 * P)) * pl + cij];
+        if (valid && (kg < P || kg >= d.N3 - P)) pz = F4(d.psi[17], (unsigned)((long)(kg < P ? kg : kg - (d.N3 - 2 * P)) * pl + cij) * 4u);
     }
 
     // own material id runs two planes ahead because the z face needs 1/rho of plane kl+1; neighbour ids
@@ -679,17 +701,17 @@ __device__ __forceinline__ void velocity_fluid_body(const bfd_dev &d, int bx, in
     unsigned mraw = 0, mraw1 = 0, mx = 0, my = 0;
     if (valid) {
         const float *bS = d.Szz + kbeg * pl;
-        sm1 = (bS - pl)[cij]; s0 = bS[cij]; sp1 = (bS + pl)[cij]; sp2 = (bS + 2 * pl)[cij];
-        vx = (d.Vx + kbeg * pl)[cij]; vy = (d.Vy + kbeg * pl)[cij]; vz = (d.Vz + kbeg * pl)[cij];
-        if (accA) av = (accP + kbeg * pl)[cij];
-        if (accK) pv = (pkP + kbeg * pl)[cij];
+        sm1 = F4((bS - pl), cij * 4u); s0 = F4(bS, cij * 4u); sp1 = F4((bS + pl), cij * 4u); sp2 = F4((bS + 2 * pl), cij * 4u);
+        vx = F4((d.Vx + kbeg * pl), cij * 4u); vy = F4((d.Vy + kbeg * pl), cij * 4u); vz = F4((d.Vz + kbeg * pl), cij * 4u);
+        if (accA) av = F4((accP + kbeg * pl), cij * 4u);
+        if (accK) pv = F4((pkP + kbeg * pl), cij * 4u);
         if (!UNI) {
             const uint16_t *bM = d.mat + kbeg * pl;
-            mraw = bM[cij]; mraw1 = (bM + pl)[cij]; mx = bM[cx]; my = bM[cy];
+            mraw = U2(bM, cij * 2u); mraw1 = U2((bM + pl), cij * 2u); mx = U2(bM, cx * 2u); my = U2(bM, cy * 2u);
             r0 = d.invRho[mraw & BFD_MAT_MASK];
         }
     }
-    float hv = t.ok ? ph[kbeg * pl] : 0.0f;
+    float hv = t.ok ? F4(ph + kbeg * pl, hofs) : 0.0f;
 
     for (int kl = kbeg; kl < kend; kl++) {
         const int b = kl & 1;
@@ -707,21 +729,21 @@ __device__ __forceinline__ void velocity_fluid_body(const bfd_dev &d, int bx, in
 
         float ns = 0, nh = 0, nvx = 0, nvy = 0, nvz = 0, nav = 0, npv = 0, npx = 0, npy = 0, npz = 0;
         unsigned nm2 = 0, nmx = 0, nmy = 0;
-        if (!UNI && valid) nm2 = (d.mat + ko + 2 * pl)[cij];     // ghost planes make kl+2 addressable
+        if (!UNI && valid) nm2 = U2((d.mat + ko + 2 * pl), cij * 2u);     // ghost planes make kl+2 addressable
         if (kl + 1 < kend) {
             if (valid) {
-                ns = (d.Szz + ko + 3 * pl)[cij];
-                nvx = (d.Vx + ko + pl)[cij]; nvy = (d.Vy + ko + pl)[cij]; nvz = (d.Vz + ko + pl)[cij];
-                if (!UNI) { nmx = (d.mat + ko + pl)[cx]; nmy = (d.mat + ko + pl)[cy]; }
-                if (accA) nav = (accP + ko + pl)[cij];
-                if (accK) npv = (pkP + ko + pl)[cij];
+                ns = F4((d.Szz + ko + 3 * pl), cij * 4u);
+                nvx = F4((d.Vx + ko + pl), cij * 4u); nvy = F4((d.Vy + ko + pl), cij * 4u); nvz = F4((d.Vz + ko + pl), cij * 4u);
+                if (!UNI) { nmx = U2((d.mat + ko + pl), cx * 2u); nmy = U2((d.mat + ko + pl), cy * 2u); }
+                if (accA) nav = F4((accP + ko + pl), cij * 4u);
+                if (accK) npv = F4((pkP + ko + pl), cij * 4u);
             }
-            if (t.ok) nh = ph[ko + pl];
+            if (t.ok) nh = F4(ph + ko + pl, hofs);
             if (PML) {
-                if (zi) npx = d.psi[9][qx + dqx];
-                if (zj) npy = d.psi[13][qy + dqy];
+                if (zi) npx = F4(d.psi[9], (unsigned)(qx + dqx) * 4u);
+                if (zj) npy = F4(d.psi[13], (unsigned)(qy + dqy) * 4u);
                 const int kn = k + 1;
-                if (valid && (kn < P || kn >= d.N3 - P)) npz = d.psi[17][(long)(kn < P ? kn : kn - (d.N3 - 2 * P)) * pl + cij];
+                if (valid && (kn < P || kn >= d.N3 - P)) npz = F4(d.psi[17], (unsigned)((long)(kn < P ? kn : kn - (d.N3 - 2 * P)) * pl + cij) * 4u);
             }
         }
         if (valid) {
@@ -729,29 +751,29 @@ __device__ __forceinline__ void velocity_fluid_body(const bfd_dev &d, int bx, in
                 if (inner && k >= d.ND && k < d.N3 - d.ND) {
                     const float s = (s0 + s0) + s0;
                     const float p = -s * (1.0f / 3.0f);
-                    if (accA) (accP + ko)[cij] = av + p * p;
-                    if (accK) { const float ap = fabsf(p); if (ap > pv) (pkP + ko)[cij] = ap; }
+                    if (accA) F4((accP + ko), cij * 4u) = av + p * p;
+                    if (accK) { const float ap = fabsf(p); if (ap > pv) F4((pkP + ko), cij * 4u) = ap; }
                 }
             }
             if (!UNI && (mraw & BFD_REFLECTOR_BIT)) {
-                (d.VxW + ko)[cij] = 0.f; (d.VyW + ko)[cij] = 0.f; (d.VzW + ko)[cij] = 0.f;
+                F4((d.VxW + ko), cij * 4u) = 0.f; F4((d.VyW + ko), cij * 4u) = 0.f; F4((d.VzW + ko), cij * 4u) = 0.f;
             } else {
                 const float *p = &sS[b][own];
                 float dx = dplus4(p[-1], s0, p[1], p[2]);
                 float dy = dplus4(p[-LW], s0, p[LW], p[2 * LW]);
                 float dz = dplus4(sm1, s0, sp1, sp2);
                 if (PML) {
-                    if (zi) { const float pn = bxc * px + ax * dx; d.psi[9][qx] = pn; dx = dx + pn; }
-                    if (zj) { const float pn = byc * py + ay * dy; d.psi[13][qy] = pn; dy = dy + pn; }
+                    if (zi) { const float pn = bxc * px + ax * dx; F4(d.psi[9], (unsigned)(qx) * 4u) = pn; dx = dx + pn; }
+                    if (zj) { const float pn = byc * py + ay * dy; F4(d.psi[13], (unsigned)(qy) * 4u) = pn; dy = dy + pn; }
                     if (k < P || k >= d.N3 - P) {
                         const float pn = d.bzH[k] * pz + d.azH[k] * dz;
-                        d.psi[17][(long)(k < P ? k : k - (d.N3 - 2 * P)) * pl + cij] = pn;
+                        F4(d.psi[17], (unsigned)((long)(k < P ? k : k - (d.N3 - 2 * P)) * pl + cij) * 4u) = pn;
                         dz = dz + pn;
                     }
                 }
-                (d.VxW + ko)[cij] = vx + (0.5f * (r0 + rx)) * dx;
-                (d.VyW + ko)[cij] = vy + (0.5f * (r0 + ry)) * dy;
-                (d.VzW + ko)[cij] = vz + (0.5f * (r0 + r1)) * dz;
+                F4((d.VxW + ko), cij * 4u) = vx + (0.5f * (r0 + rx)) * dx;
+                F4((d.VyW + ko), cij * 4u) = vy + (0.5f * (r0 + ry)) * dy;
+                F4((d.VzW + ko), cij * 4u) = vz + (0.5f * (r0 + r1)) * dz;
             }
         }
         sm1 = s0; s0 = sp1; sp1 = sp2; sp2 = ns;
@@ -823,14 +845,14 @@ __device__ __forceinline__ void fused_fluid_body(const bfd_dev &d, int bx, int b
     float oS, oR = 0, xS = 0, xR = 0;
     {
         const long k0 = (long)pFirst * pl;
-        tx0 = (d.Vx + k0)[gx0]; if (hx1) tx1 = (d.Vx + k0)[gx1];
-        ty0 = (d.Vy + k0)[gy0]; ty1 = (d.Vy + k0)[gy1]; if (hy2) ty2 = (d.Vy + k0)[gy2];
+        tx0 = F4((d.Vx + k0), gx0 * 4u); if (hx1) tx1 = F4((d.Vx + k0), gx1 * 4u);
+        ty0 = F4((d.Vy + k0), gy0 * 4u); ty1 = F4((d.Vy + k0), gy1 * 4u); if (hy2) ty2 = F4((d.Vy + k0), gy2 * 4u);
         const float *bz = d.Vz + k0;
-        ozm2 = (bz - 2 * pl)[cOwn]; ozm1 = (bz - pl)[cOwn]; oz0 = bz[cOwn]; ozp1 = (bz + pl)[cOwn];
-        oS = (d.Szz + k0)[cOwn]; if (LOSSY) oR = (d.Rzz + k0)[cOwn];
+        ozm2 = F4((bz - 2 * pl), cOwn * 4u); ozm1 = F4((bz - pl), cOwn * 4u); oz0 = F4(bz, cOwn * 4u); ozp1 = F4((bz + pl), cOwn * 4u);
+        oS = F4((d.Szz + k0), cOwn * 4u); if (LOSSY) oR = F4((d.Rzz + k0), cOwn * 4u);
         if (hasX) {
-            xzm2 = (bz - 2 * pl)[cX]; xzm1 = (bz - pl)[cX]; xz0 = bz[cX]; xzp1 = (bz + pl)[cX];
-            xS = (d.Szz + k0)[cX]; if (LOSSY) xR = (d.Rzz + k0)[cX];
+            xzm2 = F4((bz - 2 * pl), cX * 4u); xzm1 = F4((bz - pl), cX * 4u); xz0 = F4(bz, cX * 4u); xzp1 = F4((bz + pl), cX * 4u);
+            xS = F4((d.Szz + k0), cX * 4u); if (LOSSY) xR = F4((d.Rzz + k0), cX * 4u);
         }
     }
     // velocity stage lags two planes: own new-stress queue (q-1..q+2), own Vx,Vy of planes p-2, p-1, accumulators of q
@@ -849,16 +871,16 @@ __device__ __forceinline__ void fused_fluid_body(const bfd_dev &d, int bx, int b
         // loads of plane p+1
         float ntx0 = 0, ntx1 = 0, nty0 = 0, nty1 = 0, nty2 = 0, noz = 0, nxz = 0, noS = 0, noR = 0, nxS = 0, nxR = 0, nav = 0, npv = 0;
         if (p + 1 < pEnd) {
-            ntx0 = (d.Vx + ko + pl)[gx0]; if (hx1) ntx1 = (d.Vx + ko + pl)[gx1];
-            nty0 = (d.Vy + ko + pl)[gy0]; nty1 = (d.Vy + ko + pl)[gy1]; if (hy2) nty2 = (d.Vy + ko + pl)[gy2];
-            noz = (d.Vz + ko + 2 * pl)[cOwn];
-            noS = (d.Szz + ko + pl)[cOwn]; if (LOSSY) noR = (d.Rzz + ko + pl)[cOwn];
-            if (hasX) { nxz = (d.Vz + ko + 2 * pl)[cX]; nxS = (d.Szz + ko + pl)[cX]; if (LOSSY) nxR = (d.Rzz + ko + pl)[cX]; }
+            ntx0 = F4((d.Vx + ko + pl), gx0 * 4u); if (hx1) ntx1 = F4((d.Vx + ko + pl), gx1 * 4u);
+            nty0 = F4((d.Vy + ko + pl), gy0 * 4u); nty1 = F4((d.Vy + ko + pl), gy1 * 4u); if (hy2) nty2 = F4((d.Vy + ko + pl), gy2 * 4u);
+            noz = F4((d.Vz + ko + 2 * pl), cOwn * 4u);
+            noS = F4((d.Szz + ko + pl), cOwn * 4u); if (LOSSY) noR = F4((d.Rzz + ko + pl), cOwn * 4u);
+            if (hasX) { nxz = F4((d.Vz + ko + 2 * pl), cX * 4u); nxS = F4((d.Szz + ko + pl), cX * 4u); if (LOSSY) nxR = F4((d.Rzz + ko + pl), cX * 4u); }
         }
         const int q = p - 2;                             // velocity plane of this iteration
         if (ACC && q + 1 >= kbeg && q + 1 < kend) {
-            if (accA) nav = (accP + ko - pl)[cOwn];
-            if (accK) npv = (pkP + ko - pl)[cOwn];
+            if (accA) nav = F4((accP + ko - pl), cOwn * 4u);
+            if (accK) npv = F4((pkP + ko - pl), cOwn * 4u);
         }
 
         // ---- stress of plane p on the grown region (own cell, then the ring cell) ----
@@ -876,8 +898,8 @@ __device__ __forceinline__ void fused_fluid_body(const bfd_dev &d, int bx, int b
             else val = oS + AP * div;
             rS[rOwn] = val;
             if (p >= kbeg && p < kend) {
-                (d.SzzW + ko)[cOwn] = val;
-                if (LOSSY) (d.RzzW + ko)[cOwn] = rn;
+                F4((d.SzzW + ko), cOwn * 4u) = val;
+                if (LOSSY) F4((d.RzzW + ko), cOwn * 4u) = rn;
             }
             nSm1 = nS0; nS0 = nSp1; nSp1 = nSp2; nSp2 = val;
         }
@@ -902,16 +924,16 @@ __device__ __forceinline__ void fused_fluid_body(const bfd_dev &d, int bx, int b
             if (ACC) {
                 const float s = (s0 + s0) + s0;
                 const float pr = -s * (1.0f / 3.0f);
-                if (accA) (accP + kq)[cOwn] = av + pr * pr;
-                if (accK) { const float ap = fabsf(pr); if (ap > pv) (pkP + kq)[cOwn] = ap; }
+                if (accA) F4((accP + kq), cOwn * 4u) = av + pr * pr;
+                if (accK) { const float ap = fabsf(pr); if (ap > pv) F4((pkP + kq), cOwn * 4u) = ap; }
             }
             const float dx = dplus4(ps[-1], s0, ps[1], ps[2]);
             const float dy = dplus4(ps[-FR_W], s0, ps[FR_W], ps[2 * FR_W]);
             const float dz = dplus4(nSm1, nS0, nSp1, nSp2);
             const float rr = 0.5f * (ru + ru);
-            (d.VxW + kq)[cOwn] = vxA + rr * dx;
-            (d.VyW + kq)[cOwn] = vyA + rr * dy;
-            (d.VzW + kq)[cOwn] = ozm2 + rr * dz;
+            F4((d.VxW + kq), cOwn * 4u) = vxA + rr * dx;
+            F4((d.VyW + kq), cOwn * 4u) = vyA + rr * dy;
+            F4((d.VzW + kq), cOwn * 4u) = ozm2 + rr * dz;
         }
         // rotate
         vxA = vxB; vxB = vxOwn; vyA = vyB; vyB = vyOwn;
@@ -971,7 +993,9 @@ __device__ __forceinline__ void stress_solid_body(const bfd_dev &d, const int4 &
     if (tid < YT) ytask(tid, 1, i0, j0, N1, N2, t);
     else if (tid < YT + XT) xtask(tid - YT, 0, i0, j0, N1, N2, t);
     const bool has = t.lofs >= 0;
-    const float *ph = (t.arr == 0 ? d.Vx : d.Vy) + (t.ok ? t.gofs : 0);
+    // the array of the task is uniform per wave (waves 0-3: Vy rows, wave 4: Vx columns): SGPR base + 32-bit byte offset
+    const float *ph = __builtin_amdgcn_readfirstlane(t.arr) == 0 ? d.Vx : d.Vy;
+    const unsigned hofs = t.ok ? (unsigned)t.gofs * 4u : 0u;
     float *lh = &sV[0][t.arr][has ? t.lofs : 0];
     const float c1 = d.c1;
 
@@ -980,11 +1004,11 @@ __device__ __forceinline__ void stress_solid_body(const bfd_dev &d, const int4 &
     float ax = 0, bxc = 0, ay = 0, byc = 0, px = 0, py = 0, pz = 0;
     unsigned qx = 0, qy = 0;
     const unsigned dqx = (unsigned)(N2 * 2 * P), dqy = (unsigned)(2 * P * N1);
-    if (zi) { ax = d.axI[i]; bxc = d.bxI[i]; qx = (unsigned)((kbeg * N2 + j) * (2 * P) + (i < P ? i : i - (N1 - 2 * P))); px = d.psi[0][qx]; }
-    if (zj) { ay = d.ayI[j]; byc = d.byI[j]; qy = (unsigned)((kbeg * (2 * P) + (j < P ? j : j - (N2 - 2 * P))) * N1 + i); py = d.psi[1][qy]; }
+    if (zi) { ax = d.axI[i]; bxc = d.bxI[i]; qx = (unsigned)((kbeg * N2 + j) * (2 * P) + (i < P ? i : i - (N1 - 2 * P))); px = F4(d.psi[0], (unsigned)(qx) * 4u); }
+    if (zj) { ay = d.ayI[j]; byc = d.byI[j]; qy = (unsigned)((kbeg * (2 * P) + (j < P ? j : j - (N2 - 2 * P))) * N1 + i); py = F4(d.psi[1], (unsigned)(qy) * 4u); }
     if (PML) {
         const int kg = d.k0 + kbeg;
-        if (valid && (kg < P || kg >= d.N3 - P)) pz = d.psi[2][(unsigned)((kg < P ? kg : kg - (d.N3 - 2 * P)) * d.plane) + cij];
+        if (valid && (kg < P || kg >= d.N3 - P)) pz = F4(d.psi[2], (unsigned)((unsigned)((kg < P ? kg : kg - (d.N3 - 2 * P)) * d.plane) + cij) * 4u);
     }
 
     float vx0 = 0, vy0 = 0, vzm2 = 0, vzm1 = 0, vz0 = 0, vzp1 = 0;
@@ -992,45 +1016,47 @@ __device__ __forceinline__ void stress_solid_body(const bfd_dev &d, const int4 &
     unsigned mraw = 0, cl = BFD_CLS_FLUID | BFD_CLS_NOMEM, cl1 = BFD_CLS_FLUID | BFD_CLS_NOMEM;
     if (valid) {
         const float *bVz = d.Vz + kbeg * pl;
-        cl = (d.cls + kbeg * pl)[cij]; cl1 = (d.cls + kbeg * pl + pl)[cij];
-        vx0 = (d.Vx + kbeg * pl)[cij]; vy0 = (d.Vy + kbeg * pl)[cij];
-        vzm2 = (bVz - 2 * pl)[cij]; vzm1 = (bVz - pl)[cij]; vz0 = bVz[cij]; vzp1 = (bVz + pl)[cij];
-        mraw = (d.mat + kbeg * pl)[cij];
-        szz = (d.Szz + kbeg * pl)[cij];
+        cl = U1((d.cls + kbeg * pl), cij); cl1 = U1((d.cls + kbeg * pl + pl), cij);
+        vx0 = F4((d.Vx + kbeg * pl), cij * 4u); vy0 = F4((d.Vy + kbeg * pl), cij * 4u);
+        vzm2 = F4((bVz - 2 * pl), cij * 4u); vzm1 = F4((bVz - pl), cij * 4u); vz0 = F4(bVz, cij * 4u); vzp1 = F4((bVz + pl), cij * 4u);
+        mraw = U2((d.mat + kbeg * pl), cij * 2u);
+        szz = F4((d.Szz + kbeg * pl), cij * 4u);
         const bool fl = cl & BFD_CLS_FLUID, mem = !(cl & BFD_CLS_NOMEM) || !fl;
-        if (mem) rzz = (d.Rzz + kbeg * pl)[cij];
+        if (mem) rzz = F4((d.Rzz + kbeg * pl), cij * 4u);
         if (!fl) {
-            sxx = (d.Sxx + kbeg * pl)[cij]; syy = (d.Syy + kbeg * pl)[cij];
-            rxx = (d.Rxx + kbeg * pl)[cij]; ryy = (d.Ryy + kbeg * pl)[cij];
+            sxx = F4((d.Sxx + kbeg * pl), cij * 4u); syy = F4((d.Syy + kbeg * pl), cij * 4u);
+            rxx = F4((d.Rxx + kbeg * pl), cij * 4u); ryy = F4((d.Ryy + kbeg * pl), cij * 4u);
         }
     }
-    float hv = t.ok ? ph[kbeg * pl] : 0.0f;
+    float hv = t.ok ? F4(ph + kbeg * pl, hofs) : 0.0f;
 
     for (int kl = kbeg; kl < kend; kl++) {
         const int b = kl & 1;
-        const long ko = (long)kl * pl;
+        // opaque to loop strength reduction: otherwise every array gets a 64-bit per-lane pointer that is bumped each plane
+        // (a VGPR pair per array); this way the plane bases are recomputed on the scalar unit and stay in SGPRs
+        const long ko = (long)__builtin_amdgcn_readfirstlane(kl) * pl;
         const int k = d.k0 + kl;
         float nvx = 0, nvy = 0, nvz = 0, nh = 0, nsxx = 0, nsyy = 0, nszz = 0, nrxx = 0, nryy = 0, nrzz = 0, npx = 0, npy = 0, npz = 0;
         unsigned nmraw = 0, ncl2 = BFD_CLS_FLUID | BFD_CLS_NOMEM;
         auto prefetch_next = [&]() {
-        if (valid) ncl2 = (d.cls + ko + 2 * pl)[cij];           // ghost planes make kl+2 addressable
+        if (valid) ncl2 = U1((d.cls + ko + 2 * pl), cij);           // ghost planes make kl+2 addressable
             if (kl + 1 < kend) {
                 if (valid) {
                     const bool nfl = cl1 & BFD_CLS_FLUID, nmem = !(cl1 & BFD_CLS_NOMEM) || !nfl;
-                    nvx = (d.Vx + ko + pl)[cij]; nvy = (d.Vy + ko + pl)[cij]; nvz = (d.Vz + ko + 2 * pl)[cij];
-                    nmraw = (d.mat + ko + pl)[cij];
-                    nszz = (d.Szz + ko + pl)[cij];
-                    if (nmem) nrzz = (d.Rzz + ko + pl)[cij];
+                    nvx = F4((d.Vx + ko + pl), cij * 4u); nvy = F4((d.Vy + ko + pl), cij * 4u); nvz = F4((d.Vz + ko + 2 * pl), cij * 4u);
+                    nmraw = U2((d.mat + ko + pl), cij * 2u);
+                    nszz = F4((d.Szz + ko + pl), cij * 4u);
+                    if (nmem) nrzz = F4((d.Rzz + ko + pl), cij * 4u);
                     if (!nfl) {
-                        nsxx = (d.Sxx + ko + pl)[cij]; nsyy = (d.Syy + ko + pl)[cij];
-                        nrxx = (d.Rxx + ko + pl)[cij]; nryy = (d.Ryy + ko + pl)[cij];
+                        nsxx = F4((d.Sxx + ko + pl), cij * 4u); nsyy = F4((d.Syy + ko + pl), cij * 4u);
+                        nrxx = F4((d.Rxx + ko + pl), cij * 4u); nryy = F4((d.Ryy + ko + pl), cij * 4u);
                     }
                 }
-                if (t.ok) nh = ph[ko + pl];
-                if (zi) npx = d.psi[0][qx + dqx];
-                if (zj) npy = d.psi[1][qy + dqy];
+                if (t.ok) nh = F4(ph + ko + pl, hofs);
+                if (zi) npx = F4(d.psi[0], (unsigned)(qx + dqx) * 4u);
+                if (zj) npy = F4(d.psi[1], (unsigned)(qy + dqy) * 4u);
                 const int kn = k + 1;
-                if (PML && valid && (kn < P || kn >= d.N3 - P)) npz = d.psi[2][(unsigned)((kn < P ? kn : kn - (d.N3 - 2 * P)) * d.plane) + cij];
+                if (PML && valid && (kn < P || kn >= d.N3 - P)) npz = F4(d.psi[2], (unsigned)((unsigned)((kn < P ? kn : kn - (d.N3 - 2 * P)) * d.plane) + cij) * 4u);
             }
         };
         sV[b][0][own] = vx0; sV[b][1][own] = vy0;
@@ -1048,16 +1074,16 @@ __device__ __forceinline__ void stress_solid_body(const bfd_dev &d, const int4 &
             float dyVy = dminus4(sy[-2 * LW], sy[-LW], vy0, sy[LW]);
             float dzVz = dminus4(vzm2, vzm1, vz0, vzp1);
             if (cl & BFD_CLS_REFL) {
-                (d.Sxx + ko)[cij] = 0.f; (d.Syy + ko)[cij] = 0.f; (d.SzzW + ko)[cij] = 0.f;
-                (d.Rxx + ko)[cij] = 0.f; (d.Ryy + ko)[cij] = 0.f; (d.RzzW + ko)[cij] = 0.f;
-                (d.Sxy + ko)[cij] = 0.f; (d.Sxz + ko)[cij] = 0.f; (d.Syz + ko)[cij] = 0.f;
-                (d.Rxy + ko)[cij] = 0.f; (d.Rxz + ko)[cij] = 0.f; (d.Ryz + ko)[cij] = 0.f;
+                F4((d.Sxx + ko), cij * 4u) = 0.f; F4((d.Syy + ko), cij * 4u) = 0.f; F4((d.SzzW + ko), cij * 4u) = 0.f;
+                F4((d.Rxx + ko), cij * 4u) = 0.f; F4((d.Ryy + ko), cij * 4u) = 0.f; F4((d.RzzW + ko), cij * 4u) = 0.f;
+                F4((d.Sxy + ko), cij * 4u) = 0.f; F4((d.Sxz + ko), cij * 4u) = 0.f; F4((d.Syz + ko), cij * 4u) = 0.f;
+                F4((d.Rxy + ko), cij * 4u) = 0.f; F4((d.Rxz + ko), cij * 4u) = 0.f; F4((d.Ryz + ko), cij * 4u) = 0.f;
             } else {
-                if (zi) { const float pn = bxc * px + ax * dxVx; d.psi[0][qx] = pn; dxVx = dxVx + pn; }
-                if (zj) { const float pn = byc * py + ay * dyVy; d.psi[1][qy] = pn; dyVy = dyVy + pn; }
+                if (zi) { const float pn = bxc * px + ax * dxVx; F4(d.psi[0], (unsigned)(qx) * 4u) = pn; dxVx = dxVx + pn; }
+                if (zj) { const float pn = byc * py + ay * dyVy; F4(d.psi[1], (unsigned)(qy) * 4u) = pn; dyVy = dyVy + pn; }
                 if (PML && (k < P || k >= d.N3 - P)) {
                     const float pn = d.bzI[k] * pz + d.azI[k] * dzVz;
-                    d.psi[2][(unsigned)((k < P ? k : k - (d.N3 - 2 * P)) * d.plane) + cij] = pn;
+                    F4(d.psi[2], (unsigned)((unsigned)((k < P ? k : k - (d.N3 - 2 * P)) * d.plane) + cij) * 4u) = pn;
                     dzVz = dzVz + pn;
                 }
                 const float sXY = dxVx + dyVy;
@@ -1068,18 +1094,18 @@ __device__ __forceinline__ void stress_solid_body(const bfd_dev &d, const int4 &
                     else {
                         const float rn = c1 * rzz - BP * div;
                         val = szz + (AP * div + 0.5f * (rzz + rn));
-                        (d.RzzW + ko)[cij] = rn;
+                        F4((d.RzzW + ko), cij * 4u) = rn;
                     }
-                    (d.SzzW + ko)[cij] = val;
+                    F4((d.SzzW + ko), cij * 4u) = val;
                 } else {
                     const float sYZ = dyVy + dzVz, sXZ = dxVx + dzVz;
                     float rn;
                     rn = c1 * rxx - (BP * div - BS2 * sYZ);
-                    (d.Sxx + ko)[cij] = sxx + ((AP * div - AS2 * sYZ) + 0.5f * (rxx + rn)); (d.Rxx + ko)[cij] = rn;
+                    F4((d.Sxx + ko), cij * 4u) = sxx + ((AP * div - AS2 * sYZ) + 0.5f * (rxx + rn)); F4((d.Rxx + ko), cij * 4u) = rn;
                     rn = c1 * ryy - (BP * div - BS2 * sXZ);
-                    (d.Syy + ko)[cij] = syy + ((AP * div - AS2 * sXZ) + 0.5f * (ryy + rn)); (d.Ryy + ko)[cij] = rn;
+                    F4((d.Syy + ko), cij * 4u) = syy + ((AP * div - AS2 * sXZ) + 0.5f * (ryy + rn)); F4((d.Ryy + ko), cij * 4u) = rn;
                     rn = c1 * rzz - (BP * div - BS2 * sXY);
-                    (d.SzzW + ko)[cij] = szz + ((AP * div - AS2 * sXY) + 0.5f * (rzz + rn)); (d.RzzW + ko)[cij] = rn;
+                    F4((d.SzzW + ko), cij * 4u) = szz + ((AP * div - AS2 * sXY) + 0.5f * (rzz + rn)); F4((d.RzzW + ko), cij * 4u) = rn;
                 }
             }
         }
@@ -1091,7 +1117,10 @@ __device__ __forceinline__ void stress_solid_body(const bfd_dev &d, const int4 &
     }
 }
 
-__global__ __launch_bounds__(NTHREADS, 4) void stress_solid(bfd_dev d, int tilesX, int nblocks, const int4 *__restrict__ runs)
+#ifndef SOLID_STRESS_WAVES_PER_SIMD
+#define SOLID_STRESS_WAVES_PER_SIMD 4
+#endif
+__global__ __launch_bounds__(NTHREADS, SOLID_STRESS_WAVES_PER_SIMD) void stress_solid(bfd_dev d, int tilesX, int nblocks, const int4 *__restrict__ runs)
 {
     __shared__ float sV[2][2][LH * LW];
     const int4 run = runs[remap_block(blockIdx.x, nblocks)];
@@ -1104,8 +1133,8 @@ __global__ __launch_bounds__(NTHREADS, 4) void stress_solid(bfd_dev d, int tiles
 __device__ __forceinline__ float halo_value(const float *__restrict__ base, const float *__restrict__ alt, bool subst, unsigned bit,
                                             unsigned hc, unsigned off)
 {
-    if (subst) return ((hc & BFD_CLS_FLUID) ? alt : base)[off];
-    return (hc & bit) ? base[off] : 0.0f;
+    if (subst) return (hc & BFD_CLS_FLUID) ? F4(alt, off * 4u) : F4(base, off * 4u);
+    return (hc & bit) ? F4(base, off * 4u) : 0.0f;
 }
 
 // LDS set: 0 Sxx (x halo), 1 Syy (y halo), 2 Sxy (x and y halo), 3 Sxz (x halo), 4 Syz (y halo)
@@ -1163,20 +1192,20 @@ __device__ __forceinline__ void velocity_solid_body(const bfd_dev &d, const int4
     if (valid) {
         const float *bzz = d.Szz + kbeg * pl, *bxz = d.Sxz + kbeg * pl, *byz = d.Syz + kbeg * pl;
         const uint8_t *bc = d.cls + kbeg * pl;
-        const unsigned cm2 = (bc - 2 * pl)[cij], cm1 = (bc - pl)[cij], c0 = bc[cij];
-        cB = (bc + pl)[cij]; cC = (bc + 2 * pl)[cij];
-        zzm1 = (bzz - pl)[cij]; zz0 = bzz[cij]; zzp1 = (bzz + pl)[cij]; zzp2 = (bzz + 2 * pl)[cij];
-        if (cm2 & BFD_CLS_EXZ) xzm2 = (bxz - 2 * pl)[cij];
-        if (cm1 & BFD_CLS_EXZ) xzm1 = (bxz - pl)[cij];
-        if (c0 & BFD_CLS_EXZ) xz0 = bxz[cij];
-        if (cB & BFD_CLS_EXZ) xzp1 = (bxz + pl)[cij];
-        if (cm2 & BFD_CLS_EYZ) yzm2 = (byz - 2 * pl)[cij];
-        if (cm1 & BFD_CLS_EYZ) yzm1 = (byz - pl)[cij];
-        if (c0 & BFD_CLS_EYZ) yz0 = byz[cij];
-        if (cB & BFD_CLS_EYZ) yzp1 = (byz + pl)[cij];
+        const unsigned cm2 = U1((bc - 2 * pl), cij), cm1 = U1((bc - pl), cij), c0 = U1(bc, cij);
+        cB = U1((bc + pl), cij); cC = U1((bc + 2 * pl), cij);
+        zzm1 = F4((bzz - pl), cij * 4u); zz0 = F4(bzz, cij * 4u); zzp1 = F4((bzz + pl), cij * 4u); zzp2 = F4((bzz + 2 * pl), cij * 4u);
+        if (cm2 & BFD_CLS_EXZ) xzm2 = F4((bxz - 2 * pl), cij * 4u);
+        if (cm1 & BFD_CLS_EXZ) xzm1 = F4((bxz - pl), cij * 4u);
+        if (c0 & BFD_CLS_EXZ) xz0 = F4(bxz, cij * 4u);
+        if (cB & BFD_CLS_EXZ) xzp1 = F4((bxz + pl), cij * 4u);
+        if (cm2 & BFD_CLS_EYZ) yzm2 = F4((byz - 2 * pl), cij * 4u);
+        if (cm1 & BFD_CLS_EYZ) yzm1 = F4((byz - pl), cij * 4u);
+        if (c0 & BFD_CLS_EYZ) yz0 = F4(byz, cij * 4u);
+        if (cB & BFD_CLS_EYZ) yzp1 = F4((byz + pl), cij * 4u);
         if (c0 & BFD_CLS_FLUID) { sxx = zz0; syy = zz0; }
-        else { sxx = (d.Sxx + kbeg * pl)[cij]; syy = (d.Syy + kbeg * pl)[cij]; }
-        if (c0 & BFD_CLS_EXY) sxy = (d.Sxy + kbeg * pl)[cij];
+        else { sxx = F4((d.Sxx + kbeg * pl), cij * 4u); syy = F4((d.Syy + kbeg * pl), cij * 4u); }
+        if (c0 & BFD_CLS_EXY) sxy = F4((d.Sxy + kbeg * pl), cij * 4u);
     }
     // the values of a plane are staged in LDS at the end of the iteration before it (here: plane kbeg into buffer kbeg & 1)
     const int bo0 = (kbeg & 1) * bufStride;
@@ -1188,41 +1217,43 @@ __device__ __forceinline__ void velocity_solid_body(const bfd_dev &d, const int4
     unsigned mraw = 0, mraw1 = 0, mx = 0, my = 0;
     if (valid) {
         const uint16_t *bM = d.mat + kbeg * pl;
-        mraw = bM[cij]; mraw1 = (bM + pl)[cij]; mx = bM[cx]; my = bM[cy];
+        mraw = U2(bM, cij * 2u); mraw1 = U2((bM + pl), cij * 2u); mx = U2(bM, cx * 2u); my = U2(bM, cy * 2u);
         r0 = d.invRho[mraw & BFD_MAT_MASK];
     }
     // halo values of plane kbeg and the class bytes of the halo cells one plane ahead
     unsigned hcA = 0, hcB = 0;
     {
         float ha = 0.f, hb = 0.f;
-        if (ta.ok) { ha = halo_value(baseA + kbeg * pl, d.Szz + kbeg * pl, substA, bitA, (d.cls + kbeg * pl)[offA], offA); hcA = (d.cls + kbeg * pl + pl)[offA]; }
-        if (tb.ok) { hb = halo_value(baseB + kbeg * pl, d.Szz + kbeg * pl, substB, bitB, (d.cls + kbeg * pl)[offB], offB); hcB = (d.cls + kbeg * pl + pl)[offB]; }
+        if (ta.ok) { ha = halo_value(baseA + kbeg * pl, d.Szz + kbeg * pl, substA, bitA, U1((d.cls + kbeg * pl), offA), offA); hcA = U1((d.cls + kbeg * pl + pl), offA); }
+        if (tb.ok) { hb = halo_value(baseB + kbeg * pl, d.Szz + kbeg * pl, substB, bitB, U1((d.cls + kbeg * pl), offB), offB); hcB = U1((d.cls + kbeg * pl + pl), offB); }
         la[(kbeg & 1) * bufStride] = ha;
         if (hasB) lb[(kbeg & 1) * bufStride] = hb;
     }
 
     for (int kl = kbeg; kl < kend; kl++) {
         const int b = kl & 1;
-        const long ko = (long)kl * pl;
+        // opaque to loop strength reduction: otherwise every array gets a 64-bit per-lane pointer that is bumped each plane
+        // (a VGPR pair per array); this way the plane bases are recomputed on the scalar unit and stay in SGPRs
+        const long ko = (long)__builtin_amdgcn_readfirstlane(kl) * pl;
         const int k = d.k0 + kl;
         const int bn = (b ^ 1) * bufStride;     // buffer of plane kl+1 (free: every thread is past the barrier of iteration kl-1's reads)
         float nzz = 0, nxz = 0, nyz = 0, nxx = 0, nyy = 0, nxy = 0, nha = 0, nhb = 0;
         unsigned nm2 = 0, nmx = 0, nmy = 0, nc3 = BFD_CLS_FLUID, nhcA = 0, nhcB = 0;
         auto prefetch_next = [&]() {
-        if (valid) nm2 = (d.mat + ko + 2 * pl)[cij];              // ghost planes make kl+2 addressable
-        if (valid && kl + 2 < kend) nc3 = (d.cls + ko + 3 * pl)[cij];       // steers the Sxz / Syz loads of iteration kl+1 (plane kl+3 <= nk+1)
+        if (valid) nm2 = U2((d.mat + ko + 2 * pl), cij * 2u);              // ghost planes make kl+2 addressable
+        if (valid && kl + 2 < kend) nc3 = U1((d.cls + ko + 3 * pl), cij);       // steers the Sxz / Syz loads of iteration kl+1 (plane kl+3 <= nk+1)
             if (kl + 1 < kend) {
                 if (valid) {
-                    nzz = (d.Szz + ko + 3 * pl)[cij];
-                    if (cC & BFD_CLS_EXZ) nxz = (d.Sxz + ko + 2 * pl)[cij];
-                    if (cC & BFD_CLS_EYZ) nyz = (d.Syz + ko + 2 * pl)[cij];
+                    nzz = F4((d.Szz + ko + 3 * pl), cij * 4u);
+                    if (cC & BFD_CLS_EXZ) nxz = F4((d.Sxz + ko + 2 * pl), cij * 4u);
+                    if (cC & BFD_CLS_EYZ) nyz = F4((d.Syz + ko + 2 * pl), cij * 4u);
                     if (cB & BFD_CLS_FLUID) { nxx = zzp1; nyy = zzp1; }
-                    else { nxx = (d.Sxx + ko + pl)[cij]; nyy = (d.Syy + ko + pl)[cij]; }
-                    if (cB & BFD_CLS_EXY) nxy = (d.Sxy + ko + pl)[cij];
-                    nmx = (d.mat + ko + pl)[cx]; nmy = (d.mat + ko + pl)[cy];
+                    else { nxx = F4((d.Sxx + ko + pl), cij * 4u); nyy = F4((d.Syy + ko + pl), cij * 4u); }
+                    if (cB & BFD_CLS_EXY) nxy = F4((d.Sxy + ko + pl), cij * 4u);
+                    nmx = U2((d.mat + ko + pl), cx * 2u); nmy = U2((d.mat + ko + pl), cy * 2u);
                 }
-                if (ta.ok) { nha = halo_value(baseA + ko + pl, d.Szz + ko + pl, substA, bitA, hcA, offA); nhcA = (d.cls + ko + 2 * pl)[offA]; }
-                if (tb.ok) { nhb = halo_value(baseB + ko + pl, d.Szz + ko + pl, substB, bitB, hcB, offB); nhcB = (d.cls + ko + 2 * pl)[offB]; }
+                if (ta.ok) { nha = halo_value(baseA + ko + pl, d.Szz + ko + pl, substA, bitA, hcA, offA); nhcA = U1((d.cls + ko + 2 * pl), offA); }
+                if (tb.ok) { nhb = halo_value(baseB + ko + pl, d.Szz + ko + pl, substB, bitB, hcB, offB); nhcB = U1((d.cls + ko + 2 * pl), offB); }
             }
         };
         float r1 = 0, rx = 0, ry = 0, vx = 0, vy = 0, vz = 0, av = 0, pv = 0;
@@ -1230,9 +1261,9 @@ __device__ __forceinline__ void velocity_solid_body(const bfd_dev &d, const int4
             r1 = d.invRho[mraw1 & BFD_MAT_MASK];       // plane kl+1, becomes r0 of the next iteration
             rx = d.invRho[mx & BFD_MAT_MASK];
             ry = d.invRho[my & BFD_MAT_MASK];
-            vx = (d.Vx + ko)[cij]; vy = (d.Vy + ko)[cij]; vz = (d.Vz + ko)[cij];
-            if (accA) av = (accP + ko)[cij];
-            if (accK) pv = (pkP + ko)[cij];
+            vx = F4((d.Vx + ko), cij * 4u); vy = F4((d.Vy + ko), cij * 4u); vz = F4((d.Vz + ko), cij * 4u);
+            if (accA) av = F4((accP + ko), cij * 4u);
+            if (accK) pv = F4((pkP + ko), cij * 4u);
         }
         __syncthreads();
 
@@ -1244,12 +1275,12 @@ __device__ __forceinline__ void velocity_solid_body(const bfd_dev &d, const int4
                 if (inner && k >= d.ND && k < d.N3 - d.ND) {
                     const float s = (sxx + syy) + zz0;
                     const float p = -s * (1.0f / 3.0f);
-                    if (accA) (accP + ko)[cij] = av + p * p;
-                    if (accK) { const float ap = fabsf(p); if (ap > pv) (pkP + ko)[cij] = ap; }
+                    if (accA) F4((accP + ko), cij * 4u) = av + p * p;
+                    if (accK) { const float ap = fabsf(p); if (ap > pv) F4((pkP + ko), cij * 4u) = ap; }
                 }
             }
             if (mraw & BFD_REFLECTOR_BIT) {
-                wVx[cij] = 0.f; wVy[cij] = 0.f; wVz[cij] = 0.f;
+                F4(wVx, cij * 4u) = 0.f; F4(wVy, cij * 4u) = 0.f; F4(wVz, cij * 4u) = 0.f;
             } else {
                 const float *pxx = &sS[b][0][own], *pyy = &sS[b][1][own], *pxy = &sS[b][2][own];
                 const float *pxz = &sS[b][3][own], *pyz = &sS[b][4][own];
@@ -1284,9 +1315,9 @@ __device__ __forceinline__ void velocity_solid_body(const bfd_dev &d, const int4
                     dzSzz = cpml(d.psi[17], q, d.azH[k], d.bzH[k], dzSzz);
                 }
                 const float bxv = 0.5f * (r0 + rx), byv = 0.5f * (r0 + ry), bzv = 0.5f * (r0 + r1);
-                wVx[cij] = vx + bxv * ((dxSxx + dySxy) + dzSxz);
-                wVy[cij] = vy + byv * ((dxSxy + dySyy) + dzSyz);
-                wVz[cij] = vz + bzv * ((dxSxz + dySyz) + dzSzz);
+                F4(wVx, cij * 4u) = vx + bxv * ((dxSxx + dySxy) + dzSxz);
+                F4(wVy, cij * 4u) = vy + byv * ((dxSxy + dySyy) + dzSyz);
+                F4(wVz, cij * 4u) = vz + bzv * ((dxSxz + dySyz) + dzSzz);
             }
         }
         zzm1 = zz0; zz0 = zzp1; zzp1 = zzp2; zzp2 = nzz;
@@ -1304,8 +1335,11 @@ __device__ __forceinline__ void velocity_solid_body(const bfd_dev &d, const int4
 
 // two kernels (the absorbing-layer flavour needs ~18 registers more and would spill inside a common one); the solid run
 // list keeps the runs that touch the layer at its two ends (bfd_tiles::nSolidBP / nSolidIP)
+#ifndef SOLID_VELOCITY_WAVES_PER_SIMD
+#define SOLID_VELOCITY_WAVES_PER_SIMD 4
+#endif
 template <bool ACC, bool PML>
-__global__ __launch_bounds__(NTHREADS, VELOCITY_WAVES_PER_SIMD) void velocity_solid(bfd_dev d, int tilesX, int nblocks,
+__global__ __launch_bounds__(NTHREADS, SOLID_VELOCITY_WAVES_PER_SIMD) void velocity_solid(bfd_dev d, int tilesX, int nblocks,
                                                         float *__restrict__ accP, float *__restrict__ pkP,
                                                         const int4 *__restrict__ runs)
 {
