@@ -918,7 +918,6 @@ static int build_tile_lists(bfd_sim *s)
     int tx, ty, nsub; bfd_tile_grid(s->d, &tx, &ty, &nsub);
     const int n = tx * ty * nsub;
     dev_release(s, &s->tiles.runs); dev_release(s, &s->tiles.shearCells); dev_release(s, &s->tiles.shearCoef);    // lists of an earlier build
-    dev_release(s, &s->tiles.runCoef); dev_release(s, &s->tiles.runCoefBase); s->tiles.nRunCells = 0;
     const int SUB = bfd_tile_subz();
     // longest run one workgroup marches: 16 planes; 8 on small grids so that the launch still has a few thousand
     // workgroups (measured: 256^3 49 -> 58, 128^3 29 -> 46 Gvoxel-steps/s). 32 was best at 512^3 while the z-chunks of
@@ -1041,7 +1040,7 @@ static int build_tile_lists(bfd_sim *s)
     int rc = dev_alloc(s, &s->tiles.runs, all.size(), false);
     if (rc) return rc;
     BFD_HIP(hipMemcpy(s->tiles.runs, all.data(), all.size() * sizeof(int4), hipMemcpyHostToDevice));
-    s->tiles.shearCells = nullptr; s->tiles.shearCoef = nullptr; s->tiles.runCoef = nullptr; s->tiles.runCoefBase = nullptr; s->tiles.nRunCells = 0;
+    s->tiles.shearCells = nullptr; s->tiles.shearCoef = nullptr;
     s->tiles.nShear = s->tiles.shearLowEnd = s->tiles.shearHighBeg = 0;
     if (T.nSolid && s->cfg.kernelVariant != 2) {     // variant 2 stays monolithic and fully dense
         // sparse shear list: cells with a solid centre, ascending index, + their edge coefficients
@@ -1073,25 +1072,6 @@ static int build_tile_lists(bfd_sim *s)
         if (e != hipSuccess) BFD_FAIL(-10, std::string("shear list: ") + hipGetErrorString(e));
         if (rc) return rc;
         s->tiles.nShear = count;
-        // run-compact edge coefficients for the merged normal + shear kernel (BFD_SHEAR_SPARSE=1 keeps the separate sparse
-        // pass: experiments / cross-check)
-        const char *sp = getenv("BFD_SHEAR_SPARSE");
-        if (!(sp && atoi(sp) != 0)) {
-            std::vector<long> base((size_t)T.nSolid);
-            long total = 0;
-            for (int r = 0; r < T.nSolid; r++) {
-                const int4 &run = all[(size_t)T.nFluid + r];
-                base[r] = total;
-                total += (long)((run.y >> 16) - (run.y & 0xFFFF)) * (bfd_tile_threads());
-            }
-            rc = dev_alloc(s, &s->tiles.runCoefBase, (size_t)T.nSolid, false);
-            if (!rc) rc = dev_alloc(s, &s->tiles.runCoef, 6 * (size_t)total, false);
-            if (rc) return rc;
-            BFD_HIP(hipMemcpy(s->tiles.runCoefBase, base.data(), base.size() * sizeof(long), hipMemcpyHostToDevice));
-            s->tiles.nRunCells = total;
-            bfd_launch_run_shear_coefficients(s->d, s->stream, s->tiles.runs + T.nFluid, T.nSolid, s->tiles.runCoefBase, s->tiles.runCoef, total);
-            BFD_HIP(hipStreamSynchronize(s->stream));
-        }
         s->tiles.shearLowEnd = std::lower_bound(hostCells.begin(), hostCells.end(), (unsigned)lowPlanes * (unsigned)s->d.plane) - hostCells.begin();
         s->tiles.shearHighBeg = std::lower_bound(hostCells.begin(), hostCells.end(), (unsigned)hiStart * (unsigned)s->d.plane) - hostCells.begin();
     }
@@ -1161,10 +1141,7 @@ static int build_tile_lists(bfd_sim *s)
             const hipError_t e = hipStreamSynchronize(s->stream);
             hipFree(dc);
             if (e != hipSuccess) BFD_FAIL(-10, std::string("shear edge count: ") + hipGetErrorString(e));
-            if (s->tiles.runCoef)        // merged into the solid stress kernel: per active edge its two coefficients + S and R read-modify-write
-                for (int a = 0; a < 2; a++) B[a][BFD_K_STRESS_SOLID] += 24.0 * (double)hc;
-            else
-                for (int a = 0; a < 2; a++) B[a][BFD_K_STRESS_SHEAR] = 40.0 * (double)s->tiles.nShear + 16.0 * (double)hc;
+            for (int a = 0; a < 2; a++) B[a][BFD_K_STRESS_SHEAR] = 40.0 * (double)s->tiles.nShear + 16.0 * (double)hc;
         }
     }
     s->tilesReady = true;

@@ -79,7 +79,6 @@ void bfd_kmark(bfd_sim *sim, int cls, int end, hipStream_t st);
 
 struct bfd_tiles { bfd_sim *ktimer; int4 *runs;
                    unsigned *shearCells; float *shearCoef; long nShear, shearLowEnd, shearHighBeg;   /* sparse shear list */
-                   float *runCoef; long *runCoefBase; long nRunCells;   /* run-compact edge coefficients of the merged solid stress kernel (null: sparse shear pass) */
                    int nFluid, nFluidB, nSolid, nSolidB, nSolidBP /* leading boundary runs that touch the absorbing layer */, nSolidIP /* trailing interior ones */, nFused /* runs of the fused kernel, after the solid runs */;
                    int nLossless, nLossy, nSolidSub, nUni, nPml, nLean, nFusedSub; };
 
@@ -154,13 +153,11 @@ int bfd_tile_subz(void);
 void bfd_launch_classify(const bfd_dev &d, hipStream_t s, int *flagsDev, int *tileMatDev);
 void bfd_launch_mark_solid(const bfd_dev &d, hipStream_t s, unsigned char *flag, long n);
 void bfd_launch_shear_coefficients(const bfd_dev &d, hipStream_t s, const unsigned *cells, float *coef, long n);
-void bfd_launch_run_shear_coefficients(const bfd_dev &d, hipStream_t s, const int4 *solidRuns, int nSolid, const long *runBase, float *coef, long nRunCells);
 void bfd_launch_cell_classes(const bfd_dev &d, hipStream_t s, uint8_t *clsBase, long nalloc);
 // counts over the cells of the solid runs: [0] fluid no-memory, [1] fluid with memory, [2] solid no-memory, [3] solid with memory,
 // [4] active shear edges, [5] reflector cells
 void bfd_launch_count_solid_cells(const bfd_dev &d, hipStream_t s, const int4 *solidRuns, int nSolid, unsigned long long *counts6);
 int bfd_tile_zchunk(void);
-int bfd_tile_threads(void);
 // part: 0 = every tile, 1 = boundary tiles, 2 = interior tiles (variant 2 lists every tile as solid)
 void bfd_launch_stress_v2(const bfd_dev &d, hipStream_t s, const bfd_tiles *t, int part);
 // accP / pkP: Pressure RMS / peak accumulators of this step (slab-local, x-fastest) or nullptr

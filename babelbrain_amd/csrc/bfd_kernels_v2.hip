@@ -1128,277 +1128,6 @@ __global__ __launch_bounds__(NTHREADS, SOLID_STRESS_WAVES_PER_SIMD) void stress_
     else stress_solid_body<false>(d, run, tilesX, sV);
 }
 
-// ------------------------------------------------------------------------------------------------
-// Solid runs, normal AND shear stresses in one pass (default): the marching kernel already holds the velocities of the
-// plane in LDS and in its z queues, so the shear update of a cell costs its coefficients (run-compact arrays, written at
-// setup with the canonical arithmetic), the read-modify-write of its active shear entries and memory variables -- instead
-// of a separate gather pass that fetched 21 velocity values per cell a second time (stress_shear_sparse: a quarter of the
-// stress half-step's time on the shear medium). All three velocity tiles carry their full halo ring here (two halo tasks
-// per thread, array uniform per wave); Vx and Vy get z queues of four planes like Vz.
-// ------------------------------------------------------------------------------------------------
-template <bool PML>
-__device__ __forceinline__ void stress_solid_shear_body(const bfd_dev &d, const int4 &run, int tilesX, float (*sV)[3][LH * LW],
-                                                        const float *__restrict__ coef, long nRunCells, long cbase)
-{
-    const int N1 = d.N1, N2 = d.N2;
-    const int bx = run.x % tilesX, by = run.x / tilesX, kbeg = run.y & 0xFFFF, kend = run.y >> 16;
-    const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * TX + tx;
-    const int wv = __builtin_amdgcn_readfirstlane(ty);
-    const int i0 = bx * TX, j0 = by * TY;
-    const int i = i0 + tx, j = j0 + ty;
-    const bool valid = (i < N1) && (j < N2);
-    const long pl = d.plane;
-    const int P = d.P;
-    const int own = (ty + 2) * LW + tx + 2;
-    const unsigned cij = valid ? (unsigned)(j * N1 + i) : 0u;
-
-    // halo tasks (array uniform per wave): A: waves 0-3 the halo rows of Vx, waves 4-7 those of Vy;
-    // B: waves 0-3 the halo rows of Vz; lanes 0..31 of wave 4 / 5 / 6 the halo columns of Vx / Vy / Vz
-    HaloTask ta, tb;
-    const int arrA = wv < 4 ? 0 : 1;
-    ytask(tid & 255, arrA, i0, j0, N1, N2, ta);
-    const int arrB = wv < 4 ? 2 : (wv == 4 ? 0 : (wv == 5 ? 1 : 2));
-    if (wv < 4) ytask(tid, 2, i0, j0, N1, N2, tb);
-    else if (wv < 7 && tx < XT) xtask(tx, arrB, i0, j0, N1, N2, tb);
-    else { tb.lofs = -1; tb.ok = false; tb.arr = arrB; tb.gofs = 0; }
-    const float *baseA = arrA == 0 ? d.Vx : d.Vy;
-    const float *baseB = arrB == 0 ? d.Vx : (arrB == 1 ? d.Vy : d.Vz);
-    const unsigned offA = ta.ok ? (unsigned)ta.gofs * 4u : 0u, offB = tb.ok ? (unsigned)tb.gofs * 4u : 0u;
-    float *la = &sV[0][ta.arr][ta.lofs];
-    float *lb = &sV[0][tb.arr][tb.lofs < 0 ? 0 : tb.lofs];
-    const bool hasB = tb.lofs >= 0;
-    const float c1 = d.c1;
-
-    const bool zi = PML && valid && (i < P || i >= N1 - P);
-    const bool zj = PML && valid && (j < P || j >= N2 - P);
-    float ax = 0, bxc = 0, ay = 0, byc = 0, px = 0, py = 0, pz = 0;
-    unsigned qx = 0, qy = 0;
-    const unsigned dqx = (unsigned)(N2 * 2 * P), dqy = (unsigned)(2 * P * N1);
-    if (zi) { ax = d.axI[i]; bxc = d.bxI[i]; qx = (unsigned)((kbeg * N2 + j) * (2 * P) + (i < P ? i : i - (N1 - 2 * P))); px = F4(d.psi[0], qx * 4u); }
-    if (zj) { ay = d.ayI[j]; byc = d.byI[j]; qy = (unsigned)((kbeg * (2 * P) + (j < P ? j : j - (N2 - 2 * P))) * N1 + i); py = F4(d.psi[1], qy * 4u); }
-    if (PML) {
-        const int kg = d.k0 + kbeg;
-        if (valid && (kg < P || kg >= d.N3 - P)) pz = F4(d.psi[2], ((unsigned)((kg < P ? kg : kg - (d.N3 - 2 * P)) * d.plane) + cij) * 4u);
-    }
-
-    // z queues: Vx, Vy planes kl-1 .. kl+2 ; Vz planes kl-2 .. kl+1 (ghost planes make them addressable)
-    float vxm1 = 0, vx0 = 0, vxp1 = 0, vxp2 = 0, vym1 = 0, vy0 = 0, vyp1 = 0, vyp2 = 0, vzm2 = 0, vzm1 = 0, vz0 = 0, vzp1 = 0;
-    float sxx = 0, syy = 0, szz = 0, rxx = 0, ryy = 0, rzz = 0;
-    unsigned mraw = 0, cl = BFD_CLS_FLUID | BFD_CLS_NOMEM, cl1 = BFD_CLS_FLUID | BFD_CLS_NOMEM;
-    if (valid) {
-        const float *bVx = d.Vx + kbeg * pl, *bVy = d.Vy + kbeg * pl, *bVz = d.Vz + kbeg * pl;
-        cl = U1(d.cls + kbeg * pl, cij); cl1 = U1(d.cls + kbeg * pl + pl, cij);
-        vxm1 = F4(bVx - pl, cij * 4u); vx0 = F4(bVx, cij * 4u); vxp1 = F4(bVx + pl, cij * 4u); vxp2 = F4(bVx + 2 * pl, cij * 4u);
-        vym1 = F4(bVy - pl, cij * 4u); vy0 = F4(bVy, cij * 4u); vyp1 = F4(bVy + pl, cij * 4u); vyp2 = F4(bVy + 2 * pl, cij * 4u);
-        vzm2 = F4(bVz - 2 * pl, cij * 4u); vzm1 = F4(bVz - pl, cij * 4u); vz0 = F4(bVz, cij * 4u); vzp1 = F4(bVz + pl, cij * 4u);
-        mraw = U2(d.mat + kbeg * pl, cij * 2u);
-        szz = F4(d.Szz + kbeg * pl, cij * 4u);
-        const bool fl = cl & BFD_CLS_FLUID, mem = !(cl & BFD_CLS_NOMEM) || !fl;
-        if (mem) rzz = F4(d.Rzz + kbeg * pl, cij * 4u);
-        if (!fl) {
-            sxx = F4(d.Sxx + kbeg * pl, cij * 4u); syy = F4(d.Syy + kbeg * pl, cij * 4u);
-            rxx = F4(d.Rxx + kbeg * pl, cij * 4u); ryy = F4(d.Ryy + kbeg * pl, cij * 4u);
-        }
-    }
-    float ha = ta.ok ? F4(baseA + kbeg * pl, offA) : 0.0f;
-    float hb = tb.ok ? F4(baseB + kbeg * pl, offB) : 0.0f;
-    const unsigned loc0 = (unsigned)(ty * TX + tx) * 4u;       // byte offset of the own cell inside one plane of the run-compact arrays
-
-    for (int kl = kbeg; kl < kend; kl++) {
-        const int b = kl & 1;
-        const long ko = (long)__builtin_amdgcn_readfirstlane(kl) * pl;      // plane bases stay on the scalar unit (see uni())
-        const int k = d.k0 + kl;
-        const int bo = b * (3 * LH * LW);
-        sV[b][0][own] = vx0; sV[b][1][own] = vy0; sV[b][2][own] = vz0;
-        la[bo] = ha;
-        if (hasB) lb[bo] = hb;
-        const int m = mraw & BFD_MAT_MASK;
-        const bool fl = cl & BFD_CLS_FLUID, mem = !(cl & BFD_CLS_NOMEM) || !fl;
-        float AP = 0, BP = 0, AS2 = 0, BS2 = 0;
-        if (valid) { AP = d.AP[m]; if (mem) BP = d.BP[m]; if (!fl) { AS2 = d.AS2[m]; BS2 = d.BS2[m]; } }
-        __syncthreads();
-
-        float nvx = 0, nvy = 0, nvz = 0, nha = 0, nhb = 0, nsxx = 0, nsyy = 0, nszz = 0, nrxx = 0, nryy = 0, nrzz = 0, npx = 0, npy = 0, npz = 0;
-        unsigned nmraw = 0, ncl2 = BFD_CLS_FLUID | BFD_CLS_NOMEM;
-        if (valid) ncl2 = U1(d.cls + ko + 2 * pl, cij);           // ghost planes make kl+2 addressable
-        if (kl + 1 < kend) {
-            if (valid) {
-                const bool nfl = cl1 & BFD_CLS_FLUID, nmem = !(cl1 & BFD_CLS_NOMEM) || !nfl;
-                nvx = F4(d.Vx + ko + 3 * pl, cij * 4u); nvy = F4(d.Vy + ko + 3 * pl, cij * 4u); nvz = F4(d.Vz + ko + 2 * pl, cij * 4u);
-                nmraw = U2(d.mat + ko + pl, cij * 2u);
-                nszz = F4(d.Szz + ko + pl, cij * 4u);
-                if (nmem) nrzz = F4(d.Rzz + ko + pl, cij * 4u);
-                if (!nfl) {
-                    nsxx = F4(d.Sxx + ko + pl, cij * 4u); nsyy = F4(d.Syy + ko + pl, cij * 4u);
-                    nrxx = F4(d.Rxx + ko + pl, cij * 4u); nryy = F4(d.Ryy + ko + pl, cij * 4u);
-                }
-            }
-            if (ta.ok) nha = F4(baseA + ko + pl, offA);
-            if (tb.ok) nhb = F4(baseB + ko + pl, offB);
-            if (zi) npx = F4(d.psi[0], (qx + dqx) * 4u);
-            if (zj) npy = F4(d.psi[1], (qy + dqy) * 4u);
-            const int kn = k + 1;
-            if (PML && valid && (kn < P || kn >= d.N3 - P)) npz = F4(d.psi[2], ((unsigned)((kn < P ? kn : kn - (d.N3 - 2 * P)) * d.plane) + cij) * 4u);
-        }
-        if (valid) {
-            const float *sx = &sV[b][0][own], *sy = &sV[b][1][own], *sz = &sV[b][2][own];
-            float dxVx = dminus4(sx[-2], sx[-1], vx0, sx[1]);
-            float dyVy = dminus4(sy[-2 * LW], sy[-LW], vy0, sy[LW]);
-            float dzVz = dminus4(vzm2, vzm1, vz0, vzp1);
-            if (cl & BFD_CLS_REFL) {
-                F4(d.Sxx + ko, cij * 4u) = 0.f; F4(d.Syy + ko, cij * 4u) = 0.f; F4(d.SzzW + ko, cij * 4u) = 0.f;
-                F4(d.Rxx + ko, cij * 4u) = 0.f; F4(d.Ryy + ko, cij * 4u) = 0.f; F4(d.RzzW + ko, cij * 4u) = 0.f;
-                F4(d.Sxy + ko, cij * 4u) = 0.f; F4(d.Sxz + ko, cij * 4u) = 0.f; F4(d.Syz + ko, cij * 4u) = 0.f;
-                F4(d.Rxy + ko, cij * 4u) = 0.f; F4(d.Rxz + ko, cij * 4u) = 0.f; F4(d.Ryz + ko, cij * 4u) = 0.f;
-            } else {
-                if (zi) { const float pn = bxc * px + ax * dxVx; F4(d.psi[0], qx * 4u) = pn; dxVx = dxVx + pn; }
-                if (zj) { const float pn = byc * py + ay * dyVy; F4(d.psi[1], qy * 4u) = pn; dyVy = dyVy + pn; }
-                if (PML && (k < P || k >= d.N3 - P)) {
-                    const float pn = d.bzI[k] * pz + d.azI[k] * dzVz;
-                    F4(d.psi[2], ((unsigned)((k < P ? k : k - (d.N3 - 2 * P)) * d.plane) + cij) * 4u) = pn;
-                    dzVz = dzVz + pn;
-                }
-                const float sXY = dxVx + dyVy;
-                const float div = sXY + dzVz;
-                if (fl) {               // fluid cell: one copy of the identical normal stresses
-                    float val;
-                    if (!mem) val = szz + AP * div;
-                    else {
-                        const float rn = c1 * rzz - BP * div;
-                        val = szz + (AP * div + 0.5f * (rzz + rn));
-                        F4(d.RzzW + ko, cij * 4u) = rn;
-                    }
-                    F4(d.SzzW + ko, cij * 4u) = val;
-                } else {
-                    const float sYZ = dyVy + dzVz, sXZ = dxVx + dzVz;
-                    float rn;
-                    rn = c1 * rxx - (BP * div - BS2 * sYZ);
-                    F4(d.Sxx + ko, cij * 4u) = sxx + ((AP * div - AS2 * sYZ) + 0.5f * (rxx + rn)); F4(d.Rxx + ko, cij * 4u) = rn;
-                    rn = c1 * ryy - (BP * div - BS2 * sXZ);
-                    F4(d.Syy + ko, cij * 4u) = syy + ((AP * div - AS2 * sXZ) + 0.5f * (ryy + rn)); F4(d.Ryy + ko, cij * 4u) = rn;
-                    rn = c1 * rzz - (BP * div - BS2 * sXY);
-                    F4(d.SzzW + ko, cij * 4u) = szz + ((AP * div - AS2 * sXY) + 0.5f * (rzz + rn)); F4(d.RzzW + ko, cij * 4u) = rn;
-                }
-                const unsigned eb = cl & (BFD_CLS_EXY | BFD_CLS_EXZ | BFD_CLS_EYZ);
-                if (eb) {               // shear: only where an edge of this cell is ever updated
-                    float dyVx = dplus4(sx[-LW], vx0, sx[LW], sx[2 * LW]);
-                    float dxVy = dplus4(sy[-1], vy0, sy[1], sy[2]);
-                    float dzVx = dplus4(vxm1, vx0, vxp1, vxp2);
-                    float dxVz = dplus4(sz[-1], vz0, sz[1], sz[2]);
-                    float dzVy = dplus4(vym1, vy0, vyp1, vyp2);
-                    float dyVz = dplus4(sz[-LW], vz0, sz[LW], sz[2 * LW]);
-                    if (zi) {
-                        dxVy = cpml(d.psi[4], qx, d.axH[i], d.bxH[i], dxVy);
-                        dxVz = cpml(d.psi[6], qx, d.axH[i], d.bxH[i], dxVz);
-                    }
-                    if (zj) {
-                        dyVx = cpml(d.psi[3], qy, d.ayH[j], d.byH[j], dyVx);
-                        dyVz = cpml(d.psi[8], qy, d.ayH[j], d.byH[j], dyVz);
-                    }
-                    if (PML && (k < P || k >= d.N3 - P)) {
-                        const unsigned q = (unsigned)((k < P ? k : k - (d.N3 - 2 * P)) * d.plane) + cij;
-                        dzVx = cpml(d.psi[5], q, d.azH[k], d.bzH[k], dzVx);
-                        dzVy = cpml(d.psi[7], q, d.azH[k], d.bzH[k], dzVy);
-                    }
-                    // coefficients of this cell: plane (kl - kbeg) of the run's block in the run-compact arrays [6][nRunCells]
-                    const float *cf = coef + cbase + (long)(kl - kbeg) * NTHREADS;
-                    if (eb & BFD_CLS_EXY) {
-                        const float A = F4(cf, loc0), B = F4(cf + nRunCells, loc0);
-                        const float e = dyVx + dxVy;
-                        const float r = F4(d.Rxy + ko, cij * 4u), rn = c1 * r - B * e;
-                        F4(d.Sxy + ko, cij * 4u) = F4(d.Sxy + ko, cij * 4u) + (A * e + 0.5f * (r + rn)); F4(d.Rxy + ko, cij * 4u) = rn;
-                    }
-                    if (eb & BFD_CLS_EXZ) {
-                        const float A = F4(cf + 2 * nRunCells, loc0), B = F4(cf + 3 * nRunCells, loc0);
-                        const float e = dzVx + dxVz;
-                        const float r = F4(d.Rxz + ko, cij * 4u), rn = c1 * r - B * e;
-                        F4(d.Sxz + ko, cij * 4u) = F4(d.Sxz + ko, cij * 4u) + (A * e + 0.5f * (r + rn)); F4(d.Rxz + ko, cij * 4u) = rn;
-                    }
-                    if (eb & BFD_CLS_EYZ) {
-                        const float A = F4(cf + 4 * nRunCells, loc0), B = F4(cf + 5 * nRunCells, loc0);
-                        const float e = dzVy + dyVz;
-                        const float r = F4(d.Ryz + ko, cij * 4u), rn = c1 * r - B * e;
-                        F4(d.Syz + ko, cij * 4u) = F4(d.Syz + ko, cij * 4u) + (A * e + 0.5f * (r + rn)); F4(d.Ryz + ko, cij * 4u) = rn;
-                    }
-                }
-            }
-        }
-        vxm1 = vx0; vx0 = vxp1; vxp1 = vxp2; vxp2 = nvx;
-        vym1 = vy0; vy0 = vyp1; vyp1 = vyp2; vyp2 = nvy;
-        vzm2 = vzm1; vzm1 = vz0; vz0 = vzp1; vzp1 = nvz;
-        ha = nha; hb = nhb; mraw = nmraw; cl = cl1; cl1 = ncl2;
-        sxx = nsxx; syy = nsyy; szz = nszz; rxx = nrxx; ryy = nryy; rzz = nrzz;
-        px = npx; py = npy; pz = npz; qx += dqx; qy += dqy;
-    }
-}
-
-__global__ __launch_bounds__(NTHREADS, SOLID_STRESS_WAVES_PER_SIMD) void stress_solid_shear(bfd_dev d, int tilesX, int nblocks, const int4 *__restrict__ runs,
-                                                                                            const long *__restrict__ runBase, const float *__restrict__ coef, long nRunCells)
-{
-    __shared__ float sV[2][3][LH * LW];
-    const int pos = remap_block(blockIdx.x, nblocks);
-    const int4 run = runs[pos];
-    const long cbase = runBase[pos];
-    if (run.z & 8) stress_solid_shear_body<true>(d, run, tilesX, sV, coef, nRunCells, cbase);
-    else stress_solid_shear_body<false>(d, run, tilesX, sV, coef, nRunCells, cbase);
-}
-
-// setup: edge coefficients A, B of the xy, xz, yz edges of every cell of the solid runs, run-compact ([6][nRunCells], a run
-// owns (kend - kbeg) * 512 consecutive entries from runBase[r]); same arithmetic as shear_coefficients; 0 where inactive
-__global__ __launch_bounds__(NTHREADS) void run_shear_coefficients(bfd_dev d, int tilesX, const int4 *__restrict__ runs,
-                                                                   const long *__restrict__ runBase, float *__restrict__ coef, long nRunCells)
-{
-    const int4 run = runs[blockIdx.x];
-    const int bx = run.x % tilesX, by = run.x / tilesX, kbeg = run.y & 0xFFFF, kend = run.y >> 16;
-    const int N1 = d.N1, N2 = d.N2;
-    const long pl = d.plane;
-    const int i = bx * TX + threadIdx.x, j = by * TY + threadIdx.y;
-    const bool valid = i < N1 && j < N2;
-    const float k2 = d.k2;
-    for (int kl = kbeg; kl < kend; kl++) {
-        float o[6] = {0, 0, 0, 0, 0, 0};
-        if (valid) {
-            const long ko = (long)kl * pl;
-            const unsigned raw = d.mat[ko + (long)j * N1 + i];
-            const int m = raw & BFD_MAT_MASK;
-            const float iv0 = d.invMu[m], t0 = d.tauS[m];
-            if (!(raw & BFD_REFLECTOR_BIT) && iv0 > 0.f) {
-                const int i1 = min(i + 1, N1 - 1), j1 = min(j + 1, N2 - 1);
-                const long r0 = ko + (long)j * N1, r1 = ko + (long)j1 * N1;
-                const int mx = d.mat[r0 + i1] & BFD_MAT_MASK, my = d.mat[r1 + i] & BFD_MAT_MASK, mz = d.mat[r0 + pl + i] & BFD_MAT_MASK;
-                const int mxy = d.mat[r1 + i1] & BFD_MAT_MASK, mxz = d.mat[r0 + pl + i1] & BFD_MAT_MASK, myz = d.mat[r1 + pl + i] & BFD_MAT_MASK;
-                const float ivx = d.invMu[mx], ivy = d.invMu[my], ivz = d.invMu[mz];
-                {
-                    const float e4 = d.invMu[mxy];
-                    if (ivx > 0.f && ivy > 0.f && e4 > 0.f) {
-                        const float muH = 4.0f / ((iv0 + ivx) + (ivy + e4));
-                        const float tau = 0.25f * ((t0 + d.tauS[mx]) + (d.tauS[my] + d.tauS[mxy]));
-                        o[0] = muH * (1.0f + tau); o[1] = (muH * tau) * k2;
-                    }
-                }
-                {
-                    const float e4 = d.invMu[mxz];
-                    if (ivx > 0.f && ivz > 0.f && e4 > 0.f) {
-                        const float muH = 4.0f / ((iv0 + ivx) + (ivz + e4));
-                        const float tau = 0.25f * ((t0 + d.tauS[mx]) + (d.tauS[mz] + d.tauS[mxz]));
-                        o[2] = muH * (1.0f + tau); o[3] = (muH * tau) * k2;
-                    }
-                }
-                {
-                    const float e4 = d.invMu[myz];
-                    if (ivy > 0.f && ivz > 0.f && e4 > 0.f) {
-                        const float muH = 4.0f / ((iv0 + ivy) + (ivz + e4));
-                        const float tau = 0.25f * ((t0 + d.tauS[my]) + (d.tauS[mz] + d.tauS[myz]));
-                        o[4] = muH * (1.0f + tau); o[5] = (muH * tau) * k2;
-                    }
-                }
-            }
-        }
-        const long at = runBase[blockIdx.x] + (long)(kl - kbeg) * NTHREADS + threadIdx.y * TX + threadIdx.x;
-        for (int q = 0; q < 6; q++) coef[q * nRunCells + at] = o[q];
-    }
-}
-
 // one halo value of the solid velocity kernel: SUBST (Sxx / Syy halos): Szz where the halo cell is fluid; otherwise a
 // shear array, loaded only where its edge bit is set. base / alt are wave-uniform (SGPR) plane bases.
 __device__ __forceinline__ float halo_value(const float *__restrict__ base, const float *__restrict__ alt, bool subst, unsigned bit,
@@ -1426,8 +1155,10 @@ __device__ __forceinline__ void velocity_solid_body(const bfd_dev &d, const int4
     const int P = d.P;
     const int own = (ty + 2) * LW + tx + 2;
     const unsigned cij = valid ? (unsigned)(j * N1 + i) : 0u;
-    const unsigned cx = valid ? (unsigned)(j * N1 + min(i + 1, N1 - 1)) : 0u;      // (i+1, j)
-    const unsigned cy = valid ? (unsigned)(min(j + 1, N2 - 1) * N1 + i) : 0u;      // (i, j+1)
+    // ids of the cells (i+1, j) and (i, j+1), clamped at the domain edge: byte offsets derived from cij when needed (the two
+    // comparisons live in scalar masks, not in registers)
+    const bool hasX = valid && i + 1 < N1, hasY = valid && j + 1 < N2;
+    const unsigned rowBytes = (unsigned)N1 * 2u;
     const bool accA = ACC && accP != nullptr, accK = ACC && pkP != nullptr;
 
     // halo tasks, the array of a task is uniform per wave (its plane base stays in SGPRs):
@@ -1488,7 +1219,7 @@ __device__ __forceinline__ void velocity_solid_body(const bfd_dev &d, const int4
     unsigned mraw = 0, mraw1 = 0, mx = 0, my = 0;
     if (valid) {
         const uint16_t *bM = d.mat + kbeg * pl;
-        mraw = U2(bM, cij * 2u); mraw1 = U2((bM + pl), cij * 2u); mx = U2(bM, cx * 2u); my = U2(bM, cy * 2u);
+        mraw = U2(bM, cij * 2u); mraw1 = U2((bM + pl), cij * 2u); mx = U2(bM, cij * 2u + (hasX ? 2u : 0u)); my = U2(bM, cij * 2u + (hasY ? rowBytes : 0u));
         r0 = d.invRho[mraw & BFD_MAT_MASK];
     }
     // halo values of plane kbeg and the class bytes of the halo cells one plane ahead
@@ -1521,7 +1252,7 @@ __device__ __forceinline__ void velocity_solid_body(const bfd_dev &d, const int4
                     if (cB & BFD_CLS_FLUID) { nxx = zzp1; nyy = zzp1; }
                     else { nxx = F4((d.Sxx + ko + pl), cij * 4u); nyy = F4((d.Syy + ko + pl), cij * 4u); }
                     if (cB & BFD_CLS_EXY) nxy = F4((d.Sxy + ko + pl), cij * 4u);
-                    nmx = U2((d.mat + ko + pl), cx * 2u); nmy = U2((d.mat + ko + pl), cy * 2u);
+                    nmx = U2((d.mat + ko + pl), cij * 2u + (hasX ? 2u : 0u)); nmy = U2((d.mat + ko + pl), cij * 2u + (hasY ? rowBytes : 0u));
                 }
                 if (ta.ok) { nha = halo_value(baseA + ko + pl, d.Szz + ko + pl, substA, bitA, hcA, offA); nhcA = U1((d.cls + ko + 2 * pl), offA); }
                 if (tb.ok) { nhb = halo_value(baseB + ko + pl, d.Szz + ko + pl, substB, bitB, hcB, offB); nhcB = U1((d.cls + ko + 2 * pl), offB); }
@@ -1607,10 +1338,10 @@ __device__ __forceinline__ void velocity_solid_body(const bfd_dev &d, const int4
 // two kernels (the absorbing-layer flavour needs ~18 registers more and would spill inside a common one); the solid run
 // list keeps the runs that touch the layer at its two ends (bfd_tiles::nSolidBP / nSolidIP)
 #ifndef SOLID_VELOCITY_WAVES_PER_SIMD
-#define SOLID_VELOCITY_WAVES_PER_SIMD 4
+#define SOLID_VELOCITY_WAVES_PER_SIMD 4      // of the plain flavour; the absorbing-layer flavour needs 108 registers and always gets 4
 #endif
 template <bool ACC, bool PML>
-__global__ __launch_bounds__(NTHREADS, SOLID_VELOCITY_WAVES_PER_SIMD) void velocity_solid(bfd_dev d, int tilesX, int nblocks,
+__global__ __launch_bounds__(NTHREADS, PML ? 4 : SOLID_VELOCITY_WAVES_PER_SIMD) void velocity_solid(bfd_dev d, int tilesX, int nblocks,
                                                         float *__restrict__ accP, float *__restrict__ pkP,
                                                         const int4 *__restrict__ runs)
 {
@@ -1880,7 +1611,6 @@ void bfd_tile_grid(const bfd_dev &d, int *tilesX, int *tilesY, int *subZ)
     *tilesX = (d.N1 + TX - 1) / TX; *tilesY = (d.N2 + TY - 1) / TY; *subZ = (d.nk + SUBZ - 1) / SUBZ;
 }
 int bfd_tile_zchunk(void) { return ZCHUNK; }
-int bfd_tile_threads(void) { return NTHREADS; }
 int bfd_tile_subz(void) { return SUBZ; }
 
 void bfd_launch_cell_classes(const bfd_dev &d, hipStream_t s, uint8_t *clsBase, long nalloc)
@@ -1891,11 +1621,6 @@ void bfd_launch_cell_classes(const bfd_dev &d, hipStream_t s, uint8_t *clsBase, 
 void bfd_launch_count_solid_cells(const bfd_dev &d, hipStream_t s, const int4 *solidRuns, int nSolid, unsigned long long *counts6)
 {
     if (nSolid) hipLaunchKernelGGL(count_solid_cells, dim3(nSolid), dim3(TX, TY, 1), 0, s, d, (d.N1 + TX - 1) / TX, solidRuns, counts6);
-}
-
-void bfd_launch_run_shear_coefficients(const bfd_dev &d, hipStream_t s, const int4 *solidRuns, int nSolid, const long *runBase, float *coef, long nRunCells)
-{
-    if (nSolid) hipLaunchKernelGGL(run_shear_coefficients, dim3(nSolid), dim3(TX, TY, 1), 0, s, d, (d.N1 + TX - 1) / TX, solidRuns, runBase, coef, nRunCells);
 }
 
 void bfd_launch_mark_solid(const bfd_dev &d, hipStream_t s, unsigned char *flag, long n)
@@ -1935,12 +1660,11 @@ void bfd_launch_stress_v2(const bfd_dev &d, hipStream_t s0, const bfd_tiles *t, 
     hipStream_t s = s0;
     if (nS) {
         BFD_KT(BFD_K_STRESS_SOLID, 0);
-        if (t->runCoef) BFD_LAUNCH(stress_solid_shear, nS, t->runs + t->nFluid + offS, t->runCoefBase + offS, t->runCoef, t->nRunCells);   // normal + shear in one pass
-        else if (t->shearCells) BFD_LAUNCH(stress_solid, nS, t->runs + t->nFluid + offS);
+        if (t->shearCells) BFD_LAUNCH(stress_solid, nS, t->runs + t->nFluid + offS);
         else BFD_LAUNCH(stress_v2, nS, t->runs + t->nFluid + offS, (const unsigned short *)nullptr);     // variant 2: monolithic, dense
         BFD_KT(BFD_K_STRESS_SOLID, 1);
     }
-    if (!t->runCoef && t->shearCells && t->nShear) {     // sparse shear: cells sorted by index; [0,lowEnd) and [highBeg,n) are the boundary chunks
+    if (t->shearCells && t->nShear) {     // sparse shear: cells sorted by index; [0,lowEnd) and [highBeg,n) are the boundary chunks
         long b0 = 0, e0 = t->nShear, b1 = 0, e1 = 0;
         if (part == 1) { e0 = t->shearLowEnd; b1 = t->shearHighBeg; e1 = t->nShear; }
         else if (part == 2) { b0 = t->shearLowEnd; e0 = t->shearHighBeg; }
