@@ -18,6 +18,7 @@ sys.path.insert(0, ROOT)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--zadj', type=float, nargs='*', default=[0.0, -10.0, 10.0])
+    ap.add_argument('--tx', default='Single', choices=['Single', 'CTX_500'])
     ap.add_argument('--every', type=int, default=1)
     ap.add_argument('--cases', type=int, nargs='*', default=None)
     ap.add_argument('--depth-mm', type=float, default=None)
@@ -27,8 +28,8 @@ def main():
     args = ap.parse_args()
     from babelbrain_amd import PropagationModel, RayleighAndBHTE as R, _engine
     from tests import rayleigh_study as RS
-    rows = [c for c in json.load(open(os.path.join(ROOT, 'tests', 'golden', 'rayleigh_study.json')))['cases'] if c['tx'] == 'Single']
-    rows = [r for r in rows if r['zadj_mm'] in args.zadj]
+    rows = [c for c in json.load(open(os.path.join(ROOT, 'tests', 'golden', 'rayleigh_study.json')))['cases'] if c['tx'] == args.tx]
+    rows = [r for r in rows if float(r['Description'].split('_')[1]) in args.zadj]
     if args.cases is not None:
         rows = [r for r in rows if r['case'] in args.cases]
     rows = rows[::args.every]

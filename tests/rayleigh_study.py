@@ -31,24 +31,30 @@ Z_BEYOND = 80e-3              # zLengthBeyonFocalPointWhenNarrow of the Single r
 C_WATER = 1500.0              # Material['Water'][1]
 
 
-def build_case(freq, ppw, focal, diam, zadj, stable_dt_fn, forward, depth_target=DEPTH_TARGET, gap_vox=1.0, pml=None):
-    """-> dict with the solver arguments of one Single-Tx water case and the Rayleigh field on the whole domain."""
+def build_case(freq, ppw, focal, diam, zadj, stable_dt_fn, forward, depth_target=DEPTH_TARGET, gap_vox=1.0, pml=None, rings=None,
+               dout=None, zsteer=0.0, skin_offset=0.0, z_beyond=Z_BEYOND):
+    """-> dict with the solver arguments of one water case and the Rayleigh field on the whole domain.
+    Single transducer: a bowl (focal, diam). Annular array (CTX_500): rings = (InDiameters, OutDiameters) on the same bowl,
+    dout = the distance out-plane -> focus the study uses for it (52.4 mm), every ring driven with the phase that makes
+    its field arrive in phase at the steering point zsteer beyond the geometric focus (ANNULAR:359-420); skin_offset = how far
+    the skin on the line of sight lies below the top of the study's mask (enters the cone width and the steering point)."""
     pml = H.PML_THICKNESS if pml is None else pml
     h = H.SSOS_AT_WATER_DENSITY / freq / ppw                       # GetSmallestSOS(f, bShear=True) is its floor at every study frequency
     water = np.array([H.MATERIALS[500e3]['Water']], np.float64)
     dt_ideal = stable_dt_fn(water, freq, h, H.ALPHA_CFL)
     dt_water = stable_dt_fn(water, freq, h, 1.0)
     ppp, dt = H.ppp_rule(dt_ideal, freq)
-    dout = np.sqrt(focal ** 2 - (diam / 2) ** 2)
+    dout_geom = np.sqrt(focal ** 2 - (diam / 2) ** 2)
+    dout = dout_geom if dout is None else dout
     # BASE:1929-1944: the kept lateral region is the widest section of the beam cone, 1.1 * min(DistanceToFocus * tan(alpha),
     # Aperture/2), DistanceToFocus = source plane -> geometric focus = DOut + ZAdj (a transducer pulled back by 10 mm has its
     # focus 10 mm closer to the plane, and the cone is cut where it is narrower: the workbook's 'L Inf location' of those
     # cases sits at the centre of exactly this many voxels)
     alpha0 = np.arcsin(diam / 2 / focal)
-    radius_face = 1.1 * min((dout + min(zadj, 0.0)) * np.tan(alpha0), diam / 2)
+    radius_face = 1.1 * min((dout + min(zadj, 0.0) + skin_offset) * np.tan(alpha0), diam / 2)
     n_half = int(np.floor(radius_face / h + 1e-9))
     n_lat = 2 * n_half + 1
-    nz = int(np.round(depth_target / h)) + int(Z_BEYOND / h) + 1
+    nz = int(np.round(depth_target / h)) + int(z_beyond / h) + 1
     N1 = N2 = n_lat + 2 * pml
     N3 = nz + 2 * pml
     # ZAdj > 0 pushes the transducer "into the skin": the source plane moves ZIntoSkin deeper into the domain (BASE:1839-1841)
@@ -59,16 +65,39 @@ def build_case(freq, ppw, focal, diam, zadj, stable_dt_fn, forward, depth_target
     gap = gap_vox * h if zadj >= 0 else -zadj
     zs = (np.arange(N3) - zsrc) * h
     lam = 1482.0 / freq                                            # SpeedofSoundWater(20.0) ~ 1482 m/s sets the sub-source size
-    alpha = np.arcsin(diam / 2 / focal)
-    n_rings = max(int(np.ceil(alpha * focal / (lam / 5))), 4)      # GenerateFocusTx: PPWSurface = 5 (Single:132-137)
-    pts, ds = H._bowl_points(focal, diam, n_rings, 0.0)            # apex at z = 0, focus at z = focal, rim at focal - dout
-    pts = pts.copy()
-    pts[:, 2] += -(focal - dout) - gap                             # rim plane at z = -gap
+    k = np.array(2 * np.pi * freq / C_WATER + 0j).astype(np.complex64)
+    if rings is None:
+        alpha = np.arcsin(diam / 2 / focal)
+        n_rings = max(int(np.ceil(alpha * focal / (lam / 5))), 4)  # GenerateFocusTx: PPWSurface = 5 (Single:132-137)
+        pts, ds = H._bowl_points(focal, diam, n_rings, 0.0)        # apex at z = 0, focus at z = focal, rim at focal - dout
+        pts = pts.copy()
+        pts[:, 2] += -(focal - dout) - gap                         # rim plane at z = -gap
+        u0 = np.ones(len(ds), np.complex64)
+    else:
+        # the array's geometric focus sits dout + zadj below the source plane (its housing, not its outermost ring, touches
+        # the skin); sub-sources of lambda/8 (ANNULAR:131-137, PPWSurface = 8)
+        ind, outd = rings
+        alpha = np.arcsin(max(outd) / 2 / focal)
+        n_r = max(int(np.ceil(alpha * focal / (lam / 8))), 8)
+        pts, ds = H._bowl_points(focal, max(outd), n_r, 0.0)
+        rho2 = np.hypot(pts[:, 0], pts[:, 1]) * 2
+        ring = np.full(len(ds), -1)
+        for r, (a, b) in enumerate(zip(ind, outd)):
+            ring[(rho2 >= a) & (rho2 <= b)] = r
+        pts, ds, ring = pts[ring >= 0].copy(), ds[ring >= 0], ring[ring >= 0]
+        z_focus = dout + (zadj if zadj < 0 else 0.0)               # ZAdj > 0 moves the plane, not the array
+        pts[:, 2] += z_focus - focal
+        steer = np.array([[0.0, 0.0, z_focus + skin_offset + zsteer]], np.float32)
+        u0 = np.zeros(len(ds), np.complex64)
+        for r in range(len(ind)):                                   # phase of ring r = -angle(its own field at the steering point)
+            sel = ring == r
+            back = np.asarray(forward(k, pts[sel].astype(np.float32), ds[sel].astype(np.float32), np.ones(int(sel.sum()), np.complex64), steer))[0]
+            u0[sel] = np.exp(-1j * np.angle(back))
     k = np.array(2 * np.pi * freq / C_WATER + 0j).astype(np.complex64)
     X, Y, Z = np.meshgrid(xs, xs, zs, indexing='ij')
     rf = np.stack([X.ravel(), Y.ravel(), Z.ravel()], 1).astype(np.float32)
     del X, Y, Z
-    u2 = np.asarray(forward(k, pts.astype(np.float32), ds.astype(np.float32), np.ones(len(ds), np.complex64), rf)).reshape(N1, N2, N3)
+    u2 = np.asarray(forward(k, pts.astype(np.float32), ds.astype(np.float32), u0, rf)).reshape(N1, N2, N3)
     plane = u2[:, :, zsrc].copy()
     plane[:pml, :] = 0; plane[-pml:, :] = 0; plane[:, :pml] = 0; plane[:, -pml:] = 0
     T, nt, sub, start = H.time_plan(N1, N2, N3, h, dt, ppp, C_WATER)
@@ -82,7 +111,7 @@ def build_case(freq, ppw, focal, diam, zadj, stable_dt_fn, forward, depth_target
                   SelMapsSensorsList=['Pressure'], SelRMSorPeak=1, AlphaCFL=1.0, TypeSource=0, QfactorCorrection=True,
                   QCorrection=1.0, SensorSubSampling=sub, SensorStart=start, ReflectorMask=None)
     return dict(args=args, kwargs=kwargs, u2=u2, pml=pml, h=h, dt=dt, dt_water=dt_water, ppp=ppp, nt=nt, zsrc=zsrc, N=(N1, N2, N3),
-                n_sources=pulse.shape[0], focus_plane=zsrc + (dout + gap) / h)
+                n_sources=pulse.shape[0])
 
 
 def result_volumes(case, rms_pressure):
@@ -131,10 +160,22 @@ def qcheck(A, B, voxel_mm):
             'L2': float(100.0 * np.sqrt(np.sum((A - B) ** 2) / np.sum(B ** 2)))}
 
 
+CTX500 = dict(focal=62.94e-3, diam=64.0e-3, dout=52.4e-3, z_beyond=40e-3, skin_offset=0.9e-3,      # Babel_CTX500/default.yaml, PART_1 cell 8 / 16
+              rings=(np.array([0.0, 31.6988e-3, 44.2688e-3, 53.6688e-3]), np.array([31.14e-3, 43.71e-3, 53.11e-3, 60.83e-3])))
+
+
 def run_case(row, solver, stable_dt_fn, forward, depth_target=DEPTH_TARGET, gap_vox=1.0, pml=None):
-    """row: an entry of rayleigh_study.json (tx == 'Single'). solver(*args, **kwargs) -> the solver tuple."""
-    case = build_case(row['freq_khz'] * 1e3, row['ppw'], row['focal_mm'] * 1e-3, row['diam_mm'] * 1e-3, row['zadj_mm'] * 1e-3,
-                      stable_dt_fn, forward, depth_target, gap_vox, pml)
+    """row: an entry of rayleigh_study.json (tx 'Single' or 'CTX_500'). solver(*args, **kwargs) -> the solver tuple."""
+    if row['tx'] == 'CTX_500':
+        import re
+        m = re.match(r'ZAdj_(-?[\d.]+)_DEEP_CTX_500_500kHz_(\d+)PPW_ZSteering_(-?[\d.]+)\.nii', row['Description'])
+        zadj, ppw, zsteer = float(m.group(1)) * 1e-3, int(m.group(2)), float(m.group(3)) * 1e-3
+        c = CTX500
+        case = build_case(500e3, ppw, c['focal'], c['diam'], zadj, stable_dt_fn, forward, depth_target, gap_vox, pml, rings=c['rings'],
+                          dout=c['dout'], zsteer=zsteer, skin_offset=c['skin_offset'], z_beyond=c['z_beyond'])
+    else:
+        case = build_case(row['freq_khz'] * 1e3, row['ppw'], row['focal_mm'] * 1e-3, row['diam_mm'] * 1e-3, row['zadj_mm'] * 1e-3,
+                          stable_dt_fn, forward, depth_target, gap_vox, pml)
     out = solver(*case['args'], **case['kwargs'])
     A, B = result_volumes(case, out[2]['Pressure'])
     m = qcheck(A, B, case['h'] * 1e3)

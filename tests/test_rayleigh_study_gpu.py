@@ -72,3 +72,36 @@ def test_single_tx_water_cases_match_the_reference_study_row_by_row():
     for ppw, band in ((6, (0.25, 0.65)), (9, (-0.3, 0.2))):
         sel = [i for i in z if rows[CASES[i]]['ppw'] == ppw]
         assert band[0] <= np.median(mine[sel, 0]) <= band[1], (ppw, np.median(mine[sel, 0]))
+
+
+CTX_CASES = [139, 140, 141, 142, 151, 152, 153, 154, 144, 157]     # CTX_500 annular array, rim distance as designed (ZAdj 0) and 2 of ZAdj +10
+
+
+@pytest.mark.timeout(600)
+def test_ctx500_annular_array_cases_match_the_reference_study():
+    """The study's CTX_500 cases (4 rings, F = 62.94 mm, 500 kHz, focus steered -20 ... +17.5 mm along the axis by ring phases
+    computed like ANNULAR:359-420): another source builder, stronger steering-dependent structure. Per row: peak-amplitude
+    difference within 0.3 pp (observed <= 0.13 over the 16 ZAdj 0 / +10 cases), focal-centroid distance within 0.1 mm -- it
+    follows the workbook's trend with steering (0.01 / 0.10 / 0.29 / 0.37 mm against 0.04 / 0.12 / 0.31 / 0.41) -- L2 within
+    x0.45..x1.5 (observed 0.51..1.09; this engine lands closer to the Rayleigh field than the rows at 6 points per wavelength).
+    The pulled-back cases (ZAdj -10) depend on how far the skin lies below the top of the study's mask and are not held."""
+    from babelbrain_amd import PropagationModel, RayleighAndBHTE as R, _engine
+    from tests import rayleigh_study as RS
+    rows = {c['case']: c for c in json.load(open(os.path.join(ROOT, 'tests', 'golden', 'rayleigh_study.json')))['cases']}
+    model = PropagationModel()
+    dt_fn = lambda ml, f, h, c: _engine.stable_dt(ml, f, True, h, c)
+    solver = lambda *a, **k: model.StaggeredFDTD_3D_with_relaxation(*a, SILENT=True, **k)
+    cent_mine, cent_ref = [], []
+    for case in CTX_CASES:
+        r = rows[case]
+        assert r['tx'] == 'CTX_500'
+        m = RS.run_case(r, solver, dt_fn, R.ForwardSimple)
+        print('%3d %-58s amp %+5.2f (%+5.2f)  L2 %5.2f (%5.2f)  Linf %5.2f (%5.2f)  centroid %4.2f (%4.2f) mm'
+              % (case, r['Description'][:58], m['Difference amplitude'], r['Difference amplitude'], m['L2'], r['L2'], m['L Inf'], r['L Inf'],
+                 m['Distance focal centroid'], r['Distance focal centroid']))
+        assert abs(m['Difference amplitude'] - r['Difference amplitude']) <= 0.3, (case, 'amplitude difference')
+        assert abs(m['Distance focal centroid'] - r['Distance focal centroid']) <= 0.1, (case, 'focal centroid')
+        assert 0.45 <= m['L2'] / r['L2'] <= 1.5, (case, 'L2', m['L2'], r['L2'])
+        assert 0.25 <= m['L Inf'] / r['L Inf'] <= 1.6, (case, 'L Inf', m['L Inf'], r['L Inf'])
+        cent_mine.append(m['Distance focal centroid']); cent_ref.append(r['Distance focal centroid'])
+    assert np.corrcoef(cent_mine, cent_ref)[0, 1] >= 0.9
