@@ -10,11 +10,19 @@ a, k, info = H.make_problem('C3', stable_dt_fn=lambda ml, f, h, c: _engine.stabl
 t1 = time.time()
 print('inputs built in %.1f s: nt=%d ppp=%d sub=%d start=%d PulseSource %.1f GB' % (t1 - t0, info['nt'], info['ppp'], k['SensorSubSampling'], k['SensorStart'], a[4].nbytes / 1e9), flush=True)
 pm = PropagationModel()
-t2 = time.time()
-out = pm.StaggeredFDTD_3D_with_relaxation(*a, SILENT=True, ReturnSensorDFT=True, **k)
-t3 = time.time()
 N = 512 ** 3
-tm = pm.last_timing
-print('call wall %.2f s; step loop (device) %.2f s; voxel-steps %.3e' % (t3 - t2, tm['total_ms'] / 1e3, N * info['nt']))
-print('device-only %.0f Mvoxel-steps/s; PCIe-inclusive (whole call) %.0f Mvoxel-steps/s' % (N * info['nt'] / tm['total_ms'] / 1e3, N * info['nt'] / (t3 - t2) / 1e6))
-print('sensor block', out[0]['Pressure'].shape, '%.1f GB' % (out[0]['Pressure'].nbytes / 1e9), 'RMS max', float(out[2]['Pressure'].max()))
+for series in (True, False):      # the reference's return values; then without the sensor series (DFT accumulated in the loop)
+    t2 = time.time()
+    out = pm.StaggeredFDTD_3D_with_relaxation(*a, SILENT=True, ReturnSensorDFT=True, ReturnSensorSeries=series, **k)
+    t3 = time.time()
+    tm = pm.last_timing
+    print('ReturnSensorSeries=%s: call wall %.2f s; step loop (device) %.2f s; voxel-steps %.3e; device memory %.1f GB'
+          % (series, t3 - t2, tm['total_ms'] / 1e3, N * info['nt'], out[-1]['device_bytes'] / 1e9))
+    print('   device-only %.0f Mvoxel-steps/s; PCIe-inclusive (whole call) %.0f Mvoxel-steps/s'
+          % (N * info['nt'] / tm['total_ms'] / 1e3, N * info['nt'] / (t3 - t2) / 1e6))
+    if series:
+        print('   sensor block', out[0]['Pressure'].shape, '%.1f GB' % (out[0]['Pressure'].nbytes / 1e9), 'RMS max', float(out[2]['Pressure'].max()))
+        ref = out[-1]['SensorDFT']['Pressure']
+    else:
+        print('   in-loop DFT equals the DFT of the series:', bool(np.array_equal(ref, out[-1]['SensorDFT']['Pressure'])))
+    del out
