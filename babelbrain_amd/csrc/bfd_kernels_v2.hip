@@ -62,12 +62,14 @@ __device__ __forceinline__ float cpml(float *__restrict__ psi, unsigned idx, flo
 }
 
 
-// Element access as (wave-uniform plane base) + (32-bit BYTE offset in a VGPR): exactly the saddr form of global_load /
-// global_store (SGPR-pair base, 32-bit VGPR offset). Indexing a float* with a 32-bit cell index instead makes the compiler
-// build 64-bit addresses in VGPR pairs (it cannot prove that index*4 stays below 2^32): two registers and two VALU
-// instructions per access.
-// uni(): the plane base as an opaque wave-uniform value. Without it the compiler reassociates (array + plane) + lane offset
-// into (array + lane offset) + plane and hoists the first sum out of the z loop: a loop-invariant VGPR pair per array.
+// Element access as (wave-uniform plane base) + (32-bit BYTE offset in a VGPR). Indexing a float* with a 32-bit cell index
+// instead makes the compiler build 64-bit addresses in VGPR pairs that stay live (it cannot prove that index*4 stays below
+// 2^32), and it reassociates (array + plane) + lane offset into (array + lane offset) + plane, hoisting the first sum out of
+// the z loop: a loop-invariant VGPR pair per array.
+// uni(): the plane base as an opaque wave-uniform value (SGPR pair); the address of an access is then one v_lshl_add_u64 of
+// that pair and the shared offset register, live only until the access. The pointer is rebuilt from integers, so these are
+// FLAT accesses; the variant with address_space(1) pointers and saddr-form global loads (scripts/r2/patches/) needs fewer
+// registers still but measured 5-6 % slower on the solid-run kernels and equal on the fluid ones.
 template <typename T>
 __device__ __forceinline__ T *uni(T *p)
 {
