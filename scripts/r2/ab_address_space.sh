@@ -1,3 +1,5 @@
+# Builds: ab/flat = `git archive <commit before the variant> babelbrain_amd/csrc include | tar -x -C ab/flat` + make there (ab/ is
+# git-ignored and travels with the snapshot); variant libraries: apply scripts/r2/patches/*.patch, `make TAG=pin2 EXTRA=-DBFD_PIN_MODE=2` etc.
 # Same box: FLAT accesses (previous commit, ab/flat) against global-address-space accesses with the 32-bit offset pinned by a
 # volatile asm (product), a plain asm (pin2) or not at all (pin0: two thirds of the accesses keep 64-bit VGPR addresses).
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
