@@ -33,7 +33,7 @@ def _init(deviceName=None):
     return devs
 
 
-InitCuda = InitOpenCL = InitMetal = InitHIP = _init
+InitCuda = InitOpenCL = InitMetal = InitMLX = InitHIP = _init      # the reference picks one by backend (BabelBrain.py:429-439)
 
 
 def ForwardSimple(cwvnb, center, ds, u0, rf, deviceMetal=None, MacOsPlatform=None, u0step=0):

@@ -59,3 +59,17 @@ def test_engine_refuses_without_gpu(lib):
         pytest.skip('a GPU is present')
     with pytest.raises(_engine.EngineError):
         _engine.Engine(64, 64, 64, 1, 1e-3, 1e-7, 5e5, 10)
+
+
+def test_backend_entry_points_of_the_reference_exist(lib):
+    """The names BabelBrain imports from the solver package's tools (BabelBrain.py:429-439, SelFiles.py:245-263)."""
+    import babelbrain_amd
+    from babelbrain_amd import RayleighAndBHTE as R
+    for name in ('InitCuda', 'InitOpenCL', 'InitMetal', 'InitMLX', 'ForwardSimple', 'GenerateFocusTx', 'SpeedofSoundWater', 'BHTE',
+                 'BHTEMultiplePressureFields'):
+        assert callable(getattr(R, name)), name
+    names = babelbrain_amd.ListDevices()
+    assert isinstance(names, list) and len(names) == lib.bfd_device_count()
+    if not names:
+        with pytest.raises(_engine.EngineError):
+            R.InitMLX('MI355X')
