@@ -725,6 +725,7 @@ BFO_EXPORT void bfo_results(bfo_sim *S, float *sensorsOut, uint32_t *indexSensor
     }
     const int nAcc = S->step - S->accStart;
     const float cnt = (float)(nAcc > 0 ? nAcc : 1);
+    ftz_on();       /* the maps are finalised in the canonical arithmetic too: acc / cnt may land in the denormal range */
     for (int q = 0; q < S->nSelR; q++) {
         if (S->doRMS && rmsOut) for (size_t u = 0; u < N; u++) rmsOut[(size_t)q * N + u] = sqrtf(S->acc[(size_t)q * N + u] / cnt);
         if (S->doPeak && peakOut) memcpy(peakOut + (size_t)q * N, S->pk + (size_t)q * N, N * sizeof(float));
@@ -735,6 +736,7 @@ BFO_EXPORT void bfo_results(bfo_sim *S, float *sensorsOut, uint32_t *indexSensor
                 lastOut[(size_t)q * N + u] = (S->selR[q] == M_ALLV) ? sqrtf(map_sq(&S->F, M_ALLV, c)) : map_value(&S->F, S->selR[q], c);
             }
     }
+    ftz_off();
 }
 
 /* whole-domain convenience: create, nt steps, results, destroy */

@@ -1,0 +1,116 @@
+"""Parity on randomised media: the structured test media (shell, CT bins, plates) leave most per-cell class patterns
+unvisited -- single solid voxels in water, one-voxel fluid holes in bone, solid specks inside the absorbing layer, edges
+whose four cells are solid only along one diagonal. Every case here draws its grid size, absorbing-layer width, material
+map (smoothed-noise islands plus speckle), reflector pocket, source kind and placement, sensor set and map selection from a
+seeded generator and holds the HIP engine to the oracle on every output (1e-5 rel-L2 as everywhere; observed 0).
+The default variant is compared for all seeds; the dense and the simple variants for the first ones."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests.util import ALL_MAPS, compare_runs, oracle_dt
+
+pytestmark = pytest.mark.gpu
+
+#            rho     cL     cS    aL    aS
+MATERIALS = [[1000., 1500., 0., 0., 0.],          # water
+             [1896.5, 2476., 1542., 81., 164.],    # cortical bone (shear, lossy)
+             [1041., 1562., 0., 3.45, 0.],         # brain (fluid, lossy)
+             [1738., 2205., 1313., 81., 164.],     # trabecular bone
+             [2200., 3000., 1600., 0., 0.],        # a lossless solid
+             [1116., 1537., 0., 2.3, 0.]]          # skin
+
+
+def smooth(a, n):
+    for _ in range(n):
+        a = (a + np.roll(a, 1, 0) + np.roll(a, -1, 0) + np.roll(a, 1, 1) + np.roll(a, -1, 1) + np.roll(a, 1, 2) + np.roll(a, -1, 2)) / 7.0
+    return a
+
+
+def random_case(seed):
+    rng = np.random.default_rng(1000 + seed)
+    nd = int(rng.choice([5, 8, 12]))
+    N = tuple(int(v) for v in rng.integers(2 * (nd + 1) + 6, 84, 3))     # the engine wants 2 (NDelta + 1) + 4 cells per axis at least
+    if seed % 4 == 0:
+        N = (int(rng.integers(65, 140)), N[1], N[2])           # more than one tile in x, ragged
+    freq = 500e3
+    ml = np.array(MATERIALS, np.float64)
+    h = 1102.515 / freq / 6
+    # islands: two smoothed noise fields -> solids where high, lossy fluid where the second is high; then speckle
+    f1 = smooth(rng.standard_normal(N), int(rng.integers(1, 4)))
+    f2 = smooth(rng.standard_normal(N), 2)
+    mm = np.zeros(N, np.uint32)
+    mm[f2 > np.quantile(f2, 0.7)] = 2
+    mm[f2 > np.quantile(f2, 0.93)] = 5
+    q1 = np.quantile(f1, [0.6, 0.8, 0.93])
+    mm[f1 > q1[0]] = 1
+    mm[f1 > q1[1]] = 3
+    mm[f1 > q1[2]] = 4
+    speck = rng.random(N)
+    mm[speck < 0.004] = 1                                       # single solid voxels anywhere (also inside the absorbing layer)
+    mm[(speck > 0.996) & (mm == 1)] = 0                         # one-voxel fluid holes in bone
+    if seed % 3 == 1:
+        mm[:, :, : N[2] // 3] = 0                               # a fluid-only stretch: collapsed / lean tiles beside solid ones
+    refl = None
+    if seed % 2 == 0:
+        refl = np.zeros(N, np.uint32)
+        c = [int(rng.integers(nd + 2, n - nd - 6)) for n in N]
+        refl[c[0]:c[0] + 3, c[1]:c[1] + 4, c[2]:c[2] + 2] = 1
+    type_source = 2 if seed % 5 == 3 else 0
+    src = np.zeros(N, np.uint32)
+    if seed % 2 == 0:                                           # a source plane just inside the layer
+        zs = nd
+        ii, jj = np.meshgrid(np.arange(nd, N[0] - nd), np.arange(nd, N[1] - nd), indexing='ij')
+        keep = rng.random(ii.shape) < 0.5
+        src[ii[keep], jj[keep], zs] = np.arange(1, int(keep.sum()) + 1)
+    else:                                                       # scattered voxels, some sharing a row of the pulse table
+        npts = int(rng.integers(3, 40))
+        for s in range(npts):
+            p = [int(rng.integers(nd, n - nd)) for n in N]
+            src[p[0], p[1], p[2]] = 1 + s % 7
+    nsrc = int(src.max())
+    dt = oracle_dt(ml, freq, h, 0.99)
+    ppp = int(np.ceil(1.0 / (freq * dt)))
+    dt = 1.0 / (freq * ppp)
+    nt = int(rng.integers(90, 180))
+    t = np.arange(nt + 1) * dt
+    amp = 1.0 + rng.random(nsrc)
+    ph = 2 * np.pi * rng.random(nsrc)
+    pulse = amp[:, None] * np.sin(2 * np.pi * freq * t[None, :] + ph[:, None])
+    ramp = min(len(t), 2 * ppp)
+    pulse[:, :ramp] *= (0.5 * (1 - np.cos(np.pi * np.arange(ramp) / ramp)))[None, :]
+    sens = (rng.random(N) < 0.05).astype(np.uint32)
+    sens[:nd] = 0; sens[-nd:] = 0; sens[:, :nd] = 0; sens[:, -nd:] = 0; sens[:, :, :nd] = 0; sens[:, :, -nd:] = 0
+    full = np.ones(N, np.float64)
+    weights = dict(Ox=full * rng.random(), Oy=full * rng.random(), Oz=full) if seed % 3 else dict(Ox=np.array([0.3]), Oy=np.array([0.0]), Oz=np.array([1.0]))
+    sub = int(rng.choice([1, 2, 5]))
+    k = dict(NDelta=nd, DT=dt, ReflectionLimit=1e-5, USE_SINGLE=True, SelRMSorPeak=int(rng.choice([1, 2, 3])),
+             SelMapsRMSPeakList=ALL_MAPS if seed % 2 else ['Pressure', 'Vz', 'Sigmaxy'],
+             SelMapsSensorsList=['Pressure', 'Vx', 'Sigmaxz'] if seed % 2 else ['Pressure'],
+             SensorSubSampling=sub, SensorStart=int(rng.integers(0, nt // sub // 2)), TypeSource=type_source,
+             QfactorCorrection=True, QCorrection=[1.0, 3.0, 1.0, 2.0, 1.0, 1.0] if seed % 2 else 1.0, ReflectorMask=refl, **weights)
+    a = (mm, ml, freq, src, pulse, h, nt * dt, sens)
+    return a, k
+
+
+@pytest.mark.parametrize('seed', range(14))
+def test_random_media_default_variant(seed):
+    from babelbrain_amd import PropagationModel
+    a, k = random_case(seed)
+    oh = PropagationModel().StaggeredFDTD_3D_with_relaxation(*a, SILENT=True, **k)
+    orf = O.StaggeredFDTD_3D_with_relaxation(*a, **k)
+    w = compare_runs(oh, orf, 1e-5, both=(k['SelRMSorPeak'] == 3))
+    solid = np.isin(a[0], [1, 3, 4])
+    assert solid.any() and (~solid).any() and np.abs(orf[1]['Pressure']).max() > 0
+    assert all(np.isfinite(v).all() for v in orf[1].values())
+    print('seed %d grid %s layer %d: worst rel L2 %.2e' % (seed, a[0].shape, k['NDelta'], w))
+
+
+@pytest.mark.parametrize('variant', [1, 2])
+@pytest.mark.parametrize('seed', [0, 1, 3])
+def test_random_media_other_variants(seed, variant):
+    from babelbrain_amd import PropagationModel
+    a, k = random_case(seed)
+    oh = PropagationModel(kernelVariant=variant).StaggeredFDTD_3D_with_relaxation(*a, SILENT=True, **k)
+    orf = O.StaggeredFDTD_3D_with_relaxation(*a, **k)
+    compare_runs(oh, orf, 1e-5, both=(k['SelRMSorPeak'] == 3))
