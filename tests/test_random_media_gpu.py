@@ -114,3 +114,44 @@ def test_random_media_other_variants(seed, variant):
     oh = PropagationModel(kernelVariant=variant).StaggeredFDTD_3D_with_relaxation(*a, SILENT=True, **k)
     orf = O.StaggeredFDTD_3D_with_relaxation(*a, **k)
     compare_runs(oh, orf, 1e-5, both=(k['SelRMSorPeak'] == 3))
+
+
+@pytest.mark.parametrize('seed,world,split', [(0, 2, True), (1, 2, False), (4, 3, True), (5, 3, True), (8, 2, True), (9, 2, True), (12, 3, False)])
+def test_random_media_in_slabs(seed, world, split):
+    """The same media cut into Z-slabs on one GPU (halo planes moved by device copies, tests/test_slab_gpu.py): slab
+    interfaces land anywhere in the islands, sources and reflector pockets; both step orders; equal to the single domain."""
+    import torch
+    from babelbrain_amd import PropagationModel, slab
+    from babelbrain_amd._engine import HALO_STRESS, HALO_VELOCITY
+    from tests.test_slab_gpu import _exchange
+    a, k = random_case(seed)
+    ref = PropagationModel().StaggeredFDTD_3D_with_relaxation(*a, SILENT=True, **k)
+    nt = ref[-1]['nt']
+    slabs, infos = zip(*[slab.create_hip_slab(a, k, r, world, 0, kernelVariant=0) for r in range(world)])
+    for _ in range(nt):
+        if split:
+            for s in slabs: s.half_step_stress(1)
+            _exchange(slabs, HALO_STRESS)
+            for s in slabs: s.half_step_stress(2)
+            for s in slabs: s.half_step_velocity(1)
+            _exchange(slabs, HALO_VELOCITY)
+            for s in slabs: s.half_step_velocity(2)
+        else:
+            _exchange(slabs, HALO_VELOCITY)
+            for s in slabs: s.half_step_stress()
+            _exchange(slabs, HALO_STRESS)
+            for s in slabs: s.half_step_velocity()
+    torch.cuda.synchronize()
+    merged = slab.merge_slab_outputs([slab.collect_slab_outputs(s.eng, k, i) for s, i in zip(slabs, infos)])
+    assert np.array_equal(merged['IndexSensorMap'], ref[-1]['IndexSensorMap'])
+    for n in k['SelMapsSensorsList']:
+        assert np.array_equal(merged['Sensor'][n], ref[0][n]), ('sensor', n)
+    names = ref[1].keys()
+    for n in names:
+        assert np.array_equal(merged['LastMap'][n], ref[1][n]), ('last', n)
+        if k['SelRMSorPeak'] & 1:
+            assert np.array_equal(merged['RMS'][n], ref[2][n]), ('rms', n)
+        if k['SelRMSorPeak'] & 2:
+            assert np.array_equal(merged['Peak'][n], ref[-2][n]), ('peak', n)
+    for s in slabs:
+        s.eng.close()
