@@ -1,0 +1,61 @@
+"""One-off hunt: many more seeds of tests/test_random_media_gpu.py than the suite runs, held to exact equality with the oracle."""
+import sys, numpy as np, time
+sys.path.insert(0, '.')
+from tests.test_random_media_gpu import random_case
+from tests.util import compare_runs
+from oracle import oracle as O
+from babelbrain_amd import PropagationModel
+bad = []
+t0 = time.time()
+for seed in range(14, 214):
+    try:
+        a, k = random_case(seed)
+        oh = PropagationModel().StaggeredFDTD_3D_with_relaxation(*a, SILENT=True, **k)
+        orf = O.StaggeredFDTD_3D_with_relaxation(*a, **k)
+        w = compare_runs(oh, orf, 0.0, both=(k['SelRMSorPeak'] == 3))
+    except AssertionError as e:
+        bad.append((seed, str(e)[:200])); print('MISMATCH seed', seed, str(e)[:200], flush=True)
+    except Exception as e:
+        bad.append((seed, repr(e)[:200])); print('ERROR seed', seed, repr(e)[:300], flush=True)
+print('%d seeds in %.0f s, %d bad' % (200, time.time() - t0, len(bad)))
+
+# the same media cut into 2-4 slabs (both step orders)
+import torch
+from babelbrain_amd import slab
+from babelbrain_amd._engine import HALO_STRESS, HALO_VELOCITY
+from tests.test_slab_gpu import _exchange
+bad = []
+t0 = time.time()
+for seed in range(300, 360):
+    try:
+        a, k = random_case(seed)
+        world = 2 + seed % 3
+        if a[0].shape[2] < 12 * world:
+            world = 2
+        split = seed % 2 == 0
+        ref = PropagationModel().StaggeredFDTD_3D_with_relaxation(*a, SILENT=True, **k)
+        slabs, infos = zip(*[slab.create_hip_slab(a, k, r, world, 0, kernelVariant=0) for r in range(world)])
+        for _ in range(ref[-1]['nt']):
+            if split:
+                for s in slabs: s.half_step_stress(1)
+                _exchange(slabs, HALO_STRESS)
+                for s in slabs: s.half_step_stress(2)
+                for s in slabs: s.half_step_velocity(1)
+                _exchange(slabs, HALO_VELOCITY)
+                for s in slabs: s.half_step_velocity(2)
+            else:
+                _exchange(slabs, HALO_VELOCITY)
+                for s in slabs: s.half_step_stress()
+                _exchange(slabs, HALO_STRESS)
+                for s in slabs: s.half_step_velocity()
+        torch.cuda.synchronize()
+        m = slab.merge_slab_outputs([slab.collect_slab_outputs(s.eng, k, i) for s, i in zip(slabs, infos)])
+        ok = all(np.array_equal(m['Sensor'][n], ref[0][n]) for n in k['SelMapsSensorsList']) and all(np.array_equal(m['LastMap'][n], ref[1][n]) for n in ref[1])
+        if k['SelRMSorPeak'] & 1: ok = ok and all(np.array_equal(m['RMS'][n], ref[2][n]) for n in ref[1])
+        if k['SelRMSorPeak'] & 2: ok = ok and all(np.array_equal(m['Peak'][n], ref[-2][n]) for n in ref[1])
+        for s in slabs: s.eng.close()
+        if not ok:
+            bad.append(seed); print('SLAB MISMATCH seed', seed, a[0].shape, world, split, flush=True)
+    except Exception as e:
+        bad.append(seed); print('SLAB ERROR seed', seed, repr(e)[:300], flush=True)
+print('slabs: 60 seeds in %.0f s, %d bad' % (time.time() - t0, len(bad)))

@@ -54,7 +54,7 @@ def random_case(seed):
     refl = None
     if seed % 2 == 0:
         refl = np.zeros(N, np.uint32)
-        c = [int(rng.integers(nd + 2, n - nd - 6)) for n in N]
+        c = [int(rng.integers(nd + 1, max(n - nd - 5, nd + 2))) for n in N]
         refl[c[0]:c[0] + 3, c[1]:c[1] + 4, c[2]:c[2] + 2] = 1
     type_source = 2 if seed % 5 == 3 else 0
     src = np.zeros(N, np.uint32)
