@@ -59,3 +59,33 @@ for seed in range(300, 360):
     except Exception as e:
         bad.append(seed); print('SLAB ERROR seed', seed, repr(e)[:300], flush=True)
 print('slabs: 60 seeds in %.0f s, %d bad' % (time.time() - t0, len(bad)))
+
+# engine options that must not change a bit: streamed source table, graph replay, run length / order, fused variant, in-loop DFT
+import os
+def same(o1, o2, k):
+    ok = all(np.array_equal(o1[0][n], o2[0][n]) for n in o1[0]) and all(np.array_equal(o1[1][n], o2[1][n]) for n in o1[1])
+    return ok and all(np.array_equal(o1[2][n], o2[2][n]) for n in o1[2])
+bad = []
+t0 = time.time()
+for seed in range(400, 460):
+    try:
+        a, k = random_case(seed)
+        ref = PropagationModel().StaggeredFDTD_3D_with_relaxation(*a, SILENT=True, ReturnSensorDFT=True, **k)
+        trials = [('BFD_SOURCE_TILE', str(1 + seed % 37)), ('BFD_USE_GRAPH', '1'), ('BFD_ZRUN', '8' if seed % 2 else '32'), ('BFD_RUN_ORDER', str(seed % 2))]
+        for name, val in trials:
+            os.environ[name] = val
+            out = PropagationModel().StaggeredFDTD_3D_with_relaxation(*a, SILENT=True, **k)
+            del os.environ[name]
+            if not same(ref, out, k):
+                bad.append((seed, name)); print('OPTION MISMATCH seed', seed, name, val, flush=True)
+        if k['TypeSource'] < 2:
+            out = PropagationModel(kernelVariant=4).StaggeredFDTD_3D_with_relaxation(*a, SILENT=True, **k)
+            if not same(ref, out, k):
+                bad.append((seed, 'variant4')); print('OPTION MISMATCH seed', seed, 'variant 4', flush=True)
+        out = PropagationModel().StaggeredFDTD_3D_with_relaxation(*a, SILENT=True, ReturnSensorDFT=True, ReturnSensorSeries=False, **k)
+        for n in ref[-1]['SensorDFT']:
+            if not (np.array_equal(ref[-1]['SensorDFT'][n], out[-1]['SensorDFT'][n]) and np.array_equal(ref[-1]['SensorPeak'][n], out[-1]['SensorPeak'][n])):
+                bad.append((seed, 'dft')); print('OPTION MISMATCH seed', seed, 'in-loop DFT', n, flush=True)
+    except Exception as e:
+        bad.append((seed, 'error')); print('OPTION ERROR seed', seed, repr(e)[:300], flush=True)
+print('options: 60 seeds in %.0f s, %d bad' % (time.time() - t0, len(bad)))
