@@ -37,7 +37,15 @@ def compact_sources(SourceMap, Ox, Oy, Oz, k0=0, nk=None):
     N1, N2, N3 = SourceMap.shape
     nk = N3 - k0 if nk is None else nk
     sub = SourceMap[:, :, k0:k0 + nk]
-    ii, jj, kk = np.nonzero(sub)
+    # sources sit on one or a few z planes (Single:326-344): look for the planes first, then for the voxels inside them
+    # (a 3-D nonzero over the whole volume costs 0.3 s at 512^3)
+    planes = np.flatnonzero(sub.any(axis=(0, 1)))
+    if planes.size and planes.size * 8 <= nk:
+        parts = [np.nonzero(sub[:, :, kp]) for kp in planes]
+        ii = np.concatenate([p[0] for p in parts]); jj = np.concatenate([p[1] for p in parts])
+        kk = np.concatenate([np.full(p[0].shape, kp, np.int64) for p, kp in zip(parts, planes)])
+    else:
+        ii, jj, kk = np.nonzero(sub)
     lin = (ii.astype(np.int64) + N1 * (jj.astype(np.int64) + N2 * kk.astype(np.int64)))
     order = np.argsort(lin, kind='stable')
     ii, jj, kk, lin = ii[order], jj[order], kk[order], lin[order]
