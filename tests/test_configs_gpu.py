@@ -117,12 +117,12 @@ def _properties(config, steps_long, steps_short, world):
 @pytest.mark.timeout(1200)
 def test_c4_h317_512x512x1024_properties():
     """BASELINE configs[3]: 512x512x1024 domain, H317 phased array (128 elements, F = 135 mm), 700 kHz."""
-    info = _properties('C4', steps_long=1100, steps_short=200, world=8)
+    info = _properties('C4', steps_long=700, steps_short=200, world=8)
     assert info['freq'] == 700e3 and info['tx'] == 'h317'
 
 
 @pytest.mark.timeout(1800)
 def test_c5_1024_cubed_1mhz_properties():
     """BASELINE configs[4]: 1024^3 full-head domain at 1 MHz, 6 points per wavelength (81 GB on the one GPU)."""
-    info = _properties('C5', steps_long=1100, steps_short=200, world=8)
+    info = _properties('C5', steps_long=700, steps_short=200, world=8)
     assert info['freq'] == 1000e3 and info['N'] == (1024, 1024, 1024)
