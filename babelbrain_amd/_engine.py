@@ -25,7 +25,7 @@ ABI_SYMBOLS = [
     'bfd_abi_version', 'bfd_last_error', 'bfd_device_count', 'bfd_device_name', 'bfd_stable_dt',
     'bfd_material_tables', 'bfd_create', 'bfd_destroy', 'bfd_set_stream', 'bfd_use_private_stream', 'bfd_set_materials',
     'bfd_set_material_map', 'bfd_set_reflector', 'bfd_set_sources', 'bfd_set_sensor_map', 'bfd_run',
-    'bfd_half_step_stress', 'bfd_half_step_velocity', 'bfd_half_step_stress_part', 'bfd_half_step_velocity_part', 'bfd_half_step_stress_part_on', 'bfd_half_step_velocity_part_on', 'bfd_sync', 'bfd_current_step', 'bfd_halo_region',
+    'bfd_half_step_stress', 'bfd_half_step_velocity', 'bfd_half_step_stress_part', 'bfd_half_step_velocity_part', 'bfd_half_step_stress_part_on', 'bfd_half_step_velocity_part_on', 'bfd_sync', 'bfd_current_step', 'bfd_prepare', 'bfd_halo_region',
     'bfd_timing_begin', 'bfd_timing_end', 'bfd_timing_kernels', 'bfd_algorithmic_bytes', 'bfd_reset', 'bfd_num_sensors', 'bfd_num_sensor_steps', 'bfd_get_sensor_index',
     'bfd_get_sensors', 'bfd_get_map', 'bfd_get_field', 'bfd_tile_counts', 'bfd_tile_count_lean', 'bfd_tile_count_fused', 'bfd_device_bytes', 'bfd_rayleigh_forward', 'bfd_get_sensor_dft', 'bfd_dft_series', 'bfd_bhte_run', 'bfd_bhte_run_fields',
 ]
@@ -106,6 +106,7 @@ def load_library():
     lib.bfd_half_step_velocity_part_on.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
     lib.bfd_sync.argtypes = [C.c_void_p]
     lib.bfd_current_step.argtypes = [C.c_void_p]
+    lib.bfd_prepare.argtypes = [C.c_void_p]
     lib.bfd_halo_region.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p),
                                     C.POINTER(C.c_size_t)]
     lib.bfd_timing_begin.argtypes = [C.c_void_p, C.c_int32]
@@ -362,6 +363,10 @@ class Engine:
         b = np.zeros(len(KERNEL_CLASSES), np.float64)
         _check(self.lib.bfd_algorithmic_bytes(self.h, int(bool(accumulating)), _ptr(b)), 'bfd_algorithmic_bytes')
         return {c: float(b[i]) for i, c in enumerate(KERNEL_CLASSES)}
+
+    def prepare(self):
+        """Classes, run lists and the placement of the per-voxel arrays (bfd_prepare); before any halo() of a slab."""
+        _check(self.lib.bfd_prepare(self.h), 'bfd_prepare')
 
     def reset(self):
         _check(self.lib.bfd_reset(self.h), 'bfd_reset')

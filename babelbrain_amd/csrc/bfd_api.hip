@@ -624,7 +624,7 @@ int bfd_create(const bfd_config *cfg, bfd_sim **out)
     if (!rc) d.mat = s->matBase + 2 * (size_t)d.plane;
     if (!rc) rc = dev_alloc(s, &s->clsBase, s->nalloc);
     if (!rc) d.cls = s->clsBase + 2 * (size_t)d.plane;
-    s->classesReady = false;
+    s->classesReady = false; s->placementDone = false; s->haloHandedOut = false;
     d.VxW = d.Vx; d.VyW = d.Vy; d.VzW = d.Vz; d.SzzW = d.Szz; d.RzzW = d.Rzz;
     // variant 4 (fused fluid time step) needs the old fields to survive the step: second copies of V, Szz, Rzz. A
     // Z-slab keeps the in-place update (its neighbours alias the halo planes once), i.e. behaves like variant 3.
@@ -1148,6 +1148,113 @@ static int build_tile_lists(bfd_sim *s)
     return 0;
 }
 
+// ---- placement of the per-voxel arrays ----------------------------------------------------------------------------------
+// The tiled kernels stream 6 to 20 arrays at the same cell offset. Where hipMalloc put those arrays decides how often their
+// requests meet on the same HBM channel at the same time: the same kernels on the same data run 1.50 or 1.70 ms per step at
+// C3 depending on nothing but the addresses (scripts/placement_probe.py: constant over a process's lifetime, different from
+// one set of allocations to the next; TLB misses and L2 hit rates equal, TCC_EA0_RDREQ_DRAM_CREDIT_STALL up by 30-90 % on the
+// slow sets; offsets below the 2 MiB allocation granule change nothing, so it is the physical placement). It cannot be
+// predicted from the virtual addresses, so it is measured: before the first step every field is zero and a launch of the
+// tiled kernels changes nothing; they are timed on the current set of arrays and on up to BFD_PLACEMENT_TRIALS (default 3)
+// fresh sets, and the fastest set is kept. Costs a few dozen launches; skipped on small grids, for the fused variant, once a
+// halo pointer has been handed out, or when memory for a second set is short.
+static void bind_state_views(bfd_sim *s)
+{
+    bfd_dev &d = s->d;
+    const size_t g = 2 * (size_t)d.plane;
+    float **fp[15] = {&d.Vx, &d.Vy, &d.Vz, &d.Sxx, &d.Syy, &d.Szz, &d.Sxy, &d.Sxz, &d.Syz, &d.Rxx, &d.Ryy, &d.Rzz, &d.Rxy, &d.Rxz, &d.Ryz};
+    for (int a = 0; a < 15; a++) *fp[a] = s->stateBase[a] + g;
+    d.mat = s->matBase + g; d.cls = s->clsBase + g;
+    d.VxW = d.Vx; d.VyW = d.Vy; d.VzW = d.Vz; d.SzzW = d.Szz; d.RzzW = d.Rzz;      // in-place variants only (no second copies)
+}
+
+static float time_tiled_kernels(bfd_sim *s, int reps)
+{
+    float *accP = nullptr, *pkP = nullptr;
+    for (int q = 0; q < s->nSelR; q++)
+        if (s->selR[q] == BFD_MAP_PRESSURE) { accP = s->acc ? s->acc + (size_t)q * s->nloc : nullptr; pkP = s->pk ? s->pk + (size_t)q * s->nloc : nullptr; }
+    for (int r = -1; r < reps; r++) {           // r = -1: untimed
+        if (r == 0) hipEventRecord(s->evBegin, s->stream);
+        bfd_launch_stress_v2(s->d, s->stream, &s->tiles, 0);
+        bfd_launch_velocity_v2(s->d, s->stream, accP, pkP, &s->tiles, 0);
+    }
+    hipEventRecord(s->evEnd, s->stream);
+    if (hipEventSynchronize(s->evEnd) != hipSuccess || hipGetLastError() != hipSuccess) return -1.f;
+    float ms = 0;
+    hipEventElapsedTime(&ms, s->evBegin, s->evEnd);
+    return ms / reps;
+}
+
+static int choose_placement(bfd_sim *s)
+{
+    int trials = 3;
+    if (const char *ev = getenv("BFD_PLACEMENT_TRIALS")) trials = atoi(ev);
+    if (trials <= 0 || s->step != 0 || s->haloHandedOut || s->pingpong || s->cfg.kernelVariant == 1 || s->nloc < ((size_t)4 << 20)) return 0;
+    BFD_HIP(hipSetDevice(s->cfg.device));
+    struct Slot { void **base; size_t bytes; };
+    std::vector<Slot> slots;
+    const bool solids = s->tiles.nSolid > 0 || s->cfg.kernelVariant == 2;
+    static const int fluidSet[5] = {0, 1, 2, 5, 11};                         // Vx, Vy, Vz, Szz, Rzz: all the fluid kernels touch
+    for (int a = 0; a < 15; a++) {
+        const bool inFluidSet = std::find(fluidSet, fluidSet + 5, a) != fluidSet + 5;
+        if (solids || inFluidSet) slots.push_back({(void **)&s->stateBase[a], s->nalloc * sizeof(float)});
+    }
+    slots.push_back({(void **)&s->matBase, s->nalloc * sizeof(uint16_t)});
+    if (solids) slots.push_back({(void **)&s->clsBase, s->nalloc});
+    if (s->acc) slots.push_back({(void **)&s->acc, (size_t)s->nSelR * s->nloc * sizeof(float)});
+    if (s->pk) slots.push_back({(void **)&s->pk, (size_t)s->nSelR * s->nloc * sizeof(float)});
+    size_t need = 0;
+    for (const Slot &sl : slots) need += sl.bytes;
+    size_t freeB = 0, totalB = 0;
+    if (hipMemGetInfo(&freeB, &totalB) != hipSuccess || freeB < need + need / 4) return 0;
+
+    const bool verbose = getenv("BFD_PLACEMENT_VERBOSE") != nullptr;
+    float best = time_tiled_kernels(s, 3);
+    if (best <= 0) BFD_FAIL(-10, "placement: the tiled kernels failed on the zero state");
+    if (verbose) fprintf(stderr, "placement: %.3f ms per step on the first set of arrays\n", best);
+    std::vector<void *> cur(slots.size()), cand(slots.size());
+    for (size_t q = 0; q < slots.size(); q++) cur[q] = *slots[q].base;
+    // a set that lost stays allocated while the next one is drawn (otherwise hipMalloc hands the same memory out again);
+    // at most one such set at a time
+    std::vector<std::vector<void *>> discarded;
+    auto free_set = [&](const std::vector<void *> &v) {
+        hipStreamSynchronize(s->stream);
+        for (void *p : v) {
+            auto it = std::find(s->allocs.begin(), s->allocs.end(), p);
+            if (it != s->allocs.end()) s->allocs.erase(it);
+            hipFree(p);
+        }
+    };
+    for (int t = 0; t < trials; t++) {
+        while (discarded.size() > 1) { free_set(discarded.front()); discarded.erase(discarded.begin()); }
+        if (hipMemGetInfo(&freeB, &totalB) != hipSuccess || freeB < need + need / 8) {
+            for (auto &v : discarded) free_set(v);
+            discarded.clear();
+            if (hipMemGetInfo(&freeB, &totalB) != hipSuccess || freeB < need + need / 8) break;
+        }
+        bool ok = true;
+        for (size_t q = 0; q < slots.size(); q++) cand[q] = nullptr;
+        for (size_t q = 0; q < slots.size() && ok; q++) {
+            ok = hipMalloc(&cand[q], slots[q].bytes) == hipSuccess;
+            if (ok) ok = hipMemcpyAsync(cand[q], cur[q], slots[q].bytes, hipMemcpyDeviceToDevice, s->stream) == hipSuccess;
+        }
+        if (!ok) { hipStreamSynchronize(s->stream); for (void *c : cand) if (c) hipFree(c); (void)hipGetLastError(); break; }
+        for (size_t q = 0; q < slots.size(); q++) *slots[q].base = cand[q];
+        bind_state_views(s);
+        const float ms = time_tiled_kernels(s, 3);
+        if (verbose) fprintf(stderr, "placement: %.3f ms per step on set %d\n", ms, t + 1);
+        if (ms > 0 && ms < 0.985f * best) { best = ms; discarded.push_back(cur); cur = cand; }
+        else { discarded.push_back(cand); for (size_t q = 0; q < slots.size(); q++) *slots[q].base = cur[q]; bind_state_views(s); }
+    }
+    for (size_t q = 0; q < slots.size(); q++) *slots[q].base = cur[q];
+    bind_state_views(s);
+    for (auto &v : discarded) free_set(v);
+    for (void *p : cur) if (std::find(s->allocs.begin(), s->allocs.end(), p) == s->allocs.end()) s->allocs.push_back(p);
+    BFD_HIP(hipStreamSynchronize(s->stream));
+    if (verbose) fprintf(stderr, "placement: kept %.3f ms per step\n", best);
+    return 0;
+}
+
 static int check_ready(bfd_sim *s)
 {
     if (!s) BFD_FAIL(-1, "null sim");
@@ -1161,8 +1268,10 @@ static int check_ready(bfd_sim *s)
     }
     if (!s->tilesReady && s->cfg.kernelVariant != 1) {
         BFD_HIP(hipSetDevice(s->cfg.device));
-        return build_tile_lists(s);
+        const int rc = build_tile_lists(s);
+        if (rc) return rc;
     }
+    if (!s->placementDone) { s->placementDone = true; return choose_placement(s); }
     return 0;
 }
 
@@ -1374,11 +1483,13 @@ int bfd_sync(bfd_sim *s)
     return 0;
 }
 int bfd_current_step(bfd_sim *s) { return s ? s->step : -1; }
+int bfd_prepare(bfd_sim *s) { return check_ready(s); }
 
 int bfd_halo_region(bfd_sim *s, int32_t group, int32_t f, int32_t side, int32_t send, void **devPtr, size_t *bytes)
 {
     if (!s || !devPtr || !bytes) BFD_FAIL(-1, "bfd_halo_region: null argument");
     if (group < 0 || group > 1 || f < 0 || f > 2 || side < 0 || side > 1) BFD_FAIL(-2, "bfd_halo_region: bad selector");
+    s->haloHandedOut = true;              // from here on the arrays stay where they are (bfd_prepare)
     const bfd_dev &d = s->d;
     float *arr[2][3] = {{d.Vx, d.Vy, d.Vz}, {d.Sxz, d.Syz, d.Szz}};
     float *a = arr[group][f];

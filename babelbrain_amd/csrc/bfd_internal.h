@@ -92,6 +92,7 @@ struct bfd_sim {
     float *stateBase[15];           // allocation bases
     uint16_t *matBase;
     uint8_t *clsBase; bool classesReady;
+    bool placementDone, haloHandedOut;   // bfd_prepare: the per-voxel arrays may be moved until a halo pointer has been given out
     float *tables;                  // 7*nMat
     float *profiles;                // 4*(N1+N2+N3)
     std::vector<void *> allocs;     // everything to free

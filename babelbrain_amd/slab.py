@@ -293,6 +293,7 @@ def create_hip_slab(args, kwargs, rank, world, device, kernelVariant=0, local=No
         eng.set_reflector(np.ascontiguousarray(kwargs['ReflectorMask'][:, :, ks]))
     eng.set_sources(lin, row, wx, wy, wz, PulseSource)
     eng.set_sensor_map(np.ascontiguousarray(np.asarray(SensorMap)[:, :, ks]))
+    eng.prepare()            # classes, run lists, placement of the arrays: before the halo tensors alias them
     info = dict(k0=k0, nk=nk, nt=nt, DT=DT, N=(N1, N2, N3))
     return HipSlab(eng, device, host_staging=host_staging), info
 

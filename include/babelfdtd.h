@@ -150,6 +150,13 @@ int bfd_half_step_stress_part_on(bfd_sim *sim, int32_t part, void *hipStream);
 int bfd_half_step_velocity_part_on(bfd_sim *sim, int32_t part, void *hipStream);
 int bfd_sync(bfd_sim *sim);
 int bfd_current_step(bfd_sim *sim);
+/* Everything the first step would otherwise do on entry: per-cell classes, run lists, and the choice of where the per-voxel
+ * arrays live. The tiled kernels are timed on the (all-zero) initial state for the current set of arrays and for up to
+ * BFD_PLACEMENT_TRIALS (environment, default 3, 0 = off) freshly allocated sets, and the fastest set is kept: where the
+ * arrays land in HBM changes the speed of the same kernels on the same data by up to 12 %. Results
+ * do not depend on it. bfd_run and the half-step calls do this by themselves at step 0; call it explicitly BEFORE
+ * bfd_halo_region when halo pointers are taken ahead of the first step (pointers handed out pin the arrays). */
+int bfd_prepare(bfd_sim *sim);
 
 /* device pointer/bytes of a halo region: field f (0..2 within the group), side 0 = low-k face,
  * 1 = high-k face; send = 1: the 2 owned boundary planes, send = 0: the 2 ghost planes.

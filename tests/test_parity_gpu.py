@@ -376,3 +376,25 @@ def test_streamed_source_table_equals_resident(monkeypatch, tile, type_source):
     eng.run(info['nt'])
     assert np.array_equal(eng.get_map(_engine.KIND_RMS, 'Pressure'), ref[2]['Pressure'])
     eng.close()
+
+
+def test_placement_choice_does_not_change_results(monkeypatch):
+    """bfd_prepare times the tiled kernels on the zero state for several freshly allocated sets of the per-voxel arrays and
+    keeps the fastest: grids of 4 M voxels and more. The run that follows must be the run without it,
+    and the launches made for timing must leave the state untouched (also the peak map, whose initial value they compare to)."""
+    a, k, info = H.make_problem('C2', N=(192, 160, 160), steps=60, stable_dt_fn=oracle_dt)
+    k['SelMapsRMSPeakList'] = ['Pressure', 'Vz', 'Sigmaxy']
+    k['SelRMSorPeak'] = 3
+    monkeypatch.setenv('BFD_PLACEMENT_TRIALS', '0')
+    ref = hip_model().StaggeredFDTD_3D_with_relaxation(*a, SILENT=True, **k)
+    monkeypatch.setenv('BFD_PLACEMENT_TRIALS', '4')
+    out = hip_model().StaggeredFDTD_3D_with_relaxation(*a, SILENT=True, **k)
+    for idx in range(4):
+        for name in ref[idx]:
+            assert np.array_equal(ref[idx][name], out[idx][name]), (idx, name)
+    assert np.abs(ref[1]['Sigmaxy']).max() > 0
+    # the dense variant moves all 15 arrays and the class bytes
+    out2 = hip_model(2).StaggeredFDTD_3D_with_relaxation(*a, SILENT=True, **k)
+    for idx in range(4):
+        for name in ref[idx]:
+            assert np.array_equal(ref[idx][name], out2[idx][name]), (idx, name)
