@@ -1173,6 +1173,7 @@ static float time_tiled_kernels(bfd_sim *s, int reps)
     float *accP = nullptr, *pkP = nullptr;
     for (int q = 0; q < s->nSelR; q++)
         if (s->selR[q] == BFD_MAP_PRESSURE) { accP = s->acc ? s->acc + (size_t)q * s->nloc : nullptr; pkP = s->pk ? s->pk + (size_t)q * s->nloc : nullptr; }
+    (void)hipGetLastError();                    // a stale error of some earlier call is not this probe's
     for (int r = -1; r < reps; r++) {           // r = -1: untimed
         if (r == 0) hipEventRecord(s->evBegin, s->stream);
         bfd_launch_stress_v2(s->d, s->stream, &s->tiles, 0);
