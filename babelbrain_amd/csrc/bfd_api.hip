@@ -1202,6 +1202,10 @@ static int choose_placement(bfd_sim *s)
     }
     slots.push_back({(void **)&s->matBase, s->nalloc * sizeof(uint16_t)});
     if (solids) slots.push_back({(void **)&s->clsBase, s->nalloc});
+    if (s->tiles.shearCells && s->tiles.nShear > 0) {        // the sparse shear kernel streams its list and coefficients too
+        slots.push_back({(void **)&s->tiles.shearCells, (size_t)s->tiles.nShear * sizeof(unsigned)});
+        slots.push_back({(void **)&s->tiles.shearCoef, 6 * (size_t)s->tiles.nShear * sizeof(float)});
+    }
     if (s->acc) slots.push_back({(void **)&s->acc, (size_t)s->nSelR * s->nloc * sizeof(float)});
     if (s->pk) slots.push_back({(void **)&s->pk, (size_t)s->nSelR * s->nloc * sizeof(float)});
     size_t need = 0;
