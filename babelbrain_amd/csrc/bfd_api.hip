@@ -1155,7 +1155,7 @@ static int build_tile_lists(bfd_sim *s)
 // one set of allocations to the next; TLB misses and L2 hit rates equal, TCC_EA0_RDREQ_DRAM_CREDIT_STALL up by 30-90 % on the
 // slow sets; offsets below the 2 MiB allocation granule change nothing, so it is the physical placement). It cannot be
 // predicted from the virtual addresses, so it is measured: before the first step every field is zero and a launch of the
-// tiled kernels changes nothing; they are timed on the current set of arrays and on up to BFD_PLACEMENT_TRIALS (default 6)
+// tiled kernels changes nothing; they are timed on the current set of arrays and on up to BFD_PLACEMENT_TRIALS (default 5)
 // fresh sets, and the fastest set is kept. Costs a few dozen launches; skipped on small grids, for the fused variant, once a
 // halo pointer has been handed out, or when memory for a second set is short.
 static void bind_state_views(bfd_sim *s)
@@ -1188,7 +1188,7 @@ static float time_tiled_kernels(bfd_sim *s, int reps)
 
 static int choose_placement(bfd_sim *s)
 {
-    int trials = 6;
+    int trials = 5;
     if (const char *ev = getenv("BFD_PLACEMENT_TRIALS")) trials = atoi(ev);
     if (trials <= 0 || s->step != 0 || s->haloHandedOut || s->pingpong || s->cfg.kernelVariant == 1 || s->nloc < ((size_t)4 << 20)) return 0;
     BFD_HIP(hipSetDevice(s->cfg.device));
@@ -1214,76 +1214,47 @@ static int choose_placement(bfd_sim *s)
     if (hipMemGetInfo(&freeB, &totalB) != hipSuccess || freeB < need + need / 4) return 0;
 
     const bool verbose = getenv("BFD_PLACEMENT_VERBOSE") != nullptr;
-    // every third candidate is ONE allocation with the arrays an irregular number of 2 MiB granules apart (the others: one
-    // allocation per array). Where memory is unfragmented, separate allocations come out at a regular stride -- the slow case --
-    // and only such a block differs; elsewhere it is a fast set about half as often as separate allocations are
-    const int blockEvery = getenv("BFD_PLACEMENT_BLOCK_EVERY") ? atoi(getenv("BFD_PLACEMENT_BLOCK_EVERY")) : 3;
     float best = time_tiled_kernels(s, 3);
     if (best <= 0) BFD_FAIL(-10, "placement: the tiled kernels failed on the zero state");
     if (verbose) fprintf(stderr, "placement: %.3f ms per step on the first set of arrays\n", best);
-    // a candidate = where every array of the set starts + the allocations that hold them (one each, or one block for all)
-    struct PSet { std::vector<void *> ptr, own; };
-    PSet cur, cand;
-    cur.ptr.resize(slots.size());
-    for (size_t q = 0; q < slots.size(); q++) cur.ptr[q] = *slots[q].base;
-    cur.own = cur.ptr;
+    std::vector<void *> cur(slots.size()), cand(slots.size());
+    for (size_t q = 0; q < slots.size(); q++) cur[q] = *slots[q].base;
     // a set that lost stays allocated while the next one is drawn (otherwise hipMalloc hands the same memory out again);
     // at most one such set at a time
-    std::vector<PSet> discarded;
-    auto free_set = [&](const PSet &v) {
+    std::vector<std::vector<void *>> discarded;
+    auto free_set = [&](const std::vector<void *> &v) {
         hipStreamSynchronize(s->stream);
-        for (void *p : v.own) {
+        for (void *p : v) {
             auto it = std::find(s->allocs.begin(), s->allocs.end(), p);
             if (it != s->allocs.end()) s->allocs.erase(it);
             hipFree(p);
         }
     };
-    const size_t granule = (size_t)2 << 20;
     for (int t = 0; t < trials; t++) {
         while (discarded.size() > 1) { free_set(discarded.front()); discarded.erase(discarded.begin()); }
-        if (hipMemGetInfo(&freeB, &totalB) != hipSuccess || freeB < need + need / 6) {
+        if (hipMemGetInfo(&freeB, &totalB) != hipSuccess || freeB < need + need / 8) {
             for (auto &v : discarded) free_set(v);
             discarded.clear();
-            if (hipMemGetInfo(&freeB, &totalB) != hipSuccess || freeB < need + need / 6) break;
+            if (hipMemGetInfo(&freeB, &totalB) != hipSuccess || freeB < need + need / 8) break;
         }
         bool ok = true;
-        cand.ptr.assign(slots.size(), nullptr); cand.own.clear();
-        const bool blockKind = blockEvery > 0 && (t % blockEvery) == blockEvery - 1;
-        if (!blockKind) {
-            // every array in an allocation of its own: wherever the allocator puts them
-            for (size_t q = 0; q < slots.size() && ok; q++) {
-                ok = hipMalloc(&cand.ptr[q], slots[q].bytes) == hipSuccess;
-                if (ok) cand.own.push_back(cand.ptr[q]);
-            }
-        } else {
-            // one block, the arrays an irregular number of 2 MiB granules apart
-            std::vector<size_t> off(slots.size());
-            size_t total = 0;
-            unsigned x = 2654435761u * (unsigned)(t + 1);
-            for (size_t q = 0; q < slots.size(); q++) {
-                x ^= x << 13; x ^= x >> 17; x ^= x << 5;
-                total += (size_t)(x % 29u) * granule;
-                off[q] = total;
-                total += (slots[q].bytes + granule - 1) / granule * granule;
-            }
-            void *block = nullptr;
-            ok = hipMalloc(&block, total) == hipSuccess;
-            if (ok) { cand.own.push_back(block); for (size_t q = 0; q < slots.size(); q++) cand.ptr[q] = (char *)block + off[q]; }
+        for (size_t q = 0; q < slots.size(); q++) cand[q] = nullptr;
+        for (size_t q = 0; q < slots.size() && ok; q++) {
+            ok = hipMalloc(&cand[q], slots[q].bytes) == hipSuccess;
+            if (ok) ok = hipMemcpyAsync(cand[q], cur[q], slots[q].bytes, hipMemcpyDeviceToDevice, s->stream) == hipSuccess;
         }
-        for (size_t q = 0; q < slots.size() && ok; q++)
-            ok = hipMemcpyAsync(cand.ptr[q], cur.ptr[q], slots[q].bytes, hipMemcpyDeviceToDevice, s->stream) == hipSuccess;
-        if (!ok) { hipStreamSynchronize(s->stream); for (void *c : cand.own) hipFree(c); (void)hipGetLastError(); break; }
-        for (size_t q = 0; q < slots.size(); q++) *slots[q].base = cand.ptr[q];
+        if (!ok) { hipStreamSynchronize(s->stream); for (void *c : cand) if (c) hipFree(c); (void)hipGetLastError(); break; }
+        for (size_t q = 0; q < slots.size(); q++) *slots[q].base = cand[q];
         bind_state_views(s);
         const float ms = time_tiled_kernels(s, 3);
-        if (verbose) fprintf(stderr, "placement: %.3f ms per step on set %d (%s)\n", ms, t + 1, blockKind ? "one block, irregular gaps" : "separate allocations");
+        if (verbose) fprintf(stderr, "placement: %.3f ms per step on set %d\n", ms, t + 1);
         if (ms > 0 && ms < 0.985f * best) { best = ms; discarded.push_back(cur); cur = cand; }
-        else { discarded.push_back(cand); for (size_t q = 0; q < slots.size(); q++) *slots[q].base = cur.ptr[q]; bind_state_views(s); }
+        else { discarded.push_back(cand); for (size_t q = 0; q < slots.size(); q++) *slots[q].base = cur[q]; bind_state_views(s); }
     }
-    for (size_t q = 0; q < slots.size(); q++) *slots[q].base = cur.ptr[q];
+    for (size_t q = 0; q < slots.size(); q++) *slots[q].base = cur[q];
     bind_state_views(s);
     for (auto &v : discarded) free_set(v);
-    for (void *p : cur.own) if (std::find(s->allocs.begin(), s->allocs.end(), p) == s->allocs.end()) s->allocs.push_back(p);
+    for (void *p : cur) if (std::find(s->allocs.begin(), s->allocs.end(), p) == s->allocs.end()) s->allocs.push_back(p);
     BFD_HIP(hipStreamSynchronize(s->stream));
     if (verbose) fprintf(stderr, "placement: kept %.3f ms per step\n", best);
     return 0;
