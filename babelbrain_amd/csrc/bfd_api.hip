@@ -1155,7 +1155,7 @@ static int build_tile_lists(bfd_sim *s)
 // one set of allocations to the next; TLB misses and L2 hit rates equal, TCC_EA0_RDREQ_DRAM_CREDIT_STALL up by 30-90 % on the
 // slow sets; offsets below the 2 MiB allocation granule change nothing, so it is the physical placement). It cannot be
 // predicted from the virtual addresses, so it is measured: before the first step every field is zero and a launch of the
-// tiled kernels changes nothing; they are timed on the current set of arrays and on up to BFD_PLACEMENT_TRIALS (default 5)
+// tiled kernels changes nothing; they are timed on the current set of arrays and on up to BFD_PLACEMENT_TRIALS (default 6)
 // fresh sets, and the fastest set is kept. Costs a few dozen launches; skipped on small grids, for the fused variant, once a
 // halo pointer has been handed out, or when memory for a second set is short.
 static void bind_state_views(bfd_sim *s)
@@ -1188,7 +1188,7 @@ static float time_tiled_kernels(bfd_sim *s, int reps)
 
 static int choose_placement(bfd_sim *s)
 {
-    int trials = 5;
+    int trials = 6;
     if (const char *ev = getenv("BFD_PLACEMENT_TRIALS")) trials = atoi(ev);
     if (trials <= 0 || s->step != 0 || s->haloHandedOut || s->pingpong || s->cfg.kernelVariant == 1 || s->nloc < ((size_t)4 << 20)) return 0;
     BFD_HIP(hipSetDevice(s->cfg.device));

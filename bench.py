@@ -306,8 +306,8 @@ def main():
                        'n_sources': info['n_sources'], 'n_sensors_rank0': int(eng.num_sensors), 'tiles_rank0': eng.tile_counts() if args.variant != 1 else None,
                        'halo_exchange': 'overlapped' if w.runner.overlap else ('none' if world == 1 else 'blocking'),
                        'halo_exchange_check': res['exchange_check'],
-                       'array_placement': ('first allocation' if os.environ.get('BFD_PLACEMENT_TRIALS', '5') in ('0', '') else
-                                           'fastest of 1 + %s sets of allocations, timed on the zero state before the run (bfd_prepare)' % os.environ.get('BFD_PLACEMENT_TRIALS', '5')), 'untimed_steps_before_window': args.warmup + w.extra_warmup},
+                       'array_placement': ('first allocation' if os.environ.get('BFD_PLACEMENT_TRIALS', '6') in ('0', '') else
+                                           'fastest of 1 + %s sets of allocations, timed on the zero state before the run (bfd_prepare)' % os.environ.get('BFD_PLACEMENT_TRIALS', '6')), 'untimed_steps_before_window': args.warmup + w.extra_warmup},
             'device_ms_per_step': res['device_ms_per_step'], 'half_steps_ms': res['half_steps'],
             'device_bytes': int(eng.device_bytes), 'host_build_s': w.host_build_s,
         }

@@ -152,7 +152,7 @@ int bfd_sync(bfd_sim *sim);
 int bfd_current_step(bfd_sim *sim);
 /* Everything the first step would otherwise do on entry: per-cell classes, run lists, and the choice of where the per-voxel
  * arrays live. The tiled kernels are timed on the (all-zero) initial state for the current set of arrays and for up to
- * BFD_PLACEMENT_TRIALS (environment, default 5, 0 = off) freshly allocated sets, and the fastest set is kept: where the
+ * BFD_PLACEMENT_TRIALS (environment, default 6, 0 = off) freshly allocated sets, and the fastest set is kept: where the
  * arrays land in HBM changes the speed of the same kernels on the same data by up to 12 %. Results
  * do not depend on it. bfd_run and the half-step calls do this by themselves at step 0; call it explicitly BEFORE
  * bfd_halo_region when halo pointers are taken ahead of the first step (pointers handed out pin the arrays). */
