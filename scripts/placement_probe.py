@@ -18,7 +18,7 @@ keep = []
 for trial in range(int(os.environ.get('PROBE_ENGINES', '8'))):
     eng = _engine.Engine(N1, N2, N3, len(ml), h, k['DT'], f, info['nt'], NDelta=k['NDelta'], reflectionLimit=k['ReflectionLimit'], typeSource=0,
                          sensorSub=k['SensorSubSampling'], sensorStart=k['SensorStart'], selRMSorPeak=1, selMapsRMS=['Pressure'],
-                         selMapsSensors=['Pressure'], qfactorCorrection=True, device=0, rmsFirstStep=1)
+                         selMapsSensors=['Pressure'], qfactorCorrection=True, device=0, rmsFirstStep=int(os.environ.get('PROBE_RMS_FIRST_STEP', '1')))
     eng.set_materials(ml, k['QCorrection']); eng.set_material_map(mm, 0, 0)
     eng.set_sources(lin, row, wx, wy, wz, pulse); eng.set_sensor_map(sens)
     eng.run(10); torch.cuda.synchronize()
