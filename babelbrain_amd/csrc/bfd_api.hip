@@ -1190,7 +1190,9 @@ static int choose_placement(bfd_sim *s)
 {
     int trials = 6;
     if (const char *ev = getenv("BFD_PLACEMENT_TRIALS")) trials = atoi(ev);
-    if (trials <= 0 || s->step != 0 || s->haloHandedOut || s->pingpong || s->cfg.kernelVariant == 1 || s->nloc < ((size_t)4 << 20)) return 0;
+    size_t minVoxels = (size_t)4 << 20;
+    if (const char *ev = getenv("BFD_PLACEMENT_MIN_VOXELS")) minVoxels = (size_t)atol(ev);      // tests: exercise it on small grids too
+    if (trials <= 0 || s->step != 0 || s->haloHandedOut || s->pingpong || s->cfg.kernelVariant == 1 || s->nloc < minVoxels) return 0;
     BFD_HIP(hipSetDevice(s->cfg.device));
     struct Slot { void **base; size_t bytes; };
     std::vector<Slot> slots;

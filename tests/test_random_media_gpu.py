@@ -155,3 +155,17 @@ def test_random_media_in_slabs(seed, world, split):
             assert np.array_equal(merged['Peak'][n], ref[-2][n]), ('peak', n)
     for s in slabs:
         s.eng.close()
+
+
+@pytest.mark.parametrize('seed', [2, 3, 5, 8, 13])
+def test_random_media_with_the_placement_choice_forced(seed, monkeypatch):
+    """bfd_prepare launches the tiled kernels on the zero state to time candidate placements of the arrays (grids of 4 M
+    voxels and more by default). Forced here on the small random cases -- stress-type sources (seeds 3, 8, 13), peak maps,
+    reflector pockets, all selected maps -- the run that follows must still equal the oracle bit for bit."""
+    from babelbrain_amd import PropagationModel
+    monkeypatch.setenv('BFD_PLACEMENT_MIN_VOXELS', '0')
+    monkeypatch.setenv('BFD_PLACEMENT_TRIALS', '2')
+    a, k = random_case(seed)
+    oh = PropagationModel().StaggeredFDTD_3D_with_relaxation(*a, SILENT=True, **k)
+    orf = O.StaggeredFDTD_3D_with_relaxation(*a, **k)
+    assert compare_runs(oh, orf, 0.0, both=(k['SelRMSorPeak'] == 3)) == 0.0
