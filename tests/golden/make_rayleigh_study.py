@@ -61,6 +61,14 @@ def main():
     out = {'source': 'OfflineBatchExamples/CompareRayleightWithFDTD/SummaryAnalysis.xlsx', 'columns': head, 'cases': cases}
     json.dump(out, open(os.path.join(HERE, 'rayleigh_study.json'), 'w'), indent=0)
     print('wrote %d cases (%d Single)' % (len(cases), sum(c['tx'] == 'Single' for c in cases)))
+    # element centres of the H317 array (data table of the reference: 128 rows "Element,X,Y,Z" in inches, H317.py:17-21),
+    # stored in metres with z measured up from the apex plane like H317Locations does (z = F - Z)
+    rows = [l.strip().split(',') for l in open('/root/reference/TranscranialModeling/H-317 XYZ Coordinates_revB update 1.18.22.csv')][1:]
+    xyz = [[float(r[1]) * 25.4e-3, float(r[2]) * 25.4e-3, 135e-3 - float(r[3]) * 25.4e-3] for r in rows if len(r) == 4]
+    assert len(xyz) == 128
+    json.dump({'source': 'TranscranialModeling/H-317 XYZ Coordinates_revB update 1.18.22.csv', 'focal_m': 135e-3, 'element_diameter_m': 9.5e-3,
+               'centres_m': xyz}, open(os.path.join(HERE, 'h317_elements.json'), 'w'))
+    print('wrote 128 H317 element centres')
 
 
 if __name__ == '__main__':

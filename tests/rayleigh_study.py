@@ -114,6 +114,103 @@ def build_case(freq, ppw, focal, diam, zadj, stable_dt_fn, forward, depth_target
                 n_sources=pulse.shape[0])
 
 
+H317 = dict(focal=135e-3, aperture=160e-3, elem_diam=9.5e-3, z_beyond=40e-3)     # H317.py:58-59, PART_1 cells 20-22
+# how many voxels the skin on the line of sight lies below the top of the study's mask at the H317 resolutions (it enters
+# the cone width and the depth of the steering point): fitted to the workbook's domain sizes -- its 'L Inf location' rows
+# put the beam axis at lateral index 33 / 39 / 45 at 6 points per wavelength and 51 / 60 / 68 at 9
+H317_SKIN_VOXELS = {6: 0, 9: 2}
+
+
+def h317_subsources(freq, elements_json, ppw_surface=8):
+    """The 128 spherical-cap elements of the H317 array as Rayleigh sub-sources (H317.py:56-125: every element is the cap
+    GenerateFocusTx(f, 135 mm, 9.5 mm, c, PPWSurface=8) turned about the focus onto its centre). Apex plane at z = 0, focus at
+    (0, 0, F). Returns (points (M,3), areas (M,), element index of every point, element centres (128,3))."""
+    import json
+    d = json.load(open(elements_json))
+    F, ed = d['focal_m'], d['element_diameter_m']
+    cen = np.array(d['centres_m'], np.float64)
+    lam = 1482.0 / freq
+    amax = np.arcsin(ed / 2 / F)
+    n_rings = max(int(np.ceil(F * amax / (lam / ppw_surface))), 4)
+    cap, ds = H._bowl_points(F, ed, n_rings, 0.0)                 # apex at the origin, focus at (0, 0, F)
+    rel = cap - np.array([0.0, 0.0, F])                           # about the focus: the cap's axis is -z
+    focus = np.array([0.0, 0.0, F])
+    pts, areas, owner = [], [], []
+    for e, c in enumerate(cen):
+        n = (c - focus) / np.linalg.norm(c - focus)               # unit vector focus -> element centre
+        # rotation taking -z to n (Rodrigues; the cap is symmetric about its axis, so any such rotation will do)
+        a = np.array([0.0, 0.0, -1.0])
+        v = np.cross(a, n); cth = float(np.dot(a, n))
+        K = np.array([[0, -v[2], v[1]], [v[2], 0, -v[0]], [-v[1], v[0], 0]])
+        Rm = np.eye(3) + K + K @ K / (1.0 + cth)
+        pts.append(rel @ Rm.T + focus); areas.append(ds); owner.append(np.full(len(ds), e))
+    return np.concatenate(pts), np.concatenate(areas), np.concatenate(owner), cen
+
+
+def build_case_h317(freq, ppw, cone, xsteer, ysteer, zsteer, stable_dt_fn, forward, elements_json, depth_target=DEPTH_TARGET, pml=None,
+                    skin_offset=None):
+    """One H317 case of the study (PART_1 cells 8, 20-22; BabelIntegrationCONCAVE_PHASEDARRAY.py:142-147, 240-330): the array's
+    geometric focus lies DistanceConeToFocus below the source plane (TxMechanicalAdjustmentZ = cone - skin distance puts it
+    there whatever the depth of the target), the kept lateral region is 1.1 * min((cone + skin offset + max(ZSteer, 0)) *
+    tan(alpha), Aperture / 2) with alpha = asin(Aperture / 2 / (F + max(ZSteer, 0))) (BASE:1929-1944), the domain ends 40 mm
+    past the target; every element is driven with the conjugate phase of the field a point source at the steering location
+    (focus + steering + skin offset) produces at its centre (CONCAVE:296-320)."""
+    c0 = dict(H317)
+    pml = H.PML_THICKNESS if pml is None else pml
+    h = H.SSOS_AT_WATER_DENSITY / freq / ppw
+    c0['skin_offset'] = H317_SKIN_VOXELS.get(ppw, 1) * h if skin_offset is None else skin_offset
+    water = np.array([H.MATERIALS[500e3]['Water']], np.float64)
+    dt_ideal = stable_dt_fn(water, freq, h, H.ALPHA_CFL)
+    dt_water = stable_dt_fn(water, freq, h, 1.0)
+    ppp, dt = H.ppp_rule(dt_ideal, freq)
+    extra = max(zsteer, 0.0)
+    alpha = np.arcsin(c0['aperture'] / 2 / (c0['focal'] + extra))
+    radius_face = 1.1 * min((cone + c0['skin_offset'] + extra) * np.tan(alpha), c0['aperture'] / 2)
+    n_half = int(np.floor(radius_face / h + 1e-9))
+    # lateral steering: the kept region is the union of the disc around the axis and the same disc around the steered axis
+    # (ExtraAdjustX / Y = the steering, CONCAVE:86-89, BASE:1982-1990), cut to its bounding box
+    nxh = int(np.floor((max(xsteer, 0.0) + radius_face) / h + 1e-9)); nxl = int(np.floor((max(-xsteer, 0.0) + radius_face) / h + 1e-9))
+    nyh = int(np.floor((max(ysteer, 0.0) + radius_face) / h + 1e-9)); nyl = int(np.floor((max(-ysteer, 0.0) + radius_face) / h + 1e-9))
+    nz = int(np.round(depth_target / h)) + int(c0['z_beyond'] / h) + 1
+    N1 = nxl + nxh + 1 + 2 * pml
+    N2 = nyl + nyh + 1 + 2 * pml
+    N3 = nz + 2 * pml
+    zsrc = pml
+    xs = (np.arange(N1) - (pml + nxl)) * h
+    ys = (np.arange(N2) - (pml + nyl)) * h
+    zs = (np.arange(N3) - zsrc) * h
+    pts, ds, owner, cen = h317_subsources(freq, elements_json)
+    shift = np.array([0.0, 0.0, cone - c0['focal']])              # geometric focus at z = cone below the source plane
+    pts = pts + shift; cen = cen + shift
+    # whole voxels back until every sub-source is behind the plane (CONCAVE:268-274)
+    while pts[:, 2].max() >= 0.0:
+        pts[:, 2] -= h; cen[:, 2] -= h
+    k = np.array(2 * np.pi * freq / C_WATER + 0j).astype(np.complex64)
+    u0 = np.ones(len(ds), np.complex64)
+    if xsteer != 0.0 or ysteer != 0.0 or zsteer != 0.0:
+        steer = np.array([[xsteer, ysteer, cone + c0['skin_offset'] + zsteer]], np.float32)
+        back = np.asarray(forward(k, steer, np.array([h * h], np.float32), np.ones(1, np.complex64), cen.astype(np.float32)))
+        u0 = np.exp(1j * np.angle(np.conjugate(back)))[owner].astype(np.complex64)
+    X, Y, Z = np.meshgrid(xs, ys, zs, indexing='ij')
+    rf = np.stack([X.ravel(), Y.ravel(), Z.ravel()], 1).astype(np.float32)
+    del X, Y, Z
+    u2 = np.asarray(forward(k, pts.astype(np.float32), ds.astype(np.float32), u0, rf)).reshape(N1, N2, N3)
+    plane = u2[:, :, zsrc].copy()
+    plane[:pml, :] = 0; plane[-pml:, :] = 0; plane[:, :pml] = 0; plane[:, -pml:] = 0
+    T, nt, sub, start = H.time_plan(N1, N2, N3, h, dt, ppp, C_WATER)
+    smap, pulse = H.pulse_sources(plane, freq, dt, T, N3, zsrc)
+    sensor = np.zeros((N1, N2, N3), np.uint32)
+    sensor[N1 // 2, N2 // 2, zsrc + 1:-pml] = 1
+    rho_c = water[0, 0] * water[0, 1]
+    args = (np.zeros((N1, N2, N3), np.uint32), water, freq, smap, pulse, h, T, sensor)
+    kwargs = dict(Ox=np.array([0.0]), Oy=np.array([0.0]), Oz=np.array([1.0 / rho_c]), NDelta=pml, DT=dt,
+                  ReflectionLimit=H.REFLECTION_LIMIT, USE_SINGLE=True, SelMapsRMSPeakList=['Pressure'],
+                  SelMapsSensorsList=['Pressure'], SelRMSorPeak=1, AlphaCFL=1.0, TypeSource=0, QfactorCorrection=True,
+                  QCorrection=1.0, SensorSubSampling=sub, SensorStart=start, ReflectorMask=None)
+    return dict(args=args, kwargs=kwargs, u2=u2, pml=pml, h=h, dt=dt, dt_water=dt_water, ppp=ppp, nt=nt, zsrc=zsrc, N=(N1, N2, N3),
+                n_sources=pulse.shape[0])
+
+
 def result_volumes(case, rms_pressure):
     """FDTD and Rayleigh amplitude volumes as the study compares them: Correction * sqrt(2) (BASE:2433-2440), zero up to the
     source plane (BASE:2746, 2767-2769), the `_Sub` crop (interior without its last row / column and without the source
@@ -166,7 +263,15 @@ CTX500 = dict(focal=62.94e-3, diam=64.0e-3, dout=52.4e-3, z_beyond=40e-3, skin_o
 
 def run_case(row, solver, stable_dt_fn, forward, depth_target=DEPTH_TARGET, gap_vox=1.0, pml=None):
     """row: an entry of rayleigh_study.json (tx 'Single' or 'CTX_500'). solver(*args, **kwargs) -> the solver tuple."""
-    if row['tx'] == 'CTX_500':
+    if row['tx'] == 'H317':
+        import os, re
+        m = re.match(r'ConeDistance_([\d.]+)_DEEP_H317_(\d+)kHz_(\d+)PPW_XSteer_(-?[\d.]+)_YSteer_(-?[\d.]+)_ZSteer_(-?[\d.]+)\.nii', row['Description'])
+        cone, fk, ppw, xs_, ys_, zs_ = (float(m.group(1)) * 1e-3, int(m.group(2)), int(m.group(3)), float(m.group(4)) * 1e-3,
+                                         float(m.group(5)) * 1e-3, float(m.group(6)) * 1e-3)
+        case = build_case_h317(fk * 1e3, ppw, cone, xs_, ys_, zs_, stable_dt_fn, forward,
+                               os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'h317_elements.json'), depth_target, pml,
+                               skin_offset=(float(os.environ['H317_SKIN_OFFSET_MM']) * 1e-3 if 'H317_SKIN_OFFSET_MM' in os.environ else None))
+    elif row['tx'] == 'CTX_500':
         import re
         m = re.match(r'ZAdj_(-?[\d.]+)_DEEP_CTX_500_500kHz_(\d+)PPW_ZSteering_(-?[\d.]+)\.nii', row['Description'])
         zadj, ppw, zsteer = float(m.group(1)) * 1e-3, int(m.group(2)), float(m.group(3)) * 1e-3
