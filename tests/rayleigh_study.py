@@ -117,8 +117,8 @@ def build_case(freq, ppw, focal, diam, zadj, stable_dt_fn, forward, depth_target
 H317 = dict(focal=135e-3, aperture=160e-3, elem_diam=9.5e-3, z_beyond=40e-3)     # H317.py:58-59, PART_1 cells 20-22
 # how many voxels the skin on the line of sight lies below the top of the study's mask at the H317 resolutions (it enters
 # the cone width and the depth of the steering point): fitted to the workbook's domain sizes -- its 'L Inf location' rows
-# put the beam axis at lateral index 33 / 39 / 45 at 6 points per wavelength and 51 / 60 / 68 at 9
-H317_SKIN_VOXELS = {6: 0, 9: 2}
+# put the beam axis at lateral index 33 / 39 / 45 at 250 kHz, 6 points per wavelength, and 51 / 60 / 68 at 9
+H317_SKIN_VOXELS = {(250, 6): 0, (250, 9): 2, (750, 6): 5}      # (kHz, points per wavelength); 750 kHz: axis index 103 / 218
 
 
 def h317_subsources(freq, elements_json, ppw_surface=8):
@@ -158,7 +158,7 @@ def build_case_h317(freq, ppw, cone, xsteer, ysteer, zsteer, stable_dt_fn, forwa
     c0 = dict(H317)
     pml = H.PML_THICKNESS if pml is None else pml
     h = H.SSOS_AT_WATER_DENSITY / freq / ppw
-    c0['skin_offset'] = H317_SKIN_VOXELS.get(ppw, 1) * h if skin_offset is None else skin_offset
+    c0['skin_offset'] = H317_SKIN_VOXELS.get((int(round(freq / 1e3)), ppw), 1) * h if skin_offset is None else skin_offset
     water = np.array([H.MATERIALS[500e3]['Water']], np.float64)
     dt_ideal = stable_dt_fn(water, freq, h, H.ALPHA_CFL)
     dt_water = stable_dt_fn(water, freq, h, 1.0)
