@@ -114,7 +114,8 @@ def build_case(freq, ppw, focal, diam, zadj, stable_dt_fn, forward, depth_target
                 n_sources=pulse.shape[0])
 
 
-H317 = dict(focal=135e-3, aperture=160e-3, elem_diam=9.5e-3, z_beyond=40e-3)     # H317.py:58-59, PART_1 cells 20-22
+H317 = dict(focal=135e-3, aperture=160e-3, elem_diam=9.5e-3, z_beyond=40e-3,      # H317.py:58-59, PART_1 cells 20-22
+            depth_target=76.5e-3)      # source plane -> target: the workbook's far-end error locations (z index 156 at 6 points per wavelength) give it
 # how many voxels the skin on the line of sight lies below the top of the study's mask at the H317 resolutions (it enters
 # the cone width and the depth of the steering point): fitted to the workbook's domain sizes -- its 'L Inf location' rows
 # put the beam axis at lateral index 33 / 39 / 45 at 250 kHz, 6 points per wavelength, and 51 / 60 / 68 at 9
@@ -269,7 +270,8 @@ def run_case(row, solver, stable_dt_fn, forward, depth_target=DEPTH_TARGET, gap_
         cone, fk, ppw, xs_, ys_, zs_ = (float(m.group(1)) * 1e-3, int(m.group(2)), int(m.group(3)), float(m.group(4)) * 1e-3,
                                          float(m.group(5)) * 1e-3, float(m.group(6)) * 1e-3)
         case = build_case_h317(fk * 1e3, ppw, cone, xs_, ys_, zs_, stable_dt_fn, forward,
-                               os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'h317_elements.json'), depth_target, pml,
+                               os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'h317_elements.json'),
+                               H317['depth_target'] if depth_target == DEPTH_TARGET else depth_target, pml,
                                skin_offset=(float(os.environ['H317_SKIN_OFFSET_MM']) * 1e-3 if 'H317_SKIN_OFFSET_MM' in os.environ else None))
     elif row['tx'] == 'CTX_500':
         import re

@@ -118,7 +118,7 @@ def test_h317_phased_array_cases_match_the_reference_study():
     steering location, focus steered by up to 10 mm in x, y and -10 ... +20 mm in z, beam entering through a cone 30 or 65 mm
     above the focus; the domain grows sideways with the steering. 21 of the 64 cases at 250 kHz. Per row: peak-amplitude
     difference within 0.1 pp (observed <= 0.03), L-inf within 2 % where the workbook's own location of that maximum is
-    reproduced voxel for voxel (18 of the 21 here, 38 of all 64), L2 within 0.92 ... 1.04 of the row, focal-centroid distance
+    reproduced voxel for voxel (18 of the 21 here, 45 of all 64), L2 within 0.93 ... 1.07 of the row (mean over all 64: 0.999), focal-centroid distance
     within 0.1 mm. Over all 64 cases (profiles/r2/rayleigh_study_sweep_64_h317_250khz_cases.txt): mean |amplitude - row| 0.03 pp,
     Pearson 0.995. The unsteered 9-point cases (193, 194) and the centroid of the cone-65 / +20 mm cases are the exceptions
     listed in DESIGN.md 4.3."""
@@ -137,7 +137,7 @@ def test_h317_phased_array_cases_match_the_reference_study():
               % (case, r['Description'][:72], m['Difference amplitude'], r['Difference amplitude'], m['L2'], r['L2'], m['L Inf'], r['L Inf'],
                  m['L Inf location'], r['L Inf location'], m['Distance focal centroid'], r['Distance focal centroid']))
         assert abs(m['Difference amplitude'] - r['Difference amplitude']) <= 0.1, (case, 'amplitude difference')
-        assert 0.92 <= m['L2'] / r['L2'] <= 1.04, (case, 'L2', m['L2'], r['L2'])
+        assert 0.93 <= m['L2'] / r['L2'] <= 1.07, (case, 'L2', m['L2'], r['L2'])
         assert abs(m['Distance focal centroid'] - r['Distance focal centroid']) <= 0.1, (case, 'focal centroid')
         if m['L Inf location'] == r['L Inf location']:
             same_location += 1
