@@ -1241,15 +1241,24 @@ static int choose_placement(bfd_sim *s)
         }
         bool ok = true;
         for (size_t q = 0; q < slots.size(); q++) cand[q] = nullptr;
+        // every second candidate set is allocated with throw-away blocks of varying size between its arrays: where memory is
+        // unfragmented, plain allocations come out at a regular stride, which is the slow case
+        std::vector<void *> spacers;
+        const bool spaced = (t % 2) == 1;
         for (size_t q = 0; q < slots.size() && ok; q++) {
+            if (spaced) {
+                void *sp = nullptr;
+                if (hipMalloc(&sp, (size_t)(((t * 7 + (int)q * 13) % 31) + 1) << 21) == hipSuccess) spacers.push_back(sp); else (void)hipGetLastError();
+            }
             ok = hipMalloc(&cand[q], slots[q].bytes) == hipSuccess;
             if (ok) ok = hipMemcpyAsync(cand[q], cur[q], slots[q].bytes, hipMemcpyDeviceToDevice, s->stream) == hipSuccess;
         }
+        if (!spacers.empty()) { hipStreamSynchronize(s->stream); for (void *sp : spacers) hipFree(sp); }
         if (!ok) { hipStreamSynchronize(s->stream); for (void *c : cand) if (c) hipFree(c); (void)hipGetLastError(); break; }
         for (size_t q = 0; q < slots.size(); q++) *slots[q].base = cand[q];
         bind_state_views(s);
         const float ms = time_tiled_kernels(s, 3);
-        if (verbose) fprintf(stderr, "placement: %.3f ms per step on set %d\n", ms, t + 1);
+        if (verbose) fprintf(stderr, "placement: %.3f ms per step on set %d%s\n", ms, t + 1, spaced ? " (spaced)" : "");
         if (ms > 0 && ms < 0.985f * best) { best = ms; discarded.push_back(cur); cur = cand; }
         else { discarded.push_back(cand); for (size_t q = 0; q < slots.size(); q++) *slots[q].base = cur[q]; bind_state_views(s); }
     }
