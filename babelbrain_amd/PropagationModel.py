@@ -70,9 +70,31 @@ def material_slab(MaterialMap, k0, nk):
     return MaterialMap[:, :, k0 - gl:k0 + nk + gh], gl, gh
 
 
+def _device_list(spec):
+    """'all' | '0,1,2' | iterable of ordinals -> list of HIP device ordinals (an ordinal may repeat: slabs sharing a device)."""
+    if spec is None:
+        return None
+    if isinstance(spec, str):
+        spec = spec.strip()
+        if not spec:
+            return None
+        if spec.lower() == 'all':
+            return [d for d, _ in _engine.list_devices()]
+        return [int(x) for x in spec.split(',')]
+    if np.isscalar(spec):
+        return [int(spec)]
+    return [int(x) for x in spec]
+
+
 class PropagationModel:
-    def __init__(self, device=None, kernelVariant=0):
+    def __init__(self, device=None, kernelVariant=0, devices=None):
+        """device: HIP ordinal of a single-device run. devices: list of ordinals (or 'all'): ONE call is then split into
+        Z-slabs over those devices inside the library (bfd_group_*), the return values are the whole-domain ones. The
+        environment variable BABELFDTD_DEVICES ('all' or '0,1,2,3') does the same for a caller that cannot pass arguments
+        (the reference builds its module-global PModel without any, BASE:43)."""
+        import os
         self._device = device
+        self._devices = _device_list(devices if devices is not None else os.environ.get('BABELFDTD_DEVICES'))
         self._kernelVariant = kernelVariant
         self.last_timing = None
 
@@ -116,6 +138,17 @@ class PropagationModel:
         nt = n_steps(DurationSimulation, DT)
         # device: explicit ordinal of the call, else the one this object was built with, else the first device whose
         # name contains DefaultGPUDeviceName (the reference selects by name substring, BASE:2358, 918-925), else 0
+        devices = self._devices
+        if DefaultGPUDeviceNumber is not None and not np.isscalar(DefaultGPUDeviceNumber):
+            devices, DefaultGPUDeviceNumber = _device_list(DefaultGPUDeviceNumber), None
+        if DefaultGPUDeviceNumber is None and self._device is None and devices is not None and len(devices) >= 1:
+            devices = devices[:max(1, N3 // 4)]            # a slab owns at least the 2 + 2 planes its neighbours read
+            if len(devices) > 1:
+                return self._run_group(devices, MaterialMap, ml, Frequency, SourceMap, PulseSource, SpatialStep, DT, nt, SensorMap,
+                                       Ox, Oy, Oz, NDelta, ReflectionLimit, QfactorCorrection, QCorrection, TypeSource, SelRMSorPeak,
+                                       SelMapsRMSPeakList, SelMapsSensorsList, SensorSubSampling, SensorStart, ReflectorMask, SILENT,
+                                       ReturnSensorDFT, ReturnSensorSeries)
+            DefaultGPUDeviceNumber = devices[0]
         device = DefaultGPUDeviceNumber if DefaultGPUDeviceNumber is not None else self._device
         if device is None:
             device = 0
@@ -168,4 +201,55 @@ class PropagationModel:
         if not SILENT and self.last_timing['total_ms'] > 0:
             print('HIP FDTD: %d steps, %.1f Mvoxel-steps/s' % (
                 nt, self.last_timing['voxel_steps'] / self.last_timing['total_ms'] / 1e3))
+        return tuple(out)
+
+    # ------------------------------------------------------------------------------------------
+    def _run_group(self, devices, MaterialMap, ml, Frequency, SourceMap, PulseSource, SpatialStep, DT, nt, SensorMap, Ox, Oy, Oz,
+                   NDelta, ReflectionLimit, QfactorCorrection, QCorrection, TypeSource, SelRMSorPeak, SelMapsRMSPeakList,
+                   SelMapsSensorsList, SensorSubSampling, SensorStart, ReflectorMask, SILENT, ReturnSensorDFT, ReturnSensorSeries):
+        """The same call on several devices: whole-domain arrays in, whole-domain results out (bfd_group_*)."""
+        if not ReturnSensorSeries and not ReturnSensorDFT:
+            raise ValueError('ReturnSensorSeries=False needs ReturnSensorDFT=True')
+        N1, N2, N3 = MaterialMap.shape
+        grp = _engine.Group(devices, N1, N2, N3, ml.shape[0], SpatialStep, DT, Frequency, nt, NDelta=NDelta,
+                            reflectionLimit=ReflectionLimit, typeSource=TypeSource, sensorSub=SensorSubSampling,
+                            sensorStart=SensorStart, selRMSorPeak=SelRMSorPeak, selMapsRMS=SelMapsRMSPeakList,
+                            selMapsSensors=SelMapsSensorsList, qfactorCorrection=QfactorCorrection,
+                            kernelVariant=self._kernelVariant, sensorMode=1 if (ReturnSensorDFT and not ReturnSensorSeries) else 0)
+        try:
+            grp.set_materials(ml, QCorrection)
+            grp.set_material_map(MaterialMap)
+            if ReflectorMask is not None:
+                grp.set_reflector(ReflectorMask)
+            lin, row, wx, wy, wz = compact_sources(np.asarray(SourceMap), Ox, Oy, Oz)
+            grp.set_sources(lin.astype(np.int64), row, wx, wy, wz, PulseSource)
+            grp.set_sensor_map(SensorMap)
+            grp.timing_begin()
+            grp.run(nt)
+            self.last_timing = grp.timing_end()
+            self.last_timing['voxel_steps'] = float(N1) * N2 * N3 * nt
+            Sensor = {'time': sensor_steps(nt, SensorSubSampling, SensorStart) * DT}
+            if ReturnSensorSeries:
+                sens = grp.sensors()
+                for q, name in enumerate(grp.selS):
+                    Sensor[name] = sens[q]
+            InputParam = {'IndexSensorMap': grp.sensor_index(), 'DT': DT, 'nt': nt, 'device_bytes': grp.device_bytes,
+                          'timing': self.last_timing, 'devices': list(devices),
+                          'slabs': [grp.slab(r)[:3] for r in range(grp.size)]}
+            if ReturnSensorDFT:
+                F, pk = grp.sensor_dft(Frequency)
+                InputParam['SensorDFT'] = {name: F[q] for q, name in enumerate(grp.selS)}
+                InputParam['SensorPeak'] = {name: pk[q] for q, name in enumerate(grp.selS)}
+            LastMap = {name: grp.get_map(KIND_LAST, name) for name in grp.selR}
+            out = [Sensor, LastMap]
+            if SelRMSorPeak & 1:
+                out.append({name: grp.get_map(KIND_RMS, name) for name in grp.selR})
+            if SelRMSorPeak & 2:
+                out.append({name: grp.get_map(KIND_PEAK, name) for name in grp.selR})
+            out.append(InputParam)
+        finally:
+            grp.close()
+        if not SILENT and self.last_timing['total_ms'] > 0:
+            print('HIP FDTD: %d steps on %d slabs, %.1f Mvoxel-steps/s' % (
+                nt, len(devices), self.last_timing['voxel_steps'] / self.last_timing['total_ms'] / 1e3))
         return tuple(out)

@@ -28,6 +28,11 @@ ABI_SYMBOLS = [
     'bfd_half_step_stress', 'bfd_half_step_velocity', 'bfd_half_step_stress_part', 'bfd_half_step_velocity_part', 'bfd_half_step_stress_part_on', 'bfd_half_step_velocity_part_on', 'bfd_sync', 'bfd_current_step', 'bfd_prepare', 'bfd_halo_region',
     'bfd_timing_begin', 'bfd_timing_end', 'bfd_timing_kernels', 'bfd_algorithmic_bytes', 'bfd_reset', 'bfd_num_sensors', 'bfd_num_sensor_steps', 'bfd_get_sensor_index',
     'bfd_get_sensors', 'bfd_get_map', 'bfd_get_field', 'bfd_tile_counts', 'bfd_tile_count_lean', 'bfd_tile_count_fused', 'bfd_device_bytes', 'bfd_rayleigh_forward', 'bfd_get_sensor_dft', 'bfd_dft_series', 'bfd_bhte_run', 'bfd_bhte_run_fields',
+    'bfd_halo_fields',
+    'bfd_group_create', 'bfd_group_destroy', 'bfd_group_size', 'bfd_group_slab', 'bfd_group_set_materials', 'bfd_group_set_material_map',
+    'bfd_group_set_reflector', 'bfd_group_set_sources', 'bfd_group_set_sensor_map', 'bfd_group_prepare', 'bfd_group_run', 'bfd_group_sync',
+    'bfd_group_reset', 'bfd_group_timing_begin', 'bfd_group_timing_end', 'bfd_group_num_sensors', 'bfd_group_num_sensor_steps',
+    'bfd_group_get_sensor_index', 'bfd_group_get_sensors', 'bfd_group_get_sensor_dft', 'bfd_group_get_map', 'bfd_group_device_bytes',
 ]
 
 
@@ -137,7 +142,32 @@ def load_library():
     lib.bfd_dft_series.argtypes = [C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_double, C.c_double, C.c_void_p, C.c_void_p]
     lib.bfd_rayleigh_forward.argtypes = [C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double,
                                          C.c_int64, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
-    if lib.bfd_abi_version() != 2:
+    lib.bfd_halo_fields.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_uint32)]
+    lib.bfd_group_create.argtypes = [C.POINTER(Config), C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]
+    lib.bfd_group_destroy.argtypes = [C.c_void_p]
+    lib.bfd_group_destroy.restype = None
+    lib.bfd_group_size.argtypes = [C.c_void_p]
+    lib.bfd_group_slab.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_void_p)]
+    lib.bfd_group_set_materials.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.bfd_group_set_material_map.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64]
+    lib.bfd_group_set_reflector.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64]
+    lib.bfd_group_set_sources.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_int32, C.c_int32]
+    lib.bfd_group_set_sensor_map.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_int64)]
+    for fn in ('bfd_group_prepare', 'bfd_group_sync', 'bfd_group_reset', 'bfd_group_timing_begin'):
+        getattr(lib, fn).argtypes = [C.c_void_p]
+    lib.bfd_group_run.argtypes = [C.c_void_p, C.c_int32]
+    lib.bfd_group_timing_end.argtypes = [C.c_void_p] + [C.POINTER(C.c_double)] * 4 + [C.POINTER(C.c_int32)]
+    lib.bfd_group_num_sensors.argtypes = [C.c_void_p]
+    lib.bfd_group_num_sensors.restype = C.c_int64
+    lib.bfd_group_num_sensor_steps.argtypes = [C.c_void_p]
+    lib.bfd_group_get_sensor_index.argtypes = [C.c_void_p, C.c_void_p]
+    lib.bfd_group_get_sensors.argtypes = [C.c_void_p, C.c_void_p]
+    lib.bfd_group_get_sensor_dft.argtypes = [C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]
+    lib.bfd_group_get_map.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_int64, C.c_int64]
+    lib.bfd_group_device_bytes.argtypes = [C.c_void_p]
+    lib.bfd_group_device_bytes.restype = C.c_int64
+    if lib.bfd_abi_version() != 3:
         raise EngineError('libbabelfdtd_hip.so ABI version mismatch')
     _lib = lib
     return lib
@@ -323,9 +353,12 @@ class Engine:
     def halo_fields(self):
         """Which fields of each halo group this slab reads from its Z-neighbours' planes:
         an all-fluid slab (tiled kernels, no solid tile) needs only Vz and Szz."""
-        if self.cfg.kernelVariant in (0, 3, 4) and self.tile_counts()['solid'] == 0:
-            return {HALO_VELOCITY: [2], HALO_STRESS: [2]}
-        return {HALO_VELOCITY: [0, 1, 2], HALO_STRESS: [0, 1, 2]}
+        out = {}
+        for g in (HALO_VELOCITY, HALO_STRESS):
+            m = C.c_uint32()
+            _check(self.lib.bfd_halo_fields(self.h, g, C.byref(m)), 'bfd_halo_fields')
+            out[g] = [f for f in range(3) if m.value & (1 << f)]
+        return out
 
     def sync(self):
         _check(self.lib.bfd_sync(self.h), 'bfd_sync')
@@ -422,3 +455,162 @@ class Engine:
     @property
     def device_bytes(self):
         return self.lib.bfd_device_bytes(self.h)
+
+
+class _SlabView(Engine):
+    """Engine-shaped view of one slab of a Group (per-slab queries: tile counts, timing, raw fields). Owned by the group."""
+
+    def __init__(self, lib, handle, cfg, shape, selR, selS):      # noqa: super().__init__ would create an engine
+        self.lib, self.h, self.cfg, self.shape, self.selR, self.selS = lib, handle, cfg, shape, selR, selS
+
+    def close(self):
+        self.h = None
+
+    def __del__(self):
+        pass
+
+
+class Group:
+    """One solver call split into Z-slabs over several HIP devices of this process (bfd_group_*): whole-domain inputs and
+    outputs, step loop and halo copies inside the library."""
+
+    def __init__(self, devices, N1, N2, N3, nMat, h, dt, freq, nt, NDelta=12, reflectionLimit=1e-5, typeSource=0, sensorSub=1,
+                 sensorStart=0, selRMSorPeak=1, selMapsRMS=('Pressure',), selMapsSensors=('Pressure',), qfactorCorrection=True,
+                 kernelVariant=0, rmsFirstStep=0, sensorMode=0):
+        self.lib = load_library()
+        if self.lib.bfd_device_count() <= 0:
+            raise EngineError('no HIP device visible: the MI355X engine has no CPU fallback')
+        self.devices = [int(d) for d in devices]
+        self.selR = ordered(selMapsRMS)
+        self.selS = ordered(selMapsSensors)
+        self.cfg = Config(N1=N1, N2=N2, N3=N3, k0=0, nk=N3, nMat=nMat, NDelta=NDelta, typeSource=typeSource,
+                          sensorSub=sensorSub, sensorStart=sensorStart, nt=nt, selRMSorPeak=selRMSorPeak,
+                          selMapsRMS=mask_of(self.selR), selMapsSensors=mask_of(self.selS),
+                          qfactorCorrection=int(bool(qfactorCorrection)), device=self.devices[0], kernelVariant=kernelVariant,
+                          rmsFirstStep=rmsFirstStep, sensorMode=sensorMode, h=h, dt=dt, freq=freq, reflectionLimit=reflectionLimit)
+        self.h = C.c_void_p()
+        dv = np.ascontiguousarray(self.devices, np.int32)
+        _check(self.lib.bfd_group_create(C.byref(self.cfg), len(self.devices), _ptr(dv), C.byref(self.h)), 'bfd_group_create')
+        self.shape = (N1, N2, N3)
+
+    def close(self):
+        if getattr(self, 'h', None) is not None and self.h:
+            self.lib.bfd_group_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def size(self):
+        return self.lib.bfd_group_size(self.h)
+
+    def slab(self, r):
+        """(k0, nk, device, engine view) of slab r."""
+        k0, nk, dev, sim = C.c_int32(), C.c_int32(), C.c_int32(), C.c_void_p()
+        _check(self.lib.bfd_group_slab(self.h, r, C.byref(k0), C.byref(nk), C.byref(dev), C.byref(sim)), 'bfd_group_slab')
+        cfg = Config.from_buffer_copy(self.cfg)
+        cfg.k0, cfg.nk, cfg.device = k0.value, nk.value, dev.value
+        return k0.value, nk.value, dev.value, _SlabView(self.lib, sim, cfg, (self.shape[0], self.shape[1], nk.value), self.selR, self.selS)
+
+    # ---- inputs (whole domain) ----
+    def set_materials(self, MaterialList, QCorrection=1.0):
+        ml = np.ascontiguousarray(MaterialList, np.float64).reshape(-1, 5)
+        if ml.shape[0] != self.cfg.nMat:
+            raise ValueError('MaterialList rows != nMat')
+        qc = np.ascontiguousarray(np.broadcast_to(np.asarray(QCorrection, np.float64), (ml.shape[0],)))
+        _check(self.lib.bfd_group_set_materials(self.h, _ptr(ml), _ptr(qc)), 'bfd_group_set_materials')
+
+    def _u32(self, a):
+        a = np.asarray(a)
+        assert a.shape == self.shape, (a.shape, self.shape)
+        if a.dtype != np.uint32 or any(s < 0 for s in a.strides):
+            a = np.ascontiguousarray(a, np.uint32)
+        return a
+
+    def set_material_map(self, MaterialMap):
+        a = self._u32(MaterialMap)
+        _check(self.lib.bfd_group_set_material_map(self.h, _ptr(a), *_estrides(a)), 'bfd_group_set_material_map')
+
+    def set_reflector(self, mask):
+        if mask is None:
+            _check(self.lib.bfd_group_set_reflector(self.h, None, 0, 0, 0), 'bfd_group_set_reflector')
+            return
+        a = self._u32(mask)
+        _check(self.lib.bfd_group_set_reflector(self.h, _ptr(a), *_estrides(a)), 'bfd_group_set_reflector')
+
+    def set_sources(self, globalIndex, row, wx, wy, wz, PulseSource):
+        pulse = np.ascontiguousarray(np.atleast_2d(PulseSource), np.float64)
+        self._pulse = pulse     # a large table is streamed from here during the run: keep it alive with the group
+        gi = np.ascontiguousarray(globalIndex, np.int64)
+        rw = np.ascontiguousarray(row, np.uint32)
+        ws = [None if w is None else np.ascontiguousarray(w, np.float32) for w in (wx, wy, wz)]
+        _check(self.lib.bfd_group_set_sources(self.h, gi.size, _ptr(gi), _ptr(rw), _ptr(ws[0]), _ptr(ws[1]), _ptr(ws[2]),
+                                              _ptr(pulse), pulse.shape[0], pulse.shape[1]), 'bfd_group_set_sources')
+
+    def set_sensor_map(self, SensorMap):
+        a = self._u32(SensorMap)
+        n = C.c_int64()
+        _check(self.lib.bfd_group_set_sensor_map(self.h, _ptr(a), *_estrides(a), C.byref(n)), 'bfd_group_set_sensor_map')
+        return n.value
+
+    # ---- stepping ----
+    def prepare(self):
+        _check(self.lib.bfd_group_prepare(self.h), 'bfd_group_prepare')
+
+    def run(self, nSteps):
+        _check(self.lib.bfd_group_run(self.h, int(nSteps)), 'bfd_group_run')
+
+    def sync(self):
+        _check(self.lib.bfd_group_sync(self.h), 'bfd_group_sync')
+
+    def reset(self):
+        _check(self.lib.bfd_group_reset(self.h), 'bfd_group_reset')
+
+    def timing_begin(self):
+        _check(self.lib.bfd_group_timing_begin(self.h), 'bfd_group_timing_begin')
+
+    def timing_end(self):
+        d = [C.c_double() for _ in range(4)]
+        ov = C.c_int32()
+        _check(self.lib.bfd_group_timing_end(self.h, *[C.byref(x) for x in d], C.byref(ov)), 'bfd_group_timing_end')
+        return {'total_ms': d[0].value, 'max_device_ms': d[1].value, 'host_issue_ms': d[2].value, 'halo_bytes_per_step': d[3].value,
+                'overlapped': bool(ov.value), 'slabs': self.size}
+
+    # ---- outputs (whole domain) ----
+    @property
+    def num_sensors(self):
+        return self.lib.bfd_group_num_sensors(self.h)
+
+    @property
+    def num_sensor_steps(self):
+        return self.lib.bfd_group_num_sensor_steps(self.h)
+
+    def sensor_index(self):
+        idx = np.zeros(self.num_sensors, np.uint32)
+        _check(self.lib.bfd_group_get_sensor_index(self.h, _ptr(idx)), 'bfd_group_get_sensor_index')
+        return idx
+
+    def sensors(self):
+        out = np.zeros((len(self.selS), self.num_sensors, max(self.num_sensor_steps, 0)), np.float32)
+        _check(self.lib.bfd_group_get_sensors(self.h, _ptr(out)), 'bfd_group_get_sensors')
+        return out
+
+    def sensor_dft(self, freq):
+        F = np.zeros((len(self.selS), self.num_sensors), np.complex64)
+        pk = np.zeros((len(self.selS), self.num_sensors), np.float32)
+        _check(self.lib.bfd_group_get_sensor_dft(self.h, float(freq), _ptr(F.view(np.float32)), _ptr(pk)), 'bfd_group_get_sensor_dft')
+        return F, pk
+
+    def get_map(self, kind, name, out=None):
+        if out is None:
+            out = np.zeros(self.shape, np.float32)
+        _check(self.lib.bfd_group_get_map(self.h, kind, MAP_BITS[name], _ptr(out), *_estrides(out)), 'bfd_group_get_map')
+        return out
+
+    @property
+    def device_bytes(self):
+        return self.lib.bfd_group_device_bytes(self.h)

@@ -465,7 +465,7 @@ void release_streaming(bfd_sim *s)
         if (s->packJob[b].valid()) s->packJob[b].get();
         dev_release(s, &s->tileDev[b]);
         if (s->tilePinned[b]) { hipHostFree(s->tilePinned[b]); s->tilePinned[b] = nullptr; }
-        s->tileLoaded[b] = s->tilePacked[b] = -1; s->evTileUsed[b] = false;
+        s->tileLoaded[b] = s->tilePacked[b] = -1; s->evTileUsed[b] = false; s->evReadUsed[b] = false;
     }
     s->pulseHost = nullptr; s->tileSteps = s->nTiles = 0;
 }
@@ -485,7 +485,9 @@ int pulse_row(bfd_sim *s, int step, hipStream_t st, const float **row)
             s->tilePacked[b] = t;
         }
         const int len = std::min(TS, s->lengthSource - t * TS);
-        // stream order puts this copy behind the kernels that read the tile this buffer held two tiles ago
+        // the kernels that read the tile this buffer held two tiles ago may have run on another stream (split half-steps):
+        // the copy waits for the last of them
+        if (s->evReadUsed[b]) BFD_HIP(hipStreamWaitEvent(st, s->evRead[b], 0));
         BFD_HIP(hipMemcpyAsync(s->tileDev[b], s->tilePinned[b], (size_t)len * s->nSources * sizeof(float), hipMemcpyHostToDevice, st));
         BFD_HIP(hipEventRecord(s->evTile[b], st));
         s->evTileUsed[b] = true; s->tileLoaded[b] = t;
@@ -508,6 +510,14 @@ int pulse_row(bfd_sim *s, int step, hipStream_t st, const float **row)
     }
     *row = s->tileDev[b] + (size_t)(step - t * TS) * s->nSources;
     return 0;
+}
+
+// after the kernels of stream st that read the row pulse_row() returned: the tile buffer may be overwritten behind them
+void pulse_row_read(bfd_sim *s, int step, hipStream_t st)
+{
+    if (!s->pulseHost) return;
+    const int b = (step / s->tileSteps) & 1;
+    if (s->evRead[b] && hipEventRecord(s->evRead[b], st) == hipSuccess) s->evReadUsed[b] = true;
 }
 
 }  // namespace
@@ -596,7 +606,7 @@ int bfd_create(const bfd_config *cfg, bfd_sim **out)
     s->nSrcVox = 0; s->srcLin = s->srcRow = nullptr; s->srcW[0] = s->srcW[1] = s->srcW[2] = nullptr; s->pulseT = nullptr;
     s->nSources = s->lengthSource = 0;
     s->pulseHost = nullptr; s->tileSteps = s->nTiles = 0;
-    for (int b = 0; b < 2; b++) { s->tileDev[b] = s->tilePinned[b] = nullptr; s->tileLoaded[b] = s->tilePacked[b] = -1; s->evTile[b] = nullptr; s->evTileUsed[b] = false; }
+    for (int b = 0; b < 2; b++) { s->tileDev[b] = s->tilePinned[b] = nullptr; s->tileLoaded[b] = s->tilePacked[b] = -1; s->evTile[b] = nullptr; s->evTileUsed[b] = false; s->evRead[b] = nullptr; s->evReadUsed[b] = false; }
     s->nSensors = 0; s->sensLin = nullptr; s->sensOut = nullptr; s->dftAcc = nullptr; s->dftPk = nullptr; s->dftBin = 0;
     s->acc = s->pk = nullptr; s->timing = s->perKernel = false;
     s->tables = nullptr; s->profiles = nullptr; s->cmax = 0;
@@ -669,7 +679,7 @@ void bfd_destroy(bfd_sim *s)
     if (s->stepGraph) hipGraphExecDestroy(s->stepGraph);
     if (s->captureStream) hipStreamDestroy(s->captureStream);
     release_streaming(s);
-    for (int b = 0; b < 2; b++) if (s->evTile[b]) hipEventDestroy(s->evTile[b]);
+    for (int b = 0; b < 2; b++) { if (s->evTile[b]) hipEventDestroy(s->evTile[b]); if (s->evRead[b]) hipEventDestroy(s->evRead[b]); }
     for (void *p : s->allocs) hipFree(p);
     for (hipEvent_t e : s->evPool) hipEventDestroy(e);
     for (hipEvent_t e : s->evStress) hipEventDestroy(e);
@@ -845,9 +855,18 @@ int bfd_set_sources(bfd_sim *s, int64_t nVox, const uint32_t *localIndex, const 
         tile = std::min(tile, (int)lengthSource);
         s->pulseHost = pulse; s->tileSteps = tile; s->nTiles = (lengthSource + tile - 1) / tile;
         for (int b = 0; b < 2; b++) {
-            if ((rc = dev_alloc(s, &s->tileDev[b], (size_t)tile * nSources, false))) return rc;
-            BFD_HIP(hipHostMalloc((void **)&s->tilePinned[b], (size_t)tile * nSources * sizeof(float), hipHostMallocDefault));
-            if (!s->evTile[b]) BFD_HIP(hipEventCreateWithFlags(&s->evTile[b], hipEventDisableTiming));
+            hipError_t e = hipSuccess;
+            rc = dev_alloc(s, &s->tileDev[b], (size_t)tile * nSources, false);
+            if (!rc) e = hipHostMalloc((void **)&s->tilePinned[b], (size_t)tile * nSources * sizeof(float), hipHostMallocDefault);
+            if (!rc && e == hipSuccess && !s->evTile[b]) e = hipEventCreateWithFlags(&s->evTile[b], hipEventDisableTiming);
+            if (!rc && e == hipSuccess && !s->evRead[b]) e = hipEventCreateWithFlags(&s->evRead[b], hipEventDisableTiming);
+            if (rc || e != hipSuccess) {        // nothing half-built stays behind: the sim is back to "no sources"
+                const std::string why = rc ? std::string(bfd_last_error()) : std::string("bfd_set_sources: ") + hipGetErrorString(e);
+                release_streaming(s);
+                s->nSrcVox = 0; s->srcHighBeg = 0;
+                bfd_set_error(why);
+                return rc ? rc : -10;
+            }
         }
         s->graphState = -1;        // the recorded step graph indexes a resident table
         return 0;
@@ -897,7 +916,7 @@ int bfd_set_sensor_map(bfd_sim *s, const uint32_t *map, int64_t s1, int64_t s2, 
             else {
                 rc = dev_alloc(s, &s->dftAcc, 2 * (size_t)s->nSelS * (size_t)count);
                 if (!rc) rc = dev_alloc(s, &s->dftPk, (size_t)s->nSelS * (size_t)std::max(count, 1), false);
-                if (!rc) hipLaunchKernelGGL(fill_float, dim3(grid_for((long)s->nSelS * count)), dim3(256), 0, s->stream, s->dftPk, (long)s->nSelS * count, -INFINITY);
+                if (!rc && count > 0) hipLaunchKernelGGL(fill_float, dim3(grid_for((long)s->nSelS * count)), dim3(256), 0, s->stream, s->dftPk, (long)s->nSelS * count, -INFINITY);
                 s->dftBin = dft_bin(s->nTs, s->cfg.dt * s->cfg.sensorSub, s->cfg.freq);
             }
         }
@@ -1174,16 +1193,24 @@ static float time_tiled_kernels(bfd_sim *s, int reps)
     for (int q = 0; q < s->nSelR; q++)
         if (s->selR[q] == BFD_MAP_PRESSURE) { accP = s->acc ? s->acc + (size_t)q * s->nloc : nullptr; pkP = s->pk ? s->pk + (size_t)q * s->nloc : nullptr; }
     (void)hipGetLastError();                    // a stale error of some earlier call is not this probe's
+    // the probe's own event pair (evBegin / evEnd belong to bfd_timing_begin / _end, whose window may be open) and no
+    // per-kernel marks from its launches
+    hipEvent_t e0 = get_event(s), e1 = get_event(s);
+    if (!e0 || !e1) { if (e0) s->evPool.push_back(e0); if (e1) s->evPool.push_back(e1); return -1.f; }
+    bfd_sim *const kt = s->tiles.ktimer;
+    s->tiles.ktimer = nullptr;
     for (int r = -1; r < reps; r++) {           // r = -1: untimed
-        if (r == 0) hipEventRecord(s->evBegin, s->stream);
+        if (r == 0) hipEventRecord(e0, s->stream);
         bfd_launch_stress_v2(s->d, s->stream, &s->tiles, 0);
         bfd_launch_velocity_v2(s->d, s->stream, accP, pkP, &s->tiles, 0);
     }
-    hipEventRecord(s->evEnd, s->stream);
-    if (hipEventSynchronize(s->evEnd) != hipSuccess || hipGetLastError() != hipSuccess) return -1.f;
-    float ms = 0;
-    hipEventElapsedTime(&ms, s->evBegin, s->evEnd);
-    return ms / reps;
+    hipEventRecord(e1, s->stream);
+    s->tiles.ktimer = kt;
+    float ms = -1.f;
+    if (hipEventSynchronize(e1) == hipSuccess && hipGetLastError() == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) ms /= reps;
+    else ms = -1.f;
+    s->evPool.push_back(e0); s->evPool.push_back(e1);
+    return ms;
 }
 
 static int choose_placement(bfd_sim *s)
@@ -1232,12 +1259,16 @@ static int choose_placement(bfd_sim *s)
             hipFree(p);
         }
     };
+    const size_t spacerMax = slots.size() * ((size_t)31 << 21);        // throw-away blocks of a spaced candidate set (62 MiB each at most)
     for (int t = 0; t < trials; t++) {
         while (discarded.size() > 1) { free_set(discarded.front()); discarded.erase(discarded.begin()); }
-        if (hipMemGetInfo(&freeB, &totalB) != hipSuccess || freeB < need + need / 8) {
+        // peak = current set + one losing set + the candidate (+ spacers): when memory is short (other engines share the
+        // device) the losing set goes first
+        if (!discarded.empty() && (hipMemGetInfo(&freeB, &totalB) != hipSuccess || freeB < 2 * need + spacerMax)) { free_set(discarded.front()); discarded.clear(); }
+        if (hipMemGetInfo(&freeB, &totalB) != hipSuccess || freeB < need + need / 8 + spacerMax) {
             for (auto &v : discarded) free_set(v);
             discarded.clear();
-            if (hipMemGetInfo(&freeB, &totalB) != hipSuccess || freeB < need + need / 8) break;
+            if (hipMemGetInfo(&freeB, &totalB) != hipSuccess || freeB < need + need / 8 + spacerMax) break;
         }
         bool ok = true;
         for (size_t q = 0; q < slots.size(); q++) cand[q] = nullptr;
@@ -1318,6 +1349,7 @@ static int inject_part(bfd_sim *s, int part, const bfd_dev &view, hipStream_t st
                            s->srcLin + beg[r], s->srcRow + beg[r], s->srcW[0] ? s->srcW[0] + beg[r] : nullptr,
                            s->srcW[1] ? s->srcW[1] + beg[r] : nullptr, s->srcW[2] ? s->srcW[2] + beg[r] : nullptr, pulse, (long)c);
     }
+    pulse_row_read(s, s->step, st);
     return 0;
 }
 
@@ -1516,6 +1548,17 @@ int bfd_halo_region(bfd_sim *s, int32_t group, int32_t f, int32_t side, int32_t 
     return 0;
 }
 
+int bfd_halo_fields(bfd_sim *s, int32_t group, uint32_t *mask)
+{
+    if (!mask || group < 0 || group > 1) BFD_FAIL(-1, "bfd_halo_fields: bad argument");
+    int rc = check_ready(s); if (rc) return rc;
+    // an all-fluid slab of the tiled kernels keeps a single normal stress and no shear: its stencils reach across a Z face
+    // only through Vz (stress half-step) and Szz (velocity half-step) -- field 2 of either group
+    const bool tiled = s->cfg.kernelVariant != 1 && s->cfg.kernelVariant != 2;
+    *mask = (tiled && s->tilesReady && s->tiles.nSolid == 0) ? 4u : 7u;
+    return 0;
+}
+
 int bfd_timing_begin(bfd_sim *s, int32_t perKernel)
 {
     if (!s) BFD_FAIL(-1, "null sim");
@@ -1599,7 +1642,7 @@ int bfd_reset(bfd_sim *s)
     if (s->sensOut) BFD_HIP(hipMemsetAsync(s->sensOut, 0, (size_t)s->nSelS * s->nTs * (size_t)s->nSensors * sizeof(float), s->stream));
     if (s->dftAcc) {
         BFD_HIP(hipMemsetAsync(s->dftAcc, 0, 2 * (size_t)s->nSelS * (size_t)s->nSensors * sizeof(double), s->stream));
-        hipLaunchKernelGGL(fill_float, dim3(grid_for((long)s->nSelS * s->nSensors)), dim3(256), 0, s->stream, s->dftPk, (long)s->nSelS * s->nSensors, -INFINITY);
+        if (s->nSensors > 0) hipLaunchKernelGGL(fill_float, dim3(grid_for((long)s->nSelS * s->nSensors)), dim3(256), 0, s->stream, s->dftPk, (long)s->nSelS * s->nSensors, -INFINITY);
     }
     s->step = 0; s->stepDevValid = false;
     BFD_HIP(hipStreamSynchronize(s->stream));

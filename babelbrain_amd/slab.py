@@ -45,7 +45,11 @@ class _DevBuf:
 
 class HipSlab:
     """One slab on one MI355X; halo tensors alias the engine's own device memory (zero copy)."""
-    supports_parts = True     # half-steps can run boundary tiles first, so the exchange overlaps the interior
+    @property
+    def supports_parts(self):
+        """Half-steps can run the boundary runs first, so the exchange overlaps the interior (kernelVariant 1 has no run
+        lists: its part 1 is empty, an exchange started behind it would send the planes of the previous step)."""
+        return self.eng.cfg.kernelVariant != 1
 
     def __init__(self, engine, device, host_staging=False):
         """host_staging=True: halos travel through pinned host tensors (for the gloo backend: a debugging
@@ -136,17 +140,19 @@ class SlabRunner:
         # Overlapped step (boundary part + exchange on a side stream beside the interior part) by default; a thin slab has
         # too little interior work to hide anything behind and pays for the extra launches, so it takes the blocking order
         # (BFD_OVERLAP_MIN_PLANES, default 64 planes; an explicit overlap= argument wins)
-        if overlap is None:
-            import os
-            thick = getattr(getattr(slab, 'eng', None), 'shape', (0, 0, 1 << 30))[2] >= int(os.environ.get('BFD_OVERLAP_MIN_PLANES', '64'))
-            overlap = getattr(slab, 'supports_parts', False) and thick
-            if world > 1 and dist is not None:      # the two orders exchange in a different sequence: every rank must take the same one
-                flags = [None] * world
-                dist.all_gather_object(flags, bool(overlap), group=group)
-                overlap = all(flags)
-        self.overlap = overlap and world > 1
+        import os
+        thick = getattr(getattr(slab, 'eng', None), 'shape', (0, 0, 1 << 30))[2] >= int(os.environ.get('BFD_OVERLAP_MIN_PLANES', '64'))
+        able = bool(getattr(slab, 'supports_parts', False))
+        mine_overlap = (able and thick) if overlap is None else (bool(overlap) and able)
+        if world > 1 and dist is not None:
+            # the two orders exchange in a different sequence, so every rank must take the same one: every rank gathers every
+            # rank's wish (whatever overlap= each was built with -- all ranks enter this collective) and the order is
+            # overlapped only if all of them want and can
+            flags = [None] * world
+            dist.all_gather_object(flags, mine_overlap, group=group)
+            mine_overlap = all(flags)
+        self.overlap = mine_overlap and world > 1
         if self.overlap and world > 1:
-            import os
             import warnings
             try:
                 nccl = dist.get_backend(group) == 'nccl'

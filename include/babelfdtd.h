@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define BFD_ABI_VERSION 2
+#define BFD_ABI_VERSION 3
 
 enum {
     BFD_MAP_VX = 0, BFD_MAP_VY = 1, BFD_MAP_VZ = 2,
@@ -164,6 +164,11 @@ int bfd_prepare(bfd_sim *sim);
 int bfd_halo_region(bfd_sim *sim, int32_t group, int32_t f, int32_t side, int32_t send,
                     void **devPtr, size_t *bytes);
 
+/* which fields of a halo group this slab READS from its Z-neighbours' planes, as a bit mask (bit f = field f of
+ * bfd_halo_region): 7 in general; 4 (Vz / Szz only) for a slab without solid runs under the tiled kernels, whose
+ * stencils cross a Z face through those two fields alone. Across an interface each side sends what the other reads. */
+int bfd_halo_fields(bfd_sim *sim, int32_t group, uint32_t *mask);
+
 /* timing of the step loop, device time from HIP events on the sim's stream */
 int bfd_timing_begin(bfd_sim *sim, int32_t perKernel);
 int bfd_timing_end(bfd_sim *sim, double *totalMs, double *stressMs, double *velocityMs,
@@ -214,6 +219,49 @@ int bfd_tile_count_lean(bfd_sim *sim, int32_t *nLean);
 int bfd_tile_count_fused(bfd_sim *sim, int32_t *nFused);
 /* device memory this sim holds, bytes */
 int64_t bfd_device_bytes(bfd_sim *sim);
+
+/* ---- One solver call on several devices of THIS process: Z-slab decomposition behind the drop-in ----
+ * The reference's caller is one process making one call (Babel_SingleTx.py:258 spawns a single Process;
+ * BabelIntegrationBASE.py:2338-2365 calls PModel.StaggeredFDTD_3D_with_relaxation once, device chosen by
+ * DefaultGPUDeviceName :2358). A group owns one slab engine per entry of `devices` (slab r = balanced r-th share of the
+ * N3 planes, on HIP device devices[r]; an ordinal may repeat), takes the WHOLE-domain inputs exactly as bfd_set_* take a
+ * slab's, runs the step loop in C and moves the 2+2 halo planes per half-step and interface with peer copies ordered by
+ * events (hipMemcpyPeerAsync; boundary runs first, interior beside the copies). No second process, no collective.
+ * cfg: k0 = 0, nk = N3; cfg->device is ignored. Results equal the single-device run bit for bit. */
+typedef struct bfd_group bfd_group;
+int bfd_group_create(const bfd_config *cfg, int32_t nSlabs, const int32_t *devices, bfd_group **out);
+void bfd_group_destroy(bfd_group *g);
+int32_t bfd_group_size(bfd_group *g);
+/* slab r: its planes [k0, k0+nk), device and engine (for the per-slab queries above: tile counts, timing, fields) */
+int bfd_group_slab(bfd_group *g, int32_t r, int32_t *k0, int32_t *nk, int32_t *device, bfd_sim **sim);
+int bfd_group_set_materials(bfd_group *g, const double *matlist, const double *qcorr);
+/* whole-domain (N1,N2,N3) views with element strides, as bfd_set_material_map / _reflector / _sensor_map */
+int bfd_group_set_material_map(bfd_group *g, const uint32_t *map, int64_t s1, int64_t s2, int64_t s3);
+int bfd_group_set_reflector(bfd_group *g, const uint32_t *mask, int64_t s1, int64_t s2, int64_t s3);
+/* as bfd_set_sources with GLOBAL x-fastest voxel indices i + N1*(j + N2*k); the pulse table is shared by the slabs */
+int bfd_group_set_sources(bfd_group *g, int64_t nVox, const int64_t *globalIndex, const uint32_t *row,
+                          const float *wx, const float *wy, const float *wz,
+                          const double *pulse, int32_t nSources, int32_t lengthSource);
+int bfd_group_set_sensor_map(bfd_group *g, const uint32_t *map, int64_t s1, int64_t s2, int64_t s3, int64_t *nSensors);
+int bfd_group_prepare(bfd_group *g);                     /* bfd_prepare of every slab + the halo plan; bfd_group_run does it by itself */
+int bfd_group_run(bfd_group *g, int32_t nSteps);         /* queues nSteps time steps on every slab; returns without waiting */
+int bfd_group_sync(bfd_group *g);
+int bfd_group_reset(bfd_group *g);
+/* wall time of the window, the largest device time of a slab (HIP events on its main stream), the host time spent
+ * queueing work inside bfd_group_run (exposed launch overhead when it approaches the wall time), halo bytes moved per
+ * time step over all interfaces, and whether the overlapped order was used (slabs of >= 64 planes) */
+int bfd_group_timing_begin(bfd_group *g);
+int bfd_group_timing_end(bfd_group *g, double *wallMs, double *maxDeviceMs, double *hostIssueMs, double *haloBytesPerStep,
+                         int32_t *overlapped);
+/* results over the whole domain: sensors of all slabs in ascending GLOBAL index (BASE:2369, 2503), volumes into a
+ * strided (N1,N2,N3) view */
+int64_t bfd_group_num_sensors(bfd_group *g);
+int32_t bfd_group_num_sensor_steps(bfd_group *g);
+int bfd_group_get_sensor_index(bfd_group *g, uint32_t *index);
+int bfd_group_get_sensors(bfd_group *g, float *out);                  /* [nSelSensors][nSensors][nTs] */
+int bfd_group_get_sensor_dft(bfd_group *g, double freq, float *outReIm, float *outPeak);
+int bfd_group_get_map(bfd_group *g, int32_t kind, int32_t map, float *out, int64_t s1, int64_t s2, int64_t s3);
+int64_t bfd_group_device_bytes(bfd_group *g);
 
 /* ---- Rayleigh-Sommerfeld integral: replaces BabelViscoFDTD.tools.RayleighAndBHTE.ForwardSimple ----
  * (call sites BabelIntegrationSingle.py:295, BabelIntegrationANNULAR_ARRAY.py:383,411,
