@@ -210,6 +210,23 @@ __global__ __launch_bounds__(512, 4) void k_dense(Layout L, const int4 *__restri
     }
 }
 
+// two streams updated in place at the same cell offset (scripts/ubench_pairmap.hip): 7-8 % slower when both lie in the same
+// "colour" of physical memory
+__global__ __launch_bounds__(512, 8) void k_pair(char *a, char *b, long ps, int N1, const int4 *__restrict__ runs, int nblocks)
+{
+    const int4 run = runs[remap_block(blockIdx.x, nblocks)];
+    const int i = run.x * 64 + threadIdx.x, j = run.y * 8 + threadIdx.y;
+    const unsigned o = (unsigned)(j * N1 + i) * 4u;
+    float va = F4(a + run.z * ps, o), vb = F4(b + run.z * ps, o);
+    for (int kl = run.z; kl < run.w; kl++) {
+        const long ko = kl * ps;
+        float na = 0, nb = 0;
+        if (kl + 1 < run.w) { na = F4(a + ko + ps, o); nb = F4(b + ko + ps, o); }
+        F4(a + ko, o) = va + vb; F4(b + ko, o) = vb + va;
+        va = na; vb = nb;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 struct Set {
     std::vector<void *> allocs;
@@ -301,8 +318,89 @@ template <typename F> static float timeit(F f, int reps)
     return ms / reps;
 }
 
+// "colours" experiment: a pool of array-sized allocations is sorted into classes by the pair test (two arrays of one class
+// are slow together), then the proxy kernels run on sets drawn from ONE class and on sets spread evenly over the classes.
+static int colours(int pool)
+{
+    const long pl = (long)N1 * N2, nplanes = N3 + 2 * G;
+    const size_t bytes = (size_t)pl * nplanes * 4;
+    std::vector<char *> buf(pool);
+    for (int q = 0; q < pool; q++) { CK(hipMalloc((void **)&buf[q], bytes)); CK(hipMemset(buf[q], 0, bytes)); }
+    std::vector<int4> rp = make_runs(8, 16), r16 = make_runs(16, 16);
+    rp.resize(rp.size() / 2);            // the pair test marches half of the volume: 0.2 ms
+    int4 *dp, *d8;
+    CK(hipMalloc((void **)&dp, rp.size() * sizeof(int4))); CK(hipMemcpy(dp, rp.data(), rp.size() * sizeof(int4), hipMemcpyHostToDevice));
+    std::vector<int4> r8 = make_runs(8, 16);
+    CK(hipMalloc((void **)&d8, r8.size() * sizeof(int4))); CK(hipMemcpy(d8, r8.data(), r8.size() * sizeof(int4), hipMemcpyHostToDevice));
+    const int np = (int)rp.size(), n8 = (int)r8.size();
+    auto pair = [&](int x, int y) { return timeit([&] { hipLaunchKernelGGL(k_pair, dim3(np), dim3(64, 8), 0, 0, buf[x] + G * pl * 4, buf[y] + G * pl * 4, pl * 4, N1, dp, np); }, 4); };
+    // classes: compare with one representative per class; "same" = the slow level. Levels from the first column.
+    std::vector<float> t0(pool, 0.f);
+    float lo = 1e9f, hi = 0.f;
+    for (int q = 1; q < pool; q++) { t0[q] = pair(0, q); lo = std::min(lo, t0[q]); hi = std::max(hi, t0[q]); }
+    const float thr = 0.5f * (lo + hi);
+    printf("pair test against allocation 0: fast level %.4f ms, slow level %.4f ms (threshold %.4f)\n", lo, hi, thr);
+    std::vector<int> colour(pool, -1), rep;
+    colour[0] = 0; rep.push_back(0);
+    for (int q = 1; q < pool; q++) {
+        for (size_t c = 0; c < rep.size() && colour[q] < 0; c++) {
+            const float t = rep[c] == 0 ? t0[q] : pair(rep[c], q);
+            if (t > thr) colour[q] = (int)c;
+        }
+        if (colour[q] < 0) { colour[q] = (int)rep.size(); rep.push_back(q); }
+    }
+    printf("colour of each allocation (in allocation order): ");
+    for (int q = 0; q < pool; q++) printf("%d", colour[q]);
+    printf("\n");
+    const int nc = (int)rep.size();
+    std::vector<std::vector<int>> byc(nc);
+    for (int q = 0; q < pool; q++) byc[colour[q]].push_back(q);
+    for (int c = 0; c < nc; c++) printf("  colour %d: %zu allocations\n", c, byc[c].size());
+    // sets: the 18 arrays of the layout benchmark on pool buffers (the uint16 / uint8 arrays use the front of theirs)
+    auto run_set = [&](const char *name, const std::vector<int> &pick) {
+        Layout L; L.N1 = N1; L.N2 = N2; L.tilesX = N1 / 64; L.tileMode = 0;
+        for (int a = 0; a < NA; a++) { L.base[a] = buf[pick[a]] + G * pl * es_of(a); L.PS[a] = pl * es_of(a); L.BB[a] = 8u * N1 * es_of(a); }
+        const float v8 = timeit([&] { hipLaunchKernelGGL(k_vel<8>, dim3(n8), dim3(64, 8), 0, 0, L, d8, n8); }, 10);
+        const float s8 = timeit([&] { hipLaunchKernelGGL(k_str<8>, dim3(n8), dim3(64, 8), 0, 0, L, d8, n8); }, 10);
+        const float dn = timeit([&] { hipLaunchKernelGGL(k_dense, dim3(n8), dim3(64, 8), 0, 0, L, d8, n8); }, 10);
+        printf("%-34s vel8 %.3f  str8 %.3f  dense %.3f   colours:", name, v8, s8, dn);
+        for (int a = 0; a < NA; a++) printf("%d", colour[pick[a]]);
+        printf("\n");
+        fflush(stdout);
+    };
+    for (int rep_ = 0; rep_ < 2; rep_++) {
+        for (int c = 0; c < nc; c++) {
+            if ((int)byc[c].size() < NA) continue;
+            std::vector<int> pick(byc[c].begin() + (rep_ ? (int)byc[c].size() - NA : 0), byc[c].begin() + (rep_ ? (int)byc[c].size() : NA));
+            char nm[64]; snprintf(nm, sizeof nm, "all arrays in colour %d (%d)", c, rep_);
+            run_set(nm, pick);
+        }
+        if (nc >= 2) {
+            // round robin over the colours in the array order Vx Vy Vz Szz Rzz acc ids | Sxx Syy Sxy Sxz Syz Rxx Ryy Rxy Rxz Ryz class:
+            // both fluid kernels then see their six streams spread evenly
+            std::vector<size_t> used(nc, rep_ ? 3 : 0);
+            std::vector<int> pick(NA);
+            bool ok = true;
+            for (int a = 0; a < NA; a++) { const int c = a % nc; if (used[c] >= byc[c].size()) { ok = false; break; } pick[a] = byc[c][used[c]++]; }
+            if (ok) { char nm[64]; snprintf(nm, sizeof nm, "round robin over %d colours (%d)", nc, rep_); run_set(nm, pick); }
+            // two colours only
+            std::fill(used.begin(), used.end(), rep_ ? 3 : 0); ok = true;
+            for (int a = 0; a < NA; a++) { const int c = a % 2; if (used[c] >= byc[c].size()) { ok = false; break; } pick[a] = byc[c][used[c]++]; }
+            if (ok) { char nm[64]; snprintf(nm, sizeof nm, "alternating colours 0 / 1 (%d)", rep_); run_set(nm, pick); }
+        }
+        {   // allocation order (what separate hipMallocs give)
+            std::vector<int> pick(NA);
+            for (int a = 0; a < NA; a++) pick[a] = (rep_ ? pool - NA : 0) + a;
+            char nm[64]; snprintf(nm, sizeof nm, "allocation order (%d)", rep_);
+            run_set(nm, pick);
+        }
+    }
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
+    if (argc > 2 && std::string(argv[1]) == "colours") return colours(atoi(argv[2]));
     const int draws = argc > 1 ? atoi(argv[1]) : 6;
     const int reps = 12;
     std::vector<int4> r8 = make_runs(8, 16), r16 = make_runs(16, 16);

@@ -14,6 +14,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <algorithm>
+#include <string>
 #include <vector>
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
@@ -80,8 +81,39 @@ template <typename F> static float timeit(F f, int reps)
     return ms / reps;
 }
 
+// mode "regions <GiB>": one block of that size, A at a few positions, B at every 1 GiB of the block: which PAIRS OF POSITIONS are fast?
+static int region_map(size_t gib)
+{
+    const int N1 = 512, N2 = 512, N3 = 256;
+    const long pl = (long)N1 * N2 * 4, arr = pl * N3;
+    char *block;
+    CK(hipMalloc((void **)&block, gib << 30));
+    std::vector<int4> runs = make_runs(N1, N2, N3, 16);
+    int4 *dr;
+    CK(hipMalloc((void **)&dr, runs.size() * sizeof(int4))); CK(hipMemcpy(dr, runs.data(), runs.size() * sizeof(int4), hipMemcpyHostToDevice));
+    const int n = (int)runs.size();
+    printf("block of %zu GiB at %p; two arrays of 256 MiB updated in place at the same cell offset; ms per launch\n", gib, (void *)block);
+    const long posA[] = {0, 20, 70, 140, 33, 100};
+    for (long pa : posA) {
+        if ((size_t)pa + 1 > gib) continue;
+        CK(hipMemset(block + (pa << 30), 0, arr));
+        printf("A at %3ld GiB:", pa);
+        for (long pb = 0; pb + 1 <= (long)gib; pb++) {
+            if (pb == pa) { printf("   -  "); continue; }
+            char *a = block + (pa << 30), *b = block + (pb << 30);
+            CK(hipMemset(b, 0, arr));
+            const float t = timeit([&] { hipLaunchKernelGGL(k_streams<2>, dim3(n), dim3(64, 8), 0, 0, a, (long)(b - a), pl, N1, dr, n); }, 3);
+            printf(" %.3f", t);
+        }
+        printf("\n");
+        fflush(stdout);
+    }
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
+    if (argc > 2 && std::string(argv[1]) == "regions") return region_map((size_t)atol(argv[2]));
     const int N1 = 512, N2 = 512, N3 = 256;          // 256 MiB per array: deltas from 256 MiB up
     const long pl = (long)N1 * N2 * 4, arr = pl * N3;
     const size_t total = (size_t)40 << 30;
