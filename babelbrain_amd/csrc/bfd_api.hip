@@ -1168,15 +1168,24 @@ static int build_tile_lists(bfd_sim *s)
 }
 
 // ---- placement of the per-voxel arrays ----------------------------------------------------------------------------------
-// The tiled kernels stream 6 to 20 arrays at the same cell offset. Where hipMalloc put those arrays decides how often their
-// requests meet on the same HBM channel at the same time: the same kernels on the same data run 1.50 or 1.70 ms per step at
-// C3 depending on nothing but the addresses (scripts/placement_probe.py: constant over a process's lifetime, different from
-// one set of allocations to the next; TLB misses and L2 hit rates equal, TCC_EA0_RDREQ_DRAM_CREDIT_STALL up by 30-90 % on the
-// slow sets; offsets below the 2 MiB allocation granule change nothing, so it is the physical placement). It cannot be
-// predicted from the virtual addresses, so it is measured: before the first step every field is zero and a launch of the
-// tiled kernels changes nothing; they are timed on the current set of arrays and on up to BFD_PLACEMENT_TRIALS (default 6)
-// fresh sets, and the fastest set is kept. Costs a few dozen launches; skipped on small grids, for the fused variant, once a
-// halo pointer has been handed out, or when memory for a second set is short.
+// The tiled kernels stream 6 to 20 arrays at the same cell offset. Round 2 found that the same kernels on the same data run
+// 1.50 or 1.70 ms per step at C3 depending on nothing but where hipMalloc put those arrays, and chose among whole sets of
+// allocations by timing the kernels (a lottery). Round 3 found the cause (scripts/ubench_layout.hip, ubench_pairmap.hip;
+// profiles/r3/placement_*): the 288 GB of HBM fall into three contiguous physical regions of about 90 GiB (the ranks of the
+// 12-high stacks, as far as can be told from outside), and streams that advance together are slow when they all lie in ONE
+// region and fast as soon as they are spread over two: every array in one region 0.98 + 0.76 ms for the two fluid proxies,
+// arrays alternating between two regions 0.86 + 0.68 ms, on every draw. A fresh process gets all its allocations from one
+// region, a fragmented device gives a mix -- the lottery's "fast sets".
+// What counts are the arrays a kernel WRITES (mixing experiment of the same benchmark: the stress proxy turns fast when Szz and
+// Rzz lie apart, whatever V does; the velocity proxy when Vx, Vy, Vz and the accumulator are split two and two).
+// So the arrays are placed, not drawn: a pair probe (two arrays updated in place at the same cell offset along the engine's
+// own runs; zeros stay zeros, so it runs on the initial state) tells whether an array lies in the region of the reference
+// array Vx (about 7 % slower) or in another one. The arrays of the stream order Vx Vy Vz Szz Rzz [Sxx ... Ryz] then alternate
+// between "region of Vx" and "another region": first by exchanging buffers among the 15 state arrays (all the same size, all
+// zero), then, if one kind is short, with freshly allocated candidates (misses are held until the search ends, so that the
+// allocator moves on; bounded by the free memory). The Pressure accumulators are re-allocated likewise when they fall on
+// the wrong side. A few dozen probes of well under a millisecond; results do not depend on it.
+// BFD_PLACEMENT=0 (or BFD_PLACEMENT_TRIALS=0, the round-2 name) switches it off; BFD_PLACEMENT_VERBOSE=1 prints what it does.
 static void bind_state_views(bfd_sim *s)
 {
     bfd_dev &d = s->d;
@@ -1187,25 +1196,17 @@ static void bind_state_views(bfd_sim *s)
     d.VxW = d.Vx; d.VyW = d.Vy; d.VzW = d.Vz; d.SzzW = d.Szz; d.RzzW = d.Rzz;      // in-place variants only (no second copies)
 }
 
-static float time_tiled_kernels(bfd_sim *s, int reps)
+// device time of `reps` pair probes of the arrays at a and b (pointers to local plane 0), planes [0, kmax); < 0 on error
+static float time_pair(bfd_sim *s, float *a, float *b, int kmax, int reps)
 {
-    float *accP = nullptr, *pkP = nullptr;
-    for (int q = 0; q < s->nSelR; q++)
-        if (s->selR[q] == BFD_MAP_PRESSURE) { accP = s->acc ? s->acc + (size_t)q * s->nloc : nullptr; pkP = s->pk ? s->pk + (size_t)q * s->nloc : nullptr; }
     (void)hipGetLastError();                    // a stale error of some earlier call is not this probe's
-    // the probe's own event pair (evBegin / evEnd belong to bfd_timing_begin / _end, whose window may be open) and no
-    // per-kernel marks from its launches
     hipEvent_t e0 = get_event(s), e1 = get_event(s);
     if (!e0 || !e1) { if (e0) s->evPool.push_back(e0); if (e1) s->evPool.push_back(e1); return -1.f; }
-    bfd_sim *const kt = s->tiles.ktimer;
-    s->tiles.ktimer = nullptr;
     for (int r = -1; r < reps; r++) {           // r = -1: untimed
         if (r == 0) hipEventRecord(e0, s->stream);
-        bfd_launch_stress_v2(s->d, s->stream, &s->tiles, 0);
-        bfd_launch_velocity_v2(s->d, s->stream, accP, pkP, &s->tiles, 0);
+        bfd_launch_probe_pair(s->d, s->stream, &s->tiles, a, b, kmax);
     }
     hipEventRecord(e1, s->stream);
-    s->tiles.ktimer = kt;
     float ms = -1.f;
     if (hipEventSynchronize(e1) == hipSuccess && hipGetLastError() == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) ms /= reps;
     else ms = -1.f;
@@ -1215,90 +1216,188 @@ static float time_tiled_kernels(bfd_sim *s, int reps)
 
 static int choose_placement(bfd_sim *s)
 {
-    int trials = 6;
-    if (const char *ev = getenv("BFD_PLACEMENT_TRIALS")) trials = atoi(ev);
+    s->placementNote = "off";
+    bool on = true;
+    if (const char *ev = getenv("BFD_PLACEMENT")) on = atoi(ev) != 0;
+    if (const char *ev = getenv("BFD_PLACEMENT_TRIALS")) on = on && atoi(ev) != 0;
     size_t minVoxels = (size_t)4 << 20;
     if (const char *ev = getenv("BFD_PLACEMENT_MIN_VOXELS")) minVoxels = (size_t)atol(ev);      // tests: exercise it on small grids too
-    if (trials <= 0 || s->step != 0 || s->haloHandedOut || s->pingpong || s->cfg.kernelVariant == 1 || s->nloc < minVoxels) return 0;
+    if (!on) return 0;
+    if (s->step != 0 || s->haloHandedOut || s->pingpong || s->cfg.kernelVariant == 1 || s->nloc < minVoxels || s->d.nk < 8 ||
+        s->tiles.nFluid + s->tiles.nSolid == 0) { s->placementNote = "skipped (small grid, fused variant or arrays already handed out)"; return 0; }
     BFD_HIP(hipSetDevice(s->cfg.device));
-    struct Slot { void **base; size_t bytes; };
-    std::vector<Slot> slots;
-    const bool solids = s->tiles.nSolid > 0 || s->cfg.kernelVariant == 2;
-    static const int fluidSet[5] = {0, 1, 2, 5, 11};                         // Vx, Vy, Vz, Szz, Rzz: all the fluid kernels touch
-    for (int a = 0; a < 15; a++) {
-        const bool inFluidSet = std::find(fluidSet, fluidSet + 5, a) != fluidSet + 5;
-        if (solids || inFluidSet) slots.push_back({(void **)&s->stateBase[a], s->nalloc * sizeof(float)});
-    }
-    slots.push_back({(void **)&s->matBase, s->nalloc * sizeof(uint16_t)});
-    if (solids) slots.push_back({(void **)&s->clsBase, s->nalloc});
-    if (s->tiles.shearCells && s->tiles.nShear > 0) {        // the sparse shear kernel streams its list and coefficients too
-        slots.push_back({(void **)&s->tiles.shearCells, (size_t)s->tiles.nShear * sizeof(unsigned)});
-        slots.push_back({(void **)&s->tiles.shearCoef, 6 * (size_t)s->tiles.nShear * sizeof(float)});
-    }
-    if (s->acc) slots.push_back({(void **)&s->acc, (size_t)s->nSelR * s->nloc * sizeof(float)});
-    if (s->pk) slots.push_back({(void **)&s->pk, (size_t)s->nSelR * s->nloc * sizeof(float)});
-    size_t need = 0;
-    for (const Slot &sl : slots) need += sl.bytes;
-    size_t freeB = 0, totalB = 0;
-    if (hipMemGetInfo(&freeB, &totalB) != hipSuccess || freeB < need + need / 4) return 0;
-
     const bool verbose = getenv("BFD_PLACEMENT_VERBOSE") != nullptr;
-    float best = time_tiled_kernels(s, 3);
-    if (best <= 0) BFD_FAIL(-10, "placement: the tiled kernels failed on the zero state");
-    if (verbose) fprintf(stderr, "placement: %.3f ms per step on the first set of arrays\n", best);
-    std::vector<void *> cur(slots.size()), cand(slots.size());
-    for (size_t q = 0; q < slots.size(); q++) cur[q] = *slots[q].base;
-    // a set that lost stays allocated while the next one is drawn (otherwise hipMalloc hands the same memory out again);
-    // at most one such set at a time
-    std::vector<std::vector<void *>> discarded;
-    auto free_set = [&](const std::vector<void *> &v) {
-        hipStreamSynchronize(s->stream);
-        for (void *p : v) {
-            auto it = std::find(s->allocs.begin(), s->allocs.end(), p);
-            if (it != s->allocs.end()) s->allocs.erase(it);
-            hipFree(p);
-        }
-    };
-    const size_t spacerMax = slots.size() * ((size_t)31 << 21);        // throw-away blocks of a spaced candidate set (62 MiB each at most)
-    for (int t = 0; t < trials; t++) {
-        while (discarded.size() > 1) { free_set(discarded.front()); discarded.erase(discarded.begin()); }
-        // peak = current set + one losing set + the candidate (+ spacers): when memory is short (other engines share the
-        // device) the losing set goes first
-        if (!discarded.empty() && (hipMemGetInfo(&freeB, &totalB) != hipSuccess || freeB < 2 * need + spacerMax)) { free_set(discarded.front()); discarded.clear(); }
-        if (hipMemGetInfo(&freeB, &totalB) != hipSuccess || freeB < need + need / 8 + spacerMax) {
-            for (auto &v : discarded) free_set(v);
-            discarded.clear();
-            if (hipMemGetInfo(&freeB, &totalB) != hipSuccess || freeB < need + need / 8 + spacerMax) break;
-        }
-        bool ok = true;
-        for (size_t q = 0; q < slots.size(); q++) cand[q] = nullptr;
-        // every second candidate set is allocated with throw-away blocks of varying size between its arrays: where memory is
-        // unfragmented, plain allocations come out at a regular stride, which is the slow case
-        std::vector<void *> spacers;
-        const bool spaced = (t % 2) == 1;
-        for (size_t q = 0; q < slots.size() && ok; q++) {
-            if (spaced) {
-                void *sp = nullptr;
-                if (hipMalloc(&sp, (size_t)(((t * 7 + (int)q * 13) % 31) + 1) << 21) == hipSuccess) spacers.push_back(sp); else (void)hipGetLastError();
-            }
-            ok = hipMalloc(&cand[q], slots[q].bytes) == hipSuccess;
-            if (ok) ok = hipMemcpyAsync(cand[q], cur[q], slots[q].bytes, hipMemcpyDeviceToDevice, s->stream) == hipSuccess;
-        }
-        if (!spacers.empty()) { hipStreamSynchronize(s->stream); for (void *sp : spacers) hipFree(sp); }
-        if (!ok) { hipStreamSynchronize(s->stream); for (void *c : cand) if (c) hipFree(c); (void)hipGetLastError(); break; }
-        for (size_t q = 0; q < slots.size(); q++) *slots[q].base = cand[q];
-        bind_state_views(s);
-        const float ms = time_tiled_kernels(s, 3);
-        if (verbose) fprintf(stderr, "placement: %.3f ms per step on set %d%s\n", ms, t + 1, spaced ? " (spaced)" : "");
-        if (ms > 0 && ms < 0.985f * best) { best = ms; discarded.push_back(cur); cur = cand; }
-        else { discarded.push_back(cand); for (size_t q = 0; q < slots.size(); q++) *slots[q].base = cur[q]; bind_state_views(s); }
+    const size_t g = 2 * (size_t)s->d.plane;
+    const int kmax = s->d.nk / 2;
+    const size_t half = (size_t)(s->d.nk - kmax) * s->d.plane;
+    const size_t bytes = s->nalloc * sizeof(float);
+    const int reps = 3;
+    int nProbes = 0;
+    auto pair = [&](float *a, float *b) { nProbes++; return time_pair(s, a, b, kmax, reps); };
+    // Two levels of pair times: "same region" (an array against itself half a slab further on is always one of these) and,
+    // 7-15 % below, "different regions". Their absolute values move with the run lists of the medium, so the threshold is
+    // read off the samples: the five self-pairs and Vx against every other array, sorted; the widest gap below the fastest
+    // self-pair separates the levels if it is wider than 3.5 % (measured gaps: 7-10 %, scatter inside a level up to 5 %
+    // top to bottom but dense); without such a gap every array lies in the region of Vx.
+    float tSame = 0;
+    std::vector<float> samples;
+    for (int a : {0, 1, 2, 5, 11}) {
+        const float t = pair(s->stateBase[a] + g, s->stateBase[a] + g + half);
+        if (t <= 0) BFD_FAIL(-10, "placement: the pair probe failed on the zero state");
+        if (tSame == 0 || t < tSame) tSame = t;
     }
-    for (size_t q = 0; q < slots.size(); q++) *slots[q].base = cur[q];
-    bind_state_views(s);
-    for (auto &v : discarded) free_set(v);
-    for (void *p : cur) if (std::find(s->allocs.begin(), s->allocs.end(), p) == s->allocs.end()) s->allocs.push_back(p);
+    samples.push_back(tSame);
+    std::vector<float> t0(15, 0.f);
+    std::string times;
+    for (int a = 1; a < 15; a++) {
+        t0[a] = pair(s->stateBase[0] + g, s->stateBase[a] + g);
+        if (t0[a] <= 0) BFD_FAIL(-10, "placement: the pair probe failed");
+        if (t0[a] <= tSame) samples.push_back(t0[a]);
+        if (verbose) { char q[48]; snprintf(q, sizeof q, " %d:%.3f", a, t0[a]); times += q; }
+    }
+    std::sort(samples.begin(), samples.end());
+    float thr = 0.95f * samples.front(), widest = 0.f;
+    for (size_t q = 0; q + 1 < samples.size(); q++) {
+        const float gap = samples[q + 1] / samples[q] - 1.0f;
+        if (gap > widest) { widest = gap; if (gap >= 0.035f) thr = 0.5f * (samples[q] + samples[q + 1]); }
+    }
+    // region classes of the 15 state-sized buffers, by comparison with one representative per class
+    struct Buf { float *base; int cls; bool fresh; };
+    std::vector<Buf> pool;
+    std::vector<float *> repOf;                                              // class -> representative (pointer to local plane 0)
+    for (int a = 0; a < 15; a++) {
+        Buf b = {s->stateBase[a], -1, false};
+        for (size_t c = 0; c < repOf.size() && b.cls < 0; c++) {
+            const float t = (c == 0 && a > 0) ? t0[a] : pair(repOf[c], b.base + g);
+            if (t <= 0) BFD_FAIL(-10, "placement: the pair probe failed");
+            if (verbose && c > 0) { char q[48]; snprintf(q, sizeof q, " %d/%zu:%.3f", a, c, t); times += q; }
+            if (t >= thr) b.cls = (int)c;
+        }
+        if (b.cls < 0) { b.cls = (int)repOf.size(); repOf.push_back(b.base + g); }
+        pool.push_back(b);
+    }
+    const bool solids = s->tiles.nSolid > 0 || s->cfg.kernelVariant == 2;
+    // stream order: arrays that a kernel WRITES together are neighbours in this list, and neighbours get different regions:
+    //   velocity kernels write Vx Vy Vz (+ accumulator); stress_fluid Szz Rzz; stress_solid Sxx Syy Szz Rxx Ryy Rzz;
+    //   the sparse shear kernel Sxy Sxz Syz Rxy Rxz Ryz
+    std::vector<int> order = {0, 1, 2, 5, 11};                               // Vx Vy Vz Szz Rzz
+    if (solids) for (int a : {3, 9, 4, 10, 6, 12, 7, 13, 8, 14}) order.push_back(a);   // Sxx Rxx Syy Ryy Sxy Rxy Sxz Rxz Syz Ryz
+    std::string before;
+    for (int a : order) before += (char)('0' + std::min(pool[a].cls, 9));
+    std::vector<char> taken(pool.size(), 0);
+    std::vector<int> slotBuf(15, -1);
+    std::vector<void *> held;                                                // candidates in the wrong region, spacers: freed at the end
+    size_t heldBytes = 0;
+    bool gaveUp = false;
+    int nFresh = 0, nextClass = 100;
+    auto fresh = [&](int avoid) -> int {                                     // allocate until a buffer outside region `avoid` turns up
+        if (avoid < 0 || avoid >= (int)repOf.size()) return -1;
+        while (!gaveUp) {
+            size_t freeB = 0, totalB = 0;
+            if (hipMemGetInfo(&freeB, &totalB) != hipSuccess || freeB < 2 * bytes + totalB / 8 || heldBytes > ((size_t)130 << 30)) { gaveUp = true; break; }
+            float *c = nullptr;
+            if (hipMalloc((void **)&c, bytes) != hipSuccess) { (void)hipGetLastError(); gaveUp = true; break; }
+            if (hipMemsetAsync(c, 0, bytes, s->stream) != hipSuccess) { hipFree(c); gaveUp = true; break; }
+            const float t = pair(repOf[avoid], c + g);
+            if (t > 0 && t < thr) { pool.push_back({c, nextClass++, true}); taken.push_back(0); nFresh++; return (int)pool.size() - 1; }
+            held.push_back(c); heldBytes += bytes;
+            if (t <= 0) { gaveUp = true; break; }
+            // a region is ~90 GiB wide: walk on in growing strides (an unprobed throw-away block as large as everything held so
+            // far, 16 GiB at most) instead of one array at a time
+            const size_t stride = std::min(heldBytes, (size_t)16 << 30);
+            void *sp = nullptr;
+            if (hipMemGetInfo(&freeB, &totalB) == hipSuccess && freeB > stride + 2 * bytes + totalB / 8 && hipMalloc(&sp, stride) == hipSuccess) { held.push_back(sp); heldBytes += stride; }
+            else (void)hipGetLastError();
+        }
+        return -1;
+    };
+    auto other_than = [&](int avoid, int prefer) -> int {                    // an untaken buffer outside region `avoid`
+        if (!taken[prefer] && pool[prefer].cls != avoid) return prefer;
+        for (size_t q = 0; q < pool.size(); q++) if (!taken[q] && pool[q].cls != avoid) return (int)q;
+        return -1;
+    };
+    int prev = -1;                                                            // region of the previous array of the list
+    for (size_t q = 0; q < order.size(); q++) {
+        const int a = order[q];
+        int p = q == 0 ? a : other_than(prev, a);
+        if (p < 0) p = fresh(prev);
+        if (p < 0) { p = !taken[a] ? a : -1; for (size_t u = 0; u < pool.size() && p < 0; u++) if (!taken[u]) p = (int)u; }   // nothing else to be had
+        taken[p] = 1; slotBuf[a] = p; prev = pool[p].cls;
+    }
+    // the arrays outside the list take what is left of the original buffers; unused fresh ones and the held misses are released
+    for (int a = 0; a < 15; a++) {
+        if (slotBuf[a] >= 0) continue;
+        int p = -1;
+        for (size_t q = 0; q < pool.size() && p < 0; q++) if (!taken[q] && !pool[q].fresh) p = (int)q;
+        for (size_t q = 0; q < pool.size() && p < 0; q++) if (!taken[q]) p = (int)q;
+        taken[p] = 1; slotBuf[a] = p;
+    }
     BFD_HIP(hipStreamSynchronize(s->stream));
-    if (verbose) fprintf(stderr, "placement: kept %.3f ms per step\n", best);
+    for (size_t q = 0; q < pool.size(); q++) {
+        if (taken[q]) { if (pool[q].fresh) s->allocs.push_back(pool[q].base); continue; }
+        if (!pool[q].fresh) {                                                 // an original buffer displaced by a fresh one
+            auto it = std::find(s->allocs.begin(), s->allocs.end(), (void *)pool[q].base);
+            if (it != s->allocs.end()) s->allocs.erase(it);
+        }
+        hipFree(pool[q].base);
+    }
+    for (int a = 0; a < 15; a++) s->stateBase[a] = pool[slotBuf[a]].base;
+    bind_state_views(s);
+    // Pressure accumulators: written beside Vx Vy Vz by the velocity kernels: the RMS sums go to another region than Vz, a
+    // peak map beside them to another region than the sums
+    std::string accNote;
+    int sideOfPrev = pool[slotBuf[2]].cls;
+    float *prevRep = s->stateBase[2] + g;
+    for (int which = 0; which < 2; which++) {
+        float **pp = which == 0 ? &s->acc : &s->pk;
+        if (!*pp) continue;
+        int qP = -1;
+        for (int q = 0; q < s->nSelR; q++) if (s->selR[q] == BFD_MAP_PRESSURE) qP = q;
+        if (qP < 0) continue;
+        const size_t accBytes = (size_t)s->nSelR * s->nloc * sizeof(float);
+        float *cur = *pp;
+        float t = pair(prevRep, cur + (size_t)qP * s->nloc);
+        std::vector<void *> miss;
+        while (t >= thr && !gaveUp && miss.size() < 40) {                     // same region as its neighbour: look for another buffer
+            size_t freeB = 0, totalB = 0;
+            if (hipMemGetInfo(&freeB, &totalB) != hipSuccess || freeB < 2 * accBytes + totalB / 8) break;
+            float *c = nullptr;
+            if (hipMalloc((void **)&c, accBytes) != hipSuccess) { (void)hipGetLastError(); break; }
+            if (hipMemsetAsync(c, 0, accBytes, s->stream) != hipSuccess) { hipFree(c); break; }
+            t = pair(prevRep, c + (size_t)qP * s->nloc);
+            if (t > 0 && t < thr) {
+                auto it = std::find(s->allocs.begin(), s->allocs.end(), (void *)cur);
+                if (it != s->allocs.end()) s->allocs.erase(it);
+                hipStreamSynchronize(s->stream);
+                hipFree(cur);
+                cur = c; s->allocs.push_back(c);
+            } else {
+                miss.push_back(c);
+                void *sp = nullptr;                                            // walk on, as above
+                const size_t stride = std::min(miss.size() * accBytes, (size_t)16 << 30);
+                if (hipMemGetInfo(&freeB, &totalB) == hipSuccess && freeB > stride + 2 * accBytes + totalB / 8 && hipMalloc(&sp, stride) == hipSuccess) miss.push_back(sp);
+                else (void)hipGetLastError();
+                if (t <= 0) break;
+            }
+        }
+        hipStreamSynchronize(s->stream);
+        for (void *m : miss) hipFree(m);
+        *pp = cur;
+        accNote += std::string(which == 0 ? " sums " : " peaks ") + (t > 0 && t < thr ? "apart from" : "WITH") + (which == 0 ? " Vz," : " the sums,");
+        prevRep = cur + (size_t)qP * s->nloc;
+        (void)sideOfPrev;
+    }
+    BFD_HIP(hipStreamSynchronize(s->stream));
+    for (void *h : held) hipFree(h);
+    std::string after;
+    for (int a : order) { const int c = pool[slotBuf[a]].cls; after += c >= 100 ? 'n' : (char)('0' + std::min(c, 9)); }
+    char buf[640];
+    snprintf(buf, sizeof buf, "arrays placed by memory region (pair probe on the zero state: %d probes, within-region %.3f ms, threshold %.3f ms, gap between the levels %.0f %%; %zu regions seen): "
+             "regions of %s %s -> %s (n = fresh allocation elsewhere),%s %d fresh, %zu candidates released%s", nProbes, tSame, thr, 100.0 * widest, repOf.size(),
+             solids ? "Vx Vy Vz Szz Rzz Sxx Rxx Syy Ryy Sxy Rxy Sxz Rxz Syz Ryz" : "Vx Vy Vz Szz Rzz", before.c_str(), after.c_str(), accNote.c_str(), nFresh, held.size(),
+             gaveUp ? "; search for another region given up (memory)" : "");
+    s->placementNote = buf;
+    if (verbose) fprintf(stderr, "placement: %s\nplacement: probe times, array:ms against Vx, array/class:ms against the other representatives:%s\n", buf, times.c_str());
     return 0;
 }
 
@@ -1546,6 +1645,13 @@ int bfd_halo_region(bfd_sim *s, int32_t group, int32_t f, int32_t side, int32_t 
     *devPtr = a + kl * (long)d.plane;
     *bytes = 2 * (size_t)d.plane * sizeof(float);
     return 0;
+}
+
+const char *bfd_placement_note(bfd_sim *s)
+{
+    if (!s) return "";
+    if (!s->placementDone) return "not prepared yet";
+    return s->placementNote.c_str();
 }
 
 int bfd_halo_fields(bfd_sim *s, int32_t group, uint32_t *mask)

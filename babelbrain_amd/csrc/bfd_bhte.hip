@@ -8,7 +8,7 @@
 // Scheme (documented restatement; parity with the package unpinned):
 //   T' = T + cd[m] * (((((Txm+Txp)+Tym)+Typ)+Tzm)+Tzp - 6 T) + cp[m] * (Tcore - T) + (n < nStepsOn ? q : 0)
 //   cd = dt k/(rho c dx^2),  cp = dt rho_b c_b w / (6e7 c)  (w in mL/min/kg),  q = dt * duty * a_abs p^2/(rho c_s) / (rho c)
-//   dose += dt/60 * R^(43 - T'),  R = 0.5 for T' >= 43 else 0.25.     Faces of the volume keep their temperature.
+//   dose += dt/60 * R^(43 - T'),  R = 0.5 for T' >= 43 else 0.25 (evaluated as exp2).   Faces of the volume keep their temperature.
 // Bound: HBM (T read + write, q read, dose RMW, uint8 ids: ~21 B per voxel-step); x-fastest layout, one thread per voxel.
 #include "bfd_internal.h"
 #include <math.h>
@@ -34,8 +34,10 @@ __global__ __launch_bounds__(256) void bhte_step(const float *__restrict__ Tin, 
         if (heating) Tn = Tn + q[c];
     }
     Tout[c] = Tn;
-    const float R = Tn >= 43.0f ? 0.5f : 0.25f;
-    dose[c] = dose[c] + dtMin * powf(R, 43.0f - Tn);
+    // R^(43 - T') with R = 0.5 (T' >= 43) or 0.25: a power of two, so one exp2 instead of the generic powf (which set the
+    // pace of this kernel: 0.45 of the HBM peak with it, round 2)
+    const float e = 43.0f - Tn;
+    dose[c] = dose[c] + dtMin * exp2f(Tn >= 43.0f ? -e : -2.0f * e);
 }
 
 __global__ void gather_points(const float *__restrict__ T, const unsigned *__restrict__ idx, float *__restrict__ out, long n, long stride, long col)

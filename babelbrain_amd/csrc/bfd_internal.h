@@ -93,6 +93,7 @@ struct bfd_sim {
     uint16_t *matBase;
     uint8_t *clsBase; bool classesReady;
     bool placementDone, haloHandedOut;   // bfd_prepare: the per-voxel arrays may be moved until a halo pointer has been given out
+    std::string placementNote;           // what choose_placement found and did (bfd_placement_note)
     float *tables;                  // 7*nMat
     float *profiles;                // 4*(N1+N2+N3)
     std::vector<void *> allocs;     // everything to free
@@ -160,6 +161,8 @@ void bfd_launch_cell_classes(const bfd_dev &d, hipStream_t s, uint8_t *clsBase, 
 // [4] active shear edges, [5] reflector cells
 void bfd_launch_count_solid_cells(const bfd_dev &d, hipStream_t s, const int4 *solidRuns, int nSolid, unsigned long long *counts6);
 int bfd_tile_zchunk(void);
+// placement probe: arrays a and b (pointers to local plane 0) updated in place along all runs of the slab, planes [0, kmax)
+void bfd_launch_probe_pair(const bfd_dev &d, hipStream_t s, const bfd_tiles *t, float *a, float *b, int kmax);
 // part: 0 = every tile, 1 = boundary tiles, 2 = interior tiles (variant 2 lists every tile as solid)
 void bfd_launch_stress_v2(const bfd_dev &d, hipStream_t s, const bfd_tiles *t, int part);
 // accP / pkP: Pressure RMS / peak accumulators of this step (slab-local, x-fastest) or nullptr

@@ -1352,6 +1352,27 @@ __global__ __launch_bounds__(NTHREADS, PML ? 4 : SOLID_VELOCITY_WAVES_PER_SIMD) 
     velocity_solid_body<ACC, PML>(d, run, tilesX, sS, accP, pkP);
 }
 
+// placement probe (bfd_api.hip, choose_placement): two float32 arrays updated in place at the same cell offset along the
+// engine's own runs, planes below kmax only. a' = a + b, b' = b + a: the all-zero state of step 0 stays all zero.
+__global__ __launch_bounds__(NTHREADS, 8) void probe_pair(float *__restrict__ a, float *__restrict__ b, long pl, int N1, int N2, int tilesX,
+                                                          int nblocks, const int4 *__restrict__ runs, int kmax)
+{
+    const int4 run = runs[remap_block(blockIdx.x, nblocks)];
+    const int bx = run.x % tilesX, by = run.x / tilesX;
+    const int i = bx * TX + threadIdx.x, j = by * TY + threadIdx.y;
+    const int kbeg = run.y & 0xFFFF, kend = min(run.y >> 16, kmax);
+    if (i >= N1 || j >= N2 || kbeg >= kend) return;
+    const unsigned o = (unsigned)(j * N1 + i) * 4u;
+    float va = F4(a + kbeg * pl, o), vb = F4(b + kbeg * pl, o);
+    for (int kl = kbeg; kl < kend; kl++) {
+        const long ko = (long)kl * pl;
+        float na = 0.f, nb = 0.f;
+        if (kl + 1 < kend) { na = F4(a + ko + pl, o); nb = F4(b + ko + pl, o); }
+        F4(a + ko, o) = va + vb; F4(b + ko, o) = vb + va;
+        va = na; vb = nb;
+    }
+}
+
 // setup: class byte of every allocated cell (local planes -2 .. nk+1). base pointers address allocation plane 0.
 __global__ void cell_classes(bfd_dev d, const uint16_t *__restrict__ matBase, uint8_t *__restrict__ clsBase, long nalloc, int nplanes)
 {
@@ -1614,6 +1635,12 @@ void bfd_tile_grid(const bfd_dev &d, int *tilesX, int *tilesY, int *subZ)
 }
 int bfd_tile_zchunk(void) { return ZCHUNK; }
 int bfd_tile_subz(void) { return SUBZ; }
+
+void bfd_launch_probe_pair(const bfd_dev &d, hipStream_t s, const bfd_tiles *t, float *a, float *b, int kmax)
+{
+    const int n = t->nFluid + t->nSolid;
+    if (n > 0) hipLaunchKernelGGL(probe_pair, dim3(n), dim3(TX, TY, 1), 0, s, a, b, (long)d.plane, d.N1, d.N2, (d.N1 + TX - 1) / TX, n, t->runs, kmax);
+}
 
 void bfd_launch_cell_classes(const bfd_dev &d, hipStream_t s, uint8_t *clsBase, long nalloc)
 {

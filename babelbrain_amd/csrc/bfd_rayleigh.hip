@@ -10,65 +10,87 @@
 //     u2(r_n) = (i k / 2 pi) * sum_m u0_m dS_m exp(-i k R_nm) / R_nm ,   k = k_r + i k_i  (k_i < 0 attenuates)
 //
 // Bound: vector ALU (not HBM, not MFMA: one sqrt + one sincos per source/point pair, no matrix shape).
-// One thread per field point; sources are staged through LDS in blocks and read as broadcasts.
+// Two field points per thread; sources are staged through LDS in blocks and read as broadcasts.
 // Geometry and phase reduction run in float64 (inputs are float32, so differences are exact), the
-// trigonometry and amplitudes in float32, the sums in float64 -- per-term phase error ~1e-7 rad.
+// trigonometry (hardware sine / cosine of the phase in revolutions) and amplitudes in float32, block sums in float32,
+// totals in float64.
 #include "bfd_internal.h"
 #include <math.h>
 
 namespace {
 
-constexpr int RB = 256;      // threads per workgroup = field points per workgroup
+constexpr int RB = 256;      // threads per workgroup
+constexpr int PPL = 2;       // field points per lane: every source record read from LDS serves two pairs
 constexpr int SB = 512;      // sources per LDS block
 
+// Per pair: float64 difference vector and squared distance (the inputs are float32, so the differences are exact), 1/R from
+// the float32 rsqrt refined by one Newton step in float64, phase k R / 2 pi reduced to [0,1) in float64, then the hardware
+// sine / cosine (v_sin_f32 / v_cos_f32 take their argument in revolutions), amplitudes in float32. A block of 512 sources is
+// summed in float32 and added to the float64 sums of the point. Round 2 spent ~70 vector instructions per pair (libm sincosf,
+// float64 accumulation of every term, five scalar LDS reads per pair); this form about half of that.
 __global__ __launch_bounds__(RB) void rayleigh_forward(const float *__restrict__ cen, const float *__restrict__ ds,
                                                        const float *__restrict__ u0, long nSrc, double kr, double ki,
                                                        const float *__restrict__ rf, long nPts, float *__restrict__ out)
 {
-    __shared__ float sx[SB], sy[SB], sz[SB], sre[SB], sim[SB];
-    const long n = (long)blockIdx.x * RB + threadIdx.x;
-    const bool live = n < nPts;
-    double px = 0, py = 0, pz = 0;
-    if (live) { px = rf[3 * n]; py = rf[3 * n + 1]; pz = rf[3 * n + 2]; }
+    __shared__ float4 sA[SB];        // x, y, z, re(u0 dS)
+    __shared__ float sB[SB];         // im(u0 dS)
+    const long n0 = ((long)blockIdx.x * RB + threadIdx.x) * PPL;
+    double px[PPL], py[PPL], pz[PPL], accr[PPL], acci[PPL];
+#pragma unroll
+    for (int p = 0; p < PPL; p++) {
+        const long n = min(n0 + p, nPts - 1);
+        px[p] = rf[3 * n]; py[p] = rf[3 * n + 1]; pz[p] = rf[3 * n + 2];
+        accr[p] = 0.0; acci[p] = 0.0;
+    }
     const double krev = kr * (1.0 / (2.0 * M_PI));      // phase in revolutions
-    double accr = 0.0, acci = 0.0;
+    const float kif = (float)ki;
     for (long base = 0; base < nSrc; base += SB) {
         const int cnt = (int)min((long)SB, nSrc - base);
         for (int q = threadIdx.x; q < cnt; q += RB) {
             const long m = base + q;
             const float a = ds[m];
-            sx[q] = cen[3 * m]; sy[q] = cen[3 * m + 1]; sz[q] = cen[3 * m + 2];
-            sre[q] = u0[2 * m] * a; sim[q] = u0[2 * m + 1] * a;
+            sA[q] = make_float4(cen[3 * m], cen[3 * m + 1], cen[3 * m + 2], u0[2 * m] * a);
+            sB[q] = u0[2 * m + 1] * a;
         }
         __syncthreads();
-        if (live) {
-#pragma unroll 4
-            for (int q = 0; q < cnt; q++) {
-                const double dx = px - (double)sx[q], dy = py - (double)sy[q], dz = pz - (double)sz[q];
+        float br[PPL], bi[PPL];
+#pragma unroll
+        for (int p = 0; p < PPL; p++) { br[p] = 0.f; bi[p] = 0.f; }
+#pragma unroll 2
+        for (int q = 0; q < cnt; q++) {
+            const float4 s = sA[q];
+            const float sim = sB[q];
+#pragma unroll
+            for (int p = 0; p < PPL; p++) {
+                const double dx = px[p] - (double)s.x, dy = py[p] - (double)s.y, dz = pz[p] - (double)s.z;
                 const double r2 = dx * dx + dy * dy + dz * dz;
-                // 1/R: float estimate refined by one Newton step in float64
                 double inv = (double)rsqrtf((float)r2);
                 inv = inv * (1.5 - 0.5 * r2 * inv * inv);
                 const double R = r2 * inv;
                 const double rev = R * krev;
-                const float fr = (float)(rev - floor(rev));           // phase / 2pi in [0,1)
-                float sn, cs;
-                sincosf(fr * 6.283185307179586f, &sn, &cs);
+                const float fr = (float)(rev - floor(rev));           // phase / 2 pi in [0,1)
+                const float sn = __builtin_amdgcn_sinf(fr), cs = __builtin_amdgcn_cosf(fr);
                 float amp = (float)inv;
-                if (ki != 0.0) amp *= expf((float)(ki * R));     // exp(-i k R) with complex k: Im k < 0 attenuates
-                // exp(-i k R) = amp * (cos - i sin)
-                const float er = amp * cs, ei = -amp * sn;
-                accr += (double)(sre[q] * er - sim[q] * ei);
-                acci += (double)(sre[q] * ei + sim[q] * er);
+                if (ki != 0.0) amp *= __expf(kif * (float)R);        // exp(-i k R) with complex k: Im k < 0 attenuates
+                // (re + i im) * amp * (cos - i sin)
+                const float er = amp * cs, ei = amp * sn;
+                br[p] += s.w * er + sim * ei;
+                bi[p] += sim * er - s.w * ei;
             }
         }
+#pragma unroll
+        for (int p = 0; p < PPL; p++) { accr[p] += (double)br[p]; acci[p] += (double)bi[p]; }
         __syncthreads();
     }
-    if (live) {
-        // multiply by i k / (2 pi):  (i kr - ki) (a + i b) / 2pi
-        const double c = 1.0 / (2.0 * M_PI);
-        out[2 * n] = (float)((-ki * accr - kr * acci) * c);
-        out[2 * n + 1] = (float)((kr * accr - ki * acci) * c);
+    // multiply by i k / (2 pi):  (i kr - ki) (a + i b) / 2pi
+    const double c = 1.0 / (2.0 * M_PI);
+#pragma unroll
+    for (int p = 0; p < PPL; p++) {
+        const long n = n0 + p;
+        if (n < nPts) {
+            out[2 * n] = (float)((-ki * accr[p] - kr * acci[p]) * c);
+            out[2 * n + 1] = (float)((kr * accr[p] - ki * acci[p]) * c);
+        }
     }
 }
 
@@ -98,7 +120,7 @@ extern "C" int bfd_rayleigh_forward(int32_t device, int64_t nSrc, const float *c
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (e == hipSuccess) { hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, 0); }
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(rayleigh_forward, dim3((unsigned)((nPts + RB - 1) / RB)), dim3(RB), 0, 0, dc, dd, du, (long)nSrc, kReal, kImag, dr, (long)nPts, dout);
+        hipLaunchKernelGGL(rayleigh_forward, dim3((unsigned)((nPts + RB * PPL - 1) / (RB * PPL))), dim3(RB), 0, 0, dc, dd, du, (long)nSrc, kReal, kImag, dr, (long)nPts, dout);
         e = hipGetLastError();
     }
     if (e == hipSuccess) { hipEventRecord(e1, 0); e = hipEventSynchronize(e1); }

@@ -189,6 +189,12 @@ class SlabRunner:
             cache[halo_group] = (ops, nbytes)
         return cache[halo_group]
 
+    def bytes_per_step(self):
+        """Bytes this rank sends per time step (both halo groups, both neighbours)."""
+        if self.world == 1:
+            return 0
+        return sum(self._ops(g)[1] for g in (HALO_VELOCITY, HALO_STRESS))
+
     def exchange_start(self, halo_group):
         if self.world == 1:
             return []

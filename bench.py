@@ -57,6 +57,9 @@ def parse():
     ap.add_argument('--debug-gloo-shared-gpu', action='store_true', help='debug only: N ranks on GPU 0, gloo backend, halos staged through the host (validates the multi-rank code path on a 1-GPU box)')
     ap.add_argument('--lean-host', action='store_true', help='build the inputs slab-style (size-1 Ox/Oy/Oz) also at N=1')
     ap.add_argument('--cpu-sample', type=int, nargs=4, default=[384, 384, 256, 64], help='N1 N2 N3 steps of the oracle sample')
+    ap.add_argument('--no-extra-strong', action='store_true', help='N > 1: skip the extra block that splits ONE C5 volume (1024^3, 1 MHz) over the ranks')
+    ap.add_argument('--extra-strong-steps', type=int, default=40, help='timed steps of the extra strong-scaling block')
+    ap.add_argument('--no-single-domain-check', action='store_true', help='N > 1: skip the small-grid run that compares the N-slab exchange with a single-domain run')
     return ap.parse_args()
 
 
@@ -188,10 +191,12 @@ class Workload:
         self.eng.timing_begin(False)       # one event pair around the whole window; the per-kernel split comes from kernel_pass
         t0 = time.perf_counter()
         self.runner.run(self.steps)
+        issue = time.perf_counter() - t0       # the host is done queueing; what remains of the wall time is the GPU catching up
         torch.cuda.synchronize()
         self.barrier()
         wall = time.perf_counter() - t0
         tm = self.eng.timing_end()
+        tm['host_issue_ms_per_step'] = issue / self.steps * 1e3
         if self.world > 1:
             dev = 'cpu' if dist.get_backend() == 'gloo' else 'cuda'
             w = torch.tensor([wall], dtype=torch.float64, device=dev)
@@ -229,13 +234,45 @@ class Workload:
         self.slab.close()
 
 
+def single_domain_check(args, rank, world, local_rank, dist, dt_fn):
+    """world > 1: the exchange itself, against a run without one. A small grid of C2's medium (bone with shear: every halo
+    field travels) is cut into `world` Z-slabs of 64 planes and stepped with the very SlabRunner / transport of the
+    timed run (overlapped order) until the wave has crossed every interface; rank 0 also runs the whole grid on its one
+    GPU and compares every slab's Pressure RMS map bit for bit."""
+    import torch
+    from babelbrain_amd import harness as H, slab, PropagationModel
+    from babelbrain_amd._engine import KIND_RMS
+    shared = args.debug_gloo_shared_gpu
+    N = (128, 128, 64 * world)
+    steps = int(math.ceil((64 * (world - 1) + 12) / 0.13)) + 60       # 0.136 cells per step in water at C2's time step
+    a, k, info = H.make_problem('C2', N=N, steps=steps, stable_dt_fn=dt_fn, full_sensors=False)
+    s, sinfo = slab.create_hip_slab(a, k, rank, world, local_rank, kernelVariant=args.variant, host_staging=shared)
+    r = slab.SlabRunner(s, rank, world, dist, overlap=False if shared else True)
+    r.run(steps)
+    torch.cuda.synchronize()
+    mine = s.eng.get_map(KIND_RMS, 'Pressure')
+    s.close()
+    parts = [None] * world
+    dist.all_gather_object(parts, mine)
+    res = None
+    if rank == 0:
+        ref = PropagationModel(device=local_rank, kernelVariant=args.variant).StaggeredFDTD_3D_with_relaxation(*a, SILENT=True, **k)[2]['Pressure']
+        whole = np.concatenate(parts, axis=2)
+        res = {'grid': list(N), 'steps': steps, 'order': 'overlapped' if r.overlap else 'blocking',
+               'equals_single_domain': bool(np.array_equal(whole, ref)), 'wave_reached_last_slab': bool(ref[:, :, -64:].max() > 0)}
+    out = [res]
+    dist.broadcast_object_list(out, src=0)
+    return out[0]
+
+
 def measure(w, args, traffic):
     """Runs the passes of one workload; returns the fields of its JSON block (rank 0 uses them)."""
     check = w.check_exchange()
     wall, tm = w.timed()
     value = w.total_vox * w.steps / wall / 1e6
     out = {'value': value, 'ms_per_step': wall / w.steps * 1e3, 'exchange_check': check,
-           'device_ms_per_step': tm['total_ms'] / w.steps, 'half_steps': None}
+           'device_ms_per_step': tm['total_ms'] / w.steps, 'half_steps': None,
+           'host_issue_ms_per_step': tm['host_issue_ms_per_step']}
     if w.variant != 1:
         alg = w.eng.algorithmic_bytes(True)
         step_bytes = sum(alg.values())
@@ -286,6 +323,12 @@ def main():
     def dt_fn(ml, f, h, acfl):
         return _engine.stable_dt(ml, f, True, h, acfl)
 
+    sd_check = None
+    if world > 1 and not args.no_single_domain_check and args.variant != 1:
+        try:
+            sd_check = single_domain_check(args, rank, world, local_rank, dist, dt_fn)
+        except Exception as e:      # a failed check is reported, it never takes the bench line away
+            sd_check = {'equals_single_domain': None, 'error': repr(e)}
     cfg = H.CONFIGS[args.config]
     dims = tuple(args.size) if args.size else cfg['N']
     w = Workload(args, args.config, dims, args.scaling, rank, world, local_rank, dist, dt_fn, args.steps, args.warmup, args.variant)
@@ -305,10 +348,10 @@ def main():
                        'parallelism': 'z-slab x%d' % world, 'kernel_variant': args.variant, 'dt': info['dt'], 'ppp': info['ppp'],
                        'n_sources': info['n_sources'], 'n_sensors_rank0': int(eng.num_sensors), 'tiles_rank0': eng.tile_counts() if args.variant != 1 else None,
                        'halo_exchange': 'overlapped' if w.runner.overlap else ('none' if world == 1 else 'blocking'),
-                       'halo_exchange_check': res['exchange_check'],
-                       'array_placement': ('first allocation' if os.environ.get('BFD_PLACEMENT_TRIALS', '6') in ('0', '') else
-                                           'fastest of 1 + %s sets of allocations, timed on the zero state before the run (bfd_prepare)' % os.environ.get('BFD_PLACEMENT_TRIALS', '6')), 'untimed_steps_before_window': args.warmup + w.extra_warmup},
+                       'halo_exchange_check': res['exchange_check'], 'halo_exchange_vs_single_domain': sd_check,
+                       'array_placement': eng.placement_note(), 'untimed_steps_before_window': args.warmup + w.extra_warmup},
             'device_ms_per_step': res['device_ms_per_step'], 'half_steps_ms': res['half_steps'],
+            'host_issue_ms_per_step': res['host_issue_ms_per_step'],
             'device_bytes': int(eng.device_bytes), 'host_build_s': w.host_build_s,
         }
         rows = res.get('roofline_kernels')
@@ -330,6 +373,25 @@ def main():
             line['roofline_step'] = res['roofline_step']
     w.close()
 
+    if world > 1 and not args.no_extra_strong and not (args.config == 'C5' and args.scaling == 'strong'):
+        # the curve BASELINE.json's north_star names: ONE 1024^3 volume (C5, 1 MHz) split over the N ranks -- beside the weak-
+        # scaling headline above, in the same line, because the driver's invocation carries no --config / --scaling
+        try:
+            c5 = H.CONFIGS['C5']['N']
+            wx = Workload(args, 'C5', c5, 'strong', rank, world, local_rank, dist, dt_fn, max(args.extra_strong_steps, 40), min(args.warmup, 20), args.variant,
+                          full_sensors=False)
+            sx = measure(wx, argparse.Namespace(**dict(vars(args), no_kernel_pass=True)), {})
+            if rank == 0:
+                line['extra_strong_c5'] = {'workload': 'C5 1024^3 (1 MHz, water / cortical bone with shear / brain), ONE volume split into %d Z-slabs of %d planes' % (world, wx.sinfo['nk']),
+                                           'scaling': 'strong', 'value': sx['value'], 'unit': 'Mvoxel-steps/s', 'steps': wx.steps, 'warmup': wx.warmup + wx.extra_warmup,
+                                           'ms_per_step': sx['ms_per_step'], 'device_ms_per_step': sx['device_ms_per_step'],
+                                           'host_issue_ms_per_step': sx['host_issue_ms_per_step'], 'halo_exchange': 'overlapped' if wx.runner.overlap else 'blocking',
+                                           'halo_exchange_check': sx['exchange_check'], 'halo_bytes_sent_rank0_per_step': wx.runner.bytes_per_step(),
+                                           'roofline_step': sx.get('roofline_step'), 'array_placement': wx.eng.placement_note()}
+            wx.close()
+        except Exception as e:
+            if rank == 0:
+                line['extra_strong_c5'] = {'value': None, 'error': repr(e)}
     if world == 1 and not args.no_shear_workload and args.variant in (0, 3) and args.config == 'C3' and not args.size:
         # the viscoelastic kernels: C2's medium (water / cortical bone with shear / brain) on the same 512^3 grid, same K/W
         try:

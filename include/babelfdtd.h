@@ -150,13 +150,16 @@ int bfd_half_step_stress_part_on(bfd_sim *sim, int32_t part, void *hipStream);
 int bfd_half_step_velocity_part_on(bfd_sim *sim, int32_t part, void *hipStream);
 int bfd_sync(bfd_sim *sim);
 int bfd_current_step(bfd_sim *sim);
-/* Everything the first step would otherwise do on entry: per-cell classes, run lists, and the choice of where the per-voxel
- * arrays live. The tiled kernels are timed on the (all-zero) initial state for the current set of arrays and for up to
- * BFD_PLACEMENT_TRIALS (environment, default 6, 0 = off) freshly allocated sets, and the fastest set is kept: where the
- * arrays land in HBM changes the speed of the same kernels on the same data by up to 12 %. Results
- * do not depend on it. bfd_run and the half-step calls do this by themselves at step 0; call it explicitly BEFORE
- * bfd_halo_region when halo pointers are taken ahead of the first step (pointers handed out pin the arrays). */
+/* Everything the first step would otherwise do on entry: per-cell classes, run lists, and the placement of the per-voxel
+ * arrays: streams that advance together are 12 % slower when all of them lie in one of the three physical regions of the
+ * HBM than when they are spread over two, so a pair probe on the (all-zero) initial state finds the
+ * region of every array relative to Vx and the arrays a kernel reads together are made to alternate -- by exchanging
+ * buffers, and with fresh allocations where one side is short. BFD_PLACEMENT=0 switches it off. Results do not depend on
+ * it. bfd_run and the half-step calls do this by themselves at step 0; call it explicitly BEFORE bfd_halo_region when halo
+ * pointers are taken ahead of the first step (pointers handed out pin the arrays). */
 int bfd_prepare(bfd_sim *sim);
+/* one line on what the placement found and did (valid until the sim is destroyed) */
+const char *bfd_placement_note(bfd_sim *sim);
 
 /* device pointer/bytes of a halo region: field f (0..2 within the group), side 0 = low-k face,
  * 1 = high-k face; send = 1: the 2 owned boundary planes, send = 0: the 2 ghost planes.

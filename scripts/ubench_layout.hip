@@ -338,6 +338,24 @@ static int colours(int pool)
     std::vector<float> t0(pool, 0.f);
     float lo = 1e9f, hi = 0.f;
     for (int q = 1; q < pool; q++) { t0[q] = pair(0, q); lo = std::min(lo, t0[q]); hi = std::max(hi, t0[q]); }
+    {   // the raw pair times: how many levels are there?
+        std::vector<float> srt(t0.begin() + 1, t0.end());
+        std::sort(srt.begin(), srt.end());
+        printf("pair times against allocation 0, sorted:");
+        for (size_t q = 0; q < srt.size(); q++) printf(" %.4f", srt[q]);
+        printf("\n");
+        // the same allocation against itself, second stream half an array further on (same physical region for sure)
+        std::vector<int4> rh;
+        for (const int4 &r : make_runs(8, 16)) if (r.w <= N3 / 2) rh.push_back(r);
+        int4 *dh;
+        CK(hipMalloc((void **)&dh, rh.size() * sizeof(int4))); CK(hipMemcpy(dh, rh.data(), rh.size() * sizeof(int4), hipMemcpyHostToDevice));
+        const int nh = (int)rh.size();
+        for (int q = 0; q < 12; q++) {
+            const float t = timeit([&] { hipLaunchKernelGGL(k_pair, dim3(nh), dim3(64, 8), 0, 0, buf[q] + G * pl * 4, buf[q] + G * pl * 4 + (N3 / 2) * pl * 4, pl * 4, N1, dh, nh); }, 4);
+            const float u = timeit([&] { hipLaunchKernelGGL(k_pair, dim3(nh), dim3(64, 8), 0, 0, buf[0] + G * pl * 4, buf[q] + G * pl * 4, pl * 4, N1, dh, nh); }, 4);
+            printf("allocation %d: lower half with its own upper half %.4f ms; lower half with allocation 0's lower half %.4f ms (half-volume march)\n", q, t, u);
+        }
+    }
     const float thr = 0.5f * (lo + hi);
     printf("pair test against allocation 0: fast level %.4f ms, slow level %.4f ms (threshold %.4f)\n", lo, hi, thr);
     std::vector<int> colour(pool, -1), rep;
@@ -368,6 +386,47 @@ static int colours(int pool)
         printf("\n");
         fflush(stdout);
     };
+    if (nc >= 2 && byc[0].size() >= NA && byc[1].size() >= NA) {
+        // how many arrays of the other colour does it take? arrays Vx Vy Vz Szz Rzz acc ids Sxx ... in colour 0, except the listed ones
+        auto mixed = [&](const char *name, std::vector<int> other) {
+            std::vector<int> pick(NA);
+            size_t u0 = 0, u1 = 0;
+            for (int a = 0; a < NA; a++) pick[a] = std::find(other.begin(), other.end(), a) != other.end() ? byc[1][u1++] : byc[0][u0++];
+            run_set(name, pick);
+        };
+        mixed("colour 1: Szz", {A_SZZ});
+        mixed("colour 1: Vx", {A_VX});
+        mixed("colour 1: ids", {A_MAT});
+        mixed("colour 1: acc, Rzz", {A_ACC, A_RZZ});
+        mixed("colour 1: Szz, acc, Rzz", {A_SZZ, A_ACC, A_RZZ});
+        mixed("colour 1: Vx, Vy", {A_VX, A_VY});
+        mixed("colour 1: Vx, Vy, Vz", {A_VX, A_VY, A_VZ});
+        mixed("colour 1: Vx, Vy, Vz, ids", {A_VX, A_VY, A_VZ, A_MAT});
+        mixed("colour 1: Vz, Szz", {A_VZ, A_SZZ});
+        mixed("colour 1: Vy, Szz, acc", {A_VY, A_SZZ, A_ACC});
+        mixed("colour 1: the 11 solid-only arrays", {A_SXX, A_SYY, A_SXY, A_SXZ, A_SYZ, A_RXX, A_RYY, A_RXY, A_RXZ, A_RYZ, A_CLS});
+        mixed("colour 1: every second solid-only", {A_SXX, A_SXY, A_SYZ, A_RYY, A_RXZ, A_CLS});
+    }
+    {   // are large allocations of one colour throughout? four blocks of 8 GiB, every 512 MiB of them against one representative per colour
+        const size_t big = (size_t)8 << 30;
+        for (int b = 0; b < 4; b++) {
+            char *blk;
+            if (hipMalloc((void **)&blk, big) != hipSuccess) { (void)hipGetLastError(); break; }
+            CK(hipMemset(blk, 0, big));
+            printf("8 GiB allocation %d at %p, colour of every 512 MiB: ", b, (void *)blk);
+            for (size_t off = 0; off + bytes <= big; off += (size_t)512 << 20) {
+                int found = -1;
+                for (int c = 0; c < nc && found < 0; c++) {
+                    char *x = buf[rep[c]] + G * pl * 4, *y = blk + off + G * pl * 4;
+                    const float t = timeit([&] { hipLaunchKernelGGL(k_pair, dim3(np), dim3(64, 8), 0, 0, x, y, pl * 4, N1, dp, np); }, 4);
+                    if (t > thr) found = c;
+                }
+                printf("%c", found < 0 ? '?' : '0' + found);
+            }
+            printf("\n");
+            // deliberately not freed: the next block comes from elsewhere
+        }
+    }
     for (int rep_ = 0; rep_ < 2; rep_++) {
         for (int c = 0; c < nc; c++) {
             if ((int)byc[c].size() < NA) continue;

@@ -97,7 +97,7 @@ def test_group_c_abi_with_x_fastest_views_and_reset():
             out = np.zeros(MaterialMap.shape, np.float32, order='F')
             g.get_map(_engine.KIND_RMS, 'Pressure', out)
             assert np.array_equal(out, ref[2]['Pressure'])
-            assert np.array_equal(g.sensors()[0], ref[0]['Pressure'])
+            assert np.array_equal(g.sensors()[g.selS.index('Pressure')], ref[0]['Pressure'])
             assert np.array_equal(g.sensor_index(), ref[-1]['IndexSensorMap'])
             g.reset()
         k0, nk, dev, view = g.slab(1)
