@@ -10,6 +10,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <thread>
 #include <hipcub/hipcub.hpp>
 
@@ -1220,12 +1221,15 @@ static int choose_placement(bfd_sim *s)
     bool on = true;
     if (const char *ev = getenv("BFD_PLACEMENT")) on = atoi(ev) != 0;
     if (const char *ev = getenv("BFD_PLACEMENT_TRIALS")) on = on && atoi(ev) != 0;
-    size_t minVoxels = (size_t)4 << 20;
+    // below ~32 M voxels the arrays a kernel streams (5 x 4 B per voxel and up) fit the 256 MB memory-side cache, where they lie
+    // in DRAM stops mattering, and the probe (0.02 ms at 256^3) cannot tell the regions apart any more
+    size_t minVoxels = (size_t)32 << 20;
     if (const char *ev = getenv("BFD_PLACEMENT_MIN_VOXELS")) minVoxels = (size_t)atol(ev);      // tests: exercise it on small grids too
     if (!on) return 0;
     if (s->step != 0 || s->haloHandedOut || s->pingpong || s->cfg.kernelVariant == 1 || s->nloc < minVoxels || s->d.nk < 8 ||
         s->tiles.nFluid + s->tiles.nSolid == 0) { s->placementNote = "skipped (small grid, fused variant or arrays already handed out)"; return 0; }
     BFD_HIP(hipSetDevice(s->cfg.device));
+    const auto tStart = std::chrono::steady_clock::now();
     const bool verbose = getenv("BFD_PLACEMENT_VERBOSE") != nullptr;
     const size_t g = 2 * (size_t)s->d.plane;
     const int kmax = s->d.nk / 2;
@@ -1277,52 +1281,62 @@ static int choose_placement(bfd_sim *s)
         pool.push_back(b);
     }
     const bool solids = s->tiles.nSolid > 0 || s->cfg.kernelVariant == 2;
-    // stream order: arrays that a kernel WRITES together are neighbours in this list, and neighbours get different regions:
+    // stream order: arrays that a kernel WRITES together are neighbours in this list, and the list alternates between the
+    // most populated region M and "anywhere else":
     //   velocity kernels write Vx Vy Vz (+ accumulator); stress_fluid Szz Rzz; stress_solid Sxx Syy Szz Rxx Ryy Rzz;
     //   the sparse shear kernel Sxy Sxz Syz Rxy Rxz Ryz
     std::vector<int> order = {0, 1, 2, 5, 11};                               // Vx Vy Vz Szz Rzz
     if (solids) for (int a : {3, 9, 4, 10, 6, 12, 7, 13, 8, 14}) order.push_back(a);   // Sxx Rxx Syy Ryy Sxy Rxy Sxz Rxz Syz Ryz
     std::string before;
     for (int a : order) before += (char)('0' + std::min(pool[a].cls, 9));
-    std::vector<char> taken(pool.size(), 0);
-    std::vector<int> slotBuf(15, -1);
-    std::vector<void *> held;                                                // candidates in the wrong region, spacers: freed at the end
+    int M = 0;
+    {
+        std::vector<int> cnt(repOf.size(), 0);
+        for (const Buf &b : pool) cnt[b.cls]++;
+        for (size_t c = 0; c < cnt.size(); c++) if (cnt[c] > cnt[M]) M = (int)c;
+    }
+    auto sideOf = [&](const Buf &b) { return b.cls == M ? 0 : 1; };            // 0: region M, 1: elsewhere
+    int need[2] = {(int)(order.size() + 1) / 2, (int)order.size() / 2};
+    for (const Buf &b : pool) need[sideOf(b)]--;                              // spare arrays count: their buffers can be exchanged in
+    std::vector<void *> held;                                                // candidates on the side that is not short, spacers: freed at the end
     size_t heldBytes = 0;
     bool gaveUp = false;
-    int nFresh = 0, nextClass = 100;
-    auto fresh = [&](int avoid) -> int {                                     // allocate until a buffer outside region `avoid` turns up
-        if (avoid < 0 || avoid >= (int)repOf.size()) return -1;
-        while (!gaveUp) {
-            size_t freeB = 0, totalB = 0;
-            if (hipMemGetInfo(&freeB, &totalB) != hipSuccess || freeB < 2 * bytes + totalB / 8 || heldBytes > ((size_t)130 << 30)) { gaveUp = true; break; }
-            float *c = nullptr;
-            if (hipMalloc((void **)&c, bytes) != hipSuccess) { (void)hipGetLastError(); gaveUp = true; break; }
-            if (hipMemsetAsync(c, 0, bytes, s->stream) != hipSuccess) { hipFree(c); gaveUp = true; break; }
-            const float t = pair(repOf[avoid], c + g);
-            if (t > 0 && t < thr) { pool.push_back({c, nextClass++, true}); taken.push_back(0); nFresh++; return (int)pool.size() - 1; }
-            held.push_back(c); heldBytes += bytes;
-            if (t <= 0) { gaveUp = true; break; }
-            // a region is ~90 GiB wide: walk on in growing strides (an unprobed throw-away block as large as everything held so
-            // far, 16 GiB at most) instead of one array at a time
-            const size_t stride = std::min(heldBytes, (size_t)16 << 30);
-            void *sp = nullptr;
-            if (hipMemGetInfo(&freeB, &totalB) == hipSuccess && freeB > stride + 2 * bytes + totalB / 8 && hipMalloc(&sp, stride) == hipSuccess) { held.push_back(sp); heldBytes += stride; }
-            else (void)hipGetLastError();
-        }
+    int nFresh = 0;
+    bool probeTells = tSame >= 0.05f;                                          // ms; shorter probes are launch overhead, not memory time
+    size_t heldCap = (size_t)100 << 30;
+    if (const char *ev = getenv("BFD_PLACEMENT_SEARCH_MB")) { probeTells = true; heldCap = (size_t)atol(ev) << 20; }   // tests: walk a little on any grid
+    while ((need[0] > 0 || need[1] > 0) && !gaveUp && probeTells) {            // draw candidates until both sides have enough
+        size_t freeB = 0, totalB = 0;
+        if (hipMemGetInfo(&freeB, &totalB) != hipSuccess || freeB < 2 * bytes + totalB / 8 || heldBytes > heldCap) { gaveUp = true; break; }
+        float *c = nullptr;
+        if (hipMalloc((void **)&c, bytes) != hipSuccess) { (void)hipGetLastError(); gaveUp = true; break; }
+        if (hipMemsetAsync(c, 0, bytes, s->stream) != hipSuccess) { hipFree(c); gaveUp = true; break; }
+        const float t = pair(repOf[M], c + g);
+        if (t <= 0) { hipFree(c); gaveUp = true; break; }
+        const int side = t >= thr ? 0 : 1;
+        if (need[side] > 0) { pool.push_back({c, side == 0 ? M : 100 + nFresh, true}); need[side]--; nFresh++; continue; }
+        held.push_back(c); heldBytes += bytes;
+        // a region is ~90 GiB wide: walk on in growing strides (an unprobed throw-away block as large as everything held so
+        // far, 4 GiB at most: hipMalloc of 4 GiB takes 0.3 ms, of 16 GiB 650 ms -- scripts/r3/malloc_cost.hip) instead of one
+        // array at a time
+        const size_t stride = std::min(heldBytes, (size_t)4 << 30);
+        void *sp = nullptr;
+        if (hipMemGetInfo(&freeB, &totalB) == hipSuccess && freeB > stride + 2 * bytes + totalB / 8 && hipMalloc(&sp, stride) == hipSuccess) { held.push_back(sp); heldBytes += stride; }
+        else (void)hipGetLastError();
+    }
+    std::vector<char> taken(pool.size(), 0);
+    std::vector<int> slotBuf(15, -1);
+    auto pick = [&](int side, int prefer) -> int {
+        if (!taken[prefer] && sideOf(pool[prefer]) == side) return prefer;
+        for (int pass = 0; pass < 2; pass++)                                   // original buffers first, fresh ones after
+            for (size_t q = 0; q < pool.size(); q++) if (!taken[q] && sideOf(pool[q]) == side && pool[q].fresh == (pass == 1)) return (int)q;
         return -1;
     };
-    auto other_than = [&](int avoid, int prefer) -> int {                    // an untaken buffer outside region `avoid`
-        if (!taken[prefer] && pool[prefer].cls != avoid) return prefer;
-        for (size_t q = 0; q < pool.size(); q++) if (!taken[q] && pool[q].cls != avoid) return (int)q;
-        return -1;
-    };
-    int prev = -1;                                                            // region of the previous array of the list
     for (size_t q = 0; q < order.size(); q++) {
         const int a = order[q];
-        int p = q == 0 ? a : other_than(prev, a);
-        if (p < 0) p = fresh(prev);
-        if (p < 0) { p = !taken[a] ? a : -1; for (size_t u = 0; u < pool.size() && p < 0; u++) if (!taken[u]) p = (int)u; }   // nothing else to be had
-        taken[p] = 1; slotBuf[a] = p; prev = pool[p].cls;
+        int p = pick((int)(q & 1), a);
+        if (p < 0) p = pick(1 - (int)(q & 1), a);                              // nothing on the wanted side
+        taken[p] = 1; slotBuf[a] = p;
     }
     // the arrays outside the list take what is left of the original buffers; unused fresh ones and the held misses are released
     for (int a = 0; a < 15; a++) {
@@ -1346,7 +1360,6 @@ static int choose_placement(bfd_sim *s)
     // Pressure accumulators: written beside Vx Vy Vz by the velocity kernels: the RMS sums go to another region than Vz, a
     // peak map beside them to another region than the sums
     std::string accNote;
-    int sideOfPrev = pool[slotBuf[2]].cls;
     float *prevRep = s->stateBase[2] + g;
     for (int which = 0; which < 2; which++) {
         float **pp = which == 0 ? &s->acc : &s->pk;
@@ -1358,26 +1371,27 @@ static int choose_placement(bfd_sim *s)
         float *cur = *pp;
         float t = pair(prevRep, cur + (size_t)qP * s->nloc);
         std::vector<void *> miss;
-        while (t >= thr && !gaveUp && miss.size() < 40) {                     // same region as its neighbour: look for another buffer
+        size_t missBytes = 0;
+        while (t >= thr && miss.size() < 80 && probeTells) {                  // same region as its neighbour: look for another buffer
             size_t freeB = 0, totalB = 0;
-            if (hipMemGetInfo(&freeB, &totalB) != hipSuccess || freeB < 2 * accBytes + totalB / 8) break;
+            if (hipMemGetInfo(&freeB, &totalB) != hipSuccess || freeB < 2 * accBytes + totalB / 8 || missBytes > heldCap) break;
             float *c = nullptr;
             if (hipMalloc((void **)&c, accBytes) != hipSuccess) { (void)hipGetLastError(); break; }
             if (hipMemsetAsync(c, 0, accBytes, s->stream) != hipSuccess) { hipFree(c); break; }
-            t = pair(prevRep, c + (size_t)qP * s->nloc);
-            if (t > 0 && t < thr) {
+            const float tc = pair(prevRep, c + (size_t)qP * s->nloc);
+            if (tc > 0 && tc < thr) {
                 auto it = std::find(s->allocs.begin(), s->allocs.end(), (void *)cur);
                 if (it != s->allocs.end()) s->allocs.erase(it);
                 hipStreamSynchronize(s->stream);
                 hipFree(cur);
-                cur = c; s->allocs.push_back(c);
+                cur = c; s->allocs.push_back(c); t = tc;
             } else {
-                miss.push_back(c);
+                miss.push_back(c); missBytes += accBytes;
+                if (tc <= 0) break;
                 void *sp = nullptr;                                            // walk on, as above
-                const size_t stride = std::min(miss.size() * accBytes, (size_t)16 << 30);
-                if (hipMemGetInfo(&freeB, &totalB) == hipSuccess && freeB > stride + 2 * accBytes + totalB / 8 && hipMalloc(&sp, stride) == hipSuccess) miss.push_back(sp);
+                const size_t stride = std::min(missBytes, (size_t)4 << 30);
+                if (hipMemGetInfo(&freeB, &totalB) == hipSuccess && freeB > stride + 2 * accBytes + totalB / 8 && hipMalloc(&sp, stride) == hipSuccess) { miss.push_back(sp); missBytes += stride; }
                 else (void)hipGetLastError();
-                if (t <= 0) break;
             }
         }
         hipStreamSynchronize(s->stream);
@@ -1385,17 +1399,16 @@ static int choose_placement(bfd_sim *s)
         *pp = cur;
         accNote += std::string(which == 0 ? " sums " : " peaks ") + (t > 0 && t < thr ? "apart from" : "WITH") + (which == 0 ? " Vz," : " the sums,");
         prevRep = cur + (size_t)qP * s->nloc;
-        (void)sideOfPrev;
     }
     BFD_HIP(hipStreamSynchronize(s->stream));
     for (void *h : held) hipFree(h);
     std::string after;
-    for (int a : order) { const int c = pool[slotBuf[a]].cls; after += c >= 100 ? 'n' : (char)('0' + std::min(c, 9)); }
+    for (int a : order) { const Buf &b = pool[slotBuf[a]]; after += b.fresh ? (b.cls == M ? 'm' : 'n') : (char)('0' + std::min(b.cls, 9)); }
     char buf[640];
     snprintf(buf, sizeof buf, "arrays placed by memory region (pair probe on the zero state: %d probes, within-region %.3f ms, threshold %.3f ms, gap between the levels %.0f %%; %zu regions seen): "
-             "regions of %s %s -> %s (n = fresh allocation elsewhere),%s %d fresh, %zu candidates released%s", nProbes, tSame, thr, 100.0 * widest, repOf.size(),
-             solids ? "Vx Vy Vz Szz Rzz Sxx Rxx Syy Ryy Sxy Rxy Sxz Rxz Syz Ryz" : "Vx Vy Vz Szz Rzz", before.c_str(), after.c_str(), accNote.c_str(), nFresh, held.size(),
-             gaveUp ? "; search for another region given up (memory)" : "");
+             "regions of %s %s -> %s (m / n = fresh allocation in / outside the most populated region),%s %d fresh, %zu candidates / spacers (%.1f GiB) released%s; %.2f s", nProbes, tSame, thr, 100.0 * widest, repOf.size(),
+             solids ? "Vx Vy Vz Szz Rzz Sxx Rxx Syy Ryy Sxy Rxy Sxz Rxz Syz Ryz" : "Vx Vy Vz Szz Rzz", before.c_str(), after.c_str(), accNote.c_str(), nFresh, held.size(), heldBytes / 1073741824.0,
+             gaveUp ? "; search for another region given up (memory)" : "", std::chrono::duration<double>(std::chrono::steady_clock::now() - tStart).count());
     s->placementNote = buf;
     if (verbose) fprintf(stderr, "placement: %s\nplacement: probe times, array:ms against Vx, array/class:ms against the other representatives:%s\n", buf, times.c_str());
     return 0;

@@ -34,8 +34,9 @@ __global__ __launch_bounds__(256) void bhte_step(const float *__restrict__ Tin, 
         if (heating) Tn = Tn + q[c];
     }
     Tout[c] = Tn;
-    // R^(43 - T') with R = 0.5 (T' >= 43) or 0.25: a power of two, so one exp2 instead of the generic powf (which set the
-    // pace of this kernel: 0.45 of the HBM peak with it, round 2)
+    // R^(43 - T') with R = 0.5 (T' >= 43) or 0.25: a power of two, so one exp2 instead of the generic powf (0.45 -> 0.47 of the
+    // HBM peak on 21 B per voxel-step; an XCD-contiguous block order, planes k-1 / k+1 in the reading XCD's own L2, was
+    // measured slower: 163 against 181 Gvoxel-steps/s, profiles/r3)
     const float e = 43.0f - Tn;
     dose[c] = dose[c] + dtMin * exp2f(Tn >= 43.0f ? -e : -2.0f * e);
 }

@@ -22,6 +22,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <thread>
 
@@ -33,8 +34,11 @@ struct bfd_group {
     std::vector<bfd_sim *> sim;
     std::vector<int> dev, k0, nk;
     std::vector<hipStream_t> side;        // B streams
-    std::vector<hipEvent_t> evMain, evPart1, evHalo;
+    std::vector<hipEvent_t> evMain, evPart1, evPart1b, evHalo;      // evPart1 / evPart1b: even / odd half-steps
     std::vector<uint32_t> reads[2];       // per slab and halo group: bit f set = the slab reads field f of its neighbours' planes
+    struct HaloPtr { void *ptr[2][3][2][2]; size_t bytes; };               // [group][field][side][send]
+    std::vector<HaloPtr> halo;            // device pointers of every slab's halo regions, taken once in group_prepare
+    bool threads;                         // one host thread per slab queues its work (BFD_GROUP_THREADS=0: one thread for all)
     bool prepared, overlap;
     std::vector<int64_t> nSens;
     double issueSeconds; int64_t issueSteps;    // host time spent queueing work in bfd_group_run
@@ -111,67 +115,120 @@ int group_prepare(bfd_group *g)
             const int nb = (r > 0 ? 1 : 0) + (r + 1 < g->n ? 1 : 0);
             g->haloBytesPerStep += (double)__builtin_popcount(m) * nb * 2.0 * g->cfg.N1 * g->cfg.N2 * 4.0;
         }
+    g->halo.assign(g->n, bfd_group::HaloPtr());
+    for (int r = 0; r < g->n; r++)
+        for (int grp = 0; grp < 2; grp++) for (int f = 0; f < 3; f++) for (int side = 0; side < 2; side++) for (int send = 0; send < 2; send++) {
+            const int rc = bfd_halo_region(g->sim[r], grp, f, side, send, &g->halo[r].ptr[grp][f][side][send], &g->halo[r].bytes);
+            if (rc) return rc;
+        }
+    g->threads = g->n > 1;
+    if (const char *ev = getenv("BFD_GROUP_THREADS")) g->threads = g->n > 1 && atoi(ev) != 0;
     g->prepared = true;
     return 0;
 }
 
-// the copies that fill slab r's ghost planes of halo group grp from its neighbours, queued on stream st (of r's device)
-int queue_halo_copies(bfd_group *g, int r, int grp, hipStream_t st)
+static hipEvent_t part1_event(bfd_group *g, int r, long n) { return (n & 1) ? g->evPart1b[r] : g->evPart1[r]; }
+
+// half-step n (0, 1, 2, ...: even = stress, odd = velocity) of slab r: the kernels. Records the slab's part-1 event of n.
+int issue_half(bfd_group *g, int r, long n)
 {
-    for (int side = 0; side < 2; side++) {
-        const int s = side == 0 ? r - 1 : r + 1;
-        if (s < 0 || s >= g->n) continue;
-        BFD_HIP(hipStreamWaitEvent(st, g->evPart1[s], 0));
-        for (int f = 0; f < 3; f++) {
-            if (!(g->reads[grp][r] & (1u << f))) continue;
-            void *dst = nullptr, *src = nullptr; size_t nb = 0, nb2 = 0;
-            int rc = bfd_halo_region(g->sim[r], grp, f, side, 0, &dst, &nb);               // my ghost planes on that side
-            if (!rc) rc = bfd_halo_region(g->sim[s], grp, f, side ^ 1, 1, &src, &nb2);     // the neighbour's boundary planes facing me
-            if (rc) return rc;
-            if (g->dev[r] == g->dev[s]) BFD_HIP(hipMemcpyAsync(dst, src, nb, hipMemcpyDeviceToDevice, st));
-            else BFD_HIP(hipMemcpyPeerAsync(dst, g->dev[r], src, g->dev[s], nb, st));
-        }
+    const int half = (int)(n & 1);
+    bfd_sim *s = g->sim[r];
+    BFD_HIP(hipSetDevice(g->dev[r]));
+    hipStream_t M = s->stream, B = g->side[r];
+    hipEvent_t p1 = part1_event(g, r, n);
+    int rc;
+    if (g->overlap) {
+        BFD_HIP(hipEventRecord(g->evMain[r], M));
+        BFD_HIP(hipStreamWaitEvent(B, g->evMain[r], 0));
+        rc = half == 0 ? bfd_half_step_stress_part_on(s, 1, B) : bfd_half_step_velocity_part_on(s, 1, B);
+        if (rc) return rc;
+        BFD_HIP(hipEventRecord(p1, B));
+        if (half == 1) BFD_HIP(hipStreamWaitEvent(M, p1, 0));
+        rc = half == 0 ? bfd_half_step_stress_part_on(s, 2, M) : bfd_half_step_velocity_part_on(s, 2, M);
+        if (rc) return rc;
+    } else {
+        rc = half == 0 ? bfd_half_step_stress(s) : bfd_half_step_velocity(s);
+        if (rc) return rc;
+        BFD_HIP(hipEventRecord(p1, M));
     }
     return 0;
 }
 
-int group_step(bfd_group *g)
+// half-step n of slab r: the copies that fill its ghost planes from its neighbours (their part-1 events of n must have
+// been recorded by now), on the side stream (overlapped order) or the main stream
+int issue_copies(bfd_group *g, int r, long n)
 {
-    const int n = g->n;
-    for (int half = 0; half < 2; half++) {          // 0: stress half-step (produces halo group STRESS), 1: velocity (VELOCITY)
-        const int grp = half == 0 ? BFD_HALO_STRESS : BFD_HALO_VELOCITY;
-        for (int r = 0; r < n; r++) {
-            bfd_sim *s = g->sim[r];
-            BFD_HIP(hipSetDevice(g->dev[r]));
-            hipStream_t M = s->stream, B = g->side[r];
-            int rc;
-            if (g->overlap) {
-                BFD_HIP(hipEventRecord(g->evMain[r], M));
-                BFD_HIP(hipStreamWaitEvent(B, g->evMain[r], 0));
-                rc = half == 0 ? bfd_half_step_stress_part_on(s, 1, B) : bfd_half_step_velocity_part_on(s, 1, B);
-                if (rc) return rc;
-                BFD_HIP(hipEventRecord(g->evPart1[r], B));
-                if (half == 1) BFD_HIP(hipStreamWaitEvent(M, g->evPart1[r], 0));
-                rc = half == 0 ? bfd_half_step_stress_part_on(s, 2, M) : bfd_half_step_velocity_part_on(s, 2, M);
-                if (rc) return rc;
-            } else {
-                rc = half == 0 ? bfd_half_step_stress(s) : bfd_half_step_velocity(s);
-                if (rc) return rc;
-                if (n > 1) BFD_HIP(hipEventRecord(g->evPart1[r], M));
-            }
-        }
-        if (n == 1) continue;
-        for (int r = 0; r < n; r++) {
-            BFD_HIP(hipSetDevice(g->dev[r]));
-            hipStream_t M = g->sim[r]->stream, X = g->overlap ? g->side[r] : M;
-            const int rc = queue_halo_copies(g, r, grp, X);
-            if (rc) return rc;
-            if (g->overlap) {
-                BFD_HIP(hipEventRecord(g->evHalo[r], X));
-                BFD_HIP(hipStreamWaitEvent(M, g->evHalo[r], 0));
-            }
+    const int grp = (n & 1) == 0 ? BFD_HALO_STRESS : BFD_HALO_VELOCITY;     // the stress half-step produces the STRESS halo group
+    BFD_HIP(hipSetDevice(g->dev[r]));
+    hipStream_t M = g->sim[r]->stream, X = g->overlap ? g->side[r] : M;
+    for (int side = 0; side < 2; side++) {
+        const int s = side == 0 ? r - 1 : r + 1;
+        if (s < 0 || s >= g->n) continue;
+        BFD_HIP(hipStreamWaitEvent(X, part1_event(g, s, n), 0));
+        for (int f = 0; f < 3; f++) {
+            if (!(g->reads[grp][r] & (1u << f))) continue;
+            void *dst = g->halo[r].ptr[grp][f][side][0];                        // my ghost planes on that side
+            void *src = g->halo[s].ptr[grp][f][side ^ 1][1];                    // the neighbour's boundary planes facing me
+            const size_t nb = g->halo[r].bytes;
+            if (g->dev[r] == g->dev[s]) BFD_HIP(hipMemcpyAsync(dst, src, nb, hipMemcpyDeviceToDevice, X));
+            else BFD_HIP(hipMemcpyPeerAsync(dst, g->dev[r], src, g->dev[s], nb, X));
         }
     }
+    if (g->overlap) {
+        BFD_HIP(hipEventRecord(g->evHalo[r], X));
+        BFD_HIP(hipStreamWaitEvent(M, g->evHalo[r], 0));
+    }
+    return 0;
+}
+
+// nSteps time steps queued by one host thread
+int run_serial(bfd_group *g, int nSteps)
+{
+    for (long n = 0; n < 2L * nSteps; n++) {
+        for (int r = 0; r < g->n; r++) { const int rc = issue_half(g, r, n); if (rc) return rc; }
+        for (int r = 0; r < g->n; r++) { const int rc = issue_copies(g, r, n); if (rc) return rc; }
+    }
+    return 0;
+}
+
+// nSteps time steps, one host thread per slab (a step of an 8-way split is ~40 runtime calls per slab: one thread for all
+// slabs spends 0.6 ms per step on them, more than a thin slab's GPU time). Threads meet through two counters per slab:
+//   recorded[r] = half-steps whose part-1 event slab r has recorded (a neighbour waits for it before it queues
+//                 hipStreamWaitEvent on that event: a wait on an event that was not recorded yet is no wait at all);
+//   consumed[r] = half-steps whose copies slab r has queued (a neighbour re-records the event of the same parity only
+//                 after the waits on its previous record are in the queue).
+int run_threaded(bfd_group *g, int nSteps)
+{
+    const int n = g->n;
+    std::vector<std::atomic<long>> recorded(n), consumed(n);
+    for (int r = 0; r < n; r++) { recorded[r].store(0); consumed[r].store(0); }
+    std::atomic<int> failed(0);
+    std::vector<int> rcs(n, 0);
+    std::vector<std::string> errs(n);
+    auto spin_until = [&](std::atomic<long> &c, long v) {
+        int spins = 0;
+        while (c.load(std::memory_order_acquire) < v && !failed.load(std::memory_order_relaxed))
+            if (++spins > 2000) std::this_thread::yield();
+    };
+    auto worker = [&](int r) {
+        for (long h = 0; h < 2L * nSteps && !failed.load(std::memory_order_relaxed); h++) {
+            // the event of this parity was last recorded for half-step h-2: both neighbours must have queued their waits on it
+            if (h >= 2) for (int s : {r - 1, r + 1}) if (s >= 0 && s < n) spin_until(consumed[s], h - 1);
+            int rc = issue_half(g, r, h);
+            if (!rc) {
+                recorded[r].store(h + 1, std::memory_order_release);
+                for (int s : {r - 1, r + 1}) if (s >= 0 && s < n) spin_until(recorded[s], h + 1);
+                if (!failed.load(std::memory_order_relaxed)) rc = issue_copies(g, r, h);
+            }
+            if (rc) { rcs[r] = rc; errs[r] = bfd_last_error(); failed.store(1); break; }
+            consumed[r].store(h + 1, std::memory_order_release);
+        }
+    };
+    std::vector<std::thread> th;
+    for (int r = 0; r < n; r++) th.emplace_back(worker, r);
+    for (auto &t : th) t.join();
+    for (int r = 0; r < n; r++) if (rcs[r]) { bfd_set_error("slab " + std::to_string(r) + ": " + errs[r]); return rcs[r]; }
     return 0;
 }
 
@@ -192,7 +249,8 @@ int bfd_group_create(const bfd_config *cfg, int32_t nSlabs, const int32_t *devic
     if (partition(cfg->N3, nSlabs, g->k0, g->nk)) { delete g; GRP_FAIL(-2, "bfd_group_create: every slab needs at least 4 planes"); }
     g->dev.assign(devices, devices + nSlabs);
     g->sim.assign(nSlabs, nullptr); g->side.assign(nSlabs, nullptr);
-    g->evMain.assign(nSlabs, nullptr); g->evPart1.assign(nSlabs, nullptr); g->evHalo.assign(nSlabs, nullptr);
+    g->evMain.assign(nSlabs, nullptr); g->evPart1.assign(nSlabs, nullptr); g->evPart1b.assign(nSlabs, nullptr); g->evHalo.assign(nSlabs, nullptr);
+    g->threads = false;
     g->reads[0].assign(nSlabs, 7u); g->reads[1].assign(nSlabs, 7u); g->nSens.assign(nSlabs, 0);
     // peer access between the devices of neighbouring slabs (hipMemcpyPeerAsync falls back to staging without it)
     for (int r = 0; r + 1 < nSlabs; r++) {
@@ -214,6 +272,7 @@ int bfd_group_create(const bfd_config *cfg, int32_t nSlabs, const int32_t *devic
         if (e == hipSuccess) e = hipStreamCreateWithPriority(&g->side[r], hipStreamNonBlocking, hi);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&g->evMain[r], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&g->evPart1[r], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&g->evPart1b[r], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&g->evHalo[r], hipEventDisableTiming);
         if (e != hipSuccess) { bfd_set_error(std::string("bfd_group_create: ") + hipGetErrorString(e)); rc = -10; }
     }
@@ -230,6 +289,7 @@ void bfd_group_destroy(bfd_group *g)
         if (g->side[r]) hipStreamDestroy(g->side[r]);
         if (g->evMain[r]) hipEventDestroy(g->evMain[r]);
         if (g->evPart1[r]) hipEventDestroy(g->evPart1[r]);
+        if (g->evPart1b[r]) hipEventDestroy(g->evPart1b[r]);
         if (g->evHalo[r]) hipEventDestroy(g->evHalo[r]);
         if (g->sim[r]) bfd_destroy(g->sim[r]);
     }
@@ -336,7 +396,7 @@ int bfd_group_run(bfd_group *g, int32_t nSteps)
     int rc = group_prepare(g); if (rc) return rc;
     const auto t0 = std::chrono::steady_clock::now();
     if (g->n == 1) rc = bfd_run(g->sim[0], nSteps);
-    else for (int q = 0; q < nSteps && !rc; q++) rc = group_step(g);
+    else rc = g->threads ? run_threaded(g, nSteps) : run_serial(g, nSteps);
     g->issueSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     g->issueSteps += nSteps;
     return rc;

@@ -379,15 +379,18 @@ def test_streamed_source_table_equals_resident(monkeypatch, tile, type_source):
 
 
 def test_placement_choice_does_not_change_results(monkeypatch):
-    """bfd_prepare times the tiled kernels on the zero state for several freshly allocated sets of the per-voxel arrays and
-    keeps the fastest: grids of 4 M voxels and more. The run that follows must be the run without it,
-    and the launches made for timing must leave the state untouched (also the peak map, whose initial value they compare to)."""
+    """bfd_prepare probes pairs of arrays on the zero state (a += b, b += a along the run lists), exchanges buffers between the
+    state arrays and allocates fresh ones where a memory region is short (grids of 32 M voxels and more by
+    default, forced here with a short search). The run that follows must be the run without it: the probes leave the state
+    untouched (also the peak map), exchanged and fresh buffers are zero like the ones they replace."""
+    monkeypatch.setenv('BFD_PLACEMENT_MIN_VOXELS', '0')
+    monkeypatch.setenv('BFD_PLACEMENT_SEARCH_MB', '300')
     a, k, info = H.make_problem('C2', N=(192, 160, 160), steps=60, stable_dt_fn=oracle_dt)
     k['SelMapsRMSPeakList'] = ['Pressure', 'Vz', 'Sigmaxy']
     k['SelRMSorPeak'] = 3
-    monkeypatch.setenv('BFD_PLACEMENT_TRIALS', '0')
+    monkeypatch.setenv('BFD_PLACEMENT', '0')
     ref = hip_model().StaggeredFDTD_3D_with_relaxation(*a, SILENT=True, **k)
-    monkeypatch.setenv('BFD_PLACEMENT_TRIALS', '4')
+    monkeypatch.setenv('BFD_PLACEMENT', '1')
     out = hip_model().StaggeredFDTD_3D_with_relaxation(*a, SILENT=True, **k)
     for idx in range(4):
         for name in ref[idx]:

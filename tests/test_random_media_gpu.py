@@ -159,12 +159,13 @@ def test_random_media_in_slabs(seed, world, split):
 
 @pytest.mark.parametrize('seed', [2, 3, 5, 8, 13])
 def test_random_media_with_the_placement_choice_forced(seed, monkeypatch):
-    """bfd_prepare launches the tiled kernels on the zero state to time candidate placements of the arrays (grids of 4 M
-    voxels and more by default). Forced here on the small random cases -- stress-type sources (seeds 3, 8, 13), peak maps,
-    reflector pockets, all selected maps -- the run that follows must still equal the oracle bit for bit."""
+    """bfd_prepare runs pair probes on the zero state, exchanges the buffers of state arrays and draws fresh ones to spread the
+    arrays over memory regions (grids of 32 M voxels and more by default). Forced here on the small random cases, with a short
+    search for fresh buffers -- stress-type sources (seeds 3, 8, 13), peak maps, reflector pockets, all selected maps -- the run
+    that follows must still equal the oracle bit for bit."""
     from babelbrain_amd import PropagationModel
     monkeypatch.setenv('BFD_PLACEMENT_MIN_VOXELS', '0')
-    monkeypatch.setenv('BFD_PLACEMENT_TRIALS', '2')
+    monkeypatch.setenv('BFD_PLACEMENT_SEARCH_MB', '40')
     a, k = random_case(seed)
     oh = PropagationModel().StaggeredFDTD_3D_with_relaxation(*a, SILENT=True, **k)
     orf = O.StaggeredFDTD_3D_with_relaxation(*a, **k)
