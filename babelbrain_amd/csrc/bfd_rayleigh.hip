@@ -12,7 +12,8 @@
 // Bound: vector ALU (not HBM, not MFMA: one sqrt + one sincos per source/point pair, no matrix shape).
 // Two field points per thread; sources are staged through LDS in blocks and read as broadcasts.
 // Geometry and phase reduction run in float64 (inputs are float32, so differences are exact), the
-// trigonometry (polynomials on the folded phase) and amplitudes in float32, block sums in float32, totals in float64.
+// trigonometry (hardware sine / cosine of the phase in revolutions) and amplitudes in float32, sums of 16 sources in
+// float32, totals in float64.
 #include "bfd_internal.h"
 #include <math.h>
 
@@ -21,10 +22,11 @@ namespace {
 constexpr int RB = 256;      // threads per workgroup
 constexpr int PPL = 2;       // field points per lane: every source record read from LDS serves two pairs
 constexpr int SB = 512;      // sources per LDS block
+constexpr int SUB = 16;      // sources summed in float32 before the sum goes to the float64 totals
 
 // Per pair: float64 difference vector and squared distance (the inputs are float32, so the differences are exact), 1/R from
-// the float32 rsqrt refined by one Newton step in float64, phase k R / 2 pi reduced and folded in float64, then float32
-// polynomials for sine and cosine, amplitudes in float32. A block of 512 sources is
+// the float32 rsqrt refined by one Newton step in float64, phase k R / 2 pi reduced to [0,1) in float64, then the hardware
+// sine / cosine (v_sin_f32 / v_cos_f32 take their argument in revolutions), amplitudes in float32. Sixteen sources at a time are
 // summed in float32 and added to the float64 sums of the point. Round 2 spent ~70 vector instructions per pair (libm sincosf,
 // float64 accumulation of every term, five scalar LDS reads per pair); this form about half of that.
 __global__ __launch_bounds__(RB) void rayleigh_forward(const float *__restrict__ cen, const float *__restrict__ ds,
@@ -52,11 +54,13 @@ __global__ __launch_bounds__(RB) void rayleigh_forward(const float *__restrict__
             sB[q] = u0[2 * m + 1] * a;
         }
         __syncthreads();
+        for (int q0 = 0; q0 < cnt; q0 += SUB) {
+        const int q1 = min(q0 + SUB, cnt);
         float br[PPL], bi[PPL];
 #pragma unroll
         for (int p = 0; p < PPL; p++) { br[p] = 0.f; bi[p] = 0.f; }
 #pragma unroll 2
-        for (int q = 0; q < cnt; q++) {
+        for (int q = q0; q < q1; q++) {
             const float4 s = sA[q];
             const float sim = sB[q];
 #pragma unroll
@@ -67,18 +71,10 @@ __global__ __launch_bounds__(RB) void rayleigh_forward(const float *__restrict__
                 inv = inv * (1.5 - 0.5 * r2 * inv * inv);
                 const double R = r2 * inv;
                 const double rev = R * krev;
-                // phase / 2 pi folded into [-1/4, 1/4] revolutions in float64 (sin(pi - x) = sin x, cos(pi - x) = -cos x), then
-                // float32 polynomials in radians (Taylor to x^11 / x^12: truncation below 6e-8 on [-pi/2, pi/2]). The hardware
-                // v_sin_f32 / v_cos_f32 are 15 % faster (836 against 7xx Gpairs/s) and stay within 1e-5 of the float64 oracle, but
-                // their 5e-7 absolute error moved the voxel of the largest pointwise error in 3 of the 12 near-field rows of the
-                // reference study held by tests/test_rayleigh_study_gpu.py: accuracy first.
-                double fr = rev - rint(rev);                                    // [-1/2, 1/2]
-                const bool fold = fabs(fr) > 0.25;
-                if (fold) fr = copysign(0.5, fr) - fr;
-                const float x = (float)fr * 6.283185307179586f, x2 = x * x;
-                const float sn = x * (1.0f + x2 * (-1.0f / 6 + x2 * (1.0f / 120 + x2 * (-1.0f / 5040 + x2 * (1.0f / 362880 + x2 * (-1.0f / 39916800))))));
-                const float c0 = 1.0f + x2 * (-0.5f + x2 * (1.0f / 24 + x2 * (-1.0f / 720 + x2 * (1.0f / 40320 + x2 * (-1.0f / 3628800 + x2 * (1.0f / 479001600))))));
-                const float cs = fold ? -c0 : c0;
+                // hardware sine / cosine: v_sin_f32 / v_cos_f32 take their argument in revolutions (a float32 Taylor polynomial on
+                // the folded phase was measured too: 606 against 851 Gpairs/s, and less accurate -- profiles/README.md)
+                const float fr = (float)(rev - floor(rev));           // phase / 2 pi in [0,1)
+                const float sn = __builtin_amdgcn_sinf(fr), cs = __builtin_amdgcn_cosf(fr);
                 float amp = (float)inv;
                 if (ki != 0.0) amp *= __expf(kif * (float)R);        // exp(-i k R) with complex k: Im k < 0 attenuates
                 // (re + i im) * amp * (cos - i sin)
@@ -89,6 +85,7 @@ __global__ __launch_bounds__(RB) void rayleigh_forward(const float *__restrict__
         }
 #pragma unroll
         for (int p = 0; p < PPL; p++) { accr[p] += (double)br[p]; acci[p] += (double)bi[p]; }
+        }
         __syncthreads();
     }
     // multiply by i k / (2 pi):  (i kr - ki) (a + i b) / 2pi
