@@ -34,9 +34,11 @@ __global__ __launch_bounds__(256) void bhte_step(const float *__restrict__ Tin, 
         if (heating) Tn = Tn + q[c];
     }
     Tout[c] = Tn;
-    // R^(43 - T') with R = 0.5 (T' >= 43) or 0.25: a power of two, so one exp2 instead of the generic powf (0.45 -> 0.47 of the
-    // HBM peak on 21 B per voxel-step; an XCD-contiguous block order, planes k-1 / k+1 in the reading XCD's own L2, was
-    // measured slower: 163 against 181 Gvoxel-steps/s, profiles/r3)
+    // R^(43 - T') with R = 0.5 (T' >= 43) or 0.25: a power of two, so one exp2 instead of the generic powf (0.45 -> 0.47-0.48 of
+    // the HBM peak on 21 B per voxel-step). Measured in round 3 and not kept (profiles/README.md): an XCD-contiguous block order
+    // (163 against 181 Gvoxel-steps/s), a z-marching form with T(k-1), T(k), T(k+1) in registers (179-186 against 184: the
+    // re-reads of T it saves, 0.98 GB per launch where 0.62 are needed, come out of the memory-side cache), the dose array in
+    // another memory region than T (a linear pair probe cannot tell the regions apart at 226 MB per array)
     const float e = 43.0f - Tn;
     dose[c] = dose[c] + dtMin * exp2f(Tn >= 43.0f ? -e : -2.0f * e);
 }
