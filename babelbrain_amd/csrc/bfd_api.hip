@@ -937,7 +937,11 @@ static int build_tile_lists(bfd_sim *s)
 {
     int tx, ty, nsub; bfd_tile_grid(s->d, &tx, &ty, &nsub);
     const int n = tx * ty * nsub;
-    dev_release(s, &s->tiles.runs); dev_release(s, &s->tiles.shearCells); dev_release(s, &s->tiles.shearCoef);    // lists of an earlier build
+    // a list rebuilt in the middle of a run (inputs set again at step > 0): the shear memory variables travel through the
+    // full-volume arrays
+    const bool carryShearMemory = s->step > 0 && s->tilesReady == false && s->tiles.shearR && s->tiles.nShear > 0;
+    if (carryShearMemory) { bfd_launch_scatter_shear_memory(s->d, s->stream, &s->tiles); BFD_HIP(hipStreamSynchronize(s->stream)); }
+    dev_release(s, &s->tiles.runs); dev_release(s, &s->tiles.shearCells); dev_release(s, &s->tiles.shearCoef); dev_release(s, &s->tiles.shearR);    // lists of an earlier build
     const int SUB = bfd_tile_subz();
     // longest run one workgroup marches: 16 planes; 8 on small grids so that the launch still has a few thousand
     // workgroups (measured: 256^3 49 -> 58, 128^3 29 -> 46 Gvoxel-steps/s). 32 was best at 512^3 while the z-chunks of
@@ -1060,7 +1064,7 @@ static int build_tile_lists(bfd_sim *s)
     int rc = dev_alloc(s, &s->tiles.runs, all.size(), false);
     if (rc) return rc;
     BFD_HIP(hipMemcpy(s->tiles.runs, all.data(), all.size() * sizeof(int4), hipMemcpyHostToDevice));
-    s->tiles.shearCells = nullptr; s->tiles.shearCoef = nullptr;
+    s->tiles.shearCells = nullptr; s->tiles.shearCoef = nullptr; s->tiles.shearR = nullptr;
     s->tiles.nShear = s->tiles.shearLowEnd = s->tiles.shearHighBeg = 0;
     if (T.nSolid && s->cfg.kernelVariant != 2) {     // variant 2 stays monolithic and fully dense
         // sparse shear list: cells with a solid centre, ascending index, + their edge coefficients
@@ -1084,6 +1088,7 @@ static int build_tile_lists(bfd_sim *s)
         if (e == hipSuccess) {
             rc = dev_alloc(s, &s->tiles.shearCells, (size_t)std::max(count, 1), false);
             if (!rc) rc = dev_alloc(s, &s->tiles.shearCoef, 6 * (size_t)std::max(count, 1), false);
+            if (!rc) rc = dev_alloc(s, &s->tiles.shearR, 3 * (size_t)std::max(count, 1), true);      // lists are built at step 0: the memory variables start at zero
             if (!rc && count) e = hipMemcpyAsync(s->tiles.shearCells, sel, (size_t)count * sizeof(unsigned), hipMemcpyDeviceToDevice, s->stream);
             if (!rc && e == hipSuccess) bfd_launch_shear_coefficients(s->d, s->stream, s->tiles.shearCells, s->tiles.shearCoef, count);
             if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
@@ -1092,6 +1097,7 @@ static int build_tile_lists(bfd_sim *s)
         if (e != hipSuccess) BFD_FAIL(-10, std::string("shear list: ") + hipGetErrorString(e));
         if (rc) return rc;
         s->tiles.nShear = count;
+        if (s->step > 0) { bfd_launch_gather_shear_memory(s->d, s->stream, &s->tiles); BFD_HIP(hipStreamSynchronize(s->stream)); }
         s->tiles.shearLowEnd = std::lower_bound(hostCells.begin(), hostCells.end(), (unsigned)lowPlanes * (unsigned)s->d.plane) - hostCells.begin();
         s->tiles.shearHighBeg = std::lower_bound(hostCells.begin(), hostCells.end(), (unsigned)hiStart * (unsigned)s->d.plane) - hostCells.begin();
     }
@@ -1756,6 +1762,7 @@ int bfd_reset(bfd_sim *s)
         size_t n = dirOf[a] == 0 ? (size_t)d.nk * d.N2 * 2 * P : (dirOf[a] == 1 ? (size_t)d.nk * 2 * P * d.N1 : (zTouch ? (size_t)2 * P * d.plane : 0));
         if (n) BFD_HIP(hipMemsetAsync(d.psi[a], 0, n * sizeof(float), s->stream));
     }
+    if (s->tiles.shearR && s->tiles.nShear) BFD_HIP(hipMemsetAsync(s->tiles.shearR, 0, 3 * (size_t)s->tiles.nShear * sizeof(float), s->stream));
     if (s->acc) BFD_HIP(hipMemsetAsync(s->acc, 0, (size_t)s->nSelR * s->nloc * sizeof(float), s->stream));
     if (s->pk) BFD_HIP(hipMemsetAsync(s->pk, 0, (size_t)s->nSelR * s->nloc * sizeof(float), s->stream));
     if (s->sensOut) BFD_HIP(hipMemsetAsync(s->sensOut, 0, (size_t)s->nSelS * s->nTs * (size_t)s->nSensors * sizeof(float), s->stream));
@@ -1869,6 +1876,7 @@ int bfd_get_field(bfd_sim *s, int32_t a, float *out, int64_t s1, int64_t s2, int
     if (!s || !out || a < 0 || a > 14) BFD_FAIL(-1, "bfd_get_field: bad argument");
     BFD_HIP(hipSetDevice(s->cfg.device));
     expand_if_collapsed(s);
+    if (a >= 12 && s->tilesReady && s->cfg.kernelVariant != 1) bfd_launch_scatter_shear_memory(s->d, s->stream, &s->tiles);   // Rxy, Rxz, Ryz live beside the sparse list
     const bfd_dev &d = s->d;
     float *cur[15] = {d.Vx, d.Vy, d.Vz, d.Sxx, d.Syy, d.Szz, d.Sxy, d.Sxz, d.Syz, d.Rxx, d.Ryy, d.Rzz, d.Rxy, d.Rxz, d.Ryz};
     return download_volume(s, cur[a], out, s1, s2, s3);

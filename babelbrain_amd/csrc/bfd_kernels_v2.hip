@@ -1433,7 +1433,7 @@ __device__ __forceinline__ float ldv(const float *__restrict__ a, int N1, int N2
 }
 
 __global__ __launch_bounds__(256) void stress_shear_sparse(bfd_dev d, const unsigned *__restrict__ cells,
-                                                           const float *__restrict__ coef, long n)
+                                                           const float *__restrict__ coef, float *__restrict__ Rc, long nTotal, long n)
 {
     // XCD e works through the e-th contiguous eighth of the (index-sorted) list: the V values a cell gathers from its
     // row / plane neighbours were fetched by blocks just before it on the SAME XCD (its own L2)
@@ -1474,18 +1474,36 @@ __global__ __launch_bounds__(256) void stress_shear_sparse(bfd_dev d, const unsi
     const float c1 = d.c1;
     if (Axy != 0.f) {
         const float e = dyVx + dxVy;
-        const float r = d.Rxy[c], rn = c1 * r - Bxy * e;
-        d.Sxy[c] = d.Sxy[c] + (Axy * e + 0.5f * (r + rn)); d.Rxy[c] = rn;
+        const float r = Rc[t], rn = c1 * r - Bxy * e;
+        d.Sxy[c] = d.Sxy[c] + (Axy * e + 0.5f * (r + rn)); Rc[t] = rn;
     }
     if (Axz != 0.f) {
         const float e = dzVx + dxVz;
-        const float r = d.Rxz[c], rn = c1 * r - Bxz * e;
-        d.Sxz[c] = d.Sxz[c] + (Axz * e + 0.5f * (r + rn)); d.Rxz[c] = rn;
+        const float r = Rc[nTotal + t], rn = c1 * r - Bxz * e;
+        d.Sxz[c] = d.Sxz[c] + (Axz * e + 0.5f * (r + rn)); Rc[nTotal + t] = rn;
     }
     if (Ayz != 0.f) {
         const float e = dzVy + dyVz;
-        const float r = d.Ryz[c], rn = c1 * r - Byz * e;
-        d.Syz[c] = d.Syz[c] + (Ayz * e + 0.5f * (r + rn)); d.Ryz[c] = rn;
+        const float r = Rc[2 * nTotal + t], rn = c1 * r - Byz * e;
+        d.Syz[c] = d.Syz[c] + (Ayz * e + 0.5f * (r + rn)); Rc[2 * nTotal + t] = rn;
+    }
+}
+
+// outputs: the list-ordered memory variables of the shear stresses into the full-volume arrays
+__global__ void scatter_shear_memory(bfd_dev d, const unsigned *__restrict__ cells, const float *__restrict__ Rc, long n)
+{
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x) {
+        const unsigned c = cells[t];
+        d.Rxy[c] = Rc[t]; d.Rxz[c] = Rc[n + t]; d.Ryz[c] = Rc[2 * n + t];
+    }
+}
+
+// the reverse, after a list has been rebuilt in the middle of a run
+__global__ void gather_shear_memory(bfd_dev d, const unsigned *__restrict__ cells, float *__restrict__ Rc, long n)
+{
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x) {
+        const unsigned c = cells[t];
+        Rc[t] = d.Rxy[c]; Rc[n + t] = d.Rxz[c]; Rc[2 * n + t] = d.Ryz[c];
     }
 }
 
@@ -1656,6 +1674,16 @@ void bfd_launch_mark_solid(const bfd_dev &d, hipStream_t s, unsigned char *flag,
 {
     hipLaunchKernelGGL(mark_solid_cells, dim3((unsigned)std::min<long>((n + 255) / 256, 8192)), dim3(256), 0, s, d, flag, n);
 }
+void bfd_launch_scatter_shear_memory(const bfd_dev &d, hipStream_t s, const bfd_tiles *t)
+{
+    if (t->shearCells && t->shearR && t->nShear)
+        hipLaunchKernelGGL(scatter_shear_memory, dim3((unsigned)std::min<long>((t->nShear + 255) / 256, 8192)), dim3(256), 0, s, d, t->shearCells, t->shearR, t->nShear);
+}
+void bfd_launch_gather_shear_memory(const bfd_dev &d, hipStream_t s, const bfd_tiles *t)
+{
+    if (t->shearCells && t->shearR && t->nShear)
+        hipLaunchKernelGGL(gather_shear_memory, dim3((unsigned)std::min<long>((t->nShear + 255) / 256, 8192)), dim3(256), 0, s, d, t->shearCells, t->shearR, t->nShear);
+}
 void bfd_launch_shear_coefficients(const bfd_dev &d, hipStream_t s, const unsigned *cells, float *coef, long n)
 {
     if (n) hipLaunchKernelGGL(shear_coefficients, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d, cells, coef, n);
@@ -1698,8 +1726,8 @@ void bfd_launch_stress_v2(const bfd_dev &d, hipStream_t s0, const bfd_tiles *t, 
         if (part == 1) { e0 = t->shearLowEnd; b1 = t->shearHighBeg; e1 = t->nShear; }
         else if (part == 2) { b0 = t->shearLowEnd; e0 = t->shearHighBeg; }
         BFD_KT(BFD_K_STRESS_SHEAR, 0);
-        if (e0 > b0) hipLaunchKernelGGL(stress_shear_sparse, dim3((unsigned)((e0 - b0 + 255) / 256)), dim3(256), 0, s, d, t->shearCells + b0, t->shearCoef + 6 * b0, e0 - b0);
-        if (e1 > b1) hipLaunchKernelGGL(stress_shear_sparse, dim3((unsigned)((e1 - b1 + 255) / 256)), dim3(256), 0, s, d, t->shearCells + b1, t->shearCoef + 6 * b1, e1 - b1);
+        if (e0 > b0) hipLaunchKernelGGL(stress_shear_sparse, dim3((unsigned)((e0 - b0 + 255) / 256)), dim3(256), 0, s, d, t->shearCells + b0, t->shearCoef + 6 * b0, t->shearR + b0, t->nShear, e0 - b0);
+        if (e1 > b1) hipLaunchKernelGGL(stress_shear_sparse, dim3((unsigned)((e1 - b1 + 255) / 256)), dim3(256), 0, s, d, t->shearCells + b1, t->shearCoef + 6 * b1, t->shearR + b1, t->nShear, e1 - b1);
         BFD_KT(BFD_K_STRESS_SHEAR, 1);
     }
     if (n) {
