@@ -418,12 +418,16 @@ hipEvent_t get_event(bfd_sim *s)
 }
 
 // number of non-zero edge coefficients A (active shear updates) in the sparse shear list
-__global__ void count_active_edges(const float *__restrict__ coef, long n, unsigned long long *__restrict__ out)
+__global__ void count_active_edges(const float *__restrict__ coef, const unsigned *__restrict__ codes, long n, unsigned long long *__restrict__ out)
 {
-    unsigned c = 0;
-    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x)
+    unsigned c = 0, x = 0;          // out[0] active edges, out[1] edges with explicit coefficients
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x) {
         c += (coef[6 * t] != 0.f) + (coef[6 * t + 2] != 0.f) + (coef[6 * t + 4] != 0.f);
+        const unsigned w = codes[t];
+        x += ((w & 255u) == 255u) + (((w >> 8) & 255u) == 255u) + (((w >> 16) & 255u) == 255u);
+    }
     if (c) atomicAdd(out, (unsigned long long)c);
+    if (x) atomicAdd(out + 1, (unsigned long long)x);
 }
 
 
@@ -942,6 +946,7 @@ static int build_tile_lists(bfd_sim *s)
     const bool carryShearMemory = s->step > 0 && s->tilesReady == false && s->tiles.shearR && s->tiles.nShear > 0;
     if (carryShearMemory) { bfd_launch_scatter_shear_memory(s->d, s->stream, &s->tiles); BFD_HIP(hipStreamSynchronize(s->stream)); }
     dev_release(s, &s->tiles.runs); dev_release(s, &s->tiles.shearCells); dev_release(s, &s->tiles.shearCoef); dev_release(s, &s->tiles.shearR);    // lists of an earlier build
+    dev_release(s, &s->tiles.shearCodes); dev_release(s, &s->tiles.shearTab);
     const int SUB = bfd_tile_subz();
     // longest run one workgroup marches: 16 planes; 8 on small grids so that the launch still has a few thousand
     // workgroups (measured: 256^3 49 -> 58, 128^3 29 -> 46 Gvoxel-steps/s). 32 was best at 512^3 while the z-chunks of
@@ -1064,7 +1069,8 @@ static int build_tile_lists(bfd_sim *s)
     int rc = dev_alloc(s, &s->tiles.runs, all.size(), false);
     if (rc) return rc;
     BFD_HIP(hipMemcpy(s->tiles.runs, all.data(), all.size() * sizeof(int4), hipMemcpyHostToDevice));
-    s->tiles.shearCells = nullptr; s->tiles.shearCoef = nullptr; s->tiles.shearR = nullptr;
+    s->tiles.shearCells = nullptr; s->tiles.shearCoef = nullptr; s->tiles.shearR = nullptr; s->tiles.shearCodes = nullptr; s->tiles.shearTab = nullptr;
+    s->tiles.nShearExplicit = 0;
     s->tiles.nShear = s->tiles.shearLowEnd = s->tiles.shearHighBeg = 0;
     if (T.nSolid && s->cfg.kernelVariant != 2) {     // variant 2 stays monolithic and fully dense
         // sparse shear list: cells with a solid centre, ascending index, + their edge coefficients
@@ -1090,7 +1096,9 @@ static int build_tile_lists(bfd_sim *s)
             if (!rc) rc = dev_alloc(s, &s->tiles.shearCoef, 6 * (size_t)std::max(count, 1), false);
             if (!rc) rc = dev_alloc(s, &s->tiles.shearR, 3 * (size_t)std::max(count, 1), true);      // lists are built at step 0: the memory variables start at zero
             if (!rc && count) e = hipMemcpyAsync(s->tiles.shearCells, sel, (size_t)count * sizeof(unsigned), hipMemcpyDeviceToDevice, s->stream);
-            if (!rc && e == hipSuccess) bfd_launch_shear_coefficients(s->d, s->stream, s->tiles.shearCells, s->tiles.shearCoef, count);
+            if (!rc) rc = dev_alloc(s, &s->tiles.shearCodes, (size_t)std::max(count, 1), false);
+            if (!rc) rc = dev_alloc(s, &s->tiles.shearTab, 2 * (size_t)s->cfg.nMat, false);
+            if (!rc && e == hipSuccess) bfd_launch_shear_coefficients(s->d, s->stream, s->tiles.shearCells, s->tiles.shearCoef, s->tiles.shearCodes, s->tiles.shearTab, s->cfg.nMat, count);
             if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
         }
         if (flag) hipFree(flag); if (sel) hipFree(sel); if (dcount) hipFree(dcount); if (work) hipFree(work);
@@ -1159,15 +1167,17 @@ static int build_tile_lists(bfd_sim *s)
             for (int a = 0; a < 2; a++) { B[a][BFD_K_STRESS_SOLID] += bs; B[a][BFD_K_VELOCITY_SOLID] += bv; }
         }
         if (s->tiles.nShear) {       // sparse shear: cell index + 6 coefficients + V of the cell + read-modify-write of S and R per active edge
-            unsigned long long *dc = nullptr, hc = 0;
+            unsigned long long *dc = nullptr, hc[2] = {0, 0};
             BFD_HIP(hipMalloc((void **)&dc, sizeof hc));
             hipMemsetAsync(dc, 0, sizeof hc, s->stream);
-            hipLaunchKernelGGL(count_active_edges, dim3(grid_for(s->tiles.nShear)), dim3(256), 0, s->stream, s->tiles.shearCoef, s->tiles.nShear, dc);
-            hipMemcpyAsync(&hc, dc, sizeof hc, hipMemcpyDeviceToHost, s->stream);
+            hipLaunchKernelGGL(count_active_edges, dim3(grid_for(s->tiles.nShear)), dim3(256), 0, s->stream, s->tiles.shearCoef, s->tiles.shearCodes, s->tiles.nShear, dc);
+            hipMemcpyAsync(hc, dc, sizeof hc, hipMemcpyDeviceToHost, s->stream);
             const hipError_t e = hipStreamSynchronize(s->stream);
             hipFree(dc);
             if (e != hipSuccess) BFD_FAIL(-10, std::string("shear edge count: ") + hipGetErrorString(e));
-            for (int a = 0; a < 2; a++) B[a][BFD_K_STRESS_SHEAR] = 40.0 * (double)s->tiles.nShear + 16.0 * (double)hc;
+            s->tiles.nShearExplicit = (long)hc[1];
+            // per listed cell: index 4 + edge codes 4 + V 12; per edge with explicit coefficients 8; per active edge S and R r/w 16
+            for (int a = 0; a < 2; a++) B[a][BFD_K_STRESS_SHEAR] = 20.0 * (double)s->tiles.nShear + 8.0 * (double)hc[1] + 16.0 * (double)hc[0];
         }
     }
     s->tilesReady = true;

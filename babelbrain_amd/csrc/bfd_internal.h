@@ -79,6 +79,7 @@ void bfd_kmark(bfd_sim *sim, int cls, int end, hipStream_t st);
 
 struct bfd_tiles { bfd_sim *ktimer; int4 *runs;
                    unsigned *shearCells; float *shearCoef; long nShear, shearLowEnd, shearHighBeg;   /* sparse shear list */
+                   unsigned *shearCodes; float *shearTab; long nShearExplicit;   /* per listed cell a byte per edge: 0 inactive, 1 + m = one material around the edge (coefficients from shearTab[2 m ..]), 255 = explicit coefficients in shearCoef; number of explicit edges */
                    float *shearR;   /* memory variables Rxy, Rxz, Ryz of the listed cells, [3][nShear] in list order: only the sparse kernel uses them, so they live beside the list (dense, coalesced) instead of in the full-volume arrays, which are filled from here on demand (bfd_get_field) */
                    int nFluid, nFluidB, nSolid, nSolidB, nSolidBP /* leading boundary runs that touch the absorbing layer */, nSolidIP /* trailing interior ones */, nFused /* runs of the fused kernel, after the solid runs */;
                    int nLossless, nLossy, nSolidSub, nUni, nPml, nLean, nFusedSub; };
@@ -156,7 +157,7 @@ void bfd_launch_fused(const bfd_dev &d, hipStream_t s, float *accP, float *pkP, 
 int bfd_tile_subz(void);
 void bfd_launch_classify(const bfd_dev &d, hipStream_t s, int *flagsDev, int *tileMatDev);
 void bfd_launch_mark_solid(const bfd_dev &d, hipStream_t s, unsigned char *flag, long n);
-void bfd_launch_shear_coefficients(const bfd_dev &d, hipStream_t s, const unsigned *cells, float *coef, long n);
+void bfd_launch_shear_coefficients(const bfd_dev &d, hipStream_t s, const unsigned *cells, float *coef, unsigned *codes, float *tab, int nMat, long n);
 // copies the list-ordered shear memory variables into the full-volume arrays Rxy, Rxz, Ryz (outputs only)
 void bfd_launch_scatter_shear_memory(const bfd_dev &d, hipStream_t s, const bfd_tiles *t);
 void bfd_launch_gather_shear_memory(const bfd_dev &d, hipStream_t s, const bfd_tiles *t);
