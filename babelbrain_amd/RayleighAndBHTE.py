@@ -7,7 +7,8 @@
     GenerateFocusTx(f, Foc, Diam, c, PPWSurface)                   Single:241
 
 ForwardSimple runs on the MI355X through the C ABI (bfd_rayleigh_forward); there is no CPU fallback.
-The BHTE thermal solver of the same upstream module is SURVEY.md 8f "next #4" and is not here yet.
+BHTE / BHTEMultiplePressureFields (CalculateTemperatureEffects.py:365-456, 960-990) run on the device too
+(bfd_bhte_run_fields: two time steps per launch, csrc/bfd_bhte.hip).
 """
 import ctypes as C
 

@@ -9,38 +9,184 @@
 //   T' = T + cd[m] * (((((Txm+Txp)+Tym)+Typ)+Tzm)+Tzp - 6 T) + cp[m] * (Tcore - T) + (n < nStepsOn ? q : 0)
 //   cd = dt k/(rho c dx^2),  cp = dt rho_b c_b w / (6e7 c)  (w in mL/min/kg),  q = dt * duty * a_abs p^2/(rho c_s) / (rho c)
 //   dose += dt/60 * R^(43 - T'),  R = 0.5 for T' >= 43 else 0.25 (evaluated as exp2).   Faces of the volume keep their temperature.
-// Bound: HBM (T read + write, q read, dose RMW, uint8 ids: ~21 B per voxel-step); x-fastest layout, one thread per voxel.
+// Bound: HBM. One step moves T read + write, q read, dose RMW, uint8 ids: ~21 B per voxel; the default path takes TWO steps per
+// launch (bhte_step2) and moves those 21 B once for both. x-fastest layout.
 #include "bfd_internal.h"
 #include <math.h>
 #include <vector>
 
 namespace {
 
+// (wave-uniform plane base) + (32-bit byte offset in a VGPR): see bfd_kernels_v2.hip, uni() / F4()
+template <typename T>
+__device__ __forceinline__ T *uni(T *p)
+{
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (T *)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ float &F4(float *base, unsigned byteOfs) { return *(float *)((char *)uni(base) + byteOfs); }
+__device__ __forceinline__ const float &F4(const float *base, unsigned byteOfs) { return *(const float *)((const char *)uni(base) + byteOfs); }
+
+// One cell, one step, in the oracle's operation order (oracle/bhte_oracle.py); the roundings are pinned so that the one-step
+// kernel, the two-step kernel and the monitors of an intermediate step give the same bits.
+__device__ __forceinline__ float bhte_update(float T, float xm, float xp, float ym, float yp, float zm, float zp, float cd, float cp,
+                                             float Tcore, bool heating, float q)
+{
+    const float s = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(xm, xp), ym), yp), zm), zp);
+    float Tn = __fadd_rn(T, __fmul_rn(cd, __fsub_rn(s, __fmul_rn(6.0f, T))));
+    Tn = __fadd_rn(Tn, __fmul_rn(cp, __fsub_rn(Tcore, T)));
+    if (heating) Tn = __fadd_rn(Tn, q);
+    return Tn;
+}
+// dt/60 * R^(43 - T') with R = 0.5 (T' >= 43) or 0.25: a power of two, so one exp2 instead of the generic powf
+__device__ __forceinline__ float bhte_dose_rate(float Tn, float dtMin)
+{
+    const float e = 43.0f - Tn;
+    // v_exp_f32 alone: exp2f() wraps it in a range check for results below 2^-126 (five more instructions per call, two calls per
+    // cell); such a term (T' < -20 degC) is 1e-38 of a minute and flushes to zero here
+    return __fmul_rn(dtMin, __builtin_amdgcn_exp2f(Tn >= 43.0f ? -e : -2.0f * e));
+}
+__device__ __forceinline__ float bhte_cell(const float *__restrict__ Tin, const float *__restrict__ q, const unsigned char *__restrict__ mat,
+                                           const float *__restrict__ cd, const float *__restrict__ cp, int i, int j, int k, int N1, int N2, int N3,
+                                           float Tcore)
+{
+    const long pl = (long)N1 * N2, c = (long)k * pl + (long)j * N1 + i;
+    const float T = Tin[c];
+    if (!(i > 0 && i < N1 - 1 && j > 0 && j < N2 - 1 && k > 0 && k < N3 - 1)) return T;
+    const int m = mat[c];
+    return bhte_update(T, Tin[c - 1], Tin[c + 1], Tin[c - N1], Tin[c + N1], Tin[c - pl], Tin[c + pl], cd[m], cp[m], Tcore, q != nullptr, q ? q[c] : 0.0f);
+}
+
+// One step, one thread per voxel (odd step counts, BFD_BHTE_FUSE=0). q == nullptr: no heating in this step.
 __global__ __launch_bounds__(256) void bhte_step(const float *__restrict__ Tin, float *__restrict__ Tout, float *__restrict__ dose,
                                                  const float *__restrict__ q, const unsigned char *__restrict__ mat,
                                                  const float *__restrict__ cd, const float *__restrict__ cp,
-                                                 int N1, int N2, int N3, float Tcore, int heating, float dtMin)
+                                                 int N1, int N2, int N3, float Tcore, float dtMin)
 {
     const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z;
     if (i >= N1 || j >= N2) return;
-    const long pl = (long)N1 * N2, c = (long)k * pl + (long)j * N1 + i;
-    const float T = Tin[c];
-    float Tn = T;
-    if (i > 0 && i < N1 - 1 && j > 0 && j < N2 - 1 && k > 0 && k < N3 - 1) {
-        const int m = mat[c];
-        const float s = ((((Tin[c - 1] + Tin[c + 1]) + Tin[c - N1]) + Tin[c + N1]) + Tin[c - pl]) + Tin[c + pl];
-        Tn = T + cd[m] * (s - 6.0f * T);
-        Tn = Tn + cp[m] * (Tcore - T);
-        if (heating) Tn = Tn + q[c];
-    }
+    const long c = (long)k * N1 * N2 + (long)j * N1 + i;
+    const float Tn = bhte_cell(Tin, q, mat, cd, cp, i, j, k, N1, N2, N3, Tcore);
     Tout[c] = Tn;
-    // R^(43 - T') with R = 0.5 (T' >= 43) or 0.25: a power of two, so one exp2 instead of the generic powf (0.45 -> 0.47-0.48 of
-    // the HBM peak on 21 B per voxel-step). Measured in round 3 and not kept (profiles/README.md): an XCD-contiguous block order
-    // (163 against 181 Gvoxel-steps/s), a z-marching form with T(k-1), T(k), T(k+1) in registers (179-186 against 184: the
-    // re-reads of T it saves, 0.98 GB per launch where 0.62 are needed, come out of the memory-side cache), the dose array in
-    // another memory region than T (a linear pair probe cannot tell the regions apart at 226 MB per array)
-    const float e = 43.0f - Tn;
-    dose[c] = dose[c] + dtMin * exp2f(Tn >= 43.0f ? -e : -2.0f * e);
+    // Measured in round 3 and not kept (profiles/README.md): an XCD-contiguous block order (163 against 181 Gvoxel-steps/s), a
+    // z-marching form with T(k-1), T(k), T(k+1) in registers (179-186 against 184: the re-reads of T it saves come out of the
+    // memory-side cache), the dose array in another memory region than T
+    dose[c] = __fadd_rn(dose[c], bhte_dose_rate(Tn, dtMin));
+}
+
+// Two steps per launch. One step moves 21 B per voxel (T in, T out, dose in and out, heat source, material id) for ~12
+// flops; two steps in one pass move the same 21 B: T(n) in, T(n+2) out, the dose read once and written once with both
+// increments, heat source and id read once. A workgroup marches a z-run over a tile of 64 x 26 output cells: the region it
+// keeps is 68 x 30 cells (two rings: T(n+1) is needed one cell around the outputs, T(n) one cell around that), 2040 cells =
+// 4 per thread in a FIXED assignment (cell e = tid + 512 n, row-major in the region), so every thread holds the z-queues of its
+// cells in registers (T(n) at p-1, p, p+1; T(n+1) at p-2, p-1, p) and only the in-plane neighbours go through LDS: plane p of
+// T(n) and planes p-1, p of T(n+1), each double-buffered so that one barrier per plane is enough.
+constexpr int B2_W = 68, B2_H = 30, B2_TY = B2_H - 4, B2_T = 512, B2_NC = 4, B2_CELLS = B2_W * B2_H;
+// Loads: T(n) of plane p+1 and the dose at the top of iteration p, material id and heat source where they are used. Issuing
+// all of them at the top, or one plane ahead (before or after the barrier, +6 VGPRs: 6 waves/SIMD instead of 7) was measured
+// slower: 312-319 / 338-347 against 374-392 Gvoxel-steps/s at 384^3 (profiles/r3/bhte_two_steps_per_launch.txt).
+// Addressing: plane bases are wave-uniform (scalar registers), every cell keeps one unsigned 32-bit offset inside the plane.
+#define B2_ARGS const float *__restrict__ Tin, float *__restrict__ Tout, float *__restrict__ dose, const float *__restrict__ qa, const float *__restrict__ qb, \
+                const unsigned char *__restrict__ mat, const float *__restrict__ cd, const float *__restrict__ cp, int nMat, int N1, int N2, int N3, float Tcore, \
+                float dtMin, int zrun, int tilesX, int tilesY, int nBlocks, int xcdOrder
+__device__ __forceinline__ void bhte_step2_body(int b, B2_ARGS)
+{
+    __shared__ float A[2][B2_NC * B2_T], B[2][B2_NC * B2_T];
+    __shared__ float sCd[256], sCp[256];
+    const int tid = threadIdx.x;
+    for (int m = tid; m < nMat; m += B2_T) { sCd[m] = cd[m]; sCp[m] = cp[m]; }
+    const int bx = b % tilesX, by = (b / tilesX) % tilesY, bz = b / (tilesX * tilesY);
+    const int x0 = bx * 64 - 2, y0 = by * B2_TY - 2, z0 = bz * zrun, z1 = min(z0 + zrun, N3);
+    const long pl = (long)N1 * N2;
+
+    // flags: bit 0 inside the volume, 1 T(n+1) computed here (off the x / y faces), 2 output cell, 3 on an x / y face;
+    // bits 8-15: material id of the cell one plane down
+    unsigned off[B2_NC], flags[B2_NC];
+    float t0m[B2_NC], t0c[B2_NC], t1m[B2_NC], t1c[B2_NC], qprev[B2_NC];
+    #pragma unroll
+    for (int n = 0; n < B2_NC; n++) {
+        const int e = tid + n * B2_T, ry = e / B2_W, rx = e - ry * B2_W, gi = x0 + rx, gj = y0 + ry;
+        const bool in = e < B2_CELLS && gi >= 0 && gi < N1 && gj >= 0 && gj < N2;
+        const bool face = gi == 0 || gi == N1 - 1 || gj == 0 || gj == N2 - 1;
+        unsigned f = in ? 1u : 0u;
+        if (in && !face && rx >= 1 && rx <= B2_W - 2 && ry >= 1 && ry <= B2_H - 2) f |= 2u;
+        if (in && rx >= 2 && rx <= B2_W - 3 && ry >= 2 && ry <= B2_H - 3) f |= 4u;
+        if (face) f |= 8u;
+        flags[n] = f; off[n] = in ? 4u * (unsigned)(gj * N1 + gi) : 0u;          // byte offset inside a plane
+        t0m[n] = (in && z0 - 2 >= 0) ? F4(Tin + (long)(z0 - 2) * pl, off[n]) : 0.0f;
+        t0c[n] = (in && z0 - 1 >= 0) ? F4(Tin + (long)(z0 - 1) * pl, off[n]) : 0.0f;
+        t1m[n] = t1c[n] = qprev[n] = 0.0f;
+    }
+    for (int p = z0 - 1; p <= z1; p++) {                            // T(n+1) of plane p (none for p = -1, N3), then T(n+2) of plane p-1
+        float *Ap = A[p & 1], *Bp = B[p & 1]; const float *Bq = B[(p & 1) ^ 1];
+        float t0p[B2_NC], dz[B2_NC];
+        const bool outs = p - 1 >= z0 && p - 1 < z1;
+        const bool inner = p > 0 && p < N3 - 1, innerOut = p - 1 > 0 && p - 1 < N3 - 1;
+        const long cp0 = (long)__builtin_amdgcn_readfirstlane(p) * pl;                              // wave-uniform plane bases
+        const float *TinUp = Tin + cp0 + pl, *qaP = qa ? qa + cp0 : nullptr, *qbO = qb ? qb + cp0 - pl : nullptr;
+        float *doseO = dose + cp0 - pl, *ToutO = Tout + cp0 - pl;
+        const unsigned char *matP = mat + cp0;
+        #pragma unroll
+        for (int n = 0; n < B2_NC; n++) {
+            t0p[n] = (p + 1 < N3 && (flags[n] & 1u)) ? F4(TinUp, off[n]) : 0.0f;
+            dz[n] = (outs && (flags[n] & 4u)) ? F4(doseO, off[n]) : 0.0f;
+            Ap[tid + n * B2_T] = t0c[n];
+        }
+        __syncthreads();
+        #pragma unroll
+        for (int n = 0; n < B2_NC; n++) {
+            const int e = tid + n * B2_T;
+            float T1 = t0c[n], q = 0.0f; int m = 0;
+            if (inner && (flags[n] & 2u)) {
+                m = uni(matP)[off[n] >> 2]; if (qa) q = F4(qaP, off[n]);
+                T1 = bhte_update(t0c[n], Ap[e - 1], Ap[e + 1], Ap[e - B2_W], Ap[e + B2_W], t0m[n], t0p[n], sCd[m], sCp[m], Tcore, qa != nullptr, q);
+            }
+            Bp[e] = T1;
+            if (outs && (flags[n] & 4u)) {
+                float T2 = t1c[n];
+                if (innerOut && !(flags[n] & 8u)) {
+                    const int m2 = flags[n] >> 8;
+                    const float q2 = qb ? (qb == qa ? qprev[n] : F4(qbO, off[n])) : 0.0f;
+                    T2 = bhte_update(t1c[n], Bq[e - 1], Bq[e + 1], Bq[e - B2_W], Bq[e + B2_W], t1m[n], T1, sCd[m2], sCp[m2], Tcore, qb != nullptr, q2);
+                }
+                F4(ToutO, off[n]) = T2;
+                F4(doseO, off[n]) = __fadd_rn(__fadd_rn(dz[n], bhte_dose_rate(t1c[n], dtMin)), bhte_dose_rate(T2, dtMin));
+            }
+            t0m[n] = t0c[n]; t0c[n] = t0p[n]; t1m[n] = t1c[n]; t1c[n] = T1; flags[n] = (flags[n] & 15u) | ((unsigned)m << 8); qprev[n] = q;
+        }
+    }
+}
+
+__global__ __launch_bounds__(B2_T) void bhte_step2(B2_ARGS)
+{
+    int b = blockIdx.x;
+    if (xcdOrder) {                               // workgroups go to the 8 XCDs round-robin: give each XCD a contiguous piece of the tile order
+        const int per = nBlocks >> 3, rem = nBlocks & 7, x = b & 7, slot = b >> 3;
+        b = x * per + (x < rem ? x : rem) + slot;
+    }
+    bhte_step2_body(b, Tin, Tout, dose, qa, qb, mat, cd, cp, nMat, N1, N2, N3, Tcore, dtMin, zrun, tilesX, tilesY, nBlocks, xcdOrder);
+}
+// Monitors of the first of two fused steps: T(n+1) at the listed voxels / on the monitored plane, computed from T(n)
+__global__ void step_points(const float *__restrict__ Tin, const float *__restrict__ q, const unsigned char *__restrict__ mat,
+                            const float *__restrict__ cd, const float *__restrict__ cp, int N1, int N2, int N3, float Tcore,
+                            const unsigned *__restrict__ idx, float *__restrict__ out, long n, long stride, long col)
+{
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const unsigned c = idx[t];
+    const int i = (int)(c % (unsigned)N1), j = (int)((c / (unsigned)N1) % (unsigned)N2), k = (int)(c / ((unsigned)N1 * (unsigned)N2));
+    out[t * stride + col] = bhte_cell(Tin, q, mat, cd, cp, i, j, k, N1, N2, N3, Tcore);
+}
+__global__ void step_slice(const float *__restrict__ Tin, const float *__restrict__ q, const unsigned char *__restrict__ mat,
+                           const float *__restrict__ cd, const float *__restrict__ cp, int N1, int N2, int N3, float Tcore,
+                           float *__restrict__ out, int jsel, long sample, long nSamples)
+{
+    const long n = (long)N1 * N3;
+    for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (long)gridDim.x * blockDim.x) {
+        const int i = (int)(v % N1), k = (int)(v / N1);
+        out[((long)i * N3 + k) * nSamples + sample] = bhte_cell(Tin, q, mat, cd, cp, i, jsel, k, N1, N2, N3, Tcore);
+    }
 }
 
 __global__ void gather_points(const float *__restrict__ T, const unsigned *__restrict__ idx, float *__restrict__ out, long n, long stride, long col)
@@ -110,12 +256,41 @@ extern "C" int bfd_bhte_run_fields(int32_t device, int32_t N1, int32_t N2, int32
         hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, 0);
         const dim3 block(64, 4, 1), grid((N1 + 63) / 64, (N2 + 3) / 4, N3);
         const float dtMin = (float)(dt / 60.0);
-        for (int s = 0; s < nSteps; s++) {
-            const int f = fieldOfStep[s];
-            hipLaunchKernelGGL(bhte_step, grid, block, 0, 0, dT[cur], dT[1 - cur], dDose, dq + (f < 0 ? 0 : (size_t)f * n), dmat, dcd, dcp, N1, N2, N3, Tcore, f >= 0 ? 1 : 0, dtMin);
-            cur = 1 - cur;
+        // two steps per launch wherever two are left (BFD_BHTE_FUSE=0: every step on its own); the monitors of the first of the
+        // two are computed from T(n) at the monitored cells only
+        const char *ev = getenv("BFD_BHTE_FUSE");
+        const bool fuse = !(ev && atoi(ev) == 0);
+        // z-runs of 8..24 planes (every run re-reads 4 planes of T and recomputes 2 of the intermediate step), short enough for
+        // ~2900 workgroups (768 fit the chip at once). Measured at 384^3 (profiles/r3/bhte_two_steps_per_launch.txt): runs of 8 / 12 /
+        // 16 / 24 planes -> 381 / 400 / 372 / 365 Gvoxel-steps/s; 372-378 -> 386-389 with the XCD-contiguous order; not kept: loads
+        // issued a plane ahead, 8 waves/SIMD, items handed out at run time to resident workgroups (81 VGPRs: 320)
+        const int tilesX = (N1 + 63) / 64, tilesY = (N2 + B2_TY - 1) / B2_TY;
+        ev = getenv("BFD_BHTE_ZRUN");
+        int zrun = (ev && atoi(ev) > 0) ? atoi(ev) : 0;
+        if (!zrun) { const int runs = (2880 + tilesX * tilesY - 1) / (tilesX * tilesY); zrun = (N3 + runs - 1) / runs; zrun = zrun < 8 ? 8 : zrun > 24 ? 24 : zrun; }
+        ev = getenv("BFD_BHTE_XCD_ORDER");
+        const int xcdOrder = (ev && atoi(ev) == 0) ? 0 : 1;
+        const int runsZ = (N3 + zrun - 1) / zrun;
+        const long nBlocks2 = (long)tilesX * tilesY * runsZ;
+        auto Q = [&](int f) { return f < 0 ? (const float *)nullptr : dq + (size_t)f * n; };
+        auto monitors = [&](int s) {
             if (dPts) hipLaunchKernelGGL(gather_points, dim3((unsigned)((nPoints + 255) / 256)), dim3(256), 0, 0, dT[cur], dIdx, dPts, (long)nPoints, (long)nSteps, (long)s);
             if (dSlice && s % fm == 0) hipLaunchKernelGGL(gather_slice, dim3(256), dim3(256), 0, 0, dT[cur], dSlice, N1, N2, N3, sliceJ, (long)(s / fm), nSamples);
+        };
+        for (int s = 0; s < nSteps;) {
+            if (fuse && s + 1 < nSteps && nBlocks2 < 0x7fffffffL) {
+                const float *qa = Q(fieldOfStep[s]), *qb = Q(fieldOfStep[s + 1]);
+                if (dPts) hipLaunchKernelGGL(step_points, dim3((unsigned)((nPoints + 255) / 256)), dim3(256), 0, 0, dT[cur], qa, dmat, dcd, dcp, N1, N2, N3, Tcore, dIdx, dPts, (long)nPoints, (long)nSteps, (long)s);
+                if (dSlice && s % fm == 0) hipLaunchKernelGGL(step_slice, dim3(256), dim3(256), 0, 0, dT[cur], qa, dmat, dcd, dcp, N1, N2, N3, Tcore, dSlice, sliceJ, (long)(s / fm), nSamples);
+                hipLaunchKernelGGL(bhte_step2, dim3((unsigned)nBlocks2), dim3(B2_T), 0, 0, dT[cur], dT[1 - cur], dDose, qa, qb, dmat, dcd, dcp, nMat, N1, N2, N3, Tcore, dtMin,
+                                   zrun, tilesX, tilesY, (int)nBlocks2, xcdOrder);
+                cur = 1 - cur; s += 2;
+                monitors(s - 1);
+            } else {
+                hipLaunchKernelGGL(bhte_step, grid, block, 0, 0, dT[cur], dT[1 - cur], dDose, Q(fieldOfStep[s]), dmat, dcd, dcp, N1, N2, N3, Tcore, dtMin);
+                cur = 1 - cur; s += 1;
+                monitors(s - 1);
+            }
         }
         hipEventRecord(e1, 0);
         e = hipEventSynchronize(e1);

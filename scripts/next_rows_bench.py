@@ -32,8 +32,11 @@ ML = dict(Density=np.array([1000., 1896.5, 1041.]), SoS=np.array([1500., 2476., 
           Absorption=np.array([0., 0.16, 0.85]), InitTemperature=np.array([37., 37., 37.]))
 P = (2e5 * rng.random(N, dtype=np.float32)).astype(np.float32)
 steps, on = 200, 100
-t0 = time.time(); out = R.BHTE(P, mm, ML, h, steps, on, N[1] // 2, nFactorMonitoring=10, dt=0.05); wall = time.time() - t0
-vox = float(np.prod(N)) * steps
-ms = R.last_kernel_ms
-print('BHTE %dx%dx%d, %d steps (%d heating): kernel %.1f ms -> %.0f Gvoxel-steps/s, %.0f GB/s on 21 B per voxel-step = %.2f of 8 TB/s (call %.1f s); Tmax %.3f'
-      % (N + (steps, on, ms, vox / ms / 1e6, 21 * vox / ms / 1e6, 21 * vox / ms / 1e6 / 8000, wall, float(out[0].max()))))
+for fuse in ('1', '0'):
+    os.environ['BFD_BHTE_FUSE'] = fuse
+    t0 = time.time(); out = R.BHTE(P, mm, ML, h, steps, on, N[1] // 2, nFactorMonitoring=10, dt=0.05); wall = time.time() - t0
+    vox = float(np.prod(N)) * steps
+    ms = R.last_kernel_ms
+    print('BHTE %dx%dx%d, %d steps (%d heating), %s: kernel %.1f ms -> %.0f Gvoxel-steps/s, %.0f GB/s on 21 B per voxel-step = %.2f of 8 TB/s (call %.1f s); Tmax %.3f'
+          % (N + (steps, on, 'two steps per launch (21 B per voxel per launch)' if fuse == '1' else 'one step per launch', ms, vox / ms / 1e6, 21 * vox / ms / 1e6,
+             21 * vox / ms / 1e6 / 8000, wall, float(out[0].max()))))

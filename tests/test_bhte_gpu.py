@@ -119,3 +119,36 @@ def test_multiple_pressure_fields_schedule_and_oracle():
     assert np.array_equal(Tb, Tc) and np.array_equal(Db, Dc)
     with pytest.raises(ValueError):
         R.BHTEMultiplePressureFields(fields, mm, ml, dx, 10, [[1, 1]], -1, dt=dt)
+
+
+def test_two_steps_per_launch_equal_one_step_per_launch(monkeypatch):
+    """The default path takes two steps per launch (bhte_step2: z-marching tiles of 64 x 26 cells with two rings); the
+    temperature, the dose and every monitor must have the bits of the one-step kernel, on grids that do not fill the tiles,
+    with odd step counts, with the field changing between the two fused steps, and with monitors on intermediate steps."""
+    from babelbrain_amd import RayleighAndBHTE as R
+    rng = np.random.default_rng(11)
+    ml = _materials()
+    for N, nS, onoff, zrun in (((150, 61, 37), 25, [[3, 2], [2, 1]], None), ((64, 26, 16), 8, [[1, 0], [1, 1]], None),
+                               ((70, 30, 35), 13, [[5, 3]], '5'), ((3, 3, 3), 5, [[2, 1]], None), ((131, 55, 20), 7, [[1, 1], [1, 0], [2, 2]], '32')):
+        mm = rng.integers(0, 5, N).astype(np.uint8)
+        fields = (3.0e6 * rng.random((len(onoff),) + N)).astype(np.float32)
+        mpm = np.zeros(N, np.uint32); mpm[1, 1, 1] = 1; mpm[N[0] // 2, N[1] // 2, N[2] // 2] = 2; mpm[N[0] - 1, N[1] - 2, 0] = 3
+        T0 = (37.0 + 8.0 * rng.random(N)).astype(np.float32)                 # some cells above 43: both dose bases
+        out = {}
+        for fuse in ('1', '0'):
+            monkeypatch.setenv('BFD_BHTE_FUSE', fuse)
+            if zrun: monkeypatch.setenv('BFD_BHTE_ZRUN', zrun)
+            else: monkeypatch.delenv('BFD_BHTE_ZRUN', raising=False)
+            out[fuse] = R.BHTEMultiplePressureFields(fields, mm, ml, 4e-4, nS, onoff, N[1] // 2, nFactorMonitoring=3, dt=0.02, initT0=T0, MonitoringPointsMap=mpm)
+        for a, b in zip(out['1'], out['0']):
+            assert np.array_equal(a, b)
+        assert out['1'][0].max() > 44.0 and out['1'][1].max() > 0
+    # and the oracle, bit for bit on the temperature now that the roundings are pinned (the dose goes through exp2f against numpy's power)
+    N = (70, 30, 35)
+    mm = rng.integers(0, 5, N).astype(np.uint8)
+    p = (3.0e6 * rng.random(N)).astype(np.float32)
+    monkeypatch.setenv('BFD_BHTE_FUSE', '1')
+    T, D, _, Q = R.BHTE(p, mm, ml, 4e-4, 11, 6, -1, dt=0.02)
+    cd, cp, qf = R.bhte_coefficients(ml, 4e-4, 0.02, 1.0)
+    To, Do = BO.bhte(np.full(N, 37.0, np.float32), np.zeros(N, np.float32), Q, mm, cd, cp, 37.0, 0.02, 11, 6)
+    assert np.array_equal(T, To) and rel_l2(D, Do) < 1e-6
