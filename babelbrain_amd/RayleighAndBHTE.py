@@ -144,24 +144,38 @@ def _bhte_run(fields, sched, MaterialMap, MaterialList, dx, LocationMonitoring, 
         raise ValueError('MaterialMap ids must index MaterialList (at most 256 materials)')
     cd, cp, qf = bhte_coefficients(MaterialList, dx, dt, DutyCycle, blood_rho, blood_ct)
 
-    def xf(a, dtype):
-        return np.ascontiguousarray(np.asarray(a).transpose(2, 1, 0), dtype=dtype)
-    mat = xf(mm, np.uint8)
-    q = np.empty((nF, N3, N2, N1), np.float32)
-    for n in range(nF):
-        p32 = xf(P[n], np.float32)
-        q[n] = (p32 * p32) * qf[mat]                             # float32, same operation order as the oracle
-    T = xf(initT0, np.float32) if initT0 is not None else np.asarray(MaterialList['InitTemperature'], np.float32)[mat]
-    T = np.ascontiguousarray(T, np.float32)
-    dose = xf(initDose, np.float32) if initDose is not None else np.zeros((N3, N2, N1), np.float32)
+    # The volumes go to the device in the caller's C order (bfd_bhte_run_volumes: last axis fastest, neighbours summed axis 0
+    # first like the oracle does): no transposes; the heat source q = (p p) qf[material] is computed on the device and comes back.
+    mat = np.ascontiguousarray(mm, np.uint8)
+    P32 = np.ascontiguousarray(P, np.float32)
+    q = np.empty((nF, N1, N2, N3), np.float32)
+    flags = 0
+    if initT0 is not None:
+        T = np.array(initT0, np.float32, order='C'); flags |= 1
+        if T.shape != (N1, N2, N3):
+            raise ValueError('initT0 must have the shape of the pressure field')
+    else:
+        T = np.empty((N1, N2, N3), np.float32)
+    if initDose is not None:
+        dose = np.array(initDose, np.float32, order='C'); flags |= 2
+        if dose.shape != (N1, N2, N3):
+            raise ValueError('initDose must have the shape of the pressure field')
+    else:
+        dose = np.empty((N1, N2, N3), np.float32)
+    initT = np.ascontiguousarray(MaterialList['InitTemperature'], np.float32)
     nSteps = len(sched)
     fm = max(int(nFactorMonitoring), 1)
     slice_ok = LocationMonitoring is not None and int(LocationMonitoring) >= 0
+    if slice_ok and int(LocationMonitoring) >= N2:
+        raise ValueError('LocationMonitoring is outside the volume')
     nS = (nSteps + fm - 1) // fm if slice_ok else 0
     mon = np.zeros((N1, N3, nS), np.float32) if slice_ok else None
     idx = pts = None
     if MonitoringPointsMap is not None:
-        mp = xf(MonitoringPointsMap, np.uint32).ravel()
+        mp = np.asarray(MonitoringPointsMap)
+        if mp.shape != (N1, N2, N3):
+            raise ValueError('MonitoringPointsMap must have the shape of the pressure field')
+        mp = mp.ravel()
         lin = np.flatnonzero(mp)
         order = np.argsort(mp[lin], kind='stable')               # point ids 1..n label the rows
         idx = np.ascontiguousarray(lin[order], np.uint32)
@@ -173,17 +187,13 @@ def _bhte_run(fields, sched, MaterialMap, MaterialList, dx, LocationMonitoring, 
 
     def ptr(a):
         return None if a is None else a.ctypes.data_as(C.c_void_p)
-    rc = lib.bfd_bhte_run_fields(_device, N1, N2, N3, nMat, ptr(mat), ptr(cd), ptr(cp), nF, ptr(q), ptr(T), ptr(dose), float(stableTemp),
-                                 float(dt), nSteps, ptr(sched), int(LocationMonitoring) if slice_ok else -1, fm, ptr(mon),
-                                 0 if idx is None else len(idx), ptr(idx), ptr(pts), C.byref(ms))
+    rc = lib.bfd_bhte_run_volumes(_device, N1, N2, N3, nMat, ptr(mat), ptr(cd), ptr(cp), ptr(qf), ptr(initT), nF, ptr(P32), ptr(q), ptr(T), ptr(dose),
+                                  flags, float(stableTemp), float(dt), nSteps, ptr(sched), int(LocationMonitoring) if slice_ok else -1, fm, ptr(mon),
+                                  0 if idx is None else len(idx), ptr(idx), ptr(pts), C.byref(ms))
     if rc != 0:
-        raise _engine.EngineError('bfd_bhte_run_fields failed (rc=%d): %s' % (rc, lib.bfd_last_error().decode()))
+        raise _engine.EngineError('bfd_bhte_run_volumes failed (rc=%d): %s' % (rc, lib.bfd_last_error().decode()))
     last_kernel_ms = ms.value
-
-    def vol(a):
-        return np.ascontiguousarray(a.transpose(2, 1, 0))
-    qout = np.stack([vol(q[n]) for n in range(nF)])
-    out = (vol(T), vol(dose), mon if slice_ok else np.zeros((0,), np.float32), qout)
+    out = (T, dose, mon if slice_ok else np.zeros((0,), np.float32), q)
     if MonitoringPointsMap is not None:
         out = out + (pts,)
     return out

@@ -27,7 +27,7 @@ ABI_SYMBOLS = [
     'bfd_set_material_map', 'bfd_set_reflector', 'bfd_set_sources', 'bfd_set_sensor_map', 'bfd_run',
     'bfd_half_step_stress', 'bfd_half_step_velocity', 'bfd_half_step_stress_part', 'bfd_half_step_velocity_part', 'bfd_half_step_stress_part_on', 'bfd_half_step_velocity_part_on', 'bfd_sync', 'bfd_current_step', 'bfd_prepare', 'bfd_halo_region',
     'bfd_timing_begin', 'bfd_timing_end', 'bfd_timing_kernels', 'bfd_algorithmic_bytes', 'bfd_reset', 'bfd_num_sensors', 'bfd_num_sensor_steps', 'bfd_get_sensor_index',
-    'bfd_get_sensors', 'bfd_get_map', 'bfd_get_field', 'bfd_tile_counts', 'bfd_tile_count_lean', 'bfd_tile_count_fused', 'bfd_device_bytes', 'bfd_rayleigh_forward', 'bfd_get_sensor_dft', 'bfd_dft_series', 'bfd_bhte_run', 'bfd_bhte_run_fields',
+    'bfd_get_sensors', 'bfd_get_map', 'bfd_get_field', 'bfd_tile_counts', 'bfd_tile_count_lean', 'bfd_tile_count_fused', 'bfd_device_bytes', 'bfd_rayleigh_forward', 'bfd_get_sensor_dft', 'bfd_dft_series', 'bfd_bhte_run', 'bfd_bhte_run_fields', 'bfd_bhte_run_volumes',
     'bfd_halo_fields', 'bfd_placement_note',
     'bfd_group_create', 'bfd_group_destroy', 'bfd_group_size', 'bfd_group_slab', 'bfd_group_set_materials', 'bfd_group_set_material_map',
     'bfd_group_set_reflector', 'bfd_group_set_sources', 'bfd_group_set_sensor_map', 'bfd_group_prepare', 'bfd_group_run', 'bfd_group_sync',
@@ -138,6 +138,9 @@ def load_library():
     lib.bfd_bhte_run_fields.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_double, C.c_int32, C.c_void_p, C.c_int32, C.c_int32,
                                         C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
+    lib.bfd_bhte_run_volumes.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_double, C.c_int32, C.c_void_p,
+                                         C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
     lib.bfd_get_sensor_dft.argtypes = [C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]
     lib.bfd_dft_series.argtypes = [C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_double, C.c_double, C.c_void_p, C.c_void_p]
     lib.bfd_rayleigh_forward.argtypes = [C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double,
@@ -169,7 +172,7 @@ def load_library():
     lib.bfd_group_get_map.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_int64, C.c_int64]
     lib.bfd_group_device_bytes.argtypes = [C.c_void_p]
     lib.bfd_group_device_bytes.restype = C.c_int64
-    if lib.bfd_abi_version() != 3:
+    if lib.bfd_abi_version() != 4:
         raise EngineError('libbabelfdtd_hip.so ABI version mismatch')
     _lib = lib
     return lib

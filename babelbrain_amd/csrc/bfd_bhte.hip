@@ -30,10 +30,14 @@ __device__ __forceinline__ const float &F4(const float *base, unsigned byteOfs) 
 
 // One cell, one step, in the oracle's operation order (oracle/bhte_oracle.py); the roundings are pinned so that the one-step
 // kernel, the two-step kernel and the monitors of an intermediate step give the same bits.
+// REV: the neighbours are summed slowest axis first (volumes handed over in numpy C order, whose LAST axis is the fastest one
+// here: the oracle sums axis 0 first), otherwise fastest axis first (x-fastest volumes of the legacy entry points).
+template <bool REV>
 __device__ __forceinline__ float bhte_update(float T, float xm, float xp, float ym, float yp, float zm, float zp, float cd, float cp,
                                              float Tcore, bool heating, float q)
 {
-    const float s = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(xm, xp), ym), yp), zm), zp);
+    const float s = REV ? __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(zm, zp), ym), yp), xm), xp)
+                        : __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(xm, xp), ym), yp), zm), zp);
     float Tn = __fadd_rn(T, __fmul_rn(cd, __fsub_rn(s, __fmul_rn(6.0f, T))));
     Tn = __fadd_rn(Tn, __fmul_rn(cp, __fsub_rn(Tcore, T)));
     if (heating) Tn = __fadd_rn(Tn, q);
@@ -47,6 +51,7 @@ __device__ __forceinline__ float bhte_dose_rate(float Tn, float dtMin)
     // cell); such a term (T' < -20 degC) is 1e-38 of a minute and flushes to zero here
     return __fmul_rn(dtMin, __builtin_amdgcn_exp2f(Tn >= 43.0f ? -e : -2.0f * e));
 }
+template <bool REV>
 __device__ __forceinline__ float bhte_cell(const float *__restrict__ Tin, const float *__restrict__ q, const unsigned char *__restrict__ mat,
                                            const float *__restrict__ cd, const float *__restrict__ cp, int i, int j, int k, int N1, int N2, int N3,
                                            float Tcore)
@@ -55,10 +60,11 @@ __device__ __forceinline__ float bhte_cell(const float *__restrict__ Tin, const 
     const float T = Tin[c];
     if (!(i > 0 && i < N1 - 1 && j > 0 && j < N2 - 1 && k > 0 && k < N3 - 1)) return T;
     const int m = mat[c];
-    return bhte_update(T, Tin[c - 1], Tin[c + 1], Tin[c - N1], Tin[c + N1], Tin[c - pl], Tin[c + pl], cd[m], cp[m], Tcore, q != nullptr, q ? q[c] : 0.0f);
+    return bhte_update<REV>(T, Tin[c - 1], Tin[c + 1], Tin[c - N1], Tin[c + N1], Tin[c - pl], Tin[c + pl], cd[m], cp[m], Tcore, q != nullptr, q ? q[c] : 0.0f);
 }
 
 // One step, one thread per voxel (odd step counts, BFD_BHTE_FUSE=0). q == nullptr: no heating in this step.
+template <bool REV>
 __global__ __launch_bounds__(256) void bhte_step(const float *__restrict__ Tin, float *__restrict__ Tout, float *__restrict__ dose,
                                                  const float *__restrict__ q, const unsigned char *__restrict__ mat,
                                                  const float *__restrict__ cd, const float *__restrict__ cp,
@@ -67,7 +73,7 @@ __global__ __launch_bounds__(256) void bhte_step(const float *__restrict__ Tin, 
     const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z;
     if (i >= N1 || j >= N2) return;
     const long c = (long)k * N1 * N2 + (long)j * N1 + i;
-    const float Tn = bhte_cell(Tin, q, mat, cd, cp, i, j, k, N1, N2, N3, Tcore);
+    const float Tn = bhte_cell<REV>(Tin, q, mat, cd, cp, i, j, k, N1, N2, N3, Tcore);
     Tout[c] = Tn;
     // Measured in round 3 and not kept (profiles/README.md): an XCD-contiguous block order (163 against 181 Gvoxel-steps/s), a
     // z-marching form with T(k-1), T(k), T(k+1) in registers (179-186 against 184: the re-reads of T it saves come out of the
@@ -90,6 +96,7 @@ constexpr int B2_W = 68, B2_H = 30, B2_TY = B2_H - 4, B2_T = 512, B2_NC = 4, B2_
 #define B2_ARGS const float *__restrict__ Tin, float *__restrict__ Tout, float *__restrict__ dose, const float *__restrict__ qa, const float *__restrict__ qb, \
                 const unsigned char *__restrict__ mat, const float *__restrict__ cd, const float *__restrict__ cp, int nMat, int N1, int N2, int N3, float Tcore, \
                 float dtMin, int zrun, int tilesX, int tilesY, int nBlocks, int xcdOrder
+template <bool REV>
 __device__ __forceinline__ void bhte_step2_body(int b, B2_ARGS)
 {
     __shared__ float A[2][B2_NC * B2_T], B[2][B2_NC * B2_T];
@@ -140,7 +147,7 @@ __device__ __forceinline__ void bhte_step2_body(int b, B2_ARGS)
             float T1 = t0c[n], q = 0.0f; int m = 0;
             if (inner && (flags[n] & 2u)) {
                 m = uni(matP)[off[n] >> 2]; if (qa) q = F4(qaP, off[n]);
-                T1 = bhte_update(t0c[n], Ap[e - 1], Ap[e + 1], Ap[e - B2_W], Ap[e + B2_W], t0m[n], t0p[n], sCd[m], sCp[m], Tcore, qa != nullptr, q);
+                T1 = bhte_update<REV>(t0c[n], Ap[e - 1], Ap[e + 1], Ap[e - B2_W], Ap[e + B2_W], t0m[n], t0p[n], sCd[m], sCp[m], Tcore, qa != nullptr, q);
             }
             Bp[e] = T1;
             if (outs && (flags[n] & 4u)) {
@@ -148,7 +155,7 @@ __device__ __forceinline__ void bhte_step2_body(int b, B2_ARGS)
                 if (innerOut && !(flags[n] & 8u)) {
                     const int m2 = flags[n] >> 8;
                     const float q2 = qb ? (qb == qa ? qprev[n] : F4(qbO, off[n])) : 0.0f;
-                    T2 = bhte_update(t1c[n], Bq[e - 1], Bq[e + 1], Bq[e - B2_W], Bq[e + B2_W], t1m[n], T1, sCd[m2], sCp[m2], Tcore, qb != nullptr, q2);
+                    T2 = bhte_update<REV>(t1c[n], Bq[e - 1], Bq[e + 1], Bq[e - B2_W], Bq[e + B2_W], t1m[n], T1, sCd[m2], sCp[m2], Tcore, qb != nullptr, q2);
                 }
                 F4(ToutO, off[n]) = T2;
                 F4(doseO, off[n]) = __fadd_rn(__fadd_rn(dz[n], bhte_dose_rate(t1c[n], dtMin)), bhte_dose_rate(T2, dtMin));
@@ -158,6 +165,7 @@ __device__ __forceinline__ void bhte_step2_body(int b, B2_ARGS)
     }
 }
 
+template <bool REV>
 __global__ __launch_bounds__(B2_T) void bhte_step2(B2_ARGS)
 {
     int b = blockIdx.x;
@@ -165,9 +173,10 @@ __global__ __launch_bounds__(B2_T) void bhte_step2(B2_ARGS)
         const int per = nBlocks >> 3, rem = nBlocks & 7, x = b & 7, slot = b >> 3;
         b = x * per + (x < rem ? x : rem) + slot;
     }
-    bhte_step2_body(b, Tin, Tout, dose, qa, qb, mat, cd, cp, nMat, N1, N2, N3, Tcore, dtMin, zrun, tilesX, tilesY, nBlocks, xcdOrder);
+    bhte_step2_body<REV>(b, Tin, Tout, dose, qa, qb, mat, cd, cp, nMat, N1, N2, N3, Tcore, dtMin, zrun, tilesX, tilesY, nBlocks, xcdOrder);
 }
 // Monitors of the first of two fused steps: T(n+1) at the listed voxels / on the monitored plane, computed from T(n)
+template <bool REV>
 __global__ void step_points(const float *__restrict__ Tin, const float *__restrict__ q, const unsigned char *__restrict__ mat,
                             const float *__restrict__ cd, const float *__restrict__ cp, int N1, int N2, int N3, float Tcore,
                             const unsigned *__restrict__ idx, float *__restrict__ out, long n, long stride, long col)
@@ -176,8 +185,9 @@ __global__ void step_points(const float *__restrict__ Tin, const float *__restri
     if (t >= n) return;
     const unsigned c = idx[t];
     const int i = (int)(c % (unsigned)N1), j = (int)((c / (unsigned)N1) % (unsigned)N2), k = (int)(c / ((unsigned)N1 * (unsigned)N2));
-    out[t * stride + col] = bhte_cell(Tin, q, mat, cd, cp, i, j, k, N1, N2, N3, Tcore);
+    out[t * stride + col] = bhte_cell<REV>(Tin, q, mat, cd, cp, i, j, k, N1, N2, N3, Tcore);
 }
+template <bool REV>
 __global__ void step_slice(const float *__restrict__ Tin, const float *__restrict__ q, const unsigned char *__restrict__ mat,
                            const float *__restrict__ cd, const float *__restrict__ cp, int N1, int N2, int N3, float Tcore,
                            float *__restrict__ out, int jsel, long sample, long nSamples)
@@ -185,7 +195,7 @@ __global__ void step_slice(const float *__restrict__ Tin, const float *__restric
     const long n = (long)N1 * N3;
     for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (long)gridDim.x * blockDim.x) {
         const int i = (int)(v % N1), k = (int)(v / N1);
-        out[((long)i * N3 + k) * nSamples + sample] = bhte_cell(Tin, q, mat, cd, cp, i, jsel, k, N1, N2, N3, Tcore);
+        out[(REV ? (long)k * N1 + i : (long)i * N3 + k) * nSamples + sample] = bhte_cell<REV>(Tin, q, mat, cd, cp, i, jsel, k, N1, N2, N3, Tcore);
     }
 }
 
@@ -194,31 +204,42 @@ __global__ void gather_points(const float *__restrict__ T, const unsigned *__res
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t < n) out[t * stride + col] = T[idx[t]];
 }
+template <bool REV>
 __global__ void gather_slice(const float *__restrict__ T, float *__restrict__ out, int N1, int N2, int N3, int jsel, long sample, long nSamples)
-{   // out[(i*N3 + k)*nSamples + sample]
+{   // out[(i*N3 + k)*nSamples + sample]; REV: out[(k*N1 + i)*nSamples + sample] (slow axis first, the caller's C order)
     const long n = (long)N1 * N3;
     for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (long)gridDim.x * blockDim.x) {
         const int i = (int)(v % N1), k = (int)(v / N1);
-        out[((long)i * N3 + k) * nSamples + sample] = T[(long)k * N1 * N2 + (long)jsel * N1 + i];
+        out[(REV ? (long)k * N1 + i : (long)i * N3 + k) * nSamples + sample] = T[(long)k * N1 * N2 + (long)jsel * N1 + i];
+    }
+}
+
+__global__ void table_lookup(const unsigned char *__restrict__ mat, const float *__restrict__ tab, float *__restrict__ out, size_t n)
+{
+    for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (size_t)gridDim.x * blockDim.x) out[v] = tab[mat[v]];
+}
+// heat increment of one ON step from the pressure amplitude: q = (p p) qf[m], float32 with the oracle's roundings
+__global__ void heat_source(const float *p, const unsigned char *__restrict__ mat, const float *__restrict__ qf, float *q, size_t n)      // q may be p
+{
+    for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (size_t)gridDim.x * blockDim.x) {
+        const float a = p[v];
+        q[v] = __fmul_rn(__fmul_rn(a, a), qf[mat[v]]);
     }
 }
 
 }  // namespace
 
-// All volumes x-fastest (i + N1*(j + N2*k)), float32; mat uint8 ids into cd/cp (nMat <= 256).
-// T, dose: in/out (initial -> final). q: heat increment per ON step (already multiplied by dt*duty/(rho c)).
-// monitorSlice (may be NULL): [N1][N3][nSliceSamples], plane j = sliceJ sampled every nFactorMonitoring steps.
-// points (may be NULL): [nPoints][nSteps], temperature after every step at the listed voxels.
-// q: nFields volumes, one per pressure field (BHTEMultiplePressureFields: steered multi-point sonications,
-// CalculateTemperatureEffects.py:381, 978). fieldOfStep[s] = which of them heats during step s, -1 = none.
-extern "C" int bfd_bhte_run_fields(int32_t device, int32_t N1, int32_t N2, int32_t N3, int32_t nMat, const unsigned char *mat,
-                                   const float *cd, const float *cp, int32_t nFields, const float *q, float *T, float *dose,
-                                   float Tcore, double dt, int32_t nSteps, const int32_t *fieldOfStep, int32_t sliceJ,
-                                   int32_t nFactorMonitoring, float *monitorSlice, int64_t nPoints, const uint32_t *pointIndex,
-                                   float *points, double *kernelMs)
+// The run behind all entry points. F, M, S: extents of the fastest, middle and slowest axis of the volumes as they lie in memory.
+// q (host, nFields volumes) or, if null, pressure + qf: the heat increments are then computed on the device (and copied to qOut).
+// initT (per material) replaces the upload of T when flags bit 0 is clear; the dose starts from zero when bit 1 is clear.
+template <bool REV>
+static int bhte_run_core(int32_t device, int32_t F, int32_t M, int32_t S, int32_t nMat, const unsigned char *mat, const float *cd, const float *cp,
+                         const float *qf, const float *initT, int32_t nFields, const float *q, const float *pressure, float *qOut, float *T, float *dose,
+                         int32_t flags, float Tcore, double dt, int32_t nSteps, const int32_t *fieldOfStep, int32_t sliceJ, int32_t nFactorMonitoring,
+                         float *monitorSlice, int64_t nPoints, const uint32_t *pointIndex, float *points, double *kernelMs)
 {
-    if (N1 < 3 || N2 < 3 || N3 < 3 || nMat < 1 || nMat > 256 || nFields < 1 || !mat || !cd || !cp || !q || !T || !dose || nSteps < 0 ||
-        (nSteps > 0 && !fieldOfStep)) {
+    if (F < 3 || M < 3 || S < 3 || nMat < 1 || nMat > 256 || nFields < 1 || !mat || !cd || !cp || (!q && !(pressure && qf)) || !T || !dose || nSteps < 0 ||
+        (nSteps > 0 && !fieldOfStep) || (!(flags & 1) && !initT)) {
         bfd_set_error("bfd_bhte_run: bad argument"); return -1;
     }
     for (int s = 0; s < nSteps; s++)
@@ -227,10 +248,14 @@ extern "C" int bfd_bhte_run_fields(int32_t device, int32_t N1, int32_t N2, int32
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { bfd_set_error("bfd_bhte_run: no HIP device available (no CPU fallback)"); return -3; }
     if (device < 0 || device >= ndev) { bfd_set_error("bfd_bhte_run: device ordinal out of range"); return -3; }
     BFD_HIP(hipSetDevice(device));
+    const int N1 = F, N2 = M, N3 = S;                            // the kernels' names: x fastest
     const size_t n = (size_t)N1 * N2 * N3;
+    if (sliceJ >= N2) { bfd_set_error("bfd_bhte_run: monitored plane outside the volume"); return -1; }
+    for (int64_t t = 0; t < nPoints && pointIndex && points; t++)
+        if (pointIndex[t] >= n) { bfd_set_error("bfd_bhte_run: monitored point outside the volume"); return -1; }
     const int fm = nFactorMonitoring > 0 ? nFactorMonitoring : 1;
     const long nSamples = (monitorSlice && sliceJ >= 0) ? (nSteps + fm - 1) / fm : 0;
-    float *dT[2] = {nullptr, nullptr}, *dDose = nullptr, *dq = nullptr, *dcd = nullptr, *dcp = nullptr, *dSlice = nullptr, *dPts = nullptr;
+    float *dT[2] = {nullptr, nullptr}, *dDose = nullptr, *dq = nullptr, *dcd = nullptr, *dcp = nullptr, *dqf = nullptr, *dSlice = nullptr, *dPts = nullptr;
     unsigned char *dmat = nullptr; unsigned *dIdx = nullptr;
     std::vector<void *> allocs;
     auto A = [&](void **p, size_t bytes) { hipError_t e = hipMalloc(p, bytes ? bytes : 1); if (e == hipSuccess) allocs.push_back(*p); return e; };
@@ -241,14 +266,29 @@ extern "C" int bfd_bhte_run_fields(int32_t device, int32_t N1, int32_t N2, int32
     if (e == hipSuccess) e = A((void **)&dmat, n);
     if (e == hipSuccess) e = A((void **)&dcd, nMat * 4);
     if (e == hipSuccess) e = A((void **)&dcp, nMat * 4);
+    if (e == hipSuccess) e = A((void **)&dqf, nMat * 4);
     if (e == hipSuccess && nSamples) e = A((void **)&dSlice, (size_t)N1 * N3 * nSamples * 4);
     if (e == hipSuccess && nPoints && points) { e = A((void **)&dIdx, nPoints * 4); if (e == hipSuccess) e = A((void **)&dPts, (size_t)nPoints * nSteps * 4); }
-    if (e == hipSuccess) e = hipMemcpy(dT[0], T, n * 4, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(dDose, dose, n * 4, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(dq, q, n * 4 * (size_t)nFields, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(dmat, mat, n, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(dcd, cd, nMat * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(dcp, cp, nMat * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        if (flags & 1) e = hipMemcpy(dT[0], T, n * 4, hipMemcpyHostToDevice);
+        else {                                                                   // T = initT[material], via the table slot of qf
+            e = hipMemcpy(dqf, initT, nMat * 4, hipMemcpyHostToDevice);
+            if (e == hipSuccess) { hipLaunchKernelGGL(table_lookup, dim3(2048), dim3(256), 0, 0, dmat, dqf, dT[0], n); e = hipDeviceSynchronize(); }
+        }
+    }
+    if (e == hipSuccess) e = (flags & 2) ? hipMemcpy(dDose, dose, n * 4, hipMemcpyHostToDevice) : hipMemset(dDose, 0, n * 4);
+    if (e == hipSuccess) {
+        if (q) e = hipMemcpy(dq, q, n * 4 * (size_t)nFields, hipMemcpyHostToDevice);
+        else {                                                                   // q = (p p) qf[material], in place
+            e = hipMemcpy(dqf, qf, nMat * 4, hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = hipMemcpy(dq, pressure, n * 4 * (size_t)nFields, hipMemcpyHostToDevice);
+            for (int f = 0; f < nFields && e == hipSuccess; f++) hipLaunchKernelGGL(heat_source, dim3(2048), dim3(256), 0, 0, dq + (size_t)f * n, dmat, dqf, dq + (size_t)f * n, n);
+            if (e == hipSuccess && qOut) e = hipMemcpy(qOut, dq, n * 4 * (size_t)nFields, hipMemcpyDeviceToHost);
+        }
+    }
     if (e == hipSuccess && dIdx) e = hipMemcpy(dIdx, pointIndex, nPoints * 4, hipMemcpyHostToDevice);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     int cur = 0;
@@ -275,19 +315,19 @@ extern "C" int bfd_bhte_run_fields(int32_t device, int32_t N1, int32_t N2, int32
         auto Q = [&](int f) { return f < 0 ? (const float *)nullptr : dq + (size_t)f * n; };
         auto monitors = [&](int s) {
             if (dPts) hipLaunchKernelGGL(gather_points, dim3((unsigned)((nPoints + 255) / 256)), dim3(256), 0, 0, dT[cur], dIdx, dPts, (long)nPoints, (long)nSteps, (long)s);
-            if (dSlice && s % fm == 0) hipLaunchKernelGGL(gather_slice, dim3(256), dim3(256), 0, 0, dT[cur], dSlice, N1, N2, N3, sliceJ, (long)(s / fm), nSamples);
+            if (dSlice && s % fm == 0) hipLaunchKernelGGL(gather_slice<REV>, dim3(256), dim3(256), 0, 0, dT[cur], dSlice, N1, N2, N3, sliceJ, (long)(s / fm), nSamples);
         };
         for (int s = 0; s < nSteps;) {
             if (fuse && s + 1 < nSteps && nBlocks2 < 0x7fffffffL) {
                 const float *qa = Q(fieldOfStep[s]), *qb = Q(fieldOfStep[s + 1]);
-                if (dPts) hipLaunchKernelGGL(step_points, dim3((unsigned)((nPoints + 255) / 256)), dim3(256), 0, 0, dT[cur], qa, dmat, dcd, dcp, N1, N2, N3, Tcore, dIdx, dPts, (long)nPoints, (long)nSteps, (long)s);
-                if (dSlice && s % fm == 0) hipLaunchKernelGGL(step_slice, dim3(256), dim3(256), 0, 0, dT[cur], qa, dmat, dcd, dcp, N1, N2, N3, Tcore, dSlice, sliceJ, (long)(s / fm), nSamples);
-                hipLaunchKernelGGL(bhte_step2, dim3((unsigned)nBlocks2), dim3(B2_T), 0, 0, dT[cur], dT[1 - cur], dDose, qa, qb, dmat, dcd, dcp, nMat, N1, N2, N3, Tcore, dtMin,
+                if (dPts) hipLaunchKernelGGL(step_points<REV>, dim3((unsigned)((nPoints + 255) / 256)), dim3(256), 0, 0, dT[cur], qa, dmat, dcd, dcp, N1, N2, N3, Tcore, dIdx, dPts, (long)nPoints, (long)nSteps, (long)s);
+                if (dSlice && s % fm == 0) hipLaunchKernelGGL(step_slice<REV>, dim3(256), dim3(256), 0, 0, dT[cur], qa, dmat, dcd, dcp, N1, N2, N3, Tcore, dSlice, sliceJ, (long)(s / fm), nSamples);
+                hipLaunchKernelGGL(bhte_step2<REV>, dim3((unsigned)nBlocks2), dim3(B2_T), 0, 0, dT[cur], dT[1 - cur], dDose, qa, qb, dmat, dcd, dcp, nMat, N1, N2, N3, Tcore, dtMin,
                                    zrun, tilesX, tilesY, (int)nBlocks2, xcdOrder);
                 cur = 1 - cur; s += 2;
                 monitors(s - 1);
             } else {
-                hipLaunchKernelGGL(bhte_step, grid, block, 0, 0, dT[cur], dT[1 - cur], dDose, Q(fieldOfStep[s]), dmat, dcd, dcp, N1, N2, N3, Tcore, dtMin);
+                hipLaunchKernelGGL(bhte_step<REV>, grid, block, 0, 0, dT[cur], dT[1 - cur], dDose, Q(fieldOfStep[s]), dmat, dcd, dcp, N1, N2, N3, Tcore, dtMin);
                 cur = 1 - cur; s += 1;
                 monitors(s - 1);
             }
@@ -306,6 +346,41 @@ extern "C" int bfd_bhte_run_fields(int32_t device, int32_t N1, int32_t N2, int32
     for (void *p : allocs) hipFree(p);
     if (e != hipSuccess) { bfd_set_error(std::string("bfd_bhte_run: ") + hipGetErrorString(e)); return -10; }
     return 0;
+}
+
+// All volumes x-fastest (i + N1*(j + N2*k)), float32; mat uint8 ids into cd/cp (nMat <= 256).
+// T, dose: in/out (initial -> final). q: heat increment per ON step (already multiplied by dt*duty/(rho c)).
+// monitorSlice (may be NULL): [N1][N3][nSliceSamples], plane j = sliceJ sampled every nFactorMonitoring steps.
+// points (may be NULL): [nPoints][nSteps], temperature after every step at the listed voxels.
+// q: nFields volumes, one per pressure field (BHTEMultiplePressureFields: steered multi-point sonications,
+// CalculateTemperatureEffects.py:381, 978). fieldOfStep[s] = which of them heats during step s, -1 = none.
+extern "C" int bfd_bhte_run_fields(int32_t device, int32_t N1, int32_t N2, int32_t N3, int32_t nMat, const unsigned char *mat,
+                                   const float *cd, const float *cp, int32_t nFields, const float *q, float *T, float *dose,
+                                   float Tcore, double dt, int32_t nSteps, const int32_t *fieldOfStep, int32_t sliceJ,
+                                   int32_t nFactorMonitoring, float *monitorSlice, int64_t nPoints, const uint32_t *pointIndex,
+                                   float *points, double *kernelMs)
+{
+    if (!q) { bfd_set_error("bfd_bhte_run: bad argument"); return -1; }
+    return bhte_run_core<false>(device, N1, N2, N3, nMat, mat, cd, cp, nullptr, nullptr, nFields, q, nullptr, nullptr, T, dose, 3, Tcore, dt, nSteps, fieldOfStep,
+                                sliceJ, nFactorMonitoring, monitorSlice, nPoints, pointIndex, points, kernelMs);
+}
+
+// The same run on volumes in the CALLER'S numpy C order -- [N1][N2][N3], the last axis fastest -- so that the host transposes
+// nothing (at 384^3 the transposes and the float32 products of the heat source were 2 s of a 2.3 s call whose kernels take
+// 0.03 s), and with the heat source computed on the device: q = (p p) qf[material] from the pressure amplitude(s) `pressure`
+// (nFields volumes, float32 Pa) and the per-material factor qf; qOut (may be NULL) receives it. The neighbours are summed
+// axis 0 first, like the oracle does on such arrays. flags bit 0: T holds the initial temperature (else initT[material]);
+// bit 1: dose holds the initial dose (else zero). monitorSlice: [N1][N3][nSamples] = T[:, sliceJ, :]; pointIndex: C-order
+// linear indices (i*N2 + j)*N3 + k.
+extern "C" int bfd_bhte_run_volumes(int32_t device, int32_t N1, int32_t N2, int32_t N3, int32_t nMat, const unsigned char *mat,
+                                    const float *cd, const float *cp, const float *qf, const float *initT, int32_t nFields,
+                                    const float *pressure, float *qOut, float *T, float *dose, int32_t flags, float Tcore, double dt,
+                                    int32_t nSteps, const int32_t *fieldOfStep, int32_t sliceJ, int32_t nFactorMonitoring,
+                                    float *monitorSlice, int64_t nPoints, const uint32_t *pointIndex, float *points, double *kernelMs)
+{
+    if (!pressure || !qf) { bfd_set_error("bfd_bhte_run_volumes: bad argument"); return -1; }
+    return bhte_run_core<true>(device, N3, N2, N1, nMat, mat, cd, cp, qf, initT, nFields, nullptr, pressure, qOut, T, dose, flags, Tcore, dt, nSteps, fieldOfStep,
+                               sliceJ, nFactorMonitoring, monitorSlice, nPoints, pointIndex, points, kernelMs);
 }
 
 // One pressure field heating during the first nStepsOn steps (the reference's BHTE call).

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define BFD_ABI_VERSION 3
+#define BFD_ABI_VERSION 4
 
 enum {
     BFD_MAP_VX = 0, BFD_MAP_VY = 1, BFD_MAP_VZ = 2,
@@ -293,6 +293,20 @@ int bfd_bhte_run_fields(int32_t device, int32_t N1, int32_t N2, int32_t N3, int3
                         float Tcore, double dt, int32_t nSteps, const int32_t *fieldOfStep, int32_t sliceJ,
                         int32_t nFactorMonitoring, float *monitorSlice, int64_t nPoints, const uint32_t *pointIndex,
                         float *points, double *kernelMs);
+
+/* The same run on volumes in the CALLER'S numpy C order, [N1][N2][N3] with the LAST axis fastest (what BHTE() receives at
+ * CalculateTemperatureEffects.py:960: no host transposes), and with the heat source computed on the device from the
+ * pressure amplitude(s): q = (p p) qf[material], float32; `pressure` holds nFields volumes (Pa), qOut (may be NULL) receives
+ * q (the reference returns it as Qarr). The six neighbours are summed axis 0 first. flags bit 0: T holds the initial
+ * temperature (else T starts from initT[material] and is output only); bit 1: dose holds the initial dose (else zero).
+ * monitorSlice (may be NULL): [N1][N3][ceil(nSteps/nFactorMonitoring)] = T[:, sliceJ, :]; pointIndex: C-order linear
+ * indices (i N2 + j) N3 + k. Steps are taken two per launch (one kernel pass moves the 21 B per voxel of a step once for
+ * both); the monitors of the intermediate step are computed at the monitored voxels. */
+int bfd_bhte_run_volumes(int32_t device, int32_t N1, int32_t N2, int32_t N3, int32_t nMat, const unsigned char *mat,
+                         const float *cd, const float *cp, const float *qf, const float *initT, int32_t nFields,
+                         const float *pressure, float *qOut, float *T, float *dose, int32_t flags, float Tcore, double dt,
+                         int32_t nSteps, const int32_t *fieldOfStep, int32_t sliceJ, int32_t nFactorMonitoring,
+                         float *monitorSlice, int64_t nPoints, const uint32_t *pointIndex, float *points, double *kernelMs);
 
 #ifdef __cplusplus
 }

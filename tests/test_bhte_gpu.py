@@ -10,6 +10,14 @@ from tests.util import rel_l2
 pytestmark = pytest.mark.gpu
 
 
+def _ftz(a):
+    """The library's float32 arithmetic flushes subnormal results to zero (csrc/Makefile); numpy keeps them. A heat increment
+    below 1.2e-38 K per step is zero either way for the temperature."""
+    a = np.array(a, np.float32)
+    a[np.abs(a) < np.finfo(np.float32).tiny] = 0
+    return a
+
+
 def _materials():
     # water, skin, cortical, trabecular, brain rows of CalculateTemperatureEffects.py:780-791; acoustic columns of MatFreq[500e3]
     return {'Density': np.array([1000.0, 1116.0, 1896.5, 1738.0, 1041.0]), 'SoS': np.array([1500.0, 1537.0, 2476.0, 2205.0, 1562.0]),
@@ -35,7 +43,7 @@ def test_bhte_matches_oracle_and_monitors():
     To, Do = BO.bhte(T0, np.zeros(N, np.float32), q, mm, cd, cp, 37.0, dt, nS, nOn)
     assert To.max() > 40.0
     assert rel_l2(T - 37.0, To - 37.0) < 1e-5 and rel_l2(D, Do) < 1e-5
-    assert np.array_equal(Q, q)
+    assert np.array_equal(Q, _ftz(q))
     assert mon.shape == (N[0], N[2], 12) and pts.shape == (3, nS)
     # the last monitored sample is step 110: compare with a shorter oracle run
     T110, _ = BO.bhte(T0, np.zeros(N, np.float32), q, mm, cd, cp, 37.0, dt, 111, nOn)
@@ -103,7 +111,7 @@ def test_multiple_pressure_fields_schedule_and_oracle():
     To, Do = BO.bhte(T0, np.zeros(N, np.float32), q, mm, cd, cp, 37.0, dt, nS, 0, field_of_step=sched)
     assert To.max() > 39.0
     assert rel_l2(T - 37.0, To - 37.0) < 1e-5 and rel_l2(D, Do) < 1e-5
-    assert Q.shape == fields.shape and np.array_equal(Q, q)
+    assert Q.shape == fields.shape and np.array_equal(Q, _ftz(q))
     assert mon.shape == (N[0], N[2], 10) and pts.shape == (2, nS)
     # each monitored point heats fastest while its own focal spot is on
     rise = np.diff(np.concatenate([[37.0], pts[0]]))
@@ -152,3 +160,38 @@ def test_two_steps_per_launch_equal_one_step_per_launch(monkeypatch):
     cd, cp, qf = R.bhte_coefficients(ml, 4e-4, 0.02, 1.0)
     To, Do = BO.bhte(np.full(N, 37.0, np.float32), np.zeros(N, np.float32), Q, mm, cd, cp, 37.0, 0.02, 11, 6)
     assert np.array_equal(T, To) and rel_l2(D, Do) < 1e-6
+
+
+def test_x_fastest_entry_points_of_the_c_abi():
+    """bfd_bhte_run / bfd_bhte_run_fields keep their x-fastest contract (volumes [k][j][i], heat source precomputed); the
+    drop-in goes through bfd_bhte_run_volumes (caller's C order). Same run both ways: equal up to the order in which the six
+    neighbours are summed (fastest axis first there, axis 0 first here)."""
+    import ctypes as C
+    from babelbrain_amd import RayleighAndBHTE as R, _engine
+    lib = _engine.load_library()
+    rng = np.random.default_rng(21)
+    N = (45, 30, 38)
+    ml = _materials()
+    mm = rng.integers(0, 5, N).astype(np.uint8)
+    p = (3.0e6 * rng.random(N)).astype(np.float32)
+    nS, nOn, dx, dt = 15, 9, 4e-4, 0.02
+    mpm = np.zeros(N, np.uint32); mpm[7, 8, 9] = 1
+    T, D, mon, Q, pts = R.BHTE(p, mm, ml, dx, nS, nOn, 11, nFactorMonitoring=4, dt=dt, MonitoringPointsMap=mpm)
+    cd, cp, qf = R.bhte_coefficients(ml, dx, dt, 1.0)
+    xf = lambda a, t: np.ascontiguousarray(a.transpose(2, 1, 0), dtype=t)
+    mat, q = xf(mm, np.uint8), xf(Q, np.float32)
+    Tx = np.full(mat.shape, 37.0, np.float32); Dx = np.zeros(mat.shape, np.float32)
+    monx = np.zeros((N[0], N[2], 4), np.float32)
+    idx = np.array([7 + N[0] * (8 + N[1] * 9)], np.uint32); ptx = np.zeros((1, nS), np.float32)
+    ptr = lambda a: a.ctypes.data_as(C.c_void_p)
+    ms = C.c_double()
+    rc = lib.bfd_bhte_run(0, N[0], N[1], N[2], 5, ptr(mat), ptr(cd), ptr(cp), ptr(q), ptr(Tx), ptr(Dx), 37.0, dt, nS, nOn, 11, 4, ptr(monx),
+                          1, ptr(idx), ptr(ptx), C.byref(ms))
+    assert rc == 0, lib.bfd_last_error()
+    assert rel_l2(Tx.transpose(2, 1, 0) - 37.0, T - 37.0) < 1e-6 and rel_l2(Dx.transpose(2, 1, 0), D) < 1e-6
+    assert rel_l2(monx - 37.0, mon - 37.0) < 1e-6 and rel_l2(ptx - 37.0, pts - 37.0) < 1e-6
+    # bad arguments are refused, not run
+    assert lib.bfd_bhte_run_volumes(0, 2, 30, 38, 5, ptr(mat), ptr(cd), ptr(cp), ptr(qf), ptr(cd), 1, ptr(q), None, ptr(Tx), ptr(Dx), 0, 37.0, dt, 1,
+                                    ptr(np.zeros(1, np.int32)), -1, 1, None, 0, None, None, None) == -1
+    with pytest.raises(ValueError):
+        R.BHTE(p, mm, ml, dx, nS, nOn, 30, dt=dt)                    # monitored plane outside the volume
