@@ -1210,7 +1210,8 @@ static void bind_state_views(bfd_sim *s)
     float **fp[15] = {&d.Vx, &d.Vy, &d.Vz, &d.Sxx, &d.Syy, &d.Szz, &d.Sxy, &d.Sxz, &d.Syz, &d.Rxx, &d.Ryy, &d.Rzz, &d.Rxy, &d.Rxz, &d.Ryz};
     for (int a = 0; a < 15; a++) *fp[a] = s->stateBase[a] + g;
     d.mat = s->matBase + g; d.cls = s->clsBase + g;
-    d.VxW = d.Vx; d.VyW = d.Vy; d.VzW = d.Vz; d.SzzW = d.Szz; d.RzzW = d.Rzz;      // in-place variants only (no second copies)
+    d.VxW = d.Vx; d.VyW = d.Vy; d.VzW = d.Vz; d.SzzW = d.Szz; d.RzzW = d.Rzz;      // in-place variants: no second copies
+    if (s->pingpong) { d.VxW = s->ppBase[0] + g; d.VyW = s->ppBase[1] + g; d.VzW = s->ppBase[2] + g; d.SzzW = s->ppBase[3] + g; d.RzzW = s->ppBase[4] + g; }
 }
 
 // device time of `reps` pair probes of the arrays at a and b (pointers to local plane 0), planes [0, kmax); < 0 on error
@@ -1242,8 +1243,12 @@ static int choose_placement(bfd_sim *s)
     size_t minVoxels = (size_t)32 << 20;
     if (const char *ev = getenv("BFD_PLACEMENT_MIN_VOXELS")) minVoxels = (size_t)atol(ev);      // tests: exercise it on small grids too
     if (!on) return 0;
-    if (s->step != 0 || s->haloHandedOut || s->pingpong || s->cfg.kernelVariant == 1 || s->nloc < minVoxels || s->d.nk < 8 ||
-        s->tiles.nFluid + s->tiles.nSolid == 0) { s->placementNote = "skipped (small grid, fused variant or arrays already handed out)"; return 0; }
+    if (s->step != 0 || s->haloHandedOut || s->cfg.kernelVariant == 1 || s->nloc < minVoxels || s->d.nk < 8 ||
+        s->tiles.nFluid + s->tiles.nSolid == 0) { s->placementNote = "skipped (small grid or arrays already handed out)"; return 0; }
+    // buffers 0-14: the state arrays; 15-19 (variant 4 on a whole domain): the second copies of Vx Vy Vz Szz Rzz, written in
+    // the steps in which the first copies are read
+    const int nBuf = s->pingpong ? 20 : 15;
+    auto bufBase = [&](int a) -> float *& { return a < 15 ? s->stateBase[a] : s->ppBase[a - 15]; };
     BFD_HIP(hipSetDevice(s->cfg.device));
     const auto tStart = std::chrono::steady_clock::now();
     const bool verbose = getenv("BFD_PLACEMENT_VERBOSE") != nullptr;
@@ -1267,10 +1272,10 @@ static int choose_placement(bfd_sim *s)
         if (tSame == 0 || t < tSame) tSame = t;
     }
     samples.push_back(tSame);
-    std::vector<float> t0(15, 0.f);
+    std::vector<float> t0(nBuf, 0.f);
     std::string times;
-    for (int a = 1; a < 15; a++) {
-        t0[a] = pair(s->stateBase[0] + g, s->stateBase[a] + g);
+    for (int a = 1; a < nBuf; a++) {
+        t0[a] = pair(s->stateBase[0] + g, bufBase(a) + g);
         if (t0[a] <= 0) BFD_FAIL(-10, "placement: the pair probe failed");
         if (t0[a] <= tSame) samples.push_back(t0[a]);
         if (verbose) { char q[48]; snprintf(q, sizeof q, " %d:%.3f", a, t0[a]); times += q; }
@@ -1285,8 +1290,8 @@ static int choose_placement(bfd_sim *s)
     struct Buf { float *base; int cls; bool fresh; };
     std::vector<Buf> pool;
     std::vector<float *> repOf;                                              // class -> representative (pointer to local plane 0)
-    for (int a = 0; a < 15; a++) {
-        Buf b = {s->stateBase[a], -1, false};
+    for (int a = 0; a < nBuf; a++) {
+        Buf b = {bufBase(a), -1, false};
         for (size_t c = 0; c < repOf.size() && b.cls < 0; c++) {
             const float t = (c == 0 && a > 0) ? t0[a] : pair(repOf[c], b.base + g);
             if (t <= 0) BFD_FAIL(-10, "placement: the pair probe failed");
@@ -1302,7 +1307,9 @@ static int choose_placement(bfd_sim *s)
     //   velocity kernels write Vx Vy Vz (+ accumulator); stress_fluid Szz Rzz; stress_solid Sxx Syy Szz Rxx Ryy Rzz;
     //   the sparse shear kernel Sxy Sxz Syz Rxy Rxz Ryz
     std::vector<int> order = {0, 1, 2, 5, 11};                               // Vx Vy Vz Szz Rzz
-    if (solids) for (int a : {3, 9, 4, 10, 6, 12, 7, 13, 8, 14}) order.push_back(a);   // Sxx Rxx Syy Ryy Sxy Rxy Sxz Rxz Syz Ryz
+    std::vector<int> side = {0, 1, 0, 1, 0};                                 // 0: region M, 1: elsewhere
+    if (s->pingpong) for (int a = 15; a < 20; a++) { order.push_back(a); side.push_back((a - 15) & 1); }   // the second copies like the first (the sums lie apart from Vz and from its copy)
+    if (solids) { int q = 1; for (int a : {3, 9, 4, 10, 6, 12, 7, 13, 8, 14}) { order.push_back(a); side.push_back(q); q ^= 1; } }   // Sxx Rxx Syy Ryy Sxy Rxy Sxz Rxz Syz Ryz
     std::string before;
     for (int a : order) before += (char)('0' + std::min(pool[a].cls, 9));
     int M = 0;
@@ -1312,14 +1319,15 @@ static int choose_placement(bfd_sim *s)
         for (size_t c = 0; c < cnt.size(); c++) if (cnt[c] > cnt[M]) M = (int)c;
     }
     auto sideOf = [&](const Buf &b) { return b.cls == M ? 0 : 1; };            // 0: region M, 1: elsewhere
-    int need[2] = {(int)(order.size() + 1) / 2, (int)order.size() / 2};
+    int need[2] = {0, 0};
+    for (int sd : side) need[sd]++;
     for (const Buf &b : pool) need[sideOf(b)]--;                              // spare arrays count: their buffers can be exchanged in
     std::vector<void *> held;                                                // candidates on the side that is not short, spacers: freed at the end
     size_t heldBytes = 0;
     bool gaveUp = false;
     int nFresh = 0;
     bool probeTells = tSame >= 0.05f;                                          // ms; shorter probes are launch overhead, not memory time
-    size_t heldCap = (size_t)100 << 30;
+    size_t heldCap = (size_t)190 << 30;                                         // a region is up to ~96 GiB wide, and a fresh process may start at the beginning of one (the free-memory check below still applies)
     if (const char *ev = getenv("BFD_PLACEMENT_SEARCH_MB")) { probeTells = true; heldCap = (size_t)atol(ev) << 20; }   // tests: walk a little on any grid
     while ((need[0] > 0 || need[1] > 0) && !gaveUp && probeTells) {            // draw candidates until both sides have enough
         size_t freeB = 0, totalB = 0;
@@ -1341,7 +1349,7 @@ static int choose_placement(bfd_sim *s)
         else (void)hipGetLastError();
     }
     std::vector<char> taken(pool.size(), 0);
-    std::vector<int> slotBuf(15, -1);
+    std::vector<int> slotBuf(nBuf, -1);
     auto pick = [&](int side, int prefer) -> int {
         if (!taken[prefer] && sideOf(pool[prefer]) == side) return prefer;
         for (int pass = 0; pass < 2; pass++)                                   // original buffers first, fresh ones after
@@ -1350,12 +1358,12 @@ static int choose_placement(bfd_sim *s)
     };
     for (size_t q = 0; q < order.size(); q++) {
         const int a = order[q];
-        int p = pick((int)(q & 1), a);
-        if (p < 0) p = pick(1 - (int)(q & 1), a);                              // nothing on the wanted side
+        int p = pick(side[q], a);
+        if (p < 0) p = pick(1 - side[q], a);                                   // nothing on the wanted side
         taken[p] = 1; slotBuf[a] = p;
     }
     // the arrays outside the list take what is left of the original buffers; unused fresh ones and the held misses are released
-    for (int a = 0; a < 15; a++) {
+    for (int a = 0; a < nBuf; a++) {
         if (slotBuf[a] >= 0) continue;
         int p = -1;
         for (size_t q = 0; q < pool.size() && p < 0; q++) if (!taken[q] && !pool[q].fresh) p = (int)q;
@@ -1371,7 +1379,7 @@ static int choose_placement(bfd_sim *s)
         }
         hipFree(pool[q].base);
     }
-    for (int a = 0; a < 15; a++) s->stateBase[a] = pool[slotBuf[a]].base;
+    for (int a = 0; a < nBuf; a++) bufBase(a) = pool[slotBuf[a]].base;
     bind_state_views(s);
     // Pressure accumulators: written beside Vx Vy Vz by the velocity kernels: the RMS sums go to another region than Vz, a
     // peak map beside them to another region than the sums
@@ -1420,10 +1428,10 @@ static int choose_placement(bfd_sim *s)
     for (void *h : held) hipFree(h);
     std::string after;
     for (int a : order) { const Buf &b = pool[slotBuf[a]]; after += b.fresh ? (b.cls == M ? 'm' : 'n') : (char)('0' + std::min(b.cls, 9)); }
-    char buf[640];
+    char buf[768];
     snprintf(buf, sizeof buf, "arrays placed by memory region (pair probe on the zero state: %d probes, within-region %.3f ms, threshold %.3f ms, gap between the levels %.0f %%; %zu regions seen): "
              "regions of %s %s -> %s (m / n = fresh allocation in / outside the most populated region),%s %d fresh, %zu candidates / spacers (%.1f GiB) released%s; %.2f s", nProbes, tSame, thr, 100.0 * widest, repOf.size(),
-             solids ? "Vx Vy Vz Szz Rzz Sxx Rxx Syy Ryy Sxy Rxy Sxz Rxz Syz Ryz" : "Vx Vy Vz Szz Rzz", before.c_str(), after.c_str(), accNote.c_str(), nFresh, held.size(), heldBytes / 1073741824.0,
+             (std::string("Vx Vy Vz Szz Rzz") + (s->pingpong ? " + their second copies" : "") + (solids ? " Sxx Rxx Syy Ryy Sxy Rxy Sxz Rxz Syz Ryz" : "")).c_str(), before.c_str(), after.c_str(), accNote.c_str(), nFresh, held.size(), heldBytes / 1073741824.0,
              gaveUp ? "; search for another region given up (memory)" : "", std::chrono::duration<double>(std::chrono::steady_clock::now() - tStart).count());
     s->placementNote = buf;
     if (verbose) fprintf(stderr, "placement: %s\nplacement: probe times, array:ms against Vx, array/class:ms against the other representatives:%s\n", buf, times.c_str());

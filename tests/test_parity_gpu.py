@@ -401,3 +401,8 @@ def test_placement_choice_does_not_change_results(monkeypatch):
     for idx in range(4):
         for name in ref[idx]:
             assert np.array_equal(ref[idx][name], out2[idx][name]), (idx, name)
+    # the fused fluid step keeps second copies of Vx Vy Vz Szz Rzz: they are placed (and exchanged) with the others
+    out4 = hip_model(4).StaggeredFDTD_3D_with_relaxation(*a, SILENT=True, **k)
+    for idx in range(4):
+        for name in ref[idx]:
+            assert np.array_equal(ref[idx][name], out4[idx][name]), (idx, name)
