@@ -57,10 +57,44 @@ def parse():
     ap.add_argument('--debug-gloo-shared-gpu', action='store_true', help='debug only: N ranks on GPU 0, gloo backend, halos staged through the host (validates the multi-rank code path on a 1-GPU box)')
     ap.add_argument('--lean-host', action='store_true', help='build the inputs slab-style (size-1 Ox/Oy/Oz) also at N=1')
     ap.add_argument('--cpu-sample', type=int, nargs=4, default=[384, 384, 256, 64], help='N1 N2 N3 steps of the oracle sample')
+    ap.add_argument('--no-next-rows', action='store_true', help='skip the Rayleigh / BHTE kernel rates (N=1, default workload only)')
     ap.add_argument('--no-extra-strong', action='store_true', help='N > 1: skip the extra block that splits ONE C5 volume (1024^3, 1 MHz) over the ranks')
     ap.add_argument('--extra-strong-steps', type=int, default=40, help='timed steps of the extra strong-scaling block')
     ap.add_argument('--no-single-domain-check', action='store_true', help='N > 1: skip the small-grid run that compares the N-slab exchange with a single-domain run')
     return ap.parse_args()
+
+
+def next_rows(device):
+    """The kernels either side of the FDTD path, a few seconds: the Rayleigh integral of a bowl onto a
+    160 x 160 x 128 volume and 100 bio-heat steps on 320^3 (kernel times reported by the C ABI: HIP events around the launches)."""
+    import numpy as np
+    from babelbrain_amd import RayleighAndBHTE as R
+    R._device = device
+    f, c = 500e3, 1500.0
+    tx = R.GenerateFocusTx(f, 50e-3, 50e-3, c)
+    cen, ds = tx['center'].astype(np.float32), tx['ds'].astype(np.float32)
+    u0 = np.ones(len(ds), np.complex64)
+    h = 1102.515 / f / 6
+    shape = (160, 160, 128)
+    X, Y, Z = np.meshgrid((np.arange(shape[0]) - shape[0] / 2) * h, (np.arange(shape[1]) - shape[1] / 2) * h, 0.02 + np.arange(shape[2]) * h, indexing='ij')
+    rf = np.stack([X.ravel(), Y.ravel(), Z.ravel()], 1).astype(np.float32)
+    R.ForwardSimple(2 * np.pi * f / c, cen, ds, u0, rf[:1000])
+    R.ForwardSimple(2 * np.pi * f / c, cen, ds, u0, rf)
+    pairs = float(len(ds)) * len(rf)
+    out = {'rayleigh_forward': {'value': pairs / R.last_kernel_ms / 1e6, 'unit': 'Gpairs/s', 'sources': len(ds), 'points': len(rf), 'kernel_ms': R.last_kernel_ms}}
+    N = (320, 320, 320)
+    rng = np.random.default_rng(0)
+    mm = np.zeros(N, np.uint8); mm[:, :, 100:140] = 1; mm[:, :, 140:] = 2
+    ML = dict(Density=np.array([1000., 1896.5, 1041.]), SoS=np.array([1500., 2476., 1562.]), Attenuation=np.array([0., 81., 3.45]),
+              SpecificHeat=np.array([4178., 1313., 3630.]), Conductivity=np.array([0.6, 0.32, 0.51]), Perfusion=np.array([0., 10., 559.]),
+              Absorption=np.array([0., 0.16, 0.85]), InitTemperature=np.array([37., 37., 37.]))
+    P = (2e5 * rng.random(N, dtype=np.float32)).astype(np.float32)
+    steps = 100
+    t0 = time.time(); R.BHTE(P, mm, ML, h, steps, steps // 2, N[1] // 2, nFactorMonitoring=10, dt=0.05); wall = time.time() - t0
+    vox = float(np.prod(N)) * steps
+    out['bhte'] = {'value': vox / R.last_kernel_ms / 1e6, 'unit': 'Gvoxel-steps/s', 'grid': list(N), 'steps': steps, 'steps_per_launch': 2, 'kernel_ms': R.last_kernel_ms,
+                   'call_s': wall, 'frac_of_8TBps_on_21B_per_voxel_step': 21 * vox / R.last_kernel_ms / 1e6 / 8000}
+    return out
 
 
 def cpu_baseline(args, dt_fn):
@@ -142,6 +176,8 @@ class Workload:
             k0, nk = slab.partition(self.N[2], world)[rank]
             a, k, info = H.make_problem(config, N=self.N, steps=nt, stable_dt_fn=dt_fn, zslab=(k0, nk), forward=RayleighAndBHTE.ForwardSimple, full_sensors=full_sensors)
             local = (self.N[2], k0, nk) + tuple(info['ghost'])
+        if os.environ.get('BENCH_NDELTA'):          # experiments only: thickness of the absorbing layer (the configs prescribe 12)
+            k['NDelta'] = int(os.environ['BENCH_NDELTA'])
         self.host_build_s = time.time() - t0
         self.a, self.k, self.info, self.local = a, k, info, local
         # rmsFirstStep=1: the Pressure RMS accumulates in EVERY step (warm-up included); a production call accumulates
@@ -413,6 +449,11 @@ def main():
             wd.close()
         except Exception as e:
             line['dense_reference'] = {'value': None, 'error': repr(e)}
+    if world == 1 and not args.no_next_rows and args.config == 'C3' and not args.size:
+        try:
+            line['next_rows'] = next_rows(local_rank)
+        except Exception as e:
+            line['next_rows'] = {'error': repr(e)}
     if world == 1 and not args.no_cpu_baseline:
         try:
             line['cpu_baseline'] = cpu_baseline(args, dt_fn)

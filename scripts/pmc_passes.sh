@@ -12,7 +12,7 @@ groups=("FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"
 i=0
 for grp in "${groups[@]}"; do
   i=$((i+1))
-  timeout ${PMC_TIMEOUT:-300} rocprofv3 --pmc $grp --output-format csv -d gpurun_out/pmc_$tag/p$i -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-kernel-pass --no-steady-warmup --no-shear-workload "$@" > gpurun_out/pmc_$tag/p$i.log 2>&1
+  timeout ${PMC_TIMEOUT:-300} rocprofv3 --pmc $grp --output-format csv -d gpurun_out/pmc_$tag/p$i -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-kernel-pass --no-steady-warmup --no-shear-workload --no-next-rows "$@" > gpurun_out/pmc_$tag/p$i.log 2>&1
 done
 python3 scripts/pmc_summary.py gpurun_out/pmc_$tag ${TRAFFIC_KEY:-C3_512x512x512_variant0} > gpurun_out/pmc_$tag/summary.txt
 cat gpurun_out/pmc_$tag/summary.txt

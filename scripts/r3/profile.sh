@@ -3,8 +3,8 @@
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=gpurun_out/r3_prof; mkdir -p $O
 timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err; tail -c 300 $O/bench_default.err
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktrace_c3 -o k -- python3 bench.py --no-cpu-baseline --no-shear-workload > $O/bench_c3_under_rocprof.json 2>/dev/null
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktrace_c2 -o k -- python3 bench.py --config C2 --size 512 512 512 --no-cpu-baseline > $O/bench_c2_under_rocprof.json 2>/dev/null
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktrace_c3 -o k -- python3 bench.py --no-cpu-baseline --no-shear-workload --no-next-rows > $O/bench_c3_under_rocprof.json 2>/dev/null
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktrace_c2 -o k -- python3 bench.py --config C2 --size 512 512 512 --no-cpu-baseline --no-next-rows > $O/bench_c2_under_rocprof.json 2>/dev/null
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktrace_next -o k -- python3 scripts/next_rows_bench.py > $O/next_rows_under_rocprof.txt 2>/dev/null
 TRAFFIC_KEY=C3_512x512x512_variant0 bash scripts/pmc_passes.sh r3_c3 > $O/pmc_c3.log 2>&1
 TRAFFIC_KEY=C2_512x512x512_variant0 bash scripts/pmc_passes.sh r3_c2 --config C2 --size 512 512 512 > $O/pmc_c2.log 2>&1
