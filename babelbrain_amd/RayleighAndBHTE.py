@@ -11,13 +11,33 @@ BHTE / BHTEMultiplePressureFields (CalculateTemperatureEffects.py:365-456, 960-9
 (bfd_bhte_run_fields: two time steps per launch, csrc/bfd_bhte.hip).
 """
 import ctypes as C
+import os
+import threading
 
 import numpy as np
 
 from . import _engine
 
 _device = 0
+_devices = None          # several HIP ordinals: ForwardSimple shares its field points among them (set_devices / BABELFDTD_DEVICES)
 last_kernel_ms = None
+
+
+def set_devices(devices):
+    """Ordinals (or 'all') of the GPUs ForwardSimple may use together: the field points are independent, so they are dealt to
+    the devices in contiguous shares, one host thread per device, no exchange (shard, no collective). None or
+    one ordinal = single device. The environment variable BABELFDTD_DEVICES does the same for a caller that cannot pass
+    arguments (the reference selects its device by name, BASE:918-925)."""
+    global _devices, _device
+    if devices is None:
+        _devices = None
+        return
+    if isinstance(devices, str):
+        devices = [d for d, _ in _engine.list_devices()] if devices.strip().lower() == 'all' else [int(x) for x in devices.split(',') if x.strip()]
+    devices = [int(d) for d in devices]
+    _devices = devices if len(devices) > 1 else None
+    if len(devices) == 1:
+        _device = devices[0]
 
 
 def _init(deviceName=None):
@@ -51,13 +71,38 @@ def ForwardSimple(cwvnb, center, ds, u0, rf, deviceMetal=None, MacOsPlatform=Non
     if not (len(a) == len(cen) == len(u)):
         raise ValueError('center, ds and u0 must describe the same number of sources')
     out = np.zeros(len(pts), np.complex64)
-    ms = C.c_double()
-    rc = lib.bfd_rayleigh_forward(_device, len(cen), cen.ctypes.data_as(C.c_void_p), a.ctypes.data_as(C.c_void_p),
-                                  u.view(np.float32).ctypes.data_as(C.c_void_p), k.real, k.imag, len(pts),
-                                  pts.ctypes.data_as(C.c_void_p), out.view(np.float32).ctypes.data_as(C.c_void_p), C.byref(ms))
-    if rc != 0:
-        raise _engine.EngineError('bfd_rayleigh_forward failed (rc=%d): %s' % (rc, lib.bfd_last_error().decode()))
-    last_kernel_ms = ms.value
+    devices = _devices
+    if devices is None and os.environ.get('BABELFDTD_DEVICES'):
+        set_devices(os.environ['BABELFDTD_DEVICES'])
+        devices = _devices
+    if devices is None or len(pts) < 64 * len(devices):
+        devices = [_device]
+    bounds = [len(pts) * r // len(devices) for r in range(len(devices) + 1)]
+    times, errors = [0.0] * len(devices), [None] * len(devices)
+
+    def share(r):          # ctypes releases the GIL for the call: the devices work at the same time
+        n0, n1 = bounds[r], bounds[r + 1]
+        if n1 <= n0:
+            return
+        ms = C.c_double()
+        rc = lib.bfd_rayleigh_forward(devices[r], len(cen), cen.ctypes.data_as(C.c_void_p), a.ctypes.data_as(C.c_void_p),
+                                      u.view(np.float32).ctypes.data_as(C.c_void_p), k.real, k.imag, n1 - n0,
+                                      pts[n0:n1].ctypes.data_as(C.c_void_p), out[n0:n1].view(np.float32).ctypes.data_as(C.c_void_p), C.byref(ms))
+        if rc != 0:
+            errors[r] = 'bfd_rayleigh_forward failed on device %d (rc=%d): %s' % (devices[r], rc, lib.bfd_last_error().decode())
+        times[r] = ms.value
+    if len(devices) == 1:
+        share(0)
+    else:
+        th = [threading.Thread(target=share, args=(r,)) for r in range(len(devices))]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+    for e in errors:
+        if e:
+            raise _engine.EngineError(e)
+    last_kernel_ms = max(times)
     return out
 
 

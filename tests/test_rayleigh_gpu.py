@@ -55,3 +55,37 @@ def test_empty_and_errors():
     with pytest.raises(ValueError):
         R.ForwardSimple(1000.0, np.zeros((3, 3), np.float32), np.ones(2, np.float32), np.ones(3, np.complex64), np.zeros((4, 3), np.float32))
     assert abs(R.SpeedofSoundWater(20.0) - 1482.36) < 0.05
+
+
+def test_field_points_shared_among_devices(monkeypatch):
+    """set_devices([...]) / BABELFDTD_DEVICES: the field points are dealt to the listed devices in contiguous shares, one host
+    thread each (an ordinal may repeat: here all shares run on device 0, on a multi-GPU node every visible device takes one).
+    The result is the single-device one bit for bit (a point's sum does not depend on its neighbours in the launch)."""
+    import torch
+    from babelbrain_amd import RayleighAndBHTE as R
+    rng = np.random.default_rng(3)
+    pts, ds = H._bowl_points(60e-3, 55e-3, 14, 0.0)
+    u0 = (rng.normal(size=len(ds)) + 1j * rng.normal(size=len(ds))).astype(np.complex64)
+    N = 10007
+    rf = np.stack([rng.uniform(-40e-3, 40e-3, N), rng.uniform(-40e-3, 40e-3, N), rng.uniform(20e-3, 160e-3, N)], 1).astype(np.float32)
+    k = 2 * np.pi * 700e3 / 1500.0
+    R.set_devices(None)
+    monkeypatch.delenv('BABELFDTD_DEVICES', raising=False)
+    one = R.ForwardSimple(k, pts, ds, u0, rf)
+    try:
+        R.set_devices([0, 0, 0])
+        assert np.array_equal(R.ForwardSimple(k, pts, ds, u0, rf), one)
+        assert np.array_equal(R.ForwardSimple(k, pts, ds, u0, rf[:50]), one[:50])           # too few points to share: one device
+        R.set_devices('all')
+        assert np.array_equal(R.ForwardSimple(k, pts, ds, u0, rf), one)
+        nd = torch.cuda.device_count()
+        R.set_devices(list(range(nd)) + [nd])                                               # one ordinal too many: refused, not skipped
+        with pytest.raises(Exception):
+            R.ForwardSimple(k, pts, ds, u0, rf)
+    finally:
+        R.set_devices(None)
+    monkeypatch.setenv('BABELFDTD_DEVICES', '0,0')
+    try:
+        assert np.array_equal(R.ForwardSimple(k, pts, ds, u0, rf), one)
+    finally:
+        R.set_devices(None)
