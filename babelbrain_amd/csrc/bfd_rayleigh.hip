@@ -20,7 +20,6 @@
 namespace {
 
 constexpr int RB = 256;      // threads per workgroup
-constexpr int PPL = 2;       // field points per lane: every source record read from LDS serves two pairs
 constexpr int SB = 512;      // sources per LDS block
 constexpr int SUB = 16;      // sources summed in float32 before the sum goes to the float64 totals
 
@@ -29,6 +28,10 @@ constexpr int SUB = 16;      // sources summed in float32 before the sum goes to
 // sine / cosine (v_sin_f32 / v_cos_f32 take their argument in revolutions), amplitudes in float32. Sixteen sources at a time are
 // summed in float32 and added to the float64 sums of the point. Round 2 spent ~70 vector instructions per pair (libm sincosf,
 // float64 accumulation of every term, five scalar LDS reads per pair); this form about half of that.
+// PPL = field points per lane: every source record read from LDS serves that many pairs. 4 for large point sets (899-905
+// against 845-855 Gpairs/s with 2 at 6.5 M points; 128 VGPRs), 2 below a million points, 1 where even that leaves CUs without a
+// workgroup (a 488 x 488 source plane is 465 workgroups at 2)
+template <int PPL>
 __global__ __launch_bounds__(RB) void rayleigh_forward(const float *__restrict__ cen, const float *__restrict__ ds,
                                                        const float *__restrict__ u0, long nSrc, double kr, double ki,
                                                        const float *__restrict__ rf, long nPts, float *__restrict__ out)
@@ -126,7 +129,12 @@ extern "C" int bfd_rayleigh_forward(int32_t device, int64_t nSrc, const float *c
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (e == hipSuccess) { hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, 0); }
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(rayleigh_forward, dim3((unsigned)((nPts + RB * PPL - 1) / (RB * PPL))), dim3(RB), 0, 0, dc, dd, du, (long)nSrc, kReal, kImag, dr, (long)nPts, dout);
+        int ppl = nPts >= (1 << 20) ? 4 : nPts >= (1 << 18) ? 2 : 1;
+        if (const char *ev = getenv("BFD_RAYLEIGH_PPL")) { const int v = atoi(ev); if (v == 1 || v == 2 || v == 4) ppl = v; }
+        const dim3 grid((unsigned)((nPts + RB * ppl - 1) / (RB * ppl)));
+        if (ppl == 4) hipLaunchKernelGGL(rayleigh_forward<4>, grid, dim3(RB), 0, 0, dc, dd, du, (long)nSrc, kReal, kImag, dr, (long)nPts, dout);
+        else if (ppl == 2) hipLaunchKernelGGL(rayleigh_forward<2>, grid, dim3(RB), 0, 0, dc, dd, du, (long)nSrc, kReal, kImag, dr, (long)nPts, dout);
+        else hipLaunchKernelGGL(rayleigh_forward<1>, grid, dim3(RB), 0, 0, dc, dd, du, (long)nSrc, kReal, kImag, dr, (long)nPts, dout);
         e = hipGetLastError();
     }
     if (e == hipSuccess) { hipEventRecord(e1, 0); e = hipEventSynchronize(e1); }
