@@ -17,6 +17,10 @@
 #include "bfd_internal.h"
 #include <math.h>
 
+#ifndef BFD_RAYLEIGH_UNROLL
+#define BFD_RAYLEIGH_UNROLL 2
+#endif
+
 namespace {
 
 constexpr int RB = 256;      // threads per workgroup
@@ -62,7 +66,7 @@ __global__ __launch_bounds__(RB) void rayleigh_forward(const float *__restrict__
         float br[PPL], bi[PPL];
 #pragma unroll
         for (int p = 0; p < PPL; p++) { br[p] = 0.f; bi[p] = 0.f; }
-#pragma unroll 2
+#pragma unroll BFD_RAYLEIGH_UNROLL
         for (int q = q0; q < q1; q++) {
             const float4 s = sA[q];
             const float sim = sB[q];
@@ -75,8 +79,12 @@ __global__ __launch_bounds__(RB) void rayleigh_forward(const float *__restrict__
                 const double R = r2 * inv;
                 const double rev = R * krev;
                 // hardware sine / cosine: v_sin_f32 / v_cos_f32 take their argument in revolutions (a float32 Taylor polynomial on
-                // the folded phase was measured too: 606 against 851 Gpairs/s, and less accurate -- profiles/README.md)
-                const float fr = (float)(rev - floor(rev));           // phase / 2 pi in [0,1)
+                // the folded phase was measured too: 606 against 851 Gpairs/s, and less accurate -- profiles/README.md);
+                // v_fract_f64 instead of floor + subtract: 910 -> 935 Gpairs/s. A Newton step on the square root itself (R0 = r2 y,
+                // R = R0 + (r2 - R0 R0) y / 2, amplitude y: two float64 operations fewer) gives 940-953, but the amplitude then has
+                // the float32 reciprocal square root's 1.2e-7 instead of 6e-8 and one near-field tie of the reference study's flat-
+                // array rows moves (tests/test_rayleigh_study_gpu.py): not taken
+                const float fr = (float)__builtin_amdgcn_fract(rev);   // phase / 2 pi in [0,1)
                 const float sn = __builtin_amdgcn_sinf(fr), cs = __builtin_amdgcn_cosf(fr);
                 float amp = (float)inv;
                 if (ki != 0.0) amp *= __expf(kif * (float)R);        // exp(-i k R) with complex k: Im k < 0 attenuates
