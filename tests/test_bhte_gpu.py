@@ -195,3 +195,32 @@ def test_x_fastest_entry_points_of_the_c_abi():
                                     ptr(np.zeros(1, np.int32)), -1, 1, None, 0, None, None, None) == -1
     with pytest.raises(ValueError):
         R.BHTE(p, mm, ml, dx, nS, nOn, 30, dt=dt)                    # monitored plane outside the volume
+
+
+def test_input_forms_the_caller_may_hand_over():
+    """Fortran-ordered, float64 and uint32 inputs (what numpy slicing / transposes in a caller produce) give the result of the
+    canonical float32 / uint8 C-ordered ones; volumes thinner than 3 cells and a monitoring map of another shape are refused."""
+    from babelbrain_amd import RayleighAndBHTE as R, _engine
+    rng = np.random.default_rng(31)
+    N = (33, 47, 29)
+    ml = _materials()
+    mm = rng.integers(0, 5, N).astype(np.uint8)
+    p = (2.5e6 * rng.random(N)).astype(np.float32)
+    T0 = (37.0 + 2.0 * rng.random(N)).astype(np.float32)
+    D0 = rng.random(N).astype(np.float32)
+    mpm = np.zeros(N, np.uint32); mpm[5, 6, 7] = 2; mpm[20, 40, 3] = 1
+    ref = R.BHTE(p, mm, ml, 4e-4, 9, 5, 10, nFactorMonitoring=2, dt=0.02, initT0=T0, initDose=D0, MonitoringPointsMap=mpm)
+    alt = R.BHTE(np.asfortranarray(p.astype(np.float64)), np.asfortranarray(mm.astype(np.uint32)), ml, 4e-4, 9, 5, 10, nFactorMonitoring=2, dt=0.02,
+                 initT0=np.asfortranarray(T0.astype(np.float64)), initDose=np.asfortranarray(D0), MonitoringPointsMap=np.asfortranarray(mpm.astype(np.int64)))
+    for a, b in zip(ref, alt):
+        assert a.shape == b.shape and np.array_equal(a, b)
+    assert ref[4].shape == (2, 9) and ref[4][0, -1] == ref[0][20, 40, 3] and ref[4][1, -1] == ref[0][5, 6, 7]     # rows ordered by point id
+    T0c, D0c = T0.copy(), D0.copy()
+    R.BHTE(p, mm, ml, 4e-4, 4, 2, -1, dt=0.02, initT0=T0, initDose=D0)
+    assert np.array_equal(T0, T0c) and np.array_equal(D0, D0c)
+    with pytest.raises(_engine.EngineError):
+        R.BHTE(p[:2], mm[:2], ml, 4e-4, 4, 2, -1, dt=0.02)
+    with pytest.raises(ValueError):
+        R.BHTE(p, mm, ml, 4e-4, 4, 2, -1, dt=0.02, MonitoringPointsMap=mpm[:-1])
+    with pytest.raises(ValueError):
+        R.BHTE(p, mm, ml, 4e-4, 4, 2, -1, dt=0.02, initT0=T0[:-1])
