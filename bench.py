@@ -56,7 +56,7 @@ def parse():
     ap.add_argument('--no-steady-warmup', action='store_true', help='do exactly W warm-up steps (default: at least W, and enough for %.2f s of load)' % STEADY_SECONDS)
     ap.add_argument('--debug-gloo-shared-gpu', action='store_true', help='debug only: N ranks on GPU 0, gloo backend, halos staged through the host (validates the multi-rank code path on a 1-GPU box)')
     ap.add_argument('--lean-host', action='store_true', help='build the inputs slab-style (size-1 Ox/Oy/Oz) also at N=1')
-    ap.add_argument('--cpu-sample', type=int, nargs=4, default=[384, 384, 256, 64], help='N1 N2 N3 steps of the oracle sample')
+    ap.add_argument('--cpu-sample', type=int, nargs=4, default=[384, 384, 256, 224], help='N1 N2 N3 steps of the oracle sample (about 12 s of CPU work at 0.7 Gvoxel-steps/s)')
     ap.add_argument('--no-next-rows', action='store_true', help='skip the Rayleigh / BHTE kernel rates (N=1, default workload only)')
     ap.add_argument('--no-extra-strong', action='store_true', help='N > 1: skip the extra block that splits ONE C5 volume (1024^3, 1 MHz) over the ranks')
     ap.add_argument('--extra-strong-steps', type=int, default=40, help='timed steps of the extra strong-scaling block')
