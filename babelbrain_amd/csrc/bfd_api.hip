@@ -1091,6 +1091,26 @@ static int build_tile_lists(bfd_sim *s)
         }
         std::vector<unsigned> hostCells((size_t)count);
         if (e == hipSuccess && count) e = hipMemcpy(hostCells.data(), sel, (size_t)count * sizeof(unsigned), hipMemcpyDeviceToHost);
+        // list order (bfd_kernels_v2.hip, shear_order_keys): by z-chunk and band of 8 rows, so that the z neighbours a cell gathers were
+        // touched one band-plane earlier instead of one whole plane of the shell; BFD_SHEAR_ORDER=0 keeps the ascending index, 1 = by tiles
+        int orderMode = 2;
+        if (const char *ev = getenv("BFD_SHEAR_ORDER")) orderMode = atoi(ev);
+        const bool reorder = count > 0 && orderMode != 0;
+        if (e == hipSuccess && reorder) {
+            unsigned long long *k0 = nullptr, *k1 = nullptr; unsigned *v1 = nullptr; void *w2 = nullptr; size_t w2b = 0;
+            e = hipMalloc((void **)&k0, (size_t)count * 8);
+            if (e == hipSuccess) e = hipMalloc((void **)&k1, (size_t)count * 8);
+            if (e == hipSuccess) e = hipMalloc((void **)&v1, (size_t)count * 4);
+            if (e == hipSuccess) {
+                bfd_launch_shear_order_keys(s->d, s->stream, sel, k0, count, lowPlanes, hiStart, orderMode);
+                e = hipcub::DeviceRadixSort::SortPairs(nullptr, w2b, k0, k1, sel, v1, count, 0, 46, s->stream);
+            }
+            if (e == hipSuccess) e = hipMalloc(&w2, std::max<size_t>(w2b, 1));
+            if (e == hipSuccess) e = hipcub::DeviceRadixSort::SortPairs(w2, w2b, k0, k1, sel, v1, count, 0, 46, s->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(sel, v1, (size_t)count * 4, hipMemcpyDeviceToDevice, s->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+            if (k0) hipFree(k0); if (k1) hipFree(k1); if (v1) hipFree(v1); if (w2) hipFree(w2);
+        }
         if (e == hipSuccess) {
             rc = dev_alloc(s, &s->tiles.shearCells, (size_t)std::max(count, 1), false);
             if (!rc) rc = dev_alloc(s, &s->tiles.shearCoef, 6 * (size_t)std::max(count, 1), false);

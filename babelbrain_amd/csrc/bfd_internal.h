@@ -157,6 +157,7 @@ void bfd_launch_fused(const bfd_dev &d, hipStream_t s, float *accP, float *pkP, 
 int bfd_tile_subz(void);
 void bfd_launch_classify(const bfd_dev &d, hipStream_t s, int *flagsDev, int *tileMatDev);
 void bfd_launch_mark_solid(const bfd_dev &d, hipStream_t s, unsigned char *flag, long n);
+void bfd_launch_shear_order_keys(const bfd_dev &d, hipStream_t s, const unsigned *cells, unsigned long long *keys, long n, int lowPlanes, int hiStart, int mode);
 void bfd_launch_shear_coefficients(const bfd_dev &d, hipStream_t s, const unsigned *cells, float *coef, unsigned *codes, float *tab, int nMat, long n);
 // copies the list-ordered shear memory variables into the full-volume arrays Rxy, Rxz, Ryz (outputs only)
 void bfd_launch_scatter_shear_memory(const bfd_dev &d, hipStream_t s, const bfd_tiles *t);

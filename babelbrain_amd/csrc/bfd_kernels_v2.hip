@@ -1436,7 +1436,7 @@ __global__ __launch_bounds__(256) void stress_shear_sparse(bfd_dev d, const unsi
                                                            const float *__restrict__ tab, const float *__restrict__ coef,
                                                            float *__restrict__ Rc, long nTotal, long n)
 {
-    // XCD e works through the e-th contiguous eighth of the (index-sorted) list: the V values a cell gathers from its
+    // XCD e works through the e-th contiguous eighth of the list (order: shear_order_keys): the V values a cell gathers from its
     // row / plane neighbours were fetched by blocks just before it on the SAME XCD (its own L2)
     const long t = (long)remap_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
     if (t >= n) return;
@@ -1705,6 +1705,34 @@ void bfd_launch_cell_classes(const bfd_dev &d, hipStream_t s, uint8_t *clsBase, 
 void bfd_launch_count_solid_cells(const bfd_dev &d, hipStream_t s, const int4 *solidRuns, int nSolid, unsigned long long *counts6)
 {
     if (nSolid) hipLaunchKernelGGL(count_solid_cells, dim3(nSolid), dim3(TX, TY, 1), 0, s, d, (d.N1 + TX - 1) / TX, solidRuns, counts6);
+}
+
+// Order of the sparse shear list. Ascending in the cell index (k, j, i), a cell's z neighbours (planes k-2 .. k+2, 9 of its 21
+// gathered V values) were touched a whole plane of listed cells earlier: 1 MB of traffic at 512^2 planes, 3.8 MB at 1024^2, five
+// planes of that beyond the 4 MB L2 of an XCD -- at 1024^3 the kernel moved 1.68 x its algorithmic bytes (8.58 GB per launch).
+// Mode 2 (default): (z-chunk of 16 planes, band of 8 rows, plane, row, i): rows keep their whole length in x, the z neighbours are
+// one band-plane away: 6.21 GB = 1.21 x at 1024^3, unchanged at 512^3 (0.89 GB, where the planes fitted), kernel time unchanged:
+// it follows neither the bytes nor the number of gathers (the six x neighbours taken from the neighbouring lanes by shuffles: 4-9 %
+// slower). Mode 1 cuts the rows at the 64-wide tiles as well: same bytes, 3 % slower.
+// The three plane ranges the split half-steps launch separately (first / middle / last planes of a slab) stay contiguous: their
+// number leads the key. profiles/r3/shear_list_order.txt
+__global__ void shear_order_keys(bfd_dev d, const unsigned *__restrict__ cells, unsigned long long *__restrict__ keys, long n, int lowPlanes, int hiStart, int mode)
+{
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const unsigned c = cells[t];
+    const unsigned i = c % (unsigned)d.N1, j = (c / (unsigned)d.N1) % (unsigned)d.N2, k = c / (unsigned)d.plane;
+    const unsigned long long seg = (int)k < lowPlanes ? 0ull : ((int)k >= hiStart ? 2ull : 1ull);
+    if (mode == 2)       // rows keep their whole length in x: (z-chunk, band of 8 rows, plane, row, i)
+        keys[t] = (seg << 44) | ((unsigned long long)(k >> 4) << 32) | ((unsigned long long)(j >> 3) << 19) |
+                  ((unsigned long long)(k & 15u) << 15) | ((unsigned long long)(j & 7u) << 12) | (unsigned long long)(i & 4095u);
+    else
+        keys[t] = (seg << 44) | ((unsigned long long)(k >> 4) << 32) | ((unsigned long long)(j >> 3) << 19) | ((unsigned long long)(i >> 6) << 13) |
+                  ((unsigned long long)(k & 15u) << 9) | ((unsigned long long)(j & 7u) << 6) | (unsigned long long)(i & 63u);
+}
+void bfd_launch_shear_order_keys(const bfd_dev &d, hipStream_t s, const unsigned *cells, unsigned long long *keys, long n, int lowPlanes, int hiStart, int mode)
+{
+    if (n) hipLaunchKernelGGL(shear_order_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d, cells, keys, n, lowPlanes, hiStart, mode);
 }
 
 void bfd_launch_mark_solid(const bfd_dev &d, hipStream_t s, unsigned char *flag, long n)
