@@ -101,3 +101,41 @@ def test_bhte_source_forms():
     assert abs(ratio[1] - (1 - np.exp(-2 * ha)) / (2 * ha)) < 1e-6 and 0.95 < ratio[1] < 0.98
     with pytest.raises(ValueError):
         R.bhte_coefficients(ml, dx, dt, 0.5, source_form='other')
+
+
+def test_thermal_host_logic():
+    """Host side of the bio-heat drop-in (no device needed): the on/off schedule of steered multi-point sonications
+    (CalculateTemperatureEffects.py:715-736), the per-material coefficients and their stability check."""
+    import pytest
+    from babelbrain_amd import RayleighAndBHTE as R
+    assert R.field_schedule(np.array([[2, 1], [1, 2]]), 10).tolist() == [0, 0, -1, 1, -1, -1, 0, 0, -1, 1]
+    assert R.field_schedule([[3, 0]], 4).tolist() == [0, 0, 0, 0]
+    assert R.field_schedule([[1, 1]], 0).tolist() == []
+    with pytest.raises(ValueError):
+        R.field_schedule([[0, 0]], 4)
+    with pytest.raises(ValueError):
+        R.field_schedule([[2, -1]], 4)
+    ml = {'Density': np.array([1000.0, 1041.0]), 'SoS': np.array([1500.0, 1562.0]), 'Attenuation': np.array([0.0, 3.45]),
+          'SpecificHeat': np.array([4178.0, 3630.0]), 'Conductivity': np.array([0.6, 0.51]), 'Perfusion': np.array([0.0, 559.0]),
+          'Absorption': np.array([0.0, 0.85]), 'InitTemperature': np.array([37.0, 37.0])}
+    dx, dt = 5e-4, 0.05
+    cd, cp, qf = R.bhte_coefficients(ml, dx, dt, 0.3)
+    assert cd.dtype == cp.dtype == qf.dtype == np.float32
+    assert abs(cd[1] / (dt * 0.51 / (1041.0 * 3630.0 * dx ** 2)) - 1) < 1e-6
+    assert cp[0] == 0 and abs(cp[1] / (dt * 1050.0 * 3617.0 * 559.0 / (6e7 * 3630.0)) - 1) < 1e-6
+    assert qf[0] == 0 and abs(qf[1] / (dt * 0.3 * 0.85 * 3.45 / (1041.0 * 1562.0) / (1041.0 * 3630.0)) - 1) < 1e-6
+    # the exponential source form tends to the linear one for thin voxels and stays below it
+    _, _, qe = R.bhte_coefficients(ml, dx, dt, 0.3, source_form='exponential')
+    assert 0.99 < qe[1] / qf[1] < 1.0
+    with pytest.raises(ValueError):
+        R.bhte_coefficients(ml, dx, dt, 0.3, source_form='other')
+    with pytest.raises(ValueError):
+        R.bhte_coefficients(ml, 1e-4, 1.0)                 # dt k/(rho c dx^2) > 1/6: the explicit scheme would blow up
+    # device list of the Rayleigh integral: parsing only (no device is touched until a call is made)
+    R.set_devices('0, 0,0')
+    assert R._devices == [0, 0, 0]
+    R.set_devices([3])
+    assert R._devices is None and R._device == 3
+    R.set_devices(None)
+    R._device = 0
+    assert R._devices is None
