@@ -79,6 +79,17 @@ __device__ __forceinline__ T *uni(T *p)
 }
 __device__ __forceinline__ float &F4(float *base, unsigned byteOfs) { return *(float *)((char *)uni(base) + byteOfs); }
 __device__ __forceinline__ const float &F4(const float *base, unsigned byteOfs) { return *(const float *)((const char *)uni(base) + byteOfs); }
+// store of a value nobody reads before the next half-step: non-temporal, so that written lines do not displace halo lines in L2
+// (fluid kernels: C3 89.1 -> 89.8 Gvoxel-steps/s on three alternating same-box runs; solid-run kernels: shear medium 63.87 -> 64.10 on
+// five; profiles/r3/experiment_nontemporal_stores.txt). -DBFD_NT_STORES_OFF builds the plain stores.
+__device__ __forceinline__ void ST4(float *base, unsigned byteOfs, float v)
+{
+#ifndef BFD_NT_STORES_OFF
+    __builtin_nontemporal_store(v, (float *)((char *)uni(base) + byteOfs));
+#else
+    *(float *)((char *)uni(base) + byteOfs) = v;
+#endif
+}
 __device__ __forceinline__ unsigned U2(const uint16_t *base, unsigned byteOfs) { return *(const uint16_t *)((const char *)uni(base) + byteOfs); }
 __device__ __forceinline__ unsigned U1(const uint8_t *base, unsigned byteOfs) { return uni(base)[byteOfs]; }
 
@@ -499,9 +510,9 @@ __global__ __launch_bounds__(NTHREADS, VELOCITY_WAVES_PER_SIMD) void velocity_v2
                     dzSzz = cpml(d.psi[17], q, d.azH[k], d.bzH[k], dzSzz);
                 }
                 const float bxv = 0.5f * (r0 + rx), byv = 0.5f * (r0 + ry), bzv = 0.5f * (r0 + r1);
-                F4(wVx, cij * 4u) = vx + bxv * ((dxSxx + dySxy) + dzSxz);
-                F4(wVy, cij * 4u) = vy + byv * ((dxSxy + dySyy) + dzSyz);
-                F4(wVz, cij * 4u) = vz + bzv * ((dxSxz + dySyz) + dzSzz);
+                ST4(wVx, cij * 4u, vx + bxv * ((dxSxx + dySxy) + dzSxz));
+                ST4(wVy, cij * 4u, vy + byv * ((dxSxy + dySyy) + dzSyz));
+                ST4(wVz, cij * 4u, vz + bzv * ((dxSxz + dySyz) + dzSzz));
             }
         }
         zzm1 = zz0; zz0 = zzp1; zzp1 = zzp2; zzp2 = nzz;
@@ -641,10 +652,10 @@ __device__ __forceinline__ void stress_fluid_body(const bfd_dev &d, int bx, int 
             }
             // COLLAPSED (no solid tile in the slab, no per-component stress output selected): nobody
             // reads Sxx/Syy/Rxx/Ryy, so only the Szz/Rzz copy is kept (expanded on demand, bfd_api.hip)
-            F4((d.SzzW + ko), cij * 4u) = val;
+            ST4((d.SzzW + ko), cij * 4u, val);
             if (!COLLAPSED) { F4((d.Sxx + ko), cij * 4u) = val; F4((d.Syy + ko), cij * 4u) = val; }
             if (LOSSY) {
-                F4((d.RzzW + ko), cij * 4u) = rn;
+                ST4((d.RzzW + ko), cij * 4u, rn);
                 if (!COLLAPSED) { F4((d.Rxx + ko), cij * 4u) = rn; F4((d.Ryy + ko), cij * 4u) = rn; }
             }
         }
@@ -753,7 +764,7 @@ __device__ __forceinline__ void velocity_fluid_body(const bfd_dev &d, int bx, in
                 if (inner && k >= d.ND && k < d.N3 - d.ND) {
                     const float s = (s0 + s0) + s0;
                     const float p = -s * (1.0f / 3.0f);
-                    if (accA) F4((accP + ko), cij * 4u) = av + p * p;
+                    if (accA) ST4((accP + ko), cij * 4u, av + p * p);
                     if (accK) { const float ap = fabsf(p); if (ap > pv) F4((pkP + ko), cij * 4u) = ap; }
                 }
             }
@@ -773,9 +784,9 @@ __device__ __forceinline__ void velocity_fluid_body(const bfd_dev &d, int bx, in
                         dz = dz + pn;
                     }
                 }
-                F4((d.VxW + ko), cij * 4u) = vx + (0.5f * (r0 + rx)) * dx;
-                F4((d.VyW + ko), cij * 4u) = vy + (0.5f * (r0 + ry)) * dy;
-                F4((d.VzW + ko), cij * 4u) = vz + (0.5f * (r0 + r1)) * dz;
+                ST4((d.VxW + ko), cij * 4u, vx + (0.5f * (r0 + rx)) * dx);
+                ST4((d.VyW + ko), cij * 4u, vy + (0.5f * (r0 + ry)) * dy);
+                ST4((d.VzW + ko), cij * 4u, vz + (0.5f * (r0 + r1)) * dz);
             }
         }
         sm1 = s0; s0 = sp1; sp1 = sp2; sp2 = ns;
@@ -1096,18 +1107,18 @@ __device__ __forceinline__ void stress_solid_body(const bfd_dev &d, const int4 &
                     else {
                         const float rn = c1 * rzz - BP * div;
                         val = szz + (AP * div + 0.5f * (rzz + rn));
-                        F4((d.RzzW + ko), cij * 4u) = rn;
+                        ST4((d.RzzW + ko), cij * 4u, rn);
                     }
-                    F4((d.SzzW + ko), cij * 4u) = val;
+                    ST4((d.SzzW + ko), cij * 4u, val);
                 } else {
                     const float sYZ = dyVy + dzVz, sXZ = dxVx + dzVz;
                     float rn;
                     rn = c1 * rxx - (BP * div - BS2 * sYZ);
-                    F4((d.Sxx + ko), cij * 4u) = sxx + ((AP * div - AS2 * sYZ) + 0.5f * (rxx + rn)); F4((d.Rxx + ko), cij * 4u) = rn;
+                    ST4((d.Sxx + ko), cij * 4u, sxx + ((AP * div - AS2 * sYZ) + 0.5f * (rxx + rn))); ST4((d.Rxx + ko), cij * 4u, rn);
                     rn = c1 * ryy - (BP * div - BS2 * sXZ);
-                    F4((d.Syy + ko), cij * 4u) = syy + ((AP * div - AS2 * sXZ) + 0.5f * (ryy + rn)); F4((d.Ryy + ko), cij * 4u) = rn;
+                    ST4((d.Syy + ko), cij * 4u, syy + ((AP * div - AS2 * sXZ) + 0.5f * (ryy + rn))); ST4((d.Ryy + ko), cij * 4u, rn);
                     rn = c1 * rzz - (BP * div - BS2 * sXY);
-                    F4((d.SzzW + ko), cij * 4u) = szz + ((AP * div - AS2 * sXY) + 0.5f * (rzz + rn)); F4((d.RzzW + ko), cij * 4u) = rn;
+                    ST4((d.SzzW + ko), cij * 4u, szz + ((AP * div - AS2 * sXY) + 0.5f * (rzz + rn))); ST4((d.RzzW + ko), cij * 4u, rn);
                 }
             }
         }
@@ -1319,9 +1330,9 @@ __device__ __forceinline__ void velocity_solid_body(const bfd_dev &d, const int4
                     dzSzz = cpml(d.psi[17], q, d.azH[k], d.bzH[k], dzSzz);
                 }
                 const float bxv = 0.5f * (r0 + rx), byv = 0.5f * (r0 + ry), bzv = 0.5f * (r0 + r1);
-                F4(wVx, cij * 4u) = vx + bxv * ((dxSxx + dySxy) + dzSxz);
-                F4(wVy, cij * 4u) = vy + byv * ((dxSxy + dySyy) + dzSyz);
-                F4(wVz, cij * 4u) = vz + bzv * ((dxSxz + dySyz) + dzSzz);
+                ST4(wVx, cij * 4u, vx + bxv * ((dxSxx + dySxy) + dzSxz));
+                ST4(wVy, cij * 4u, vy + byv * ((dxSxy + dySyy) + dzSyz));
+                ST4(wVz, cij * 4u, vz + bzv * ((dxSxz + dySyz) + dzSzz));
             }
         }
         zzm1 = zz0; zz0 = zzp1; zzp1 = zzp2; zzp2 = nzz;
