@@ -90,6 +90,26 @@ __device__ __forceinline__ void ST4(float *base, unsigned byteOfs, float v)
     *(float *)((char *)uni(base) + byteOfs) = v;
 #endif
 }
+// load of a value only this lane reads in this half-step: non-temporal, it need not stay in L2 (fluid stress half-step: Szz / Rzz of
+// the own cell, Vz; velocity half-steps: V of the own cell, the RMS sums; the sparse shear kernel's list, coefficients and entries).
+// C3 89.7 -> 91.0, shear medium 64.1 -> 66.3 Gvoxel-steps/s on alternating same-box runs; NOT for the own-cell stresses of
+// stress_solid (0.300 -> 0.313 ms). profiles/r3/experiment_nontemporal_stores.txt. -DBFD_NT_STORES_OFF builds the plain accesses.
+__device__ __forceinline__ float LD4(const float *base, unsigned byteOfs)
+{
+#ifndef BFD_NT_STORES_OFF
+    return __builtin_nontemporal_load((const float *)((const char *)uni(base) + byteOfs));
+#else
+    return *(const float *)((const char *)uni(base) + byteOfs);
+#endif
+}
+template <typename T> __device__ __forceinline__ T LDNT(const T *p)               // sparse shear kernel: list entries, coefficients, its own S and R entries
+{
+#ifndef BFD_NT_STORES_OFF
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
 __device__ __forceinline__ unsigned U2(const uint16_t *base, unsigned byteOfs) { return *(const uint16_t *)((const char *)uni(base) + byteOfs); }
 __device__ __forceinline__ unsigned U1(const uint8_t *base, unsigned byteOfs) { return uni(base)[byteOfs]; }
 
@@ -591,9 +611,9 @@ __device__ __forceinline__ void stress_fluid_body(const bfd_dev &d, int bx, int 
     if (valid) {
         const float *bVz = d.Vz + kbeg * pl;
         vx0 = F4((d.Vx + kbeg * pl), cij * 4u); vy0 = F4((d.Vy + kbeg * pl), cij * 4u);
-        vzm2 = F4((bVz - 2 * pl), cij * 4u); vzm1 = F4((bVz - pl), cij * 4u); vz0 = F4(bVz, cij * 4u); vzp1 = F4((bVz + pl), cij * 4u);
-        szz = F4((d.Szz + kbeg * pl), cij * 4u);
-        if (LOSSY) rzz = F4((d.Rzz + kbeg * pl), cij * 4u);
+        vzm2 = LD4((bVz - 2 * pl), cij * 4u); vzm1 = LD4((bVz - pl), cij * 4u); vz0 = LD4(bVz, cij * 4u); vzp1 = LD4((bVz + pl), cij * 4u);
+        szz = LD4((d.Szz + kbeg * pl), cij * 4u);
+        if (LOSSY) rzz = LD4((d.Rzz + kbeg * pl), cij * 4u);
         if (!UNI) mraw = U2((d.mat + kbeg * pl), cij * 2u);
     }
     float hv = t.ok ? F4(ph + kbeg * pl, hofs) : 0.0f;
@@ -613,9 +633,9 @@ __device__ __forceinline__ void stress_fluid_body(const bfd_dev &d, int bx, int 
         unsigned nmraw = 0;
         if (kl + 1 < kend) {
             if (valid) {
-                nvx = F4((d.Vx + ko + pl), cij * 4u); nvy = F4((d.Vy + ko + pl), cij * 4u); nvz = F4((d.Vz + ko + 2 * pl), cij * 4u);
-                nszz = F4((d.Szz + ko + pl), cij * 4u);
-                if (LOSSY) nrzz = F4((d.Rzz + ko + pl), cij * 4u);
+                nvx = F4((d.Vx + ko + pl), cij * 4u); nvy = F4((d.Vy + ko + pl), cij * 4u); nvz = LD4((d.Vz + ko + 2 * pl), cij * 4u);
+                nszz = LD4((d.Szz + ko + pl), cij * 4u);
+                if (LOSSY) nrzz = LD4((d.Rzz + ko + pl), cij * 4u);
                 if (!UNI) nmraw = U2((d.mat + ko + pl), cij * 2u);
             }
             if (t.ok) nh = F4(ph + ko + pl, hofs);
@@ -715,8 +735,8 @@ __device__ __forceinline__ void velocity_fluid_body(const bfd_dev &d, int bx, in
     if (valid) {
         const float *bS = d.Szz + kbeg * pl;
         sm1 = F4((bS - pl), cij * 4u); s0 = F4(bS, cij * 4u); sp1 = F4((bS + pl), cij * 4u); sp2 = F4((bS + 2 * pl), cij * 4u);
-        vx = F4((d.Vx + kbeg * pl), cij * 4u); vy = F4((d.Vy + kbeg * pl), cij * 4u); vz = F4((d.Vz + kbeg * pl), cij * 4u);
-        if (accA) av = F4((accP + kbeg * pl), cij * 4u);
+        vx = LD4((d.Vx + kbeg * pl), cij * 4u); vy = LD4((d.Vy + kbeg * pl), cij * 4u); vz = LD4((d.Vz + kbeg * pl), cij * 4u);
+        if (accA) av = LD4((accP + kbeg * pl), cij * 4u);
         if (accK) pv = F4((pkP + kbeg * pl), cij * 4u);
         if (!UNI) {
             const uint16_t *bM = d.mat + kbeg * pl;
@@ -746,9 +766,9 @@ __device__ __forceinline__ void velocity_fluid_body(const bfd_dev &d, int bx, in
         if (kl + 1 < kend) {
             if (valid) {
                 ns = F4((d.Szz + ko + 3 * pl), cij * 4u);
-                nvx = F4((d.Vx + ko + pl), cij * 4u); nvy = F4((d.Vy + ko + pl), cij * 4u); nvz = F4((d.Vz + ko + pl), cij * 4u);
+                nvx = LD4((d.Vx + ko + pl), cij * 4u); nvy = LD4((d.Vy + ko + pl), cij * 4u); nvz = LD4((d.Vz + ko + pl), cij * 4u);
                 if (!UNI) { nmx = U2((d.mat + ko + pl), cx * 2u); nmy = U2((d.mat + ko + pl), cy * 2u); }
-                if (accA) nav = F4((accP + ko + pl), cij * 4u);
+                if (accA) nav = LD4((accP + ko + pl), cij * 4u);
                 if (accK) npv = F4((pkP + ko + pl), cij * 4u);
             }
             if (t.ok) nh = F4(ph + ko + pl, hofs);
@@ -1276,8 +1296,8 @@ __device__ __forceinline__ void velocity_solid_body(const bfd_dev &d, const int4
             r1 = d.invRho[mraw1 & BFD_MAT_MASK];       // plane kl+1, becomes r0 of the next iteration
             rx = d.invRho[mx & BFD_MAT_MASK];
             ry = d.invRho[my & BFD_MAT_MASK];
-            vx = F4((d.Vx + ko), cij * 4u); vy = F4((d.Vy + ko), cij * 4u); vz = F4((d.Vz + ko), cij * 4u);
-            if (accA) av = F4((accP + ko), cij * 4u);
+            vx = LD4((d.Vx + ko), cij * 4u); vy = LD4((d.Vy + ko), cij * 4u); vz = LD4((d.Vz + ko), cij * 4u);
+            if (accA) av = LD4((accP + ko), cij * 4u);
             if (accK) pv = F4((pkP + ko), cij * 4u);
         }
         __syncthreads();
@@ -1453,25 +1473,25 @@ __global__ __launch_bounds__(256) void stress_shear_sparse(bfd_dev d, const unsi
     if (t >= n) return;
     const int N1 = d.N1, N2 = d.N2, P = d.P;
     const long pl = d.plane;
-    const unsigned c = cells[t];
+    const unsigned c = LDNT(cells + t);
     const int i = (int)(c % (unsigned)N1), j = (int)((c / (unsigned)N1) % (unsigned)N2), kl = (int)(c / (unsigned)d.plane);
     const long ko = (long)kl * pl;
     const int k = d.k0 + kl;
     // edge coefficients: from the per-material table where the four cells of the edge hold one material (most of a bone's
     // interior), explicit otherwise (24 B per cell less to stream)
-    const unsigned cw = codes[t];
+    const unsigned cw = LDNT(codes + t);
     float Axy = 0.f, Bxy = 0.f, Axz = 0.f, Bxz = 0.f, Ayz = 0.f, Byz = 0.f;
     {
         const unsigned q = cw & 255u;
-        if (q == 255u) { Axy = coef[6 * t]; Bxy = coef[6 * t + 1]; } else if (q) { Axy = tab[2 * (q - 1)]; Bxy = tab[2 * (q - 1) + 1]; }
+        if (q == 255u) { Axy = LDNT(coef + 6 * t); Bxy = LDNT(coef + 6 * t + 1); } else if (q) { Axy = tab[2 * (q - 1)]; Bxy = tab[2 * (q - 1) + 1]; }
     }
     {
         const unsigned q = (cw >> 8) & 255u;
-        if (q == 255u) { Axz = coef[6 * t + 2]; Bxz = coef[6 * t + 3]; } else if (q) { Axz = tab[2 * (q - 1)]; Bxz = tab[2 * (q - 1) + 1]; }
+        if (q == 255u) { Axz = LDNT(coef + 6 * t + 2); Bxz = LDNT(coef + 6 * t + 3); } else if (q) { Axz = tab[2 * (q - 1)]; Bxz = tab[2 * (q - 1) + 1]; }
     }
     {
         const unsigned q = (cw >> 16) & 255u;
-        if (q == 255u) { Ayz = coef[6 * t + 4]; Byz = coef[6 * t + 5]; } else if (q) { Ayz = tab[2 * (q - 1)]; Byz = tab[2 * (q - 1) + 1]; }
+        if (q == 255u) { Ayz = LDNT(coef + 6 * t + 4); Byz = LDNT(coef + 6 * t + 5); } else if (q) { Ayz = tab[2 * (q - 1)]; Byz = tab[2 * (q - 1) + 1]; }
     }
     const float vx0 = d.Vx[c], vy0 = d.Vy[c], vz0 = d.Vz[c];
     float dyVx = dplus4(ldv(d.Vx, N1, N2, i, j - 1, ko), vx0, ldv(d.Vx, N1, N2, i, j + 1, ko), ldv(d.Vx, N1, N2, i, j + 2, ko));
@@ -1501,18 +1521,18 @@ __global__ __launch_bounds__(256) void stress_shear_sparse(bfd_dev d, const unsi
     const float c1 = d.c1;
     if (Axy != 0.f) {
         const float e = dyVx + dxVy;
-        const float r = Rc[t], rn = c1 * r - Bxy * e;
-        d.Sxy[c] = d.Sxy[c] + (Axy * e + 0.5f * (r + rn)); Rc[t] = rn;
+        const float r = LDNT(Rc + t), rn = c1 * r - Bxy * e;
+        d.Sxy[c] = LDNT(d.Sxy + c) + (Axy * e + 0.5f * (r + rn)); Rc[t] = rn;
     }
     if (Axz != 0.f) {
         const float e = dzVx + dxVz;
-        const float r = Rc[nTotal + t], rn = c1 * r - Bxz * e;
-        d.Sxz[c] = d.Sxz[c] + (Axz * e + 0.5f * (r + rn)); Rc[nTotal + t] = rn;
+        const float r = LDNT(Rc + nTotal + t), rn = c1 * r - Bxz * e;
+        d.Sxz[c] = LDNT(d.Sxz + c) + (Axz * e + 0.5f * (r + rn)); Rc[nTotal + t] = rn;
     }
     if (Ayz != 0.f) {
         const float e = dzVy + dyVz;
-        const float r = Rc[2 * nTotal + t], rn = c1 * r - Byz * e;
-        d.Syz[c] = d.Syz[c] + (Ayz * e + 0.5f * (r + rn)); Rc[2 * nTotal + t] = rn;
+        const float r = LDNT(Rc + 2 * nTotal + t), rn = c1 * r - Byz * e;
+        d.Syz[c] = LDNT(d.Syz + c) + (Ayz * e + 0.5f * (r + rn)); Rc[2 * nTotal + t] = rn;
     }
 }
 
