@@ -10,6 +10,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <array>
 #include <chrono>
 #include <thread>
 #include <hipcub/hipcub.hpp>
@@ -984,15 +985,80 @@ static int build_tile_lists(bfd_sim *s)
     const int hiStart = std::max(((nkl - 2) / SUB) * SUB, lowPlanes);
     auto subBnd = [&](int q) { return q * SUB < lowPlanes || std::min((q + 1) * SUB, nkl) > hiStart; };
     std::vector<int4> lists[5];      // fluid boundary, fluid interior, solid boundary, solid interior, fused fluid
-    // runs of the fused kernel (variant 4, see fused_fluid_body): fluid + UNI + single-copy normal stresses, nothing of
-    // the absorbing layer within 2 cells, not a boundary sub-tile, sources of velocity type (bit5)
+    std::vector<char> taken((size_t)n, 0);
+    // Runs of the fused time step (variant 4, bfd_kernels_fused.hip): 64 x 24 cells = three tiles of this grid in y, a z-run of
+    // 2 .. fusedSub sub-tiles. A sub-tile qualifies (bit5) when it is fluid, has nothing of the absorbing layer or the domain
+    // edge within 2 cells (bit6), is not a boundary sub-tile of the slab, and the sources are of velocity type. Per column and
+    // z-chunk the rows are scanned upwards: where three consecutive tile rows qualify over a z-stretch they form a run and the
+    // scan moves on by three rows. A run is UNI when every sub-tile is (one material in the grown regions) and lossy when a
+    // cell of a grown region relaxes (bit7); stretches are cut where that class changes (a single sub-tile joins its neighbour).
+    int fusedSub = 32 / SUB;
+    if (const char *ev = getenv("BFD_FUSED_ZRUN")) { const int z = atoi(ev); if (z >= 2 * SUB && z % SUB == 0 && z <= 0x7000) fusedSub = z / SUB; }
+    struct FusedRun { int bx, by, q0, q1, cls, mat; };
+    std::vector<FusedRun> fruns;
     if (s->pingpong && s->cfg.typeSource < 2) {
-        for (int q = 0; q < nsub; q++) {
-            if (subBnd(q)) continue;
-            for (int txy = 0; txy < tx * ty; txy++) {
-                int &f = flags[(size_t)q * tx * ty + txy];
-                if (!(f & 1) && (f & 4) && !(f & 64)) f |= 32;
+        const int FRW = bfd_fused_rows() / 8;
+        const size_t layer = (size_t)tx * ty;
+        for (int q = 0; q < nsub; q++)
+            for (size_t txy = 0; txy < layer; txy++) { int &f = flags[(size_t)q * layer + txy]; if (!(f & 1) && !(f & 64) && !(f & 256) && !subBnd(q)) f |= 32; }
+        for (int bx = 0; bx < tx; bx++)
+            for (int qc = 0; qc < nsub; qc += fusedSub) {
+                const int qe = std::min(qc + fusedSub, nsub), L = qe - qc;
+                int by = 0;
+                while (by + FRW <= ty) {
+                    // class of the three rows at every q of the chunk: -1 = not available, else bit0 UNI, bit1 lossy
+                    std::vector<int> cls(L, -1);
+                    for (int q = qc; q < qe; q++) {
+                        bool ok = true; int uni = 1, lossy = 0;
+                        const int m0 = mats[(size_t)q * layer + (size_t)by * tx + bx];
+                        for (int r = 0; r < FRW; r++) {
+                            const size_t id = (size_t)q * layer + (size_t)(by + r) * tx + bx;
+                            const int f = flags[id];
+                            if (!(f & 32) || taken[id]) ok = false;
+                            if (!(f & 4) || mats[id] != m0) uni = 0;
+                            if (f & 128) lossy = 1;
+                        }
+                        if (ok) cls[q - qc] = uni | (lossy << 1);
+                    }
+                    bool any = false;
+                    int a = 0;
+                    while (a < L) {
+                        if (cls[a] < 0) { a++; continue; }
+                        int b = a; while (b < L && cls[b] >= 0) b++;        // stretch [a, b)
+                        if (b - a >= 2) {
+                            any = true;
+                            // segments of equal class (start, end, class); a segment of one sub-tile joins a neighbour
+                            std::vector<std::array<int, 3>> seg;
+                            for (int q = a; q < b; q++) {
+                                if (seg.empty() || seg.back()[2] != cls[q]) seg.push_back({q, q + 1, cls[q]});
+                                else seg.back()[1] = q + 1;
+                            }
+                            for (size_t u = 0; u < seg.size() && seg.size() > 1;) {
+                                if (seg[u][1] - seg[u][0] >= 2) { u++; continue; }
+                                const size_t v = u > 0 ? u - 1 : u + 1;      // UNI only if both are, lossy if either is
+                                seg[v][0] = std::min(seg[v][0], seg[u][0]); seg[v][1] = std::max(seg[v][1], seg[u][1]);
+                                seg[v][2] = (seg[v][2] & seg[u][2] & 1) | ((seg[v][2] | seg[u][2]) & 2);
+                                seg.erase(seg.begin() + u);
+                                u = 0;
+                            }
+                            for (const auto &rq : seg) {
+                                fruns.push_back({bx, by, qc + rq[0], qc + rq[1], rq[2], mats[(size_t)(qc + rq[0]) * layer + (size_t)by * tx + bx]});
+                                for (int q = qc + rq[0]; q < qc + rq[1]; q++)
+                                    for (int r = 0; r < FRW; r++) { taken[(size_t)q * layer + (size_t)(by + r) * tx + bx] = 1; T.nFusedSub++; }
+                            }
+                        }
+                        a = b;
+                    }
+                    by += any ? FRW : 1;
+                }
             }
+        // list order like the other runs: eight y-bands, inside a band z-chunk slowest, then row, bx fastest
+        auto key = [&](const FusedRun &r) { const long band = (long)r.by * 8 / ty; return ((band * 4096 + r.q0 / fusedSub) * 4096 + r.by) * 4096 + r.bx; };
+        std::stable_sort(fruns.begin(), fruns.end(), [&](const FusedRun &x, const FusedRun &y) { return key(x) < key(y); });
+        for (const auto &r : fruns) {
+            int4 run; run.x = r.by * tx + r.bx; run.y = (r.q0 * SUB) | (std::min(r.q1 * SUB, s->d.nk) << 16);
+            run.z = 32 | 16 | ((r.cls & 2) ? 2 : 0) | ((r.cls & 1) ? 4 : 0); run.w = r.mat;
+            lists[4].push_back(run);
         }
     }
     // List order = what is in flight together. The launch gives XCD e the e-th contiguous eighth of the list
@@ -1018,11 +1084,6 @@ static int build_tile_lists(bfd_sim *s)
             }
         }
     }
-    // fused runs may be longer than a z-chunk (their 3 extra stress planes and 5 extra velocity planes are pure
-    // overhead): up to fusedSub sub-tiles, crossing chunk boundaries; sub-tiles taken that way are skipped later
-    int fusedSub = 32 / SUB;
-    if (const char *ev = getenv("BFD_FUSED_ZRUN")) { const int z = atoi(ev); if (z >= SUB && z % SUB == 0 && z <= 0x7000) fusedSub = z / SUB; }
-    std::vector<char> taken((size_t)n, 0);
     for (const auto &pc : seq) {
         const int txy = pc.first, c = pc.second;
             const int sb = c * perChunk, se0 = std::min(sb + perChunk, nsub);
@@ -1032,23 +1093,23 @@ static int build_tile_lists(bfd_sim *s)
                 const int f = flags[(size_t)q * tx * ty + txy], m = mats[(size_t)q * tx * ty + txy];
                 const bool solid = f & 1;
                 const bool bnd = subBnd(q);
-                const int se = (!solid && (f & 32)) ? std::min(q + fusedSub, nsub) : se0;
+                const int se = se0;
                 int r = q + 1, pmlAny = f & 8;
                 while (r < se) {
                     const int f2 = flags[(size_t)r * tx * ty + txy], m2 = mats[(size_t)r * tx * ty + txy];
-                    if (subBnd(r) != bnd) break;
-                    if (solid ? !(f2 & 1) : (f2 != f || ((f & 4) && m2 != m))) break;
+                    if (subBnd(r) != bnd || taken[(size_t)r * tx * ty + txy]) break;
+                    if (solid ? !(f2 & 1) : (((f2 ^ f) & ~(32 | 128 | 256)) != 0 || ((f & 4) && m2 != m))) break;
                     pmlAny |= f2 & 8;
                     r++;
                 }
                 const int kbeg = q * SUB, kend = std::min(r * SUB, s->d.nk);
                 // solid runs: bit0 + bit3 (a sub-tile of the run touches the absorbing layer)
-                int4 run; run.x = txy; run.y = kbeg | (kend << 16); run.z = solid ? (1 | pmlAny) : f; run.w = m;
-                lists[(!solid && (f & 32)) ? 4 : (solid ? 2 : 0) + (bnd ? 0 : 1)].push_back(run);
+                int4 run; run.x = txy; run.y = kbeg | (kend << 16); run.z = solid ? (1 | pmlAny) : (f & ~(32 | 128 | 256)); run.w = m;
+                lists[(solid ? 2 : 0) + (bnd ? 0 : 1)].push_back(run);
                 for (int u = q; u < r; u++) {
                     taken[(size_t)u * tx * ty + txy] = 1;
                     if (solid) T.nSolidSub++;
-                    else { if (f & 2) T.nLossy++; else T.nLossless++; if (f & 4) T.nUni++; if (f & 8) T.nPml++; if (f & 16) T.nLean++; if (f & 32) T.nFusedSub++; }
+                    else { if (f & 2) T.nLossy++; else T.nLossless++; if (f & 4) T.nUni++; if (f & 8) T.nPml++; if (f & 16) T.nLean++; }
                 }
                 q = r;
             }
@@ -1161,9 +1222,10 @@ static int build_tile_lists(bfd_sim *s)
             const double cells = (double)(xb - xa) * (yb - ya) * (ke - kb);
             const double inner = overlap(xa, xb, ND, N1 - ND) * overlap(ya, yb, ND, N2 - ND) * overlap(k0g + kb, k0g + ke, ND, N3 - ND);
             const bool fusedRun = r >= (size_t)(T.nFluid + T.nSolid);
-            if (fusedRun) {          // V, Szz (Rzz) read and written once per step
-                const double b = 32.0 + ((f & 2) ? 8.0 : 0.0);
-                B[0][BFD_K_FUSED] += b * cells; B[1][BFD_K_FUSED] += b * cells + 8.0 * inner;
+            if (fusedRun) {          // 64 x 24 cells per plane, all outside the absorbing layer: V, Szz (Rzz) read and written once per step (+ ids)
+                const double fc = 64.0 * bfd_fused_rows() * (ke - kb);
+                const double b = 32.0 + ((f & 2) ? 8.0 : 0.0) + ((f & 4) ? 0.0 : 2.0);
+                B[0][BFD_K_FUSED] += b * fc; B[1][BFD_K_FUSED] += b * fc + 8.0 * fc;
             } else if (r < (size_t)T.nFluid) {
                 const bool lossy = f & 2, uni = f & 4, single = (f & 16) != 0;
                 double bs = 12.0 + 8.0 + (lossy ? 8.0 : 0.0) + (uni ? 0.0 : 2.0);
@@ -1554,7 +1616,7 @@ static int velocity_part(bfd_sim *s, int part, hipStream_t st)
         float *pkP = (qP >= 0 && s->pk) ? s->pk + (size_t)qP * s->nloc : nullptr;
         if (s->pingpong) {
             if (part != 0) BFD_FAIL(-2, "split half-steps are not available with kernelVariant 4 on a whole domain");
-            bfd_launch_fused(d, st, accP, pkP, &s->tiles);        // both half-steps of its runs: old fields -> W copies
+            bfd_launch_fused(d, st, accP, pkP, &s->tiles, 0, s->tiles.nFused);        // both half-steps of its runs: old fields -> W copies
         }
         bfd_launch_velocity_v2(new_stress_view(d), st, accP, pkP, &s->tiles, part);
     }

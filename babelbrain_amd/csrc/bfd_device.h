@@ -1,0 +1,87 @@
+// Device-side helpers shared by the tiled kernels (bfd_kernels_v2.hip, bfd_kernels_fused.hip). gfx950 only.
+#pragma once
+#include "bfd_internal.h"
+
+namespace {
+
+__device__ __forceinline__ float dminus4(float fm2, float fm1, float f0, float fp1)
+{
+    float t1 = f0 - fm1;
+    float t2 = fp1 - fm2;
+    return BFD_CA * t1 - BFD_CB * t2;
+}
+__device__ __forceinline__ float dplus4(float fm1, float f0, float fp1, float fp2)
+{
+    float t1 = fp1 - f0;
+    float t2 = fp2 - fm1;
+    return BFD_CA * t1 - BFD_CB * t2;
+}
+__device__ __forceinline__ float cpml(float *__restrict__ psi, unsigned idx, float a, float b, float D)
+{
+    float pn = b * psi[idx] + a * D;
+    psi[idx] = pn;
+    return D + pn;
+}
+
+
+// Element access as (wave-uniform plane base) + (32-bit BYTE offset in a VGPR). Indexing a float* with a 32-bit cell index
+// instead makes the compiler build 64-bit addresses in VGPR pairs that stay live (it cannot prove that index*4 stays below
+// 2^32), and it reassociates (array + plane) + lane offset into (array + lane offset) + plane, hoisting the first sum out of
+// the z loop: a loop-invariant VGPR pair per array.
+// uni(): the plane base as an opaque wave-uniform value (SGPR pair); the address of an access is then one v_lshl_add_u64 of
+// that pair and the shared offset register, live only until the access. The pointer is rebuilt from integers, so these are
+// FLAT accesses; the variant with address_space(1) pointers and saddr-form global loads (scripts/r2/patches/) needs fewer
+// registers still but measured 5-6 % slower on the solid-run kernels and equal on the fluid ones.
+template <typename T>
+__device__ __forceinline__ T *uni(T *p)
+{
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (T *)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ float &F4(float *base, unsigned byteOfs) { return *(float *)((char *)uni(base) + byteOfs); }
+__device__ __forceinline__ const float &F4(const float *base, unsigned byteOfs) { return *(const float *)((const char *)uni(base) + byteOfs); }
+// store of a value nobody reads before the next half-step: non-temporal, so that written lines do not displace halo lines in L2
+// (fluid kernels: C3 89.1 -> 89.8 Gvoxel-steps/s on three alternating same-box runs; solid-run kernels: shear medium 63.87 -> 64.10 on
+// five; profiles/r3/experiment_nontemporal_stores.txt). -DBFD_NT_STORES_OFF builds the plain stores.
+__device__ __forceinline__ void ST4(float *base, unsigned byteOfs, float v)
+{
+#ifndef BFD_NT_STORES_OFF
+    __builtin_nontemporal_store(v, (float *)((char *)uni(base) + byteOfs));
+#else
+    *(float *)((char *)uni(base) + byteOfs) = v;
+#endif
+}
+// load of a value only this lane reads in this half-step: non-temporal, it need not stay in L2 (fluid stress half-step: Szz / Rzz of
+// the own cell, Vz; velocity half-steps: V of the own cell, the RMS sums; the sparse shear kernel's list, coefficients and entries).
+// C3 89.7 -> 91.0, shear medium 64.1 -> 66.3 Gvoxel-steps/s on alternating same-box runs; NOT for the own-cell stresses of
+// stress_solid (0.300 -> 0.313 ms). profiles/r3/experiment_nontemporal_stores.txt. -DBFD_NT_STORES_OFF builds the plain accesses.
+__device__ __forceinline__ float LD4(const float *base, unsigned byteOfs)
+{
+#ifndef BFD_NT_STORES_OFF
+    return __builtin_nontemporal_load((const float *)((const char *)uni(base) + byteOfs));
+#else
+    return *(const float *)((const char *)uni(base) + byteOfs);
+#endif
+}
+template <typename T> __device__ __forceinline__ T LDNT(const T *p)               // sparse shear kernel: list entries, coefficients, its own S and R entries
+{
+#ifndef BFD_NT_STORES_OFF
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ unsigned U2(const uint16_t *base, unsigned byteOfs) { return *(const uint16_t *)((const char *)uni(base) + byteOfs); }
+__device__ __forceinline__ unsigned U1(const uint8_t *base, unsigned byteOfs) { return uni(base)[byteOfs]; }
+
+// XCD-aware tile order: consecutive block ids land on different XCDs (round robin over 8), so give
+// XCD e the e-th contiguous run of tiles.
+__device__ __forceinline__ int remap_block(int bid, int nblocks)
+{
+    const int per = nblocks >> 3;
+    if (per == 0 || bid >= (per << 3)) return bid;     // tail blocks keep their id
+    return (bid & 7) * per + (bid >> 3);
+}
+
+}  // namespace

@@ -35,6 +35,8 @@
 #ifndef BFD_SUBZ
 #define BFD_SUBZ 8
 #endif
+// output rows of a workgroup of the fused time step (bfd_kernels_fused.hip): three tiles of the classification grid
+#define BFD_FUSED_ROWS 24
 
 // device-side view of one slab; passed by value to kernels
 struct bfd_dev {
@@ -153,7 +155,9 @@ void bfd_set_error(const std::string &s);
 void bfd_launch_stress_v1(const bfd_dev &d, hipStream_t s);
 void bfd_launch_velocity_v1(const bfd_dev &d, hipStream_t s);
 void bfd_tile_grid(const bfd_dev &d, int *tilesX, int *tilesY, int *subZ);
-void bfd_launch_fused(const bfd_dev &d, hipStream_t s, float *accP, float *pkP, const bfd_tiles *t);
+// runs [off, off + n) of the fused list (bfd_kernels_fused.hip)
+void bfd_launch_fused(const bfd_dev &d, hipStream_t s, float *accP, float *pkP, const bfd_tiles *t, int off, int n);
+int bfd_fused_rows(void);
 int bfd_tile_subz(void);
 void bfd_launch_classify(const bfd_dev &d, hipStream_t s, int *flagsDev, int *tileMatDev);
 void bfd_launch_mark_solid(const bfd_dev &d, hipStream_t s, unsigned char *flag, long n);

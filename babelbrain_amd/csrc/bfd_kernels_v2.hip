@@ -16,6 +16,7 @@
 //    share one L2.
 //  * Arithmetic is the canonical float32 sequence of oracle/fdtd_oracle.c (no contraction).
 #include "bfd_internal.h"
+#include "bfd_device.h"
 #include <algorithm>
 
 namespace {
@@ -41,86 +42,6 @@ constexpr int SUBZ = BFD_SUBZ;             // z granularity of the fluid/solid c
 #ifndef VELOCITY_WAVES_PER_SIMD
 #define VELOCITY_WAVES_PER_SIMD 4
 #endif
-
-__device__ __forceinline__ float dminus4(float fm2, float fm1, float f0, float fp1)
-{
-    float t1 = f0 - fm1;
-    float t2 = fp1 - fm2;
-    return BFD_CA * t1 - BFD_CB * t2;
-}
-__device__ __forceinline__ float dplus4(float fm1, float f0, float fp1, float fp2)
-{
-    float t1 = fp1 - f0;
-    float t2 = fp2 - fm1;
-    return BFD_CA * t1 - BFD_CB * t2;
-}
-__device__ __forceinline__ float cpml(float *__restrict__ psi, unsigned idx, float a, float b, float D)
-{
-    float pn = b * psi[idx] + a * D;
-    psi[idx] = pn;
-    return D + pn;
-}
-
-
-// Element access as (wave-uniform plane base) + (32-bit BYTE offset in a VGPR). Indexing a float* with a 32-bit cell index
-// instead makes the compiler build 64-bit addresses in VGPR pairs that stay live (it cannot prove that index*4 stays below
-// 2^32), and it reassociates (array + plane) + lane offset into (array + lane offset) + plane, hoisting the first sum out of
-// the z loop: a loop-invariant VGPR pair per array.
-// uni(): the plane base as an opaque wave-uniform value (SGPR pair); the address of an access is then one v_lshl_add_u64 of
-// that pair and the shared offset register, live only until the access. The pointer is rebuilt from integers, so these are
-// FLAT accesses; the variant with address_space(1) pointers and saddr-form global loads (scripts/r2/patches/) needs fewer
-// registers still but measured 5-6 % slower on the solid-run kernels and equal on the fluid ones.
-template <typename T>
-__device__ __forceinline__ T *uni(T *p)
-{
-    const unsigned long long v = (unsigned long long)p;
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-    return (T *)(((unsigned long long)hi << 32) | lo);
-}
-__device__ __forceinline__ float &F4(float *base, unsigned byteOfs) { return *(float *)((char *)uni(base) + byteOfs); }
-__device__ __forceinline__ const float &F4(const float *base, unsigned byteOfs) { return *(const float *)((const char *)uni(base) + byteOfs); }
-// store of a value nobody reads before the next half-step: non-temporal, so that written lines do not displace halo lines in L2
-// (fluid kernels: C3 89.1 -> 89.8 Gvoxel-steps/s on three alternating same-box runs; solid-run kernels: shear medium 63.87 -> 64.10 on
-// five; profiles/r3/experiment_nontemporal_stores.txt). -DBFD_NT_STORES_OFF builds the plain stores.
-__device__ __forceinline__ void ST4(float *base, unsigned byteOfs, float v)
-{
-#ifndef BFD_NT_STORES_OFF
-    __builtin_nontemporal_store(v, (float *)((char *)uni(base) + byteOfs));
-#else
-    *(float *)((char *)uni(base) + byteOfs) = v;
-#endif
-}
-// load of a value only this lane reads in this half-step: non-temporal, it need not stay in L2 (fluid stress half-step: Szz / Rzz of
-// the own cell, Vz; velocity half-steps: V of the own cell, the RMS sums; the sparse shear kernel's list, coefficients and entries).
-// C3 89.7 -> 91.0, shear medium 64.1 -> 66.3 Gvoxel-steps/s on alternating same-box runs; NOT for the own-cell stresses of
-// stress_solid (0.300 -> 0.313 ms). profiles/r3/experiment_nontemporal_stores.txt. -DBFD_NT_STORES_OFF builds the plain accesses.
-__device__ __forceinline__ float LD4(const float *base, unsigned byteOfs)
-{
-#ifndef BFD_NT_STORES_OFF
-    return __builtin_nontemporal_load((const float *)((const char *)uni(base) + byteOfs));
-#else
-    return *(const float *)((const char *)uni(base) + byteOfs);
-#endif
-}
-template <typename T> __device__ __forceinline__ T LDNT(const T *p)               // sparse shear kernel: list entries, coefficients, its own S and R entries
-{
-#ifndef BFD_NT_STORES_OFF
-    return __builtin_nontemporal_load(p);
-#else
-    return *p;
-#endif
-}
-__device__ __forceinline__ unsigned U2(const uint16_t *base, unsigned byteOfs) { return *(const uint16_t *)((const char *)uni(base) + byteOfs); }
-__device__ __forceinline__ unsigned U1(const uint8_t *base, unsigned byteOfs) { return uni(base)[byteOfs]; }
-
-// XCD-aware tile order: consecutive block ids land on different XCDs (round robin over 8), so give
-// XCD e the e-th contiguous run of tiles.
-__device__ __forceinline__ int remap_block(int bid, int nblocks)
-{
-    const int per = nblocks >> 3;
-    if (per == 0 || bid >= (per << 3)) return bid;     // tail blocks keep their id
-    return (bid & 7) * per + (bid >> 3);
-}
 
 struct HaloTask {
     int lofs;       // offset inside one LDS tile (floats), -1 = no task
@@ -814,180 +735,6 @@ __device__ __forceinline__ void velocity_fluid_body(const bfd_dev &d, int bx, in
         r0 = r1; mraw = mraw1; mraw1 = nm2; mx = nmx; my = nmy;
         px = npx; py = npy; pz = npz; qx += dqx; qy += dqy;
     }
-}
-
-// ------------------------------------------------------------------------------------------------
-// FUSED time step of a fluid run (variant 4): stress and velocity half-steps of the tile in ONE pass, so V, Szz
-// (and Rzz) are read once and written once per time step (40 B/voxel with the RMS accumulator instead of 22 + 38).
-// The velocity update of the tile needs the NEW stress two cells around it and two planes ahead: the workgroup
-// recomputes it there (68 x 12 region per plane, z-run extended by 1 plane below and 2 above) from the OLD fields,
-// which is why this variant keeps two copies of V, Szz, Rzz (read from d.X, written to d.XW, swapped after the
-// step) -- a neighbour tile must still find the old values after this one has finished.
-// Eligible runs (flag bit5, set at setup): FLUID and LEAN/collapsed, UNI (one material, no reflector in the region
-// grown by 2 cells in x, y, z), no absorbing-layer cell in that grown region, not the first/last sub-tile of the
-// slab, sources of velocity type. Then every recomputed cell follows the same one-material arithmetic as its owner
-// computes for it, and every index stays inside the domain. Same operation order as stress_fluid_body /
-// velocity_fluid_body (UNI, non-PML flavours): results are bit-identical.
-// ------------------------------------------------------------------------------------------------
-constexpr int FR_W = TX + 4, FR_H = TY + 4, FR_N = FR_W * FR_H;      // region grown by 2: 68 x 12 = 816 cells
-constexpr int FVX_W = TX + 8;                                       // Vx tile: columns i0-4 .. i0+67 (71 used)
-constexpr int FVY_H = TY + 8;                                       // Vy tile: rows j0-4 .. j0+10 (15 used)
-constexpr int FVX_N = FR_H * FVX_W, FVY_N = FVY_H * FR_W;           // 864, 1088
-constexpr int FEXTRA = FR_N - NTHREADS;                             // 304 ring cells, one per thread tid < 304
-#ifndef FUSED_WAVES_PER_SIMD
-#define FUSED_WAVES_PER_SIMD 4
-#endif
-
-template <bool LOSSY, bool ACC>
-__device__ __forceinline__ void fused_fluid_body(const bfd_dev &d, int bx, int by, int kbeg, int kend, int tm,
-                                                 float *__restrict__ sVx, float *__restrict__ sVy, float *__restrict__ sS,
-                                                 float *__restrict__ accP, float *__restrict__ pkP)
-{
-    const int N1 = d.N1;
-    const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * TX + tx;
-    const int i0 = bx * TX, j0 = by * TY;
-    const long pl = d.plane;
-    const float AP = d.AP[tm], BP = d.BP[tm], ru = d.invRho[tm], c1 = d.c1;
-    const bool accA = ACC && accP != nullptr, accK = ACC && pkP != nullptr;
-
-    // own cell and (tid < 304) one cell of the ring: region coordinates (lx, ly), in-plane global offsets
-    const int rOwn = (ty + 2) * FR_W + tx + 2;
-    const unsigned cOwn = (unsigned)((j0 + ty) * N1 + i0 + tx);
-    const bool hasX = tid < FEXTRA;
-    int lxX = 0, lyX = 0;
-    if (tid < 2 * FR_W) { lyX = tid / FR_W; lxX = tid % FR_W; }
-    else if (tid < 4 * FR_W) { const int u = tid - 2 * FR_W; lyX = TY + 2 + u / FR_W; lxX = u % FR_W; }
-    else { const int u = tid - 4 * FR_W, c = u & 3; lyX = 2 + (u >> 2); lxX = c < 2 ? c : TX + c; }
-    const int rX = lyX * FR_W + lxX;
-    const unsigned cX = hasX ? (unsigned)((j0 - 2 + lyX) * N1 + i0 - 2 + lxX) : cOwn;
-    // tile loads: Vx tile element e -> row e / 72 (j0-2+row), col e % 72 (i0-4+col); Vy tile e -> row e / 68 (j0-4+row), col (i0-2+col)
-    const int ex1 = tid + NTHREADS;
-    const bool hx1 = ex1 < FVX_N;
-    const unsigned gx0 = (unsigned)((j0 - 2 + tid / FVX_W) * N1 + i0 - 4 + tid % FVX_W);
-    const unsigned gx1 = hx1 ? (unsigned)((j0 - 2 + ex1 / FVX_W) * N1 + i0 - 4 + ex1 % FVX_W) : gx0;
-    const int ey1 = tid + NTHREADS, ey2 = tid + 2 * NTHREADS;
-    const bool hy2 = ey2 < FVY_N;
-    const unsigned gy0 = (unsigned)((j0 - 4 + tid / FR_W) * N1 + i0 - 2 + tid % FR_W);
-    const unsigned gy1 = (unsigned)((j0 - 4 + ey1 / FR_W) * N1 + i0 - 2 + ey1 % FR_W);
-    const unsigned gy2 = hy2 ? (unsigned)((j0 - 4 + ey2 / FR_W) * N1 + i0 - 2 + ey2 % FR_W) : gy0;
-
-    const int pFirst = kbeg - 1, pEnd = kend + 2;       // stress planes [kbeg-1, kend+2)
-    // registers for plane p: tile values to stage, z-queues of Vz (p-2..p+1) and old Szz/Rzz of the two cells
-    float tx0, tx1 = 0, ty0, ty1, ty2 = 0;
-    float ozm2, ozm1, oz0, ozp1, xzm2 = 0, xzm1 = 0, xz0 = 0, xzp1 = 0;
-    float oS, oR = 0, xS = 0, xR = 0;
-    {
-        const long k0 = (long)pFirst * pl;
-        tx0 = F4((d.Vx + k0), gx0 * 4u); if (hx1) tx1 = F4((d.Vx + k0), gx1 * 4u);
-        ty0 = F4((d.Vy + k0), gy0 * 4u); ty1 = F4((d.Vy + k0), gy1 * 4u); if (hy2) ty2 = F4((d.Vy + k0), gy2 * 4u);
-        const float *bz = d.Vz + k0;
-        ozm2 = F4((bz - 2 * pl), cOwn * 4u); ozm1 = F4((bz - pl), cOwn * 4u); oz0 = F4(bz, cOwn * 4u); ozp1 = F4((bz + pl), cOwn * 4u);
-        oS = F4((d.Szz + k0), cOwn * 4u); if (LOSSY) oR = F4((d.Rzz + k0), cOwn * 4u);
-        if (hasX) {
-            xzm2 = F4((bz - 2 * pl), cX * 4u); xzm1 = F4((bz - pl), cX * 4u); xz0 = F4(bz, cX * 4u); xzp1 = F4((bz + pl), cX * 4u);
-            xS = F4((d.Szz + k0), cX * 4u); if (LOSSY) xR = F4((d.Rzz + k0), cX * 4u);
-        }
-    }
-    // velocity stage lags two planes: own new-stress queue (q-1..q+2), own Vx,Vy of planes p-2, p-1, accumulators of q
-    float nSm1 = 0, nS0 = 0, nSp1 = 0, nSp2 = 0;
-    float vxA = 0, vxB = 0, vyA = 0, vyB = 0;           // A = plane p-2, B = plane p-1
-    float av = 0, pv = 0;
-
-    for (int p = pFirst; p < pEnd; p++) {
-        const int b = (p - pFirst) & 1;
-        const long ko = (long)p * pl;
-        float *tVx = sVx + b * FVX_N, *tVy = sVy + b * FVY_N;
-        tVx[tid] = tx0; if (hx1) tVx[ex1] = tx1;
-        tVy[tid] = ty0; tVy[ey1] = ty1; if (hy2) tVy[ey2] = ty2;
-        __syncthreads();
-
-        // loads of plane p+1
-        float ntx0 = 0, ntx1 = 0, nty0 = 0, nty1 = 0, nty2 = 0, noz = 0, nxz = 0, noS = 0, noR = 0, nxS = 0, nxR = 0, nav = 0, npv = 0;
-        if (p + 1 < pEnd) {
-            ntx0 = F4((d.Vx + ko + pl), gx0 * 4u); if (hx1) ntx1 = F4((d.Vx + ko + pl), gx1 * 4u);
-            nty0 = F4((d.Vy + ko + pl), gy0 * 4u); nty1 = F4((d.Vy + ko + pl), gy1 * 4u); if (hy2) nty2 = F4((d.Vy + ko + pl), gy2 * 4u);
-            noz = F4((d.Vz + ko + 2 * pl), cOwn * 4u);
-            noS = F4((d.Szz + ko + pl), cOwn * 4u); if (LOSSY) noR = F4((d.Rzz + ko + pl), cOwn * 4u);
-            if (hasX) { nxz = F4((d.Vz + ko + 2 * pl), cX * 4u); nxS = F4((d.Szz + ko + pl), cX * 4u); if (LOSSY) nxR = F4((d.Rzz + ko + pl), cX * 4u); }
-        }
-        const int q = p - 2;                             // velocity plane of this iteration
-        if (ACC && q + 1 >= kbeg && q + 1 < kend) {
-            if (accA) nav = F4((accP + ko - pl), cOwn * 4u);
-            if (accK) npv = F4((pkP + ko - pl), cOwn * 4u);
-        }
-
-        // ---- stress of plane p on the grown region (own cell, then the ring cell) ----
-        float *rS = sS + ((p - pFirst) % 3) * FR_N;
-        float vxOwn, vyOwn;
-        {
-            const float *sx = tVx + (ty + 2) * FVX_W + tx + 4, *sy = tVy + (ty + 4) * FR_W + tx + 2;
-            vxOwn = sx[0]; vyOwn = sy[0];
-            const float dxVx = dminus4(sx[-2], sx[-1], vxOwn, sx[1]);
-            const float dyVy = dminus4(sy[-2 * FR_W], sy[-FR_W], vyOwn, sy[FR_W]);
-            const float dzVz = dminus4(ozm2, ozm1, oz0, ozp1);
-            const float div = (dxVx + dyVy) + dzVz;
-            float val, rn = 0.f;
-            if (LOSSY) { rn = c1 * oR - BP * div; val = oS + (AP * div + 0.5f * (oR + rn)); }
-            else val = oS + AP * div;
-            rS[rOwn] = val;
-            if (p >= kbeg && p < kend) {
-                F4((d.SzzW + ko), cOwn * 4u) = val;
-                if (LOSSY) F4((d.RzzW + ko), cOwn * 4u) = rn;
-            }
-            nSm1 = nS0; nS0 = nSp1; nSp1 = nSp2; nSp2 = val;
-        }
-        if (hasX) {
-            const float *sx = tVx + lyX * FVX_W + lxX + 2, *sy = tVy + (lyX + 2) * FR_W + lxX;
-            const float dxVx = dminus4(sx[-2], sx[-1], sx[0], sx[1]);
-            const float dyVy = dminus4(sy[-2 * FR_W], sy[-FR_W], sy[0], sy[FR_W]);
-            const float dzVz = dminus4(xzm2, xzm1, xz0, xzp1);
-            const float div = (dxVx + dyVy) + dzVz;
-            float val;
-            if (LOSSY) { const float rn = c1 * xR - BP * div; val = xS + (AP * div + 0.5f * (xR + rn)); }
-            else val = xS + AP * div;
-            rS[rX] = val;
-        }
-        __syncthreads();
-
-        // ---- velocity of plane q = p-2 on the tile: new stress of planes q-1 .. q+2 is in the queue ----
-        if (q >= kbeg && q < kend) {
-            const long kq = ko - 2 * pl;
-            const float *ps = sS + ((q - pFirst) % 3) * FR_N + rOwn;
-            const float s0 = nS0;
-            if (ACC) {
-                const float s = (s0 + s0) + s0;
-                const float pr = -s * (1.0f / 3.0f);
-                if (accA) F4((accP + kq), cOwn * 4u) = av + pr * pr;
-                if (accK) { const float ap = fabsf(pr); if (ap > pv) F4((pkP + kq), cOwn * 4u) = ap; }
-            }
-            const float dx = dplus4(ps[-1], s0, ps[1], ps[2]);
-            const float dy = dplus4(ps[-FR_W], s0, ps[FR_W], ps[2 * FR_W]);
-            const float dz = dplus4(nSm1, nS0, nSp1, nSp2);
-            const float rr = 0.5f * (ru + ru);
-            F4((d.VxW + kq), cOwn * 4u) = vxA + rr * dx;
-            F4((d.VyW + kq), cOwn * 4u) = vyA + rr * dy;
-            F4((d.VzW + kq), cOwn * 4u) = ozm2 + rr * dz;
-        }
-        // rotate
-        vxA = vxB; vxB = vxOwn; vyA = vyB; vyB = vyOwn;
-        ozm2 = ozm1; ozm1 = oz0; oz0 = ozp1; ozp1 = noz;
-        xzm2 = xzm1; xzm1 = xz0; xz0 = xzp1; xzp1 = nxz;
-        oS = noS; oR = noR; xS = nxS; xR = nxR;
-        tx0 = ntx0; tx1 = ntx1; ty0 = nty0; ty1 = nty1; ty2 = nty2;
-        av = nav; pv = npv;
-    }
-}
-
-template <bool ACC>
-__global__ __launch_bounds__(NTHREADS, FUSED_WAVES_PER_SIMD) void fused_fluid(bfd_dev d, int tilesX, int nblocks,
-                                                                               const int4 *__restrict__ runs,
-                                                                               float *__restrict__ accP, float *__restrict__ pkP)
-{
-    __shared__ float sVx[2 * FVX_N], sVy[2 * FVY_N], sS[3 * FR_N];
-    const int4 run = runs[remap_block(blockIdx.x, nblocks)];
-    const int bx = run.x % tilesX, by = run.x / tilesX, kbeg = run.y & 0xFFFF, kend = run.y >> 16, tm = run.w;
-    if (run.z & 2) fused_fluid_body<true, ACC>(d, bx, by, kbeg, kend, tm, sVx, sVy, sS, accP, pkP);
-    else fused_fluid_body<false, ACC>(d, bx, by, kbeg, kend, tm, sVx, sVy, sS, accP, pkP);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1685,7 +1432,7 @@ __global__ void classify_tiles(bfd_dev d, int tilesX, int tilesY, int *__restric
     const int nzOwn = min(SUBZ, d.nk - bz * SUBZ);
     const int nx = TX + 4, ny = TY + 4, nz = nzOwn + 4;
     const unsigned first = d.mat[(long)(bz * SUBZ) * d.plane + (long)min(by * TY, d.N2 - 1) * d.N1 + min(bx * TX, d.N1 - 1)];
-    int solid = 0, lossy = 0, mixed = (first & BFD_REFLECTOR_BIT) ? 1 : 0;
+    int solid = 0, lossy = 0, lossyG = 0, refl = 0, mixed = (first & BFD_REFLECTOR_BIT) ? 1 : 0;
     for (int v = threadIdx.x; v < nx * ny * nz; v += blockDim.x) {
         const int li = v % nx, lj = (v / nx) % ny, lk = v / (nx * ny);
         const int i = i0 + li, j = j0 + lj, kl = k0 + lk;       // kl in [-2, nk+2): ghost planes exist
@@ -1693,11 +1440,14 @@ __global__ void classify_tiles(bfd_dev d, int tilesX, int tilesY, int *__restric
         const unsigned raw = d.mat[(long)kl * d.plane + (long)j * d.N1 + i];
         const int m = raw & BFD_MAT_MASK;
         if (raw != first) mixed = 1;
+        if (raw & BFD_REFLECTOR_BIT) refl = 1;
         if (d.invMu[m] > 0.f) solid = 1;
-        if (li >= 2 && li < nx - 2 && lj >= 2 && lj < ny - 2 && lk >= 2 && lk < nz - 2 && d.BP[m] != 0.f) lossy = 1;
+        if (d.BP[m] != 0.f) { lossyG = 1; if (li >= 2 && li < nx - 2 && lj >= 2 && lj < ny - 2 && lk >= 2 && lk < nz - 2) lossy = 1; }
     }
     solid = __syncthreads_or(solid);
     lossy = __syncthreads_or(lossy);
+    lossyG = __syncthreads_or(lossyG);
+    refl = __syncthreads_or(refl);
     mixed = __syncthreads_or(mixed);
     if (threadIdx.x == 0) {
         const int P = d.P;
@@ -1707,7 +1457,8 @@ __global__ void classify_tiles(bfd_dev d, int tilesX, int tilesY, int *__restric
         // bit6: an absorbing-layer cell (or the domain edge) within the sub-tile grown by 2 cells, or a ragged tile
         const bool pmlGrown = xa - 2 < P || xb + 2 > d.N1 - P || ya - 2 < P || yb + 2 > d.N2 - P || za - 2 < P || zb + 2 > d.N3 - P ||
                               xb - xa < TX || yb - ya < TY;
-        flags[tile] = solid | (lossy << 1) | (mixed ? 0 : 4) | (pml ? 8 : 0) | (pmlGrown ? 64 : 0);
+        // bit7: a cell of the GROWN region relaxes (the fused time step recomputes the stress there)
+        flags[tile] = solid | (lossy << 1) | (mixed ? 0 : 4) | (pml ? 8 : 0) | (pmlGrown ? 64 : 0) | (lossyG ? 128 : 0) | (refl ? 256 : 0);      // bit8: a reflector voxel in the grown region
         tileMat[tile] = (int)(first & BFD_MAT_MASK);
     }
 }
@@ -1832,19 +1583,6 @@ void bfd_launch_stress_v2(const bfd_dev &d, hipStream_t s0, const bfd_tiles *t, 
         BFD_LAUNCH((stress_fluid<true>), n, t->runs + off);      // fluid cells keep one copy of their normal stresses (bfd_dev::cls)
         BFD_KT(BFD_K_STRESS_FLUID, 1);
     }
-}
-
-// fused time step of the eligible fluid runs (variant 4; whole half-steps only); d = stress-side view of the fields
-void bfd_launch_fused(const bfd_dev &d, hipStream_t s, float *accP, float *pkP, const bfd_tiles *t)
-{
-    const int tilesX = (d.N1 + TX - 1) / TX;
-    const int n = t->nFused;
-    if (!n) return;
-    const int4 *runs = t->runs + t->nFluid + t->nSolid;
-    BFD_KT(BFD_K_FUSED, 0);
-    if (accP || pkP) BFD_LAUNCH((fused_fluid<true>), n, runs, accP, pkP);
-    else BFD_LAUNCH((fused_fluid<false>), n, runs, accP, pkP);
-    BFD_KT(BFD_K_FUSED, 1);
 }
 
 void bfd_launch_velocity_v2(const bfd_dev &d, hipStream_t s0, float *accP, float *pkP, const bfd_tiles *t, int part)

@@ -289,18 +289,22 @@ def test_graph_replay_equals_direct_launches(monkeypatch):
                 assert np.array_equal(x, y)
 
 
-@pytest.mark.parametrize('config', ['C1', 'C1-lossy', 'C2', 'C3'])
+@pytest.mark.parametrize('config', ['C1', 'C1-lossy', 'C2', 'C3', 'C3-lossless'])
 def test_fused_fluid_step_variant4(config):
-    """kernelVariant 4: eligible fluid runs advance both half-steps in one pass over two copies of V, Szz, Rzz
-    (fused_fluid_body); everything else runs the variant-3 kernels out of place. Outputs and raw fields must equal
-    the oracle's like every other variant."""
+    """kernelVariant 4: eligible fluid runs (64 x 24 cells, bfd_kernels_fused.hip) advance both half-steps in one pass over
+    two copies of V, Szz, Rzz; everything else runs the variant-3 kernels out of place. Outputs and raw fields must equal
+    the oracle's like every other variant. The grid holds two columns of fused tiles in x, two groups of three tile rows and
+    a left-over row in y, a short and a full z-run; the media cover the four flavours of the fused body (one material / ids
+    per cell, with / without memory variables)."""
     from babelbrain_amd import _engine
     from babelbrain_amd.PropagationModel import compact_sources
-    N = (150, 62, 80)
+    N = (214, 90, 80)
     a, k, info = H.make_problem(config.split('-')[0], N=N, steps=170, stable_dt_fn=oracle_dt)
     if config == 'C1-lossy':                                   # one attenuating fluid everywhere: the LOSSY flavour of the fused body
         a = list(a); a[1] = np.array([[1041.0, 1562.0, 0.0, 30.0, 0.0]]); a = tuple(a)
         assert k['DT'] <= oracle_dt(a[1], a[2], a[5], 0.95)
+    if config == 'C3-lossless':                                # many fluids, none attenuating: ids per cell, no memory variables
+        a = list(a); ml = np.array(a[1], np.float64); ml[:, 3:] = 0.0; a[1] = ml; a = tuple(a)
     k['SelMapsRMSPeakList'] = ['Pressure', 'Vx', 'Vz']
     k['SelMapsSensorsList'] = ['Pressure', 'Vy']
     k['SelRMSorPeak'] = 3
@@ -317,7 +321,7 @@ def test_fused_fluid_step_variant4(config):
     eng.set_sensor_map(sensor)
     tc = eng.tile_counts()
     print(config, tc)
-    assert tc['fused_fluid'] > 0 or config in ('C2', 'C3'), tc   # the small shells leave no eligible run; their ping-pong path is still covered
+    assert tc['fused_fluid'] > 0, tc
     if config == 'C1-lossy':
         assert tc['lossy_fluid'] > 0 and tc['lossless_fluid'] == 0
     eng.run(info['nt'] - 1)
