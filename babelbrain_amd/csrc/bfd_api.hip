@@ -632,9 +632,12 @@ int bfd_create(const bfd_config *cfg, bfd_sim **out)
     int rc = 0;
     float **fp[15] = {&d.Vx, &d.Vy, &d.Vz, &d.Sxx, &d.Syy, &d.Szz, &d.Sxy, &d.Sxz, &d.Syz,
                       &d.Rxx, &d.Ryy, &d.Rzz, &d.Rxy, &d.Rxz, &d.Ryz};
+    // experiment knob (use with BFD_PLACEMENT=0): array a starts a * BFD_SKEW_LINES cache lines into its allocation, so that the
+    // same cell of different arrays falls into different L2 sets / channels
+    const size_t skew = getenv("BFD_SKEW_LINES") ? (size_t)std::max(atoi(getenv("BFD_SKEW_LINES")), 0) * 32 : 0;
     for (int a = 0; a < 15 && !rc; a++) {
-        rc = dev_alloc(s, &s->stateBase[a], s->nalloc);
-        if (!rc) *fp[a] = s->stateBase[a] + 2 * (size_t)d.plane;
+        rc = dev_alloc(s, &s->stateBase[a], s->nalloc + 24 * skew);
+        if (!rc) { s->stateBase[a] += a * skew; *fp[a] = s->stateBase[a] + 2 * (size_t)d.plane; }
     }
     if (!rc) rc = dev_alloc(s, &s->matBase, s->nalloc);
     if (!rc) d.mat = s->matBase + 2 * (size_t)d.plane;
@@ -648,8 +651,8 @@ int bfd_create(const bfd_config *cfg, bfd_sim **out)
     if (s->pingpong) {
         float **wp[5] = {&d.VxW, &d.VyW, &d.VzW, &d.SzzW, &d.RzzW};
         for (int a = 0; a < 5 && !rc; a++) {
-            rc = dev_alloc(s, &s->ppBase[a], s->nalloc);
-            if (!rc) *wp[a] = s->ppBase[a] + 2 * (size_t)d.plane;
+            rc = dev_alloc(s, &s->ppBase[a], s->nalloc + 24 * skew);
+            if (!rc) { s->ppBase[a] += (15 + a) * skew; *wp[a] = s->ppBase[a] + 2 * (size_t)d.plane; }
         }
     }
     // CPML memory variables
@@ -973,6 +976,7 @@ static int build_tile_lists(bfd_sim *s)
         if (e != hipSuccess) BFD_FAIL(-10, std::string("classify tiles: ") + hipGetErrorString(e));
     }
     bfd_tiles &T = s->tiles;
+    T.nMat = s->cfg.nMat;
     T.nFluid = T.nFluidB = T.nSolid = T.nSolidB = T.nSolidBP = T.nSolidIP = T.nFused = T.nLossless = T.nLossy = T.nSolidSub = T.nUni = T.nPml = T.nLean = T.nFusedSub = 0;
     s->d.tilesX = tx; s->d.tilesY = ty;
     // Every fluid sub-tile is LEAN (bit4): fluid cells keep a single copy of their identical normal stresses, whatever
@@ -1018,6 +1022,7 @@ static int build_tile_lists(bfd_sim *s)
                             if (!(f & 4) || mats[id] != m0) uni = 0;
                             if (f & 128) lossy = 1;
                         }
+                        if (!uni && s->cfg.nMat > bfd_fused_max_materials()) ok = false;
                         if (ok) cls[q - qc] = uni | (lossy << 1);
                     }
                     bool any = false;

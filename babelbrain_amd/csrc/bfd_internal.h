@@ -37,6 +37,8 @@
 #endif
 // output rows of a workgroup of the fused time step (bfd_kernels_fused.hip): three tiles of the classification grid
 #define BFD_FUSED_ROWS 24
+// multi-material runs of the fused time step keep AP, BP, 1/rho of every material in LDS: media with more materials fuse only their one-material runs
+#define BFD_FUSED_MAX_MATERIALS 1024
 
 // device-side view of one slab; passed by value to kernels
 struct bfd_dev {
@@ -79,7 +81,7 @@ struct bfd_sim;
 // records an event before (end = 0) / after (end = 1) a launch of class cls (bfd_api.hip); t->ktimer != null while class timing is on
 void bfd_kmark(bfd_sim *sim, int cls, int end, hipStream_t st);
 
-struct bfd_tiles { bfd_sim *ktimer; int4 *runs;
+struct bfd_tiles { bfd_sim *ktimer; int nMat; int4 *runs;
                    unsigned *shearCells; float *shearCoef; long nShear, shearLowEnd, shearHighBeg;   /* sparse shear list */
                    unsigned *shearCodes; float *shearTab; long nShearExplicit;   /* per listed cell a byte per edge: 0 inactive, 1 + m = one material around the edge (coefficients from shearTab[2 m ..]), 255 = explicit coefficients in shearCoef; number of explicit edges */
                    float *shearR;   /* memory variables Rxy, Rxz, Ryz of the listed cells, [3][nShear] in list order: only the sparse kernel uses them, so they live beside the list (dense, coalesced) instead of in the full-volume arrays, which are filled from here on demand (bfd_get_field) */
@@ -158,6 +160,7 @@ void bfd_tile_grid(const bfd_dev &d, int *tilesX, int *tilesY, int *subZ);
 // runs [off, off + n) of the fused list (bfd_kernels_fused.hip)
 void bfd_launch_fused(const bfd_dev &d, hipStream_t s, float *accP, float *pkP, const bfd_tiles *t, int off, int n);
 int bfd_fused_rows(void);
+int bfd_fused_max_materials(void);
 int bfd_tile_subz(void);
 void bfd_launch_classify(const bfd_dev &d, hipStream_t s, int *flagsDev, int *tileMatDev);
 void bfd_launch_mark_solid(const bfd_dev &d, hipStream_t s, unsigned char *flag, long n);
