@@ -59,7 +59,8 @@ def compact_sources(SourceMap, Ox, Oy, Oz, k0=0, nk=None):
         if o.shape != SourceMap.shape:
             raise ValueError('Ox/Oy/Oz must be size-1 or have the shape of the domain')
         return o[ii, jj, kk + k0].astype(np.float32)
-    return lin.astype(np.uint32), row.astype(np.uint32), w(Ox), w(Oy), w(Oz)
+    # int64: a multi-device domain may hold more than 2^32 voxels; the single-engine ABI takes uint32 (Engine.set_sources checks)
+    return lin.astype(np.int64), row.astype(np.uint32), w(Ox), w(Oy), w(Oz)
 
 
 def material_slab(MaterialMap, k0, nk):
@@ -222,7 +223,7 @@ class PropagationModel:
             if ReflectorMask is not None:
                 grp.set_reflector(ReflectorMask)
             lin, row, wx, wy, wz = compact_sources(np.asarray(SourceMap), Ox, Oy, Oz)
-            grp.set_sources(lin.astype(np.int64), row, wx, wy, wz, PulseSource)
+            grp.set_sources(lin, row, wx, wy, wz, PulseSource)
             grp.set_sensor_map(SensorMap)
             grp.timing_begin()
             grp.run(nt)

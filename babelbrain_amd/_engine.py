@@ -326,7 +326,10 @@ class Engine:
     def set_sources(self, localIndex, row, wx, wy, wz, PulseSource):
         pulse = np.ascontiguousarray(np.atleast_2d(PulseSource), np.float64)
         self._pulse = pulse     # a large table is streamed from here in time tiles during the run: keep it alive with the engine
-        li = np.ascontiguousarray(localIndex, np.uint32)
+        li = np.asarray(localIndex)
+        if li.size and (int(li.max()) >= 2 ** 32 or int(li.min()) < 0):
+            raise ValueError('source index beyond 2^32 voxels: split the domain over devices (devices=[...])')
+        li = np.ascontiguousarray(li, np.uint32)
         rw = np.ascontiguousarray(row, np.uint32)
         ws = [None if w is None else np.ascontiguousarray(w, np.float32) for w in (wx, wy, wz)]
         _check(self.lib.bfd_set_sources(self.h, li.size, _ptr(li), _ptr(rw), _ptr(ws[0]), _ptr(ws[1]), _ptr(ws[2]),

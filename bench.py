@@ -15,8 +15,16 @@ transducer, PML on"), the configuration the metric is quoted on.
 Neighbour slabs exchange 2+2 halo planes per half-step over RCCL (babelbrain_amd/slab.py); there is no collective on
 the step path.
 
-Prints ONE JSON line on rank 0. `value` = voxel-steps of all ranks / max-over-ranks wall time of the K timed steps
-(inputs resident in HBM), in Mvoxel-steps/s. `roofline` describes the kernel with the longest average launch:
+Without a launcher (`WORLD_SIZE` unset) `--gpus N` with N > 1 runs the ONE-PROCESS split behind the drop-in call
+(bfd_group_*, what PropagationModel(devices=[...]) uses; the reference's caller is one process making one call,
+BabelIntegrationBASE.py:2338): headline = strong scaling of ONE C5 volume (1024^3) over devices 0..N-1, the weak-scaling C3
+figure as a secondary block. If fewer than N devices are visible the ordinals repeat and the line says "emulated": true.
+Under torchrun the ranks take the RCCL path (slab.py) and rank 0 adds `group_strong_c3` (one 512^3 C3 volume split over the N
+devices through bfd_group) after the ranks have released their slabs; `--gpus 1` adds `group_one_slab`.
+
+Prints ONE JSON line on rank 0. `value` = voxel-steps of all ranks / max-over-ranks wall time of K timed steps (median of
+`--windows` windows of exactly K steps, each between barrier + synchronize; min / max beside it; inputs resident in HBM), in
+Mvoxel-steps/s. `roofline` describes the kernel with the longest average launch:
 achieved = ALGORITHMIC bytes of one launch (per-cell byte tables of the tile classes the engine built, DESIGN.md
 section 6; bfd_algorithmic_bytes) / average launch duration from HIP events on the engine's stream. At N=1 the line also
 carries `shear_workload` (the C2 medium -- cortical bone with shear -- on the same 512^3 grid: the viscoelastic kernels)
@@ -45,6 +53,7 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=300)
     ap.add_argument('--warmup', type=int, default=50)
+    ap.add_argument('--windows', type=int, default=3, help='timed windows of K steps each; value = the median window (SURVEY 8d: median of >= 3 runs)')
     ap.add_argument('--config', default='C3')
     ap.add_argument('--scaling', choices=['weak', 'strong'], default='weak')
     ap.add_argument('--size', type=int, nargs=3, default=None, help='override the grid N1 N2 N3 (per GPU if weak, total if strong)')
@@ -56,7 +65,8 @@ def parse():
     ap.add_argument('--no-steady-warmup', action='store_true', help='do exactly W warm-up steps (default: at least W, and enough for %.2f s of load)' % STEADY_SECONDS)
     ap.add_argument('--debug-gloo-shared-gpu', action='store_true', help='debug only: N ranks on GPU 0, gloo backend, halos staged through the host (validates the multi-rank code path on a 1-GPU box)')
     ap.add_argument('--lean-host', action='store_true', help='build the inputs slab-style (size-1 Ox/Oy/Oz) also at N=1')
-    ap.add_argument('--cpu-sample', type=int, nargs=4, default=[384, 384, 256, 224], help='N1 N2 N3 steps of the oracle sample (about 12 s of CPU work at 0.7 Gvoxel-steps/s)')
+    ap.add_argument('--cpu-sample', type=int, nargs=4, default=None, help='N1 N2 N3 steps of the oracle sample (default: the grid of the config itself, 56 steps, when the host has the memory; else 384 384 256 224)')
+    ap.add_argument('--no-group', action='store_true', help='skip the one-process bfd_group figures (group_one_slab at N=1, group_strong_c3 under torchrun)')
     ap.add_argument('--no-next-rows', action='store_true', help='skip the Rayleigh / BHTE kernel rates (N=1, default workload only)')
     ap.add_argument('--no-extra-strong', action='store_true', help='N > 1: skip the extra block that splits ONE C5 volume (1024^3, 1 MHz) over the ranks')
     ap.add_argument('--extra-strong-steps', type=int, default=40, help='timed steps of the extra strong-scaling block')
@@ -93,24 +103,37 @@ def next_rows(device):
     t0 = time.time(); R.BHTE(P, mm, ML, h, steps, steps // 2, N[1] // 2, nFactorMonitoring=10, dt=0.05); wall = time.time() - t0
     vox = float(np.prod(N)) * steps
     out['bhte'] = {'value': vox / R.last_kernel_ms / 1e6, 'unit': 'Gvoxel-steps/s', 'grid': list(N), 'steps': steps, 'steps_per_launch': 2, 'kernel_ms': R.last_kernel_ms,
-                   'call_s': wall, 'frac_of_8TBps_on_21B_per_voxel_step': 21 * vox / R.last_kernel_ms / 1e6 / 8000}
+                   'call_s': wall, 'bytes_per_voxel_step': 10.5, 'frac_of_8TBps': 10.5 * vox / R.last_kernel_ms / 1e6 / 8000,
+                   'note': 'the fused launch moves 21 B per voxel for TWO steps (T in / out, dose in / out, heat source, id): 10.5 B per voxel-step'}
     return out
 
 
 def cpu_baseline(args, dt_fn):
-    """The oracle (build's own CPU restatement, kind 'port') timed on this host on a bounded
-    sample of the same workload: a smaller grid of the same medium/source/sensor construction."""
+    """The oracle (build's own CPU restatement, kind 'port') timed on this host on a bounded sample of the same workload:
+    the grid of the config itself for 56 steps when the host has the memory for it (C3 >= 50 steps), else a
+    smaller grid of the same medium / source / sensor construction."""
     from babelbrain_amd import harness as H
     from oracle import oracle as O
-    n1, n2, n3, steps = args.cpu_sample
-    a, k, info = H.make_problem(args.config, N=(n1, n2, n3), steps=steps, stable_dt_fn=dt_fn, accumulate_all_steps=True)
+    if args.cpu_sample:
+        n1, n2, n3, steps = args.cpu_sample
+    else:
+        n1, n2, n3 = tuple(args.size) if args.size else H.CONFIGS[args.config]['N']
+        steps = 56
+        need = 110.0 * n1 * n2 * n3           # 15 float32 fields + maps, sums and the inputs of the call
+        try:
+            import psutil
+            avail = psutil.virtual_memory().available
+        except Exception:
+            avail = 0
+        if avail < 1.5 * need or n1 * n2 * n3 > 200e6:
+            n1, n2, n3, steps = 384, 384, 256, 224
     cores = O.usable_cpus()
-    # the box may grant fewer CPUs than it shows (cgroup quota): probe a few thread counts on 3 steps and
+    # the box may grant fewer CPUs than it shows (cgroup quota): probe a few thread counts on 3 steps of a small grid and
     # time the sample with the best one (measured on the GPU box: 16 threads 645, 64 threads 225, 256 threads 13)
     if 'OMP_NUM_THREADS' in os.environ:
         threads = int(os.environ['OMP_NUM_THREADS'])
     else:
-        ap, kp, _ = H.make_problem(args.config, N=(n1, n2, n3), steps=3, stable_dt_fn=dt_fn, accumulate_all_steps=True)
+        ap, kp, _ = H.make_problem(args.config, N=(256, 256, 192), steps=3, stable_dt_fn=dt_fn, accumulate_all_steps=True)
         best = (0.0, 1)
         for cand in (8, 16, 32, 64, 128, 256):
             if cand > cores:
@@ -122,6 +145,8 @@ def cpu_baseline(args, dt_fn):
             elif rate < 0.6 * best[0]:
                 break
         threads = best[1]
+        del ap, kp, o
+    a, k, info = H.make_problem(args.config, N=(n1, n2, n3), steps=steps, stable_dt_fn=dt_fn, accumulate_all_steps=True, full_sensors=False)
     out = O.StaggeredFDTD_3D_with_relaxation(*a, nthreads=threads, **k)
     secs = out[-1]['stepLoopSeconds']
     model = ''
@@ -133,14 +158,15 @@ def cpu_baseline(args, dt_fn):
     except Exception:
         pass
     return {'value': n1 * n2 * n3 * steps / secs / 1e6, 'unit': 'Mvoxel-steps/s', 'cores': threads, 'kind': 'port',
-            'sample': '%s medium/source on a %dx%dx%d grid, %d steps, OpenMP float32 oracle (oracle/fdtd_oracle.c), thread count picked by a 3-step probe' % (args.config, n1, n2, n3, steps),
+            'sample': '%s medium/source on a %dx%dx%d grid, %d steps (%.1f s), OpenMP float32 oracle (oracle/fdtd_oracle.c), thread count picked by a 3-step probe on 256x256x192'
+                      % (args.config, n1, n2, n3, steps, secs),
             'cpu_model': model, 'host_cores': cores}
 
 
 def profile_traffic(config, n1, n2, n3, variant):
     """HBM bytes per launch and kernel from the committed rocprofv3 PMC profile of this workload, if one exists
     (profiles/traffic.json, written from the PMC passes of scripts/pmc_passes.sh). A constant from the repository,
-    not a measurement of this run."""
+    not a measurement of this run; '_profile' names the files it came from."""
     try:
         t = json.load(open(os.path.join(ROOT, 'profiles', 'traffic.json')))
         return t.get('%s_%dx%dx%d_variant%d' % (config, n1, n2, n3, variant), {})
@@ -151,7 +177,8 @@ def profile_traffic(config, n1, n2, n3, variant):
 class Workload:
     """One slab engine per rank for a config, with the two timing passes of the bench."""
 
-    def __init__(self, args, config, dims, scaling, rank, world, local_rank, dist, dt_fn, steps, warmup, variant, full_sensors=True):
+    def __init__(self, args, config, dims, scaling, rank, world, local_rank, dist, dt_fn, steps, warmup, variant, full_sensors=True,
+                 connect=True):
         import torch
         from babelbrain_amd import harness as H, slab, RayleighAndBHTE
         self.torch, self.dist, self.rank, self.world = torch, dist, rank, world
@@ -164,7 +191,8 @@ class Workload:
             est_step = nvox_rank_est / 55e9 + 25e-6            # rough: only sizes the untimed load
             extra = max(int(math.ceil(STEADY_SECONDS / est_step)) - warmup, 0)
         self.steps, self.warmup, self.extra_warmup = steps, warmup, min(extra, 2000)
-        nt = steps + warmup + self.extra_warmup
+        self.windows = max(int(getattr(args, 'windows', 1)), 1)
+        nt = steps * self.windows + warmup + self.extra_warmup
         shared = args.debug_gloo_shared_gpu
         t0 = time.time()
         lean = world > 1 or args.lean_host or nvox_rank_est > 300e6
@@ -185,9 +213,18 @@ class Workload:
         self.slab, self.sinfo = slab.create_hip_slab(a, k, rank, world, local_rank, kernelVariant=variant, local=local,
                                                      host_staging=shared, rmsFirstStep=1)
         self.eng = self.slab.eng
-        self.runner = slab.SlabRunner(self.slab, rank, world, dist, overlap=False if shared else None)
+        self._shared = shared
+        self.runner = None
         self.nvox_rank = float(n1) * n2 * self.sinfo['nk']
         self.total_vox = float(self.N[0]) * self.N[1] * self.N[2]
+        if connect:
+            self.connect()
+
+    def connect(self):
+        """The collective part of the set-up (the ranks agree on the halo set and on the step order): called by every rank
+        or by none (main() agrees on that first, so that a rank whose build failed does not leave the others in a collective)."""
+        from babelbrain_amd import slab
+        self.runner = slab.SlabRunner(self.slab, self.rank, self.world, self.dist, overlap=False if self._shared else None)
 
     def barrier(self):
         if self.world > 1:
@@ -220,25 +257,32 @@ class Workload:
         return {'steps': nsteps, 'overlapped_equals_blocking': ok_all, 'order_used': 'overlapped' if ok_all else 'blocking'}
 
     def timed(self):
-        """W (+ steady-state) untimed steps, then exactly K timed steps between barrier + synchronize; max over ranks."""
+        """W (+ steady-state) untimed steps, then `windows` windows of exactly K timed steps, each between barrier + synchronize,
+        max over ranks per window; the median window is the result (all of them are reported)."""
         torch, dist = self.torch, self.dist
         self.runner.run(self.warmup + self.extra_warmup)
-        self.barrier()
-        self.eng.timing_begin(False)       # one event pair around the whole window; the per-kernel split comes from kernel_pass
-        t0 = time.perf_counter()
-        self.runner.run(self.steps)
-        issue = time.perf_counter() - t0       # the host is done queueing; what remains of the wall time is the GPU catching up
-        torch.cuda.synchronize()
-        self.barrier()
-        wall = time.perf_counter() - t0
-        tm = self.eng.timing_end()
-        tm['host_issue_ms_per_step'] = issue / self.steps * 1e3
-        if self.world > 1:
-            dev = 'cpu' if dist.get_backend() == 'gloo' else 'cuda'
-            w = torch.tensor([wall], dtype=torch.float64, device=dev)
-            dist.all_reduce(w, op=dist.ReduceOp.MAX)
-            wall = float(w.item())
+        rows = []
+        for _ in range(self.windows):
+            self.barrier()
+            self.eng.timing_begin(False)       # one event pair around the whole window; the per-kernel split comes from kernel_pass
+            t0 = time.perf_counter()
+            self.runner.run(self.steps)
+            issue = time.perf_counter() - t0       # the host is done queueing; what remains of the wall time is the GPU catching up
+            torch.cuda.synchronize()
+            self.barrier()
+            wall = time.perf_counter() - t0
+            tm = self.eng.timing_end()
+            tm['host_issue_ms_per_step'] = issue / self.steps * 1e3
+            if self.world > 1:
+                dev = 'cpu' if dist.get_backend() == 'gloo' else 'cuda'
+                w = torch.tensor([wall], dtype=torch.float64, device=dev)
+                dist.all_reduce(w, op=dist.ReduceOp.MAX)
+                wall = float(w.item())
+            rows.append((wall, tm))
+        order = sorted(range(len(rows)), key=lambda i: rows[i][0])
+        wall, tm = rows[order[len(order) // 2]]
         self.wall, self.tm = wall, tm
+        self.window_walls = [r[0] for r in rows]
         return wall, tm
 
     def kernel_pass(self, nsteps):
@@ -262,6 +306,9 @@ class Workload:
             ach = alg[c] / avg / 1e9
             rows[c] = {'achieved': ach, 'frac': ach / HBM_PEAK_GBS, 'algorithmic_bytes_per_launch': alg[c], 'avg_launch_ms': avg * 1e3,
                        'launches': n, 'traffic_from_profile': traffic.get(c)}
+            if traffic.get(c) and traffic.get('_profile'):
+                pr = traffic['_profile']
+                rows[c]['profile_ref'] = {'pmc': pr.get('pmc'), 'kernel_stats': pr.get('kernel_stats'), 'kernel_avg_us_in_profile': (pr.get('kernel_avg_us') or {}).get(c)}
             if traffic.get(c):
                 rows[c]['frac_of_peak_by_profile_traffic'] = traffic[c] / avg / 1e9 / HBM_PEAK_GBS
         return rows, alg
@@ -270,35 +317,183 @@ class Workload:
         self.slab.close()
 
 
+def all_ok(dist, ok):
+    """True if every rank says ok (one collective that every rank enters, whatever happened to it before)."""
+    if dist is None:
+        return bool(ok)
+    flags = [None] * dist.get_world_size()
+    dist.all_gather_object(flags, bool(ok))
+    return all(flags)
+
+
 def single_domain_check(args, rank, world, local_rank, dist, dt_fn):
     """world > 1: the exchange itself, against a run without one. A small grid of C2's medium (bone with shear: every halo
     field travels) is cut into `world` Z-slabs of 64 planes and stepped with the very SlabRunner / transport of the
     timed run (overlapped order) until the wave has crossed every interface; rank 0 also runs the whole grid on its one
-    GPU and compares every slab's Pressure RMS map bit for bit."""
+    GPU and compares every slab's Pressure RMS map bit for bit.
+    Every rank goes through the same sequence of collectives whatever fails locally: a failed build or run is agreed on
+    (all_ok) before the next collective, and rank 0 always broadcasts a record."""
     import torch
     from babelbrain_amd import harness as H, slab, PropagationModel
     from babelbrain_amd._engine import KIND_RMS
     shared = args.debug_gloo_shared_gpu
     N = (128, 128, 64 * world)
     steps = int(math.ceil((64 * (world - 1) + 12) / 0.13)) + 60       # 0.136 cells per step in water at C2's time step
-    a, k, info = H.make_problem('C2', N=N, steps=steps, stable_dt_fn=dt_fn, full_sensors=False)
-    s, sinfo = slab.create_hip_slab(a, k, rank, world, local_rank, kernelVariant=args.variant, host_staging=shared)
-    r = slab.SlabRunner(s, rank, world, dist, overlap=False if shared else True)
-    r.run(steps)
-    torch.cuda.synchronize()
-    mine = s.eng.get_map(KIND_RMS, 'Pressure')
+    s = a = k = None
+    err = None
+    try:
+        a, k, info = H.make_problem('C2', N=N, steps=steps, stable_dt_fn=dt_fn, full_sensors=False)
+        s, sinfo = slab.create_hip_slab(a, k, rank, world, local_rank, kernelVariant=args.variant, host_staging=shared)
+    except Exception as e:
+        err = repr(e)
+    if not all_ok(dist, err is None):
+        if s is not None:
+            s.close()
+        return {'equals_single_domain': None, 'error': err or 'another rank failed to build its slab'}
+    r = slab.SlabRunner(s, rank, world, dist, overlap=False if shared else True)       # collective: every rank is here
+    mine = None
+    try:
+        r.run(steps)
+        torch.cuda.synchronize()
+        mine = s.eng.get_map(KIND_RMS, 'Pressure')
+    except Exception as e:
+        err = repr(e)
     s.close()
     parts = [None] * world
     dist.all_gather_object(parts, mine)
     res = None
     if rank == 0:
-        ref = PropagationModel(device=local_rank, kernelVariant=args.variant).StaggeredFDTD_3D_with_relaxation(*a, SILENT=True, **k)[2]['Pressure']
-        whole = np.concatenate(parts, axis=2)
-        res = {'grid': list(N), 'steps': steps, 'order': 'overlapped' if r.overlap else 'blocking',
-               'equals_single_domain': bool(np.array_equal(whole, ref)), 'wave_reached_last_slab': bool(ref[:, :, -64:].max() > 0)}
+        try:
+            if any(x is None for x in parts):
+                raise RuntimeError('a rank failed while stepping: %s' % err)
+            ref = PropagationModel(device=local_rank, kernelVariant=args.variant).StaggeredFDTD_3D_with_relaxation(*a, SILENT=True, **k)[2]['Pressure']
+            whole = np.concatenate(parts, axis=2)
+            res = {'grid': list(N), 'steps': steps, 'order': 'overlapped' if r.overlap else 'blocking',
+                   'equals_single_domain': bool(np.array_equal(whole, ref)), 'wave_reached_last_slab': bool(ref[:, :, -64:].max() > 0)}
+        except Exception as e:
+            res = {'equals_single_domain': None, 'error': repr(e)}
     out = [res]
     dist.broadcast_object_list(out, src=0)
     return out[0]
+
+
+def group_run(args, config, N, ndev, dt_fn, steps, warmup, windows, variant, label):
+    """ONE volume split into `ndev` Z-slabs inside the library (bfd_group_*): the path PropagationModel(devices=[...]) takes.
+    Devices 0 .. ndev-1 when that many are visible, otherwise the visible ordinals repeat ("emulated")."""
+    from babelbrain_amd import _engine, harness as H, RayleighAndBHTE
+    from babelbrain_amd.PropagationModel import compact_sources
+    devs = [d for d, _ in _engine.list_devices()]
+    emulated = len(devs) < ndev
+    devices = list(range(ndev)) if not emulated else [devs[r % len(devs)] for r in range(ndev)]
+    nt = warmup + windows * steps
+    t0 = time.time()
+    RayleighAndBHTE._device = devices[0]
+    a, k, info = H.make_problem(config, N=N, steps=nt, stable_dt_fn=dt_fn, zslab=(0, N[2]), full_sensors=False, forward=RayleighAndBHTE.ForwardSimple)
+    MaterialMap, ml, f, SourceMap, Pulse, h, T, SensorMap = a
+    lin, row, wx, wy, wz = compact_sources(np.asarray(SourceMap), k['Ox'], k['Oy'], k['Oz'])
+    host_build = time.time() - t0
+    vox = float(N[0]) * N[1] * N[2]
+    g = _engine.Group(devices, *N, len(ml), h, k['DT'], f, nt, sensorSub=k['SensorSubSampling'], sensorStart=k['SensorStart'],
+                      selRMSorPeak=1, selMapsRMS=['Pressure'], selMapsSensors=['Pressure'], rmsFirstStep=1, kernelVariant=variant)
+    try:
+        t0 = time.time()
+        g.set_materials(ml, k.get('QCorrection', 1.0))
+        g.set_material_map(MaterialMap)
+        g.set_sources(lin, row, wx, wy, wz, Pulse)
+        g.set_sensor_map(SensorMap)
+        g.prepare()
+        setup = time.time() - t0
+        g.run(warmup)
+        g.sync()
+        rows = []
+        for _ in range(windows):
+            g.timing_begin()
+            g.run(steps)
+            rows.append(g.timing_end())
+        order = sorted(range(len(rows)), key=lambda i: rows[i]['total_ms'])
+        tm = rows[order[len(order) // 2]]
+        slabs = [g.slab(r) for r in range(g.size)]
+        alg = 0.0
+        for _, _, _, view in slabs:
+            try:
+                alg += sum(view.algorithmic_bytes(True).values())
+            except Exception:
+                alg = float('nan')
+        out = {'workload': '%s %dx%dx%d, ONE volume split into %d Z-slabs inside one process (bfd_group_*: per-slab host threads, peer copies of the halo planes)'
+                           % (config, N[0], N[1], N[2], ndev),
+               'label': label, 'value': vox * steps / tm['total_ms'] / 1e3, 'unit': 'Mvoxel-steps/s', 'ms_per_step': tm['total_ms'] / steps,
+               'windows_ms_per_step': [r['total_ms'] / steps for r in rows], 'steps': steps, 'warmup': warmup,
+               'max_device_ms_per_step': tm['max_device_ms'] / steps, 'host_issue_ms_per_step': tm['host_issue_ms'] / steps,
+               'halo_MB_per_step': tm['halo_bytes_per_step'] / 1e6, 'overlapped': tm['overlapped'], 'devices': devices, 'emulated': emulated,
+               'slabs': [[k0, nk, dev] for k0, nk, dev, _ in slabs], 'device_bytes': int(g.device_bytes), 'host_build_s': host_build, 'setup_s': setup,
+               'dt': info['dt'], 'ppp': info['ppp'], 'n_sources': info['n_sources'], 'medium': info['medium'], 'tx': info['tx'], 'n_mat': info['n_mat'],
+               'array_placement_slab0': slabs[0][3].placement_note()}
+        if alg == alg and alg > 0:
+            ach = alg / (tm['total_ms'] / steps * 1e-3) / 1e9
+            out['roofline_step'] = {'achieved': ach, 'peak': HBM_PEAK_GBS * (1 if emulated else ndev), 'frac': ach / (HBM_PEAK_GBS * (1 if emulated else ndev)),
+                                    'unit': 'GB/s', 'algorithmic_bytes_per_step': alg, 'algorithmic_bytes_per_voxel_step': alg / vox,
+                                    'note': 'all slabs; peak = 8 TB/s per distinct device'}
+        return out
+    finally:
+        g.close()
+
+
+def group_equals_single(args, ndev, dt_fn, variant):
+    """The split behind the drop-in call against the same call on one device, small grid of C2's medium (every halo field
+    travels), stepped until the wave has crossed every interface: Pressure RMS bit for bit."""
+    from babelbrain_amd import _engine, harness as H, PropagationModel
+    devs = [d for d, _ in _engine.list_devices()]
+    devices = list(range(ndev)) if len(devs) >= ndev else [devs[r % len(devs)] for r in range(ndev)]
+    N = (128, 128, 64 * ndev)
+    steps = int(math.ceil((64 * (ndev - 1) + 12) / 0.13)) + 60
+    a, k, info = H.make_problem('C2', N=N, steps=steps, stable_dt_fn=dt_fn, full_sensors=False)
+    one = PropagationModel(device=devices[0], kernelVariant=variant).StaggeredFDTD_3D_with_relaxation(*a, SILENT=True, **k)[2]['Pressure']
+    many = PropagationModel(devices=devices, kernelVariant=variant).StaggeredFDTD_3D_with_relaxation(*a, SILENT=True, **k)[2]['Pressure']
+    return {'grid': list(N), 'steps': steps, 'devices': devices, 'equals_single_domain': bool(np.array_equal(one, many)),
+            'wave_reached_last_slab': bool(one[:, :, -64:].max() > 0)}
+
+
+def main_group(args):
+    """`--gpus N` (N > 1) without a launcher: the one-process split (bfd_group_*) over devices 0 .. N-1."""
+    from babelbrain_amd import _engine, harness as H
+    ndev = args.gpus
+    if _engine.load_library().bfd_device_count() <= 0:
+        raise SystemExit('bench.py needs a GPU (the HIP engine has no CPU fallback)')
+
+    def dt_fn(ml, f, h, acfl):
+        return _engine.stable_dt(ml, f, True, h, acfl)
+
+    strong_cfg = args.config if (args.scaling == 'strong' and args.config != 'C3') else 'C5'
+    dims = tuple(args.size) if (args.size and args.scaling == 'strong') else H.CONFIGS[strong_cfg]['N']
+    head = group_run(args, strong_cfg, dims, ndev, dt_fn, args.steps, args.warmup, args.windows, args.variant, 'strong scaling of ONE volume')
+    line = {'metric': 'Mvoxel-steps/sec, 512^3 skull FDTD (achieved HBM GB/s in roofline)', 'value': head['value'], 'unit': 'Mvoxel-steps/s',
+            'n_gpus': ndev, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': head['ms_per_step'], 'higher_is_better': True,
+            'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic', 'emulated': head['emulated'],
+            'config': {'workload': head['workload'] + ', %s medium, %s source, PML 12, %d materials, Pressure RMS accumulated in every step' % (head['medium'], head['tx'], head['n_mat']),
+                       'parallelism': 'z-slab x%d, one process' % ndev, 'kernel_variant': args.variant, 'launcher': 'none (bfd_group_*)',
+                       'devices': head['devices'], 'slabs': head['slabs'], 'dt': head['dt'], 'ppp': head['ppp'], 'n_sources': head['n_sources'],
+                       'array_placement_slab0': head['array_placement_slab0'], 'untimed_steps_before_window': args.warmup},
+            'windows_ms_per_step': head['windows_ms_per_step'], 'max_device_ms_per_step': head['max_device_ms_per_step'],
+            'host_issue_ms_per_step': head['host_issue_ms_per_step'], 'halo_MB_per_step': head['halo_MB_per_step'],
+            'halo_exchange': 'overlapped' if head['overlapped'] else 'blocking', 'device_bytes': head['device_bytes'], 'host_build_s': head['host_build_s']}
+    if 'roofline_step' in head:
+        r = head['roofline_step']
+        line['roofline'] = dict(bound='hbm', kernel='whole time step, all slabs', achieved=r['achieved'], peak=r['peak'], unit='GB/s', frac=r['frac'], traffic=None,
+                                note='algorithmic bytes of the slabs per step / wall time per step; peak = 8 TB/s x distinct devices; the per-kernel figures are in the N=1 line')
+        line['roofline_step'] = r
+    line['cpu_baseline'] = {'value': None, 'note': 'timed at N=1 only'}
+    try:
+        line['group_check'] = group_equals_single(args, ndev, dt_fn, args.variant)
+    except Exception as e:
+        line['group_check'] = {'equals_single_domain': None, 'error': repr(e)}
+    if not args.no_extra_strong:
+        try:       # the weak-scaling companion: N grids of the metric's config as one 512 x 512 x (512 N) domain
+            c3 = H.CONFIGS['C3']['N']
+            line['secondary_weak_c3'] = group_run(args, 'C3', (c3[0], c3[1], c3[2] * ndev), ndev, dt_fn, args.steps, args.warmup, 1, args.variant,
+                                                  'weak scaling: one 512^3 grid of the metric config per device')
+        except Exception as e:
+            line['secondary_weak_c3'] = {'value': None, 'error': repr(e)}
+    print(json.dumps(line))
 
 
 def measure(w, args, traffic):
@@ -307,6 +502,9 @@ def measure(w, args, traffic):
     wall, tm = w.timed()
     value = w.total_vox * w.steps / wall / 1e6
     out = {'value': value, 'ms_per_step': wall / w.steps * 1e3, 'exchange_check': check,
+           'windows': {'n': len(w.window_walls), 'steps_each': w.steps, 'ms_per_step': [x / w.steps * 1e3 for x in w.window_walls],
+                       'value_min': w.total_vox * w.steps / max(w.window_walls) / 1e6, 'value_max': w.total_vox * w.steps / min(w.window_walls) / 1e6,
+                       'note': 'value = the median window'},
            'device_ms_per_step': tm['total_ms'] / w.steps, 'half_steps': None,
            'host_issue_ms_per_step': tm['host_issue_ms_per_step']}
     if w.variant != 1:
@@ -333,9 +531,9 @@ def main():
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        return main_group(args)          # no launcher: the one-process split behind the drop-in call
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('launch with torch.distributed.run --nproc-per-node %d for --gpus %d' % (args.gpus, args.gpus))
         args.gpus = world
     import torch
     from babelbrain_amd import _engine, harness as H
@@ -361,10 +559,7 @@ def main():
 
     sd_check = None
     if world > 1 and not args.no_single_domain_check and args.variant != 1:
-        try:
-            sd_check = single_domain_check(args, rank, world, local_rank, dist, dt_fn)
-        except Exception as e:      # a failed check is reported, it never takes the bench line away
-            sd_check = {'equals_single_domain': None, 'error': repr(e)}
+        sd_check = single_domain_check(args, rank, world, local_rank, dist, dt_fn)      # catches locally and agrees across the ranks
     cfg = H.CONFIGS[args.config]
     dims = tuple(args.size) if args.size else cfg['N']
     w = Workload(args, args.config, dims, args.scaling, rank, world, local_rank, dist, dt_fn, args.steps, args.warmup, args.variant)
@@ -386,7 +581,7 @@ def main():
                        'halo_exchange': 'overlapped' if w.runner.overlap else ('none' if world == 1 else 'blocking'),
                        'halo_exchange_check': res['exchange_check'], 'halo_exchange_vs_single_domain': sd_check,
                        'array_placement': eng.placement_note(), 'untimed_steps_before_window': args.warmup + w.extra_warmup},
-            'device_ms_per_step': res['device_ms_per_step'], 'half_steps_ms': res['half_steps'],
+            'windows': res['windows'], 'device_ms_per_step': res['device_ms_per_step'], 'half_steps_ms': res['half_steps'],
             'host_issue_ms_per_step': res['host_issue_ms_per_step'],
             'device_bytes': int(eng.device_bytes), 'host_build_s': w.host_build_s,
         }
@@ -398,7 +593,7 @@ def main():
             dom = max(rows, key=lambda c: rows[c]['avg_launch_ms'])
             r = rows[dom]
             line['roofline'] = dict(bound='hbm', kernel=dom, achieved=r['achieved'], peak=HBM_PEAK_GBS, unit='GB/s', frac=r['frac'],
-                                    traffic=r['traffic_from_profile'], traffic_from_profile=r['traffic_from_profile'],
+                                    traffic=r['traffic_from_profile'], traffic_from_profile=r['traffic_from_profile'], profile_ref=r.get('profile_ref'),
                                     algorithmic_bytes_per_launch=r['algorithmic_bytes_per_launch'], avg_launch_ms=r['avg_launch_ms'], note=note)
             line['roofline_kernels'] = rows
         elif 'roofline_step' in res:
@@ -411,12 +606,19 @@ def main():
 
     if world > 1 and not args.no_extra_strong and not (args.config == 'C5' and args.scaling == 'strong'):
         # the curve BASELINE.json's north_star names: ONE 1024^3 volume (C5, 1 MHz) split over the N ranks -- beside the weak-
-        # scaling headline above, in the same line, because the driver's invocation carries no --config / --scaling
+        # scaling headline above, in the same line, because the driver's invocation carries no --config / --scaling.
+        # The build is local to every rank; the ranks agree that all of them succeeded BEFORE the first collective of the block
+        # (a rank that ran out of memory must not leave the others inside one).
+        wx, err = None, None
         try:
             c5 = H.CONFIGS['C5']['N']
             wx = Workload(args, 'C5', c5, 'strong', rank, world, local_rank, dist, dt_fn, max(args.extra_strong_steps, 40), min(args.warmup, 20), args.variant,
-                          full_sensors=False)
-            sx = measure(wx, argparse.Namespace(**dict(vars(args), no_kernel_pass=True)), {})
+                          full_sensors=False, connect=False)
+        except Exception as e:
+            err = repr(e)
+        if all_ok(dist, err is None):
+            wx.connect()
+            sx = measure(wx, argparse.Namespace(**dict(vars(args), no_kernel_pass=True, windows=1)), {})
             if rank == 0:
                 line['extra_strong_c5'] = {'workload': 'C5 1024^3 (1 MHz, water / cortical bone with shear / brain), ONE volume split into %d Z-slabs of %d planes' % (world, wx.sinfo['nk']),
                                            'scaling': 'strong', 'value': sx['value'], 'unit': 'Mvoxel-steps/s', 'steps': wx.steps, 'warmup': wx.warmup + wx.extra_warmup,
@@ -424,10 +626,25 @@ def main():
                                            'host_issue_ms_per_step': sx['host_issue_ms_per_step'], 'halo_exchange': 'overlapped' if wx.runner.overlap else 'blocking',
                                            'halo_exchange_check': sx['exchange_check'], 'halo_bytes_sent_rank0_per_step': wx.runner.bytes_per_step(),
                                            'roofline_step': sx.get('roofline_step'), 'array_placement': wx.eng.placement_note()}
+        elif rank == 0:
+            line['extra_strong_c5'] = {'value': None, 'error': err or 'another rank failed to build its slab'}
+        if wx is not None:
             wx.close()
+    if world > 1 and not args.no_group and not shared:
+        # the path the reference's caller gets (one process, one call): ONE 512^3 C3 volume split over the N devices through
+        # bfd_group_*, run by rank 0 after every rank has released its slabs; the other ranks wait at the barrier below
+        dist.barrier()
+        if rank == 0:
+            try:
+                line['group_strong_c3'] = group_run(args, 'C3', H.CONFIGS['C3']['N'], world, dt_fn, args.steps, min(args.warmup, 20), 1, args.variant,
+                                                    'strong scaling of the metric config through the drop-in path, rank 0 driving all devices')
+            except Exception as e:
+                line['group_strong_c3'] = {'value': None, 'error': repr(e)}
+    if world == 1 and not args.no_group and args.config == 'C3' and not args.size:
+        try:       # the same workload through the one-process group path with one slab: SCALE N=1 on both paths
+            line['group_one_slab'] = group_run(args, 'C3', dims, 1, dt_fn, args.steps, args.warmup, 1, args.variant, 'one slab through bfd_group_*')
         except Exception as e:
-            if rank == 0:
-                line['extra_strong_c5'] = {'value': None, 'error': repr(e)}
+            line['group_one_slab'] = {'value': None, 'error': repr(e)}
     if world == 1 and not args.no_shear_workload and args.variant in (0, 3) and args.config == 'C3' and not args.size:
         # the viscoelastic kernels: C2's medium (water / cortical bone with shear / brain) on the same 512^3 grid, same K/W
         try:

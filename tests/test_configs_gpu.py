@@ -2,7 +2,7 @@
 
   C1 128^3 water, SingleTx 500 kHz, 500 steps        -> against the oracle, full size
   C2 256^3 skull+brain (3 materials), 2000 steps     -> against the oracle, full size
-  C3 512^3 CT-like skull, CTX-500                    -> tests/test_fullsize_gpu.py
+  C3 512^3 CT-like skull, CTX-500, 140 steps         -> against the oracle, full size (+ tests/test_fullsize_gpu.py)
   C4 512x512x1024, H317 phased array, 700 kHz        -> size-independent properties (below)
   C5 1024^3, 1 MHz                                   -> size-independent properties (below)
 
@@ -55,6 +55,26 @@ def test_c2_full_size_against_oracle():
     inside = rms[128, 128, 150]              # behind the skull: the wave went through bone
     assert rms.max() > 0 and inside > 0
     print('C2 256^3 x 2000 steps: worst rel L2 vs oracle %.3e (oracle step loop %.1f s)' % (worst, out_o[-1]['stepLoopSeconds']))
+
+
+@pytest.mark.timeout(900)
+def test_c3_full_size_against_oracle():
+    """BASELINE configs[2], the configuration the metric is quoted on: 512^3 CT-derived heterogeneous skull (515 materials,
+    QCorrection 3 on bone), CTX-500 annular array, absorbing layer on -- compared with the oracle DIRECTLY at full size:
+    140 steps (the wave reaches the skull), Pressure RMS + last map + the sensors of two lines through the focus. The
+    oracle needs about 30 s on the box's 16 threads and 9 GB of host memory. Both the default kernels and the fused time
+    step (variant 4) are held to it."""
+    from babelbrain_amd import PropagationModel, RayleighAndBHTE
+    from oracle import oracle as O
+    a, k, info = H.make_problem('C3', steps=140, stable_dt_fn=oracle_dt, full_sensors=False, forward=RayleighAndBHTE.ForwardSimple)
+    assert a[0].shape == (512, 512, 512) and info['nt'] == 140 and info['n_mat'] == 515
+    out_o = O.StaggeredFDTD_3D_with_relaxation(*a, **k)
+    assert out_o[2]['Pressure'].max() > 0 and np.count_nonzero(out_o[1]['Pressure']) > 1e6
+    for variant in (0, 4):
+        out_h = PropagationModel(kernelVariant=variant).StaggeredFDTD_3D_with_relaxation(*a, SILENT=True, **k)
+        worst = compare_runs(out_h, out_o, tol=1e-5)
+        print('C3 512^3 x 140 steps, variant %d: worst rel L2 vs oracle %.3e (oracle step loop %.1f s)' % (variant, worst, out_o[-1]['stepLoopSeconds']))
+        del out_h
 
 
 def _exchange(slabs, group):

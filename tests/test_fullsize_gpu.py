@@ -1,5 +1,5 @@
-"""Parity at BASELINE.json's full single-GPU size (C3, 512^3) through size-independent properties, since
-the CPU oracle cannot finish that grid in seconds:
+"""BASELINE.json's full single-GPU size (C3, 512^3) through size-independent properties, beside the direct comparison
+with the oracle at that size (tests/test_configs_gpu.py::test_c3_full_size_against_oracle):
   * the three independent device implementations (one-thread-per-voxel variant 1, dense LDS-tiled variant 2,
     class-specialised variant 3) must agree exactly on the same inputs;
   * linearity: a source scaled by 2 scales every output by 2 (to rounding: the flushed-denormal arithmetic
