@@ -183,7 +183,7 @@ class PropagationModel:
                 for q, name in enumerate(eng.selS):
                     Sensor[name] = sens[q]
             InputParam = {'IndexSensorMap': eng.sensor_index(), 'DT': DT, 'nt': nt,
-                          'device_bytes': eng.device_bytes, 'timing': self.last_timing}
+                          'device_bytes': eng.device_bytes, 'timing': self.last_timing, 'placement': eng.placement_note()}
             if ReturnSensorDFT:
                 # extension: what CalculatePhaseData extracts from the sensor block
                 # (BASE:2498-2520), computed on the device
@@ -236,7 +236,8 @@ class PropagationModel:
                     Sensor[name] = sens[q]
             InputParam = {'IndexSensorMap': grp.sensor_index(), 'DT': DT, 'nt': nt, 'device_bytes': grp.device_bytes,
                           'timing': self.last_timing, 'devices': list(devices),
-                          'slabs': [grp.slab(r)[:3] for r in range(grp.size)]}
+                          'slabs': [grp.slab(r)[:3] for r in range(grp.size)],
+                          'placement': [grp.slab(r)[3].placement_note() for r in range(grp.size)]}
             if ReturnSensorDFT:
                 F, pk = grp.sensor_dft(Frequency)
                 InputParam['SensorDFT'] = {name: F[q] for q, name in enumerate(grp.selS)}

@@ -28,7 +28,7 @@ ABI_SYMBOLS = [
     'bfd_half_step_stress', 'bfd_half_step_velocity', 'bfd_half_step_stress_part', 'bfd_half_step_velocity_part', 'bfd_half_step_stress_part_on', 'bfd_half_step_velocity_part_on', 'bfd_sync', 'bfd_current_step', 'bfd_prepare', 'bfd_halo_region',
     'bfd_timing_begin', 'bfd_timing_end', 'bfd_timing_kernels', 'bfd_algorithmic_bytes', 'bfd_reset', 'bfd_num_sensors', 'bfd_num_sensor_steps', 'bfd_get_sensor_index',
     'bfd_get_sensors', 'bfd_get_map', 'bfd_get_field', 'bfd_tile_counts', 'bfd_tile_count_lean', 'bfd_tile_count_fused', 'bfd_device_bytes', 'bfd_rayleigh_forward', 'bfd_get_sensor_dft', 'bfd_dft_series', 'bfd_bhte_run', 'bfd_bhte_run_fields', 'bfd_bhte_run_volumes',
-    'bfd_halo_fields', 'bfd_placement_note',
+    'bfd_halo_fields', 'bfd_placement_note', 'bfd_set_placement', 'bfd_group_set_placement',
     'bfd_group_create', 'bfd_group_destroy', 'bfd_group_size', 'bfd_group_slab', 'bfd_group_set_materials', 'bfd_group_set_material_map',
     'bfd_group_set_reflector', 'bfd_group_set_sources', 'bfd_group_set_sensor_map', 'bfd_group_prepare', 'bfd_group_run', 'bfd_group_sync',
     'bfd_group_reset', 'bfd_group_timing_begin', 'bfd_group_timing_end', 'bfd_group_num_sensors', 'bfd_group_num_sensor_steps',
@@ -148,6 +148,8 @@ def load_library():
     lib.bfd_halo_fields.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_uint32)]
     lib.bfd_placement_note.argtypes = [C.c_void_p]
     lib.bfd_placement_note.restype = C.c_char_p
+    lib.bfd_set_placement.argtypes = [C.c_void_p, C.c_int32, C.c_int64]
+    lib.bfd_group_set_placement.argtypes = [C.c_void_p, C.c_int32, C.c_int64]
     lib.bfd_group_create.argtypes = [C.POINTER(Config), C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]
     lib.bfd_group_destroy.argtypes = [C.c_void_p]
     lib.bfd_group_destroy.restype = None
@@ -172,7 +174,7 @@ def load_library():
     lib.bfd_group_get_map.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_int64, C.c_int64]
     lib.bfd_group_device_bytes.argtypes = [C.c_void_p]
     lib.bfd_group_device_bytes.restype = C.c_int64
-    if lib.bfd_abi_version() != 4:
+    if lib.bfd_abi_version() != 5:
         raise EngineError('libbabelfdtd_hip.so ABI version mismatch')
     _lib = lib
     return lib
@@ -412,6 +414,11 @@ class Engine:
     def reset(self):
         _check(self.lib.bfd_reset(self.h), 'bfd_reset')
 
+    def set_placement(self, mode=1, search_limit_bytes=-1):
+        """Placement policy of the per-voxel arrays (bfd_set_placement), before the first step: mode 0 = off; search_limit_bytes =
+        throw-away memory the search for another memory region may hold (< 0: default rule, nothing on a shared device)."""
+        _check(self.lib.bfd_set_placement(self.h, int(mode), int(search_limit_bytes)), 'bfd_set_placement')
+
     def placement_note(self):
         """What bfd_prepare found about the memory regions of the arrays and did about it."""
         return self.lib.bfd_placement_note(self.h).decode()
@@ -570,6 +577,9 @@ class Group:
         return n.value
 
     # ---- stepping ----
+    def set_placement(self, mode=1, search_limit_bytes=-1):
+        _check(self.lib.bfd_group_set_placement(self.h, int(mode), int(search_limit_bytes)), 'bfd_group_set_placement')
+
     def prepare(self):
         _check(self.lib.bfd_group_prepare(self.h), 'bfd_group_prepare')
 

@@ -632,18 +632,16 @@ int bfd_create(const bfd_config *cfg, bfd_sim **out)
     int rc = 0;
     float **fp[15] = {&d.Vx, &d.Vy, &d.Vz, &d.Sxx, &d.Syy, &d.Szz, &d.Sxy, &d.Sxz, &d.Syz,
                       &d.Rxx, &d.Ryy, &d.Rzz, &d.Rxy, &d.Rxz, &d.Ryz};
-    // experiment knob (use with BFD_PLACEMENT=0): array a starts a * BFD_SKEW_LINES cache lines into its allocation, so that the
-    // same cell of different arrays falls into different L2 sets / channels
-    const size_t skew = getenv("BFD_SKEW_LINES") ? (size_t)std::max(atoi(getenv("BFD_SKEW_LINES")), 0) * 32 : 0;
     for (int a = 0; a < 15 && !rc; a++) {
-        rc = dev_alloc(s, &s->stateBase[a], s->nalloc + 24 * skew);
-        if (!rc) { s->stateBase[a] += a * skew; *fp[a] = s->stateBase[a] + 2 * (size_t)d.plane; }
+        rc = dev_alloc(s, &s->stateBase[a], s->nalloc);
+        if (!rc) *fp[a] = s->stateBase[a] + 2 * (size_t)d.plane;
     }
     if (!rc) rc = dev_alloc(s, &s->matBase, s->nalloc);
     if (!rc) d.mat = s->matBase + 2 * (size_t)d.plane;
     if (!rc) rc = dev_alloc(s, &s->clsBase, s->nalloc);
     if (!rc) d.cls = s->clsBase + 2 * (size_t)d.plane;
     s->classesReady = false; s->placementDone = false; s->haloHandedOut = false;
+    s->placementMode = 1; s->placementLimit = -1;
     d.VxW = d.Vx; d.VyW = d.Vy; d.VzW = d.Vz; d.SzzW = d.Szz; d.RzzW = d.Rzz;
     // variant 4 (fused fluid time step) needs the old fields to survive the step: second copies of V, Szz, Rzz. A
     // Z-slab keeps the in-place update (its neighbours alias the halo planes once), i.e. behaves like variant 3.
@@ -651,8 +649,8 @@ int bfd_create(const bfd_config *cfg, bfd_sim **out)
     if (s->pingpong) {
         float **wp[5] = {&d.VxW, &d.VyW, &d.VzW, &d.SzzW, &d.RzzW};
         for (int a = 0; a < 5 && !rc; a++) {
-            rc = dev_alloc(s, &s->ppBase[a], s->nalloc + 24 * skew);
-            if (!rc) { s->ppBase[a] += (15 + a) * skew; *wp[a] = s->ppBase[a] + 2 * (size_t)d.plane; }
+            rc = dev_alloc(s, &s->ppBase[a], s->nalloc);
+            if (!rc) *wp[a] = s->ppBase[a] + 2 * (size_t)d.plane;
         }
     }
     // CPML memory variables
@@ -1322,7 +1320,7 @@ static float time_pair(bfd_sim *s, float *a, float *b, int kmax, int reps)
 static int choose_placement(bfd_sim *s)
 {
     s->placementNote = "off";
-    bool on = true;
+    bool on = s->placementMode != 0;
     if (const char *ev = getenv("BFD_PLACEMENT")) on = atoi(ev) != 0;
     if (const char *ev = getenv("BFD_PLACEMENT_TRIALS")) on = on && atoi(ev) != 0;
     // below ~32 M voxels the arrays a kernel streams (5 x 4 B per voxel and up) fit the 256 MB memory-side cache, where they lie
@@ -1414,11 +1412,25 @@ static int choose_placement(bfd_sim *s)
     bool gaveUp = false;
     int nFresh = 0;
     bool probeTells = tSame >= 0.05f;                                          // ms; shorter probes are launch overhead, not memory time
-    size_t heldCap = (size_t)190 << 30;                                         // a region is up to ~96 GiB wide, and a fresh process may start at the beginning of one (the free-memory check below still applies)
-    if (const char *ev = getenv("BFD_PLACEMENT_SEARCH_MB")) { probeTells = true; heldCap = (size_t)atol(ev) << 20; }   // tests: walk a little on any grid
+    // How much throw-away memory the search for another region may hold at a time (candidates that missed + spacers, all freed
+    // before this function returns). A region is up to ~96 GiB wide and a fresh process may start at the beginning of one (one
+    // box needed 142 GiB of candidates), but a solver call must not take the device away from whoever shares it: by default
+    // at most 64 GiB and at most half of what was free on entry, and NOTHING when other allocations than this engine's are
+    // present on the device (another process, the other slabs of a group, a GUI's bio-heat volumes): the buffers are then only
+    // exchanged among themselves. bfd_set_placement(sim, mode, limitBytes) / BFD_PLACEMENT_SEARCH_MB set the limit explicitly
+    // (then the shared-device rule is off: the caller has decided).
+    size_t free0 = 0, total0 = 0;
+    if (hipMemGetInfo(&free0, &total0) != hipSuccess) { free0 = total0 = 0; (void)hipGetLastError(); }
+    const size_t others = total0 > free0 + (size_t)s->devBytes ? total0 - free0 - (size_t)s->devBytes : 0;
+    size_t heldCap = std::min((size_t)64 << 30, free0 / 2);
+    std::string capNote;
+    if (others > ((size_t)6 << 30)) { heldCap = 0; char q[96]; snprintf(q, sizeof q, "; device shared (%.0f GiB of other allocations): no search beyond the own buffers", others / 1073741824.0); capNote = q; }
+    if (s->placementLimit >= 0) { heldCap = (size_t)s->placementLimit; capNote.clear(); }
+    if (const char *ev = getenv("BFD_PLACEMENT_SEARCH_MB")) { probeTells = true; heldCap = (size_t)atol(ev) << 20; capNote.clear(); }   // tests: walk a little on any grid
+    if (heldCap == 0) probeTells = false;
     while ((need[0] > 0 || need[1] > 0) && !gaveUp && probeTells) {            // draw candidates until both sides have enough
         size_t freeB = 0, totalB = 0;
-        if (hipMemGetInfo(&freeB, &totalB) != hipSuccess || freeB < 2 * bytes + totalB / 8 || heldBytes > heldCap) { gaveUp = true; break; }
+        if (hipMemGetInfo(&freeB, &totalB) != hipSuccess || freeB < 2 * bytes + totalB / 8 || heldBytes + bytes > heldCap) { gaveUp = true; break; }
         float *c = nullptr;
         if (hipMalloc((void **)&c, bytes) != hipSuccess) { (void)hipGetLastError(); gaveUp = true; break; }
         if (hipMemsetAsync(c, 0, bytes, s->stream) != hipSuccess) { hipFree(c); gaveUp = true; break; }
@@ -1432,7 +1444,7 @@ static int choose_placement(bfd_sim *s)
         // array at a time
         const size_t stride = std::min(heldBytes, (size_t)4 << 30);
         void *sp = nullptr;
-        if (hipMemGetInfo(&freeB, &totalB) == hipSuccess && freeB > stride + 2 * bytes + totalB / 8 && hipMalloc(&sp, stride) == hipSuccess) { held.push_back(sp); heldBytes += stride; }
+        if (heldBytes + stride <= heldCap && hipMemGetInfo(&freeB, &totalB) == hipSuccess && freeB > stride + 2 * bytes + totalB / 8 && hipMalloc(&sp, stride) == hipSuccess) { held.push_back(sp); heldBytes += stride; }
         else (void)hipGetLastError();
     }
     std::vector<char> taken(pool.size(), 0);
@@ -1485,7 +1497,7 @@ static int choose_placement(bfd_sim *s)
         size_t missBytes = 0;
         while (t >= thr && miss.size() < 80 && probeTells) {                  // same region as its neighbour: look for another buffer
             size_t freeB = 0, totalB = 0;
-            if (hipMemGetInfo(&freeB, &totalB) != hipSuccess || freeB < 2 * accBytes + totalB / 8 || missBytes > heldCap) break;
+            if (hipMemGetInfo(&freeB, &totalB) != hipSuccess || freeB < 2 * accBytes + totalB / 8 || missBytes + accBytes > heldCap) break;
             float *c = nullptr;
             if (hipMalloc((void **)&c, accBytes) != hipSuccess) { (void)hipGetLastError(); break; }
             if (hipMemsetAsync(c, 0, accBytes, s->stream) != hipSuccess) { hipFree(c); break; }
@@ -1501,7 +1513,7 @@ static int choose_placement(bfd_sim *s)
                 if (tc <= 0) break;
                 void *sp = nullptr;                                            // walk on, as above
                 const size_t stride = std::min(missBytes, (size_t)4 << 30);
-                if (hipMemGetInfo(&freeB, &totalB) == hipSuccess && freeB > stride + 2 * accBytes + totalB / 8 && hipMalloc(&sp, stride) == hipSuccess) { miss.push_back(sp); missBytes += stride; }
+                if (missBytes + stride <= heldCap && hipMemGetInfo(&freeB, &totalB) == hipSuccess && freeB > stride + 2 * accBytes + totalB / 8 && hipMalloc(&sp, stride) == hipSuccess) { miss.push_back(sp); missBytes += stride; }
                 else (void)hipGetLastError();
             }
         }
@@ -1515,11 +1527,11 @@ static int choose_placement(bfd_sim *s)
     for (void *h : held) hipFree(h);
     std::string after;
     for (int a : order) { const Buf &b = pool[slotBuf[a]]; after += b.fresh ? (b.cls == M ? 'm' : 'n') : (char)('0' + std::min(b.cls, 9)); }
-    char buf[768];
+    char buf[1024];
     snprintf(buf, sizeof buf, "arrays placed by memory region (pair probe on the zero state: %d probes, within-region %.3f ms, threshold %.3f ms, gap between the levels %.0f %%; %zu regions seen): "
              "regions of %s %s -> %s (m / n = fresh allocation in / outside the most populated region),%s %d fresh, %zu candidates / spacers (%.1f GiB) released%s; %.2f s", nProbes, tSame, thr, 100.0 * widest, repOf.size(),
              (std::string("Vx Vy Vz Szz Rzz") + (s->pingpong ? " + their second copies" : "") + (solids ? " Sxx Rxx Syy Ryy Sxy Rxy Sxz Rxz Syz Ryz" : "")).c_str(), before.c_str(), after.c_str(), accNote.c_str(), nFresh, held.size(), heldBytes / 1073741824.0,
-             gaveUp ? "; search for another region given up (memory)" : "", std::chrono::duration<double>(std::chrono::steady_clock::now() - tStart).count());
+             (std::string(gaveUp ? "; search for another region given up (limit / memory)" : "") + capNote).c_str(), std::chrono::duration<double>(std::chrono::steady_clock::now() - tStart).count());
     s->placementNote = buf;
     if (verbose) fprintf(stderr, "placement: %s\nplacement: probe times, array:ms against Vx, array/class:ms against the other representatives:%s\n", buf, times.c_str());
     return 0;
@@ -1768,6 +1780,14 @@ int bfd_halo_region(bfd_sim *s, int32_t group, int32_t f, int32_t side, int32_t 
     if (side == 0) kl = send ? 0 : -2; else kl = send ? d.nk - 2 : d.nk;
     *devPtr = a + kl * (long)d.plane;
     *bytes = 2 * (size_t)d.plane * sizeof(float);
+    return 0;
+}
+
+int bfd_set_placement(bfd_sim *s, int32_t mode, int64_t searchLimitBytes)
+{
+    if (!s) BFD_FAIL(-1, "null sim");
+    if (s->placementDone) BFD_FAIL(-6, "bfd_set_placement: the arrays are placed already (call it before the first step / bfd_prepare)");
+    s->placementMode = mode != 0; s->placementLimit = searchLimitBytes;
     return 0;
 }
 

@@ -384,6 +384,13 @@ int bfd_group_set_sensor_map(bfd_group *g, const uint32_t *map, int64_t s1, int6
     return 0;
 }
 
+int bfd_group_set_placement(bfd_group *g, int32_t mode, int64_t searchLimitBytes)
+{
+    if (!g) GRP_FAIL(-1, "null group");
+    for (int r = 0; r < g->n; r++) { const int rc = bfd_set_placement(g->sim[r], mode, searchLimitBytes); if (rc) return rc; }
+    return 0;
+}
+
 int bfd_group_prepare(bfd_group *g)
 {
     if (!g) GRP_FAIL(-1, "null group");

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define BFD_ABI_VERSION 4
+#define BFD_ABI_VERSION 5
 
 enum {
     BFD_MAP_VX = 0, BFD_MAP_VY = 1, BFD_MAP_VZ = 2,
@@ -160,6 +160,12 @@ int bfd_current_step(bfd_sim *sim);
 int bfd_prepare(bfd_sim *sim);
 /* one line on what the placement found and did (valid until the sim is destroyed) */
 const char *bfd_placement_note(bfd_sim *sim);
+/* Placement policy, before the first step / bfd_prepare. mode 0 = leave the arrays where hipMalloc put them. searchLimitBytes =
+ * how much throw-away device memory the search for a buffer in another region may hold at a time (all of it is released
+ * before bfd_prepare returns); < 0 = the default rule: at most 64 GiB and half of the free memory, and nothing at all when the
+ * device carries other allocations than this engine's (another process, the other slabs of a group): the engine's own buffers
+ * are then only exchanged among themselves. bfd_prepare never fails for lack of memory where mode 0 succeeds. */
+int bfd_set_placement(bfd_sim *sim, int32_t mode, int64_t searchLimitBytes);
 
 /* device pointer/bytes of a halo region: field f (0..2 within the group), side 0 = low-k face,
  * 1 = high-k face; send = 1: the 2 owned boundary planes, send = 0: the 2 ghost planes.
@@ -246,6 +252,7 @@ int bfd_group_set_sources(bfd_group *g, int64_t nVox, const int64_t *globalIndex
                           const float *wx, const float *wy, const float *wz,
                           const double *pulse, int32_t nSources, int32_t lengthSource);
 int bfd_group_set_sensor_map(bfd_group *g, const uint32_t *map, int64_t s1, int64_t s2, int64_t s3, int64_t *nSensors);
+int bfd_group_set_placement(bfd_group *g, int32_t mode, int64_t searchLimitBytes);   /* bfd_set_placement of every slab */
 int bfd_group_prepare(bfd_group *g);                     /* bfd_prepare of every slab + the halo plan; bfd_group_run does it by itself */
 int bfd_group_run(bfd_group *g, int32_t nSteps);         /* queues nSteps time steps on every slab; returns without waiting */
 int bfd_group_sync(bfd_group *g);
