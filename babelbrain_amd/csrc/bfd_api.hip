@@ -471,7 +471,7 @@ void release_streaming(bfd_sim *s)
         if (s->packJob[b].valid()) s->packJob[b].get();
         dev_release(s, &s->tileDev[b]);
         if (s->tilePinned[b]) { hipHostFree(s->tilePinned[b]); s->tilePinned[b] = nullptr; }
-        s->tileLoaded[b] = s->tilePacked[b] = -1; s->evTileUsed[b] = false; s->evReadUsed[b] = false;
+        s->tileLoaded[b] = s->tilePacked[b] = -1; s->evTileUsed[b] = false; s->evReadUsed[b][0] = s->evReadUsed[b][1] = false;
     }
     s->pulseHost = nullptr; s->tileSteps = s->nTiles = 0;
 }
@@ -493,7 +493,7 @@ int pulse_row(bfd_sim *s, int step, hipStream_t st, const float **row)
         const int len = std::min(TS, s->lengthSource - t * TS);
         // the kernels that read the tile this buffer held two tiles ago may have run on another stream (split half-steps):
         // the copy waits for the last of them
-        if (s->evReadUsed[b]) BFD_HIP(hipStreamWaitEvent(st, s->evRead[b], 0));
+        for (int q = 0; q < 2; q++) if (s->evReadUsed[b][q]) BFD_HIP(hipStreamWaitEvent(st, s->evRead[b][q], 0));      // the readers on the engine's stream and on a caller's side stream
         BFD_HIP(hipMemcpyAsync(s->tileDev[b], s->tilePinned[b], (size_t)len * s->nSources * sizeof(float), hipMemcpyHostToDevice, st));
         BFD_HIP(hipEventRecord(s->evTile[b], st));
         s->evTileUsed[b] = true; s->tileLoaded[b] = t;
@@ -522,8 +522,10 @@ int pulse_row(bfd_sim *s, int step, hipStream_t st, const float **row)
 void pulse_row_read(bfd_sim *s, int step, hipStream_t st)
 {
     if (!s->pulseHost) return;
-    const int b = (step / s->tileSteps) & 1;
-    if (s->evRead[b] && hipEventRecord(s->evRead[b], st) == hipSuccess) s->evReadUsed[b] = true;
+    // one event per buffer and stream kind: the parts of a split half-step run on two streams at the same time, and a single
+    // event recorded by both would keep only the later record
+    const int b = (step / s->tileSteps) & 1, q = st == s->stream ? 0 : 1;
+    if (s->evRead[b][q] && hipEventRecord(s->evRead[b][q], st) == hipSuccess) s->evReadUsed[b][q] = true;
 }
 
 }  // namespace
@@ -612,7 +614,7 @@ int bfd_create(const bfd_config *cfg, bfd_sim **out)
     s->nSrcVox = 0; s->srcLin = s->srcRow = nullptr; s->srcW[0] = s->srcW[1] = s->srcW[2] = nullptr; s->pulseT = nullptr;
     s->nSources = s->lengthSource = 0;
     s->pulseHost = nullptr; s->tileSteps = s->nTiles = 0;
-    for (int b = 0; b < 2; b++) { s->tileDev[b] = s->tilePinned[b] = nullptr; s->tileLoaded[b] = s->tilePacked[b] = -1; s->evTile[b] = nullptr; s->evTileUsed[b] = false; s->evRead[b] = nullptr; s->evReadUsed[b] = false; }
+    for (int b = 0; b < 2; b++) { s->tileDev[b] = s->tilePinned[b] = nullptr; s->tileLoaded[b] = s->tilePacked[b] = -1; s->evTile[b] = nullptr; s->evTileUsed[b] = false; for (int q = 0; q < 2; q++) { s->evRead[b][q] = nullptr; s->evReadUsed[b][q] = false; } }
     s->nSensors = 0; s->sensLin = nullptr; s->sensOut = nullptr; s->dftAcc = nullptr; s->dftPk = nullptr; s->dftBin = 0;
     s->acc = s->pk = nullptr; s->timing = s->perKernel = false;
     s->tables = nullptr; s->profiles = nullptr; s->cmax = 0;
@@ -686,7 +688,7 @@ void bfd_destroy(bfd_sim *s)
     if (s->stepGraph) hipGraphExecDestroy(s->stepGraph);
     if (s->captureStream) hipStreamDestroy(s->captureStream);
     release_streaming(s);
-    for (int b = 0; b < 2; b++) { if (s->evTile[b]) hipEventDestroy(s->evTile[b]); if (s->evRead[b]) hipEventDestroy(s->evRead[b]); }
+    for (int b = 0; b < 2; b++) { if (s->evTile[b]) hipEventDestroy(s->evTile[b]); for (int q = 0; q < 2; q++) if (s->evRead[b][q]) hipEventDestroy(s->evRead[b][q]); }
     for (void *p : s->allocs) hipFree(p);
     for (hipEvent_t e : s->evPool) hipEventDestroy(e);
     for (hipEvent_t e : s->evStress) hipEventDestroy(e);
@@ -866,7 +868,7 @@ int bfd_set_sources(bfd_sim *s, int64_t nVox, const uint32_t *localIndex, const 
             rc = dev_alloc(s, &s->tileDev[b], (size_t)tile * nSources, false);
             if (!rc) e = hipHostMalloc((void **)&s->tilePinned[b], (size_t)tile * nSources * sizeof(float), hipHostMallocDefault);
             if (!rc && e == hipSuccess && !s->evTile[b]) e = hipEventCreateWithFlags(&s->evTile[b], hipEventDisableTiming);
-            if (!rc && e == hipSuccess && !s->evRead[b]) e = hipEventCreateWithFlags(&s->evRead[b], hipEventDisableTiming);
+            for (int q = 0; q < 2; q++) if (!rc && e == hipSuccess && !s->evRead[b][q]) e = hipEventCreateWithFlags(&s->evRead[b][q], hipEventDisableTiming);
             if (rc || e != hipSuccess) {        // nothing half-built stays behind: the sim is back to "no sources"
                 const std::string why = rc ? std::string(bfd_last_error()) : std::string("bfd_set_sources: ") + hipGetErrorString(e);
                 release_streaming(s);

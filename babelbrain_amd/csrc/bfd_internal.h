@@ -119,7 +119,7 @@ struct bfd_sim {
     const double *pulseHost; int tileSteps, nTiles;
     float *tileDev[2], *tilePinned[2]; int tileLoaded[2], tilePacked[2];
     hipEvent_t evTile[2]; bool evTileUsed[2];
-    hipEvent_t evRead[2]; bool evReadUsed[2];      // behind the last kernels that read the tile a buffer holds (any stream)
+    hipEvent_t evRead[2][2]; bool evReadUsed[2][2];      // [buffer][0 = engine stream, 1 = a side stream]: behind the last kernels that read the tile the buffer holds
     std::future<void> packJob[2];
     // sensors
     int64_t nSensors; uint32_t *sensLin; float *sensOut; int nTs; int nSelS; int selS[BFD_MAP_COUNT];

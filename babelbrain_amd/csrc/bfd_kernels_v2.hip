@@ -42,6 +42,9 @@ constexpr int SUBZ = BFD_SUBZ;             // z granularity of the fluid/solid c
 #ifndef VELOCITY_WAVES_PER_SIMD
 #define VELOCITY_WAVES_PER_SIMD 4
 #endif
+#ifndef VELOCITY_FLUID_WAVES_PER_SIMD
+#define VELOCITY_FLUID_WAVES_PER_SIMD FLUID_WAVES_PER_SIMD     // of velocity_fluid alone (64 VGPRs + one 8-byte spill at 8 waves; at 7 no spill): A/B in profiles/r4/
+#endif
 
 struct HaloTask {
     int lofs;       // offset inside one LDS tile (floats), -1 = no task
@@ -1406,7 +1409,7 @@ __global__ __launch_bounds__(NTHREADS, FLUID_WAVES_PER_SIMD) void stress_fluid(b
 }
 
 template <bool ACC>
-__global__ __launch_bounds__(NTHREADS, FLUID_WAVES_PER_SIMD) void velocity_fluid(bfd_dev d, int tilesX, int nblocks,
+__global__ __launch_bounds__(NTHREADS, VELOCITY_FLUID_WAVES_PER_SIMD) void velocity_fluid(bfd_dev d, int tilesX, int nblocks,
                                                                                  const int4 *__restrict__ runs,
                                                                                  float *__restrict__ accP, float *__restrict__ pkP)
 {
