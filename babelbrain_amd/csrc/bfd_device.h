@@ -32,6 +32,54 @@ __device__ __forceinline__ float cpml(float *__restrict__ psi, unsigned idx, flo
 // that pair and the shared offset register, live only until the access. The pointer is rebuilt from integers, so these are
 // FLAT accesses; the variant with address_space(1) pointers and saddr-form global loads (scripts/r2/patches/) needs fewer
 // registers still but measured 5-6 % slower on the solid-run kernels and equal on the fluid ones.
+#ifdef BFD_GLOBAL_ACCESS
+// Experiment build (-DBFD_GLOBAL_ACCESS): the same accessors as GLOBAL instructions (address_space(1), saddr form: SGPR base +
+// 32-bit VGPR offset). A FLAT load counts on lgkmcnt as well as on vmcnt, so the first wait for an LDS read also waits for every
+// load of the next plane issued before it; global loads wait on vmcnt alone. Round 2 measured this form 5-6 % slower on the
+// solid-run kernels (one more workgroup per CU in flight); profiles/r4/ has the round-4 numbers.
+#define BFD_GLOBAL __attribute__((address_space(1)))
+template <typename T>
+__device__ __forceinline__ BFD_GLOBAL T *uni(T *p)
+{
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (BFD_GLOBAL T *)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ unsigned pinofs(unsigned v) { asm("" : "+v"(v)); return v; }
+struct GlobalF4 {
+    BFD_GLOBAL float *p;
+    __device__ __forceinline__ operator float() const { return *p; }
+    __device__ __forceinline__ void operator=(float v) const { *p = v; }
+    __device__ __forceinline__ void operator=(const GlobalF4 &o) const { *p = *o.p; }
+};
+__device__ __forceinline__ GlobalF4 F4(const float *base, unsigned byteOfs) { return GlobalF4{(BFD_GLOBAL float *)((BFD_GLOBAL char *)uni(const_cast<float *>(base)) + pinofs(byteOfs))}; }
+__device__ __forceinline__ void ST4(float *base, unsigned byteOfs, float v)
+{
+#ifndef BFD_NT_STORES_OFF
+    __builtin_nontemporal_store(v, (BFD_GLOBAL float *)((BFD_GLOBAL char *)uni(base) + pinofs(byteOfs)));
+#else
+    *(BFD_GLOBAL float *)((BFD_GLOBAL char *)uni(base) + pinofs(byteOfs)) = v;
+#endif
+}
+__device__ __forceinline__ float LD4(const float *base, unsigned byteOfs)
+{
+#ifndef BFD_NT_STORES_OFF
+    return __builtin_nontemporal_load((BFD_GLOBAL const float *)((BFD_GLOBAL const char *)uni(base) + pinofs(byteOfs)));
+#else
+    return *(BFD_GLOBAL const float *)((BFD_GLOBAL const char *)uni(base) + pinofs(byteOfs));
+#endif
+}
+template <typename T> __device__ __forceinline__ T LDNT(const T *p)
+{
+#ifndef BFD_NT_STORES_OFF
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ unsigned U2(const uint16_t *base, unsigned byteOfs) { return *(BFD_GLOBAL const uint16_t *)((BFD_GLOBAL const char *)uni(base) + pinofs(byteOfs)); }
+__device__ __forceinline__ unsigned U1(const uint8_t *base, unsigned byteOfs) { return *(BFD_GLOBAL const uint8_t *)((BFD_GLOBAL const uint8_t *)uni(base) + pinofs(byteOfs)); }
+#else
 template <typename T>
 __device__ __forceinline__ T *uni(T *p)
 {
@@ -74,6 +122,8 @@ template <typename T> __device__ __forceinline__ T LDNT(const T *p)             
 }
 __device__ __forceinline__ unsigned U2(const uint16_t *base, unsigned byteOfs) { return *(const uint16_t *)((const char *)uni(base) + byteOfs); }
 __device__ __forceinline__ unsigned U1(const uint8_t *base, unsigned byteOfs) { return uni(base)[byteOfs]; }
+
+#endif
 
 // XCD-aware tile order: consecutive block ids land on different XCDs (round robin over 8), so give
 // XCD e the e-th contiguous run of tiles.

@@ -3,7 +3,7 @@ cd $GRAFT_REPO_ROOT; O=gpurun_out/r4_exp; mkdir -p $O
 for tag in ${TAGS:-base noring occ1 plainst}; do
   lib=babelbrain_amd/libbabelfdtd_hip.so; [ $tag != base ] && lib=babelbrain_amd/libbabelfdtd_hip_$tag.so
   for cfg in ${CFGS:-C1}; do
-    BABELFDTD_HIP_LIB=$PWD/$lib timeout 600 python bench.py --no-cpu-baseline --no-shear-workload --no-next-rows --config $cfg --size 512 512 512 --variant 4 ${BENCH_ARGS} > $O/${cfg}_$tag.json 2>$O/${cfg}_$tag.err
+    BABELFDTD_HIP_LIB=$PWD/$lib timeout 600 python bench.py --no-cpu-baseline --no-shear-workload --no-next-rows --config $cfg --size 512 512 512 --variant ${VARIANT:-4} ${BENCH_ARGS} > $O/${cfg}_$tag.json 2>$O/${cfg}_$tag.err
     python - $O/${cfg}_$tag.json "${cfg}_$tag" <<'PY'
 import json,sys
 try:
