@@ -66,6 +66,7 @@ def parse():
     ap.add_argument('--debug-gloo-shared-gpu', action='store_true', help='debug only: N ranks on GPU 0, gloo backend, halos staged through the host (validates the multi-rank code path on a 1-GPU box)')
     ap.add_argument('--lean-host', action='store_true', help='build the inputs slab-style (size-1 Ox/Oy/Oz) also at N=1')
     ap.add_argument('--cpu-sample', type=int, nargs=4, default=None, help='N1 N2 N3 steps of the oracle sample (default: the grid of the config itself, 56 steps, when the host has the memory; else 384 384 256 224)')
+    ap.add_argument('--group-child', nargs=4, default=None, metavar=('CONFIG', 'N1', 'N2', 'N3'), help='internal: run ONE volume through bfd_group over --gpus devices and print its block (the parent bench starts this as a child process with a timeout)')
     ap.add_argument('--no-group', action='store_true', help='skip the one-process bfd_group figures (group_one_slab at N=1, group_strong_c3 under torchrun)')
     ap.add_argument('--no-next-rows', action='store_true', help='skip the Rayleigh / BHTE kernel rates (N=1, default workload only)')
     ap.add_argument('--no-extra-strong', action='store_true', help='N > 1: skip the extra block that splits ONE C5 volume (1024^3, 1 MHz) over the ranks')
@@ -453,6 +454,29 @@ def group_equals_single(args, ndev, dt_fn, variant):
             'wave_reached_last_slab': bool(one[:, :, -64:].max() > 0)}
 
 
+def group_child(args):
+    """`--group-child`: one group_run, its block as the only line on stdout."""
+    from babelbrain_amd import _engine
+    cfg, n1, n2, n3 = args.group_child
+    out = group_run(args, cfg, (int(n1), int(n2), int(n3)), args.gpus, lambda ml, f, h, c: _engine.stable_dt(ml, f, True, h, c),
+                    args.steps, args.warmup, max(args.windows, 1), args.variant, 'child process of the bench')
+    print(json.dumps(out))
+
+
+def group_in_child(args, config, N, ndev, steps, warmup, timeout=900):
+    """The group figure from a child process (its own HIP context on every device, a time limit): whatever happens to it, the
+    parent's line survives. The launcher's variables are removed so that the child takes the launcher-free path."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'LOCAL_WORLD_SIZE', 'GROUP_RANK', 'ROLE_RANK',
+                                                             'MASTER_ADDR', 'MASTER_PORT', 'TORCHELASTIC_RUN_ID', 'TORCH_NCCL_HIGH_PRIORITY')}
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(ndev), '--steps', str(steps), '--warmup', str(warmup), '--windows', '1',
+           '--variant', str(args.variant), '--group-child', config, str(N[0]), str(N[1]), str(N[2])]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+    if r.returncode != 0:
+        return {'value': None, 'error': 'child exit code %d: %s' % (r.returncode, r.stderr[-400:])}
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
 def main_group(args):
     """`--gpus N` (N > 1) without a launcher: the one-process split (bfd_group_*) over devices 0 .. N-1."""
     from babelbrain_amd import _engine, harness as H
@@ -531,6 +555,8 @@ def main():
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
+    if args.group_child:
+        return group_child(args)
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
         return main_group(args)          # no launcher: the one-process split behind the drop-in call
     if world != args.gpus:
@@ -630,14 +656,14 @@ def main():
             line['extra_strong_c5'] = {'value': None, 'error': err or 'another rank failed to build its slab'}
         if wx is not None:
             wx.close()
-    if world > 1 and not args.no_group and not shared:
+    if world > 1 and not args.no_group:
         # the path the reference's caller gets (one process, one call): ONE 512^3 C3 volume split over the N devices through
         # bfd_group_*, run by rank 0 after every rank has released its slabs; the other ranks wait at the barrier below
         dist.barrier()
         if rank == 0:
             try:
-                line['group_strong_c3'] = group_run(args, 'C3', H.CONFIGS['C3']['N'], world, dt_fn, args.steps, min(args.warmup, 20), 1, args.variant,
-                                                    'strong scaling of the metric config through the drop-in path, rank 0 driving all devices')
+                line['group_strong_c3'] = group_in_child(args, 'C3', H.CONFIGS['C3']['N'], world, args.steps, min(args.warmup, 20))
+                line['group_strong_c3']['label'] = 'strong scaling of the metric config through the drop-in path: a child process of rank 0 drives all devices'
             except Exception as e:
                 line['group_strong_c3'] = {'value': None, 'error': repr(e)}
     if world == 1 and not args.no_group and args.config == 'C3' and not args.size:
