@@ -1129,6 +1129,10 @@ __global__ __launch_bounds__(NTHREADS, PML ? 4 : SOLID_VELOCITY_WAVES_PER_SIMD) 
                                                         const int4 *__restrict__ runs)
 {
     __shared__ float sS[2][5][LH * LW];
+#ifdef VELOCITY_SOLID_LDS_PAD     // experiment: caps the workgroups per CU through the LDS footprint
+    __shared__ float sPad[VELOCITY_SOLID_LDS_PAD];
+    if (nblocks < 0) { sPad[threadIdx.x] = 1.f; sS[0][0][0] = sPad[(threadIdx.x + 1) & 511]; }
+#endif
     const int4 run = runs[remap_block(blockIdx.x, nblocks)];
     velocity_solid_body<ACC, PML>(d, run, tilesX, sS, accP, pkP);
 }
