@@ -941,6 +941,9 @@ int bfd_set_sensor_map(bfd_sim *s, const uint32_t *map, int64_t s1, int64_t s2, 
 // Build the run lists of the tiled kernels (bfd_kernels_v2.hip). Sub-tiles of 64 x 8 x 8 cells are
 // classified on the device; consecutive sub-tiles of one (bx,by) column with identical class merge into
 // runs that never cross a 32-plane chunk boundary. Variant 2: every sub-tile counts as solid (dense kernels).
+#ifndef BFD_SOLID_MERGED_DEFAULT
+#define BFD_SOLID_MERGED_DEFAULT 0
+#endif
 static int build_tile_lists(bfd_sim *s)
 {
     int tx, ty, nsub; bfd_tile_grid(s->d, &tx, &ty, &nsub);
@@ -977,6 +980,11 @@ static int build_tile_lists(bfd_sim *s)
     }
     bfd_tiles &T = s->tiles;
     T.nMat = s->cfg.nMat;
+    // solid runs: normal and shear stresses in one kernel (stress_solid_merged), the sparse list keeps the cells with an edge between
+    // different solids. BFD_SOLID_MERGED=0 selects the two-kernel form (stress_solid + stress_shear_sparse over every solid cell).
+    T.merged = BFD_SOLID_MERGED_DEFAULT != 0;
+    if (const char *ev = getenv("BFD_SOLID_MERGED")) T.merged = atoi(ev) != 0;
+    if (s->step > 0 && s->tiles.shearR) T.merged = false;       // a list rebuilt in the middle of a run keeps the form it started with
     T.nFluid = T.nFluidB = T.nSolid = T.nSolidB = T.nSolidBP = T.nSolidIP = T.nFused = T.nLossless = T.nLossy = T.nSolidSub = T.nUni = T.nPml = T.nLean = T.nFusedSub = 0;
     s->d.tilesX = tx; s->d.tilesY = ty;
     // Every fluid sub-tile is LEAN (bit4): fluid cells keep a single copy of their identical normal stresses, whatever
@@ -1146,7 +1154,7 @@ static int build_tile_lists(bfd_sim *s)
         if (e == hipSuccess) e = hipMalloc((void **)&dcount, sizeof(int));
         int count = 0;
         if (e == hipSuccess) {
-            bfd_launch_mark_solid(s->d, s->stream, flag, (long)s->nloc);
+            bfd_launch_mark_solid(s->d, s->stream, flag, (long)s->nloc, T.merged);
             size_t wbytes = 0;
             hipcub::CountingInputIterator<unsigned> ids(0);
             e = hipcub::DeviceSelect::Flagged(nullptr, wbytes, ids, flag, sel, dcount, (int)s->nloc, s->stream);
@@ -1180,7 +1188,7 @@ static int build_tile_lists(bfd_sim *s)
         if (e == hipSuccess) {
             rc = dev_alloc(s, &s->tiles.shearCells, (size_t)std::max(count, 1), false);
             if (!rc) rc = dev_alloc(s, &s->tiles.shearCoef, 6 * (size_t)std::max(count, 1), false);
-            if (!rc) rc = dev_alloc(s, &s->tiles.shearR, 3 * (size_t)std::max(count, 1), true);      // lists are built at step 0: the memory variables start at zero
+            if (!rc && !T.merged) rc = dev_alloc(s, &s->tiles.shearR, 3 * (size_t)std::max(count, 1), true);      // lists are built at step 0: the memory variables start at zero (merged form: they live in the full-volume arrays)
             if (!rc && count) e = hipMemcpyAsync(s->tiles.shearCells, sel, (size_t)count * sizeof(unsigned), hipMemcpyDeviceToDevice, s->stream);
             if (!rc) rc = dev_alloc(s, &s->tiles.shearCodes, (size_t)std::max(count, 1), false);
             if (!rc) rc = dev_alloc(s, &s->tiles.shearTab, 2 * (size_t)s->cfg.nMat, false);
@@ -1191,7 +1199,7 @@ static int build_tile_lists(bfd_sim *s)
         if (e != hipSuccess) BFD_FAIL(-10, std::string("shear list: ") + hipGetErrorString(e));
         if (rc) return rc;
         s->tiles.nShear = count;
-        if (s->step > 0) { bfd_launch_gather_shear_memory(s->d, s->stream, &s->tiles); BFD_HIP(hipStreamSynchronize(s->stream)); }
+        if (s->step > 0 && s->tiles.shearR) { bfd_launch_gather_shear_memory(s->d, s->stream, &s->tiles); BFD_HIP(hipStreamSynchronize(s->stream)); }
         s->tiles.shearLowEnd = std::lower_bound(hostCells.begin(), hostCells.end(), (unsigned)lowPlanes * (unsigned)s->d.plane) - hostCells.begin();
         s->tiles.shearHighBeg = std::lower_bound(hostCells.begin(), hostCells.end(), (unsigned)hiStart * (unsigned)s->d.plane) - hostCells.begin();
     }
@@ -1265,7 +1273,9 @@ static int build_tile_lists(bfd_sim *s)
             s->tiles.nShearExplicit = (long)hc[1];
             // per listed cell: index 4 + edge codes 4 + V 12; per edge with explicit coefficients 8; per active edge S and R r/w 16
             for (int a = 0; a < 2; a++) B[a][BFD_K_STRESS_SHEAR] = 20.0 * (double)s->tiles.nShear + 8.0 * (double)hc[1] + 16.0 * (double)hc[0];
+            if (T.merged) for (int a = 0; a < 2; a++) B[a][BFD_K_STRESS_SOLID] -= 16.0 * (double)hc[0];      // those edges are the sparse kernel's
         }
+        if (T.merged && T.nSolid && s->cfg.kernelVariant != 2) for (int a = 0; a < 2; a++) B[a][BFD_K_STRESS_SOLID] += 16.0 * (double)cnt[4];   // S and R of every active edge, read and written
     }
     s->tilesReady = true;
     return 0;

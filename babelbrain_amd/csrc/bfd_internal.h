@@ -16,6 +16,7 @@
 #define BFD_CLS_EXZ 8u
 #define BFD_CLS_EYZ 16u
 #define BFD_CLS_REFL 32u    // reflector voxel
+#define BFD_CLS_MIXED 64u   // an updated shear edge of this cell lies between different materials (coefficients are not the per-material ones)
 
 // CA, CB of the O(4) staggered first derivative (Taylor coefficients) and the matching stability constant
 // 1/(CA+CB) of dt <= BFD_STAB h / (sqrt(3) cmax). Overridable for scheme experiments (tests/rayleigh_study.py):
@@ -81,7 +82,7 @@ struct bfd_sim;
 // records an event before (end = 0) / after (end = 1) a launch of class cls (bfd_api.hip); t->ktimer != null while class timing is on
 void bfd_kmark(bfd_sim *sim, int cls, int end, hipStream_t st);
 
-struct bfd_tiles { bfd_sim *ktimer; int nMat; int4 *runs;
+struct bfd_tiles { bfd_sim *ktimer; int nMat; bool merged /* solid runs: normal and shear stresses in one kernel, the sparse list holds the MIXED cells only */; int4 *runs;
                    unsigned *shearCells; float *shearCoef; long nShear, shearLowEnd, shearHighBeg;   /* sparse shear list */
                    unsigned *shearCodes; float *shearTab; long nShearExplicit;   /* per listed cell a byte per edge: 0 inactive, 1 + m = one material around the edge (coefficients from shearTab[2 m ..]), 255 = explicit coefficients in shearCoef; number of explicit edges */
                    float *shearR;   /* memory variables Rxy, Rxz, Ryz of the listed cells, [3][nShear] in list order: only the sparse kernel uses them, so they live beside the list (dense, coalesced) instead of in the full-volume arrays, which are filled from here on demand (bfd_get_field) */
@@ -164,7 +165,8 @@ int bfd_fused_rows(void);
 int bfd_fused_max_materials(void);
 int bfd_tile_subz(void);
 void bfd_launch_classify(const bfd_dev &d, hipStream_t s, int *flagsDev, int *tileMatDev);
-void bfd_launch_mark_solid(const bfd_dev &d, hipStream_t s, unsigned char *flag, long n);
+// flags the cells of the sparse shear list: solid, non-reflector centre; mixedOnly: only those with BFD_CLS_MIXED (merged solid stress kernel)
+void bfd_launch_mark_solid(const bfd_dev &d, hipStream_t s, unsigned char *flag, long n, bool mixedOnly);
 void bfd_launch_shear_order_keys(const bfd_dev &d, hipStream_t s, const unsigned *cells, unsigned long long *keys, long n, int lowPlanes, int hiStart, int mode);
 void bfd_launch_shear_coefficients(const bfd_dev &d, hipStream_t s, const unsigned *cells, float *coef, unsigned *codes, float *tab, int nMat, long n);
 // copies the list-ordered shear memory variables into the full-volume arrays Rxy, Rxz, Ryz (outputs only)

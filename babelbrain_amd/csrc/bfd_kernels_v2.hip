@@ -911,6 +911,220 @@ __global__ __launch_bounds__(NTHREADS, SOLID_STRESS_WAVES_PER_SIMD) void stress_
     else stress_solid_body<false>(d, run, tilesX, sV);
 }
 
+// ------------------------------------------------------------------------------------------------
+// SOLID runs, normal AND shear stresses in one pass (BFD_SOLID_MERGED=1): stress_solid_body plus the shear update of the
+// lanes whose class byte carries an edge bit, from the V planes the kernel stages anyway -- all three components with
+// their full ring in LDS, Vx / Vy queues k-1 .. k+2 in registers -- instead of the sparse kernel's 21-value gather, its
+// list and one launch. Edge coefficients come from the per-material table (the four cells of an active edge hold ONE
+// material: class bit MIXED clear); cells with an edge between different solids (BFD_CLS_MIXED) keep the sparse kernel,
+// whose list then holds only them. The memory variables Rxy, Rxz, Ryz live in the full-volume arrays in this mode.
+// CPML memory variables of the cross derivatives advance where their edge is active (each belongs to one edge of one cell).
+// Same arithmetic and operation order as stress_v2 / stress_shear_sparse: bit-identical.
+// ------------------------------------------------------------------------------------------------
+template <bool PML>
+__device__ __forceinline__ void stress_solid_merged_body(const bfd_dev &d, const int4 &run, int tilesX, const float *__restrict__ shearTab,
+                                                         float (*sV)[3][LH * LW])
+{
+    const int N1 = d.N1, N2 = d.N2;
+    const int bx = run.x % tilesX, by = run.x / tilesX, kbeg = run.y & 0xFFFF, kend = run.y >> 16;
+    const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * TX + tx;
+    const int wv = __builtin_amdgcn_readfirstlane(ty);
+    const int i0 = bx * TX, j0 = by * TY;
+    const int i = i0 + tx, j = j0 + ty;
+    const bool valid = (i < N1) && (j < N2);
+    const long pl = d.plane;
+    const int P = d.P;
+    const int own = (ty + 2) * LW + tx + 2;
+    const unsigned cij = valid ? (unsigned)(j * N1 + i) : 0u;
+
+    // halo tasks, the array of a task uniform per wave: A: waves 0-3 the 4 halo rows of Vx, waves 4-7 those of Vy;
+    // B: waves 0-3 the 4 halo rows of Vz; lanes 0..31 of waves 4 / 5 / 6 the halo columns of Vx / Vy / Vz
+    HaloTask ta, tb;
+    const int arrA = wv < 4 ? 0 : 1;
+    ytask(tid & 255, arrA, i0, j0, N1, N2, ta);
+    const int arrB = wv < 4 ? 2 : (wv == 4 ? 0 : (wv == 5 ? 1 : 2));
+    if (wv < 4) ytask(tid, 2, i0, j0, N1, N2, tb);
+    else if (wv < 7 && tx < XT) xtask(tx, arrB, i0, j0, N1, N2, tb);
+    else { tb.lofs = -1; tb.ok = false; tb.arr = arrB; tb.gofs = 0; }
+    const float *baseA = arrA == 0 ? d.Vx : d.Vy;
+    const float *baseB = arrB == 0 ? d.Vx : (arrB == 1 ? d.Vy : d.Vz);
+    const unsigned offA = ta.ok ? (unsigned)ta.gofs * 4u : 0u, offB = tb.ok ? (unsigned)tb.gofs * 4u : 0u;
+    float *la = &sV[0][ta.arr][ta.lofs];
+    float *lb = &sV[0][tb.arr][tb.lofs < 0 ? 0 : tb.lofs];
+    const bool hasB = tb.lofs >= 0;
+    const int bufStride = 3 * LH * LW;
+    const float c1 = d.c1;
+
+    const bool zi = PML && valid && (i < P || i >= N1 - P);
+    const bool zj = PML && valid && (j < P || j >= N2 - P);
+    float ax = 0, bxc = 0, ay = 0, byc = 0, px = 0, py = 0, pz = 0;
+    unsigned qx = 0, qy = 0;
+    const unsigned dqx = (unsigned)(N2 * 2 * P), dqy = (unsigned)(2 * P * N1);
+    if (zi) { ax = d.axI[i]; bxc = d.bxI[i]; qx = (unsigned)((kbeg * N2 + j) * (2 * P) + (i < P ? i : i - (N1 - 2 * P))); px = F4(d.psi[0], (unsigned)(qx) * 4u); }
+    if (zj) { ay = d.ayI[j]; byc = d.byI[j]; qy = (unsigned)((kbeg * (2 * P) + (j < P ? j : j - (N2 - 2 * P))) * N1 + i); py = F4(d.psi[1], (unsigned)(qy) * 4u); }
+    if (PML) {
+        const int kg = d.k0 + kbeg;
+        if (valid && (kg < P || kg >= d.N3 - P)) pz = F4(d.psi[2], (unsigned)((unsigned)((kg < P ? kg : kg - (d.N3 - 2 * P)) * d.plane) + cij) * 4u);
+    }
+
+    // z queues: Vx, Vy planes k-1 .. k+2, Vz planes k-2 .. k+1
+    float vxm1 = 0, vx0 = 0, vxp1 = 0, vxp2 = 0, vym1 = 0, vy0 = 0, vyp1 = 0, vyp2 = 0, vzm2 = 0, vzm1 = 0, vz0 = 0, vzp1 = 0;
+    float sxx = 0, syy = 0, szz = 0, rxx = 0, ryy = 0, rzz = 0;
+    unsigned mraw = 0, cl = BFD_CLS_FLUID | BFD_CLS_NOMEM, cl1 = BFD_CLS_FLUID | BFD_CLS_NOMEM;
+    if (valid) {
+        const float *bVx = d.Vx + kbeg * pl, *bVy = d.Vy + kbeg * pl, *bVz = d.Vz + kbeg * pl;
+        cl = U1((d.cls + kbeg * pl), cij); cl1 = U1((d.cls + kbeg * pl + pl), cij);
+        vxm1 = F4((bVx - pl), cij * 4u); vx0 = F4(bVx, cij * 4u); vxp1 = F4((bVx + pl), cij * 4u); vxp2 = F4((bVx + 2 * pl), cij * 4u);
+        vym1 = F4((bVy - pl), cij * 4u); vy0 = F4(bVy, cij * 4u); vyp1 = F4((bVy + pl), cij * 4u); vyp2 = F4((bVy + 2 * pl), cij * 4u);
+        vzm2 = F4((bVz - 2 * pl), cij * 4u); vzm1 = F4((bVz - pl), cij * 4u); vz0 = F4(bVz, cij * 4u); vzp1 = F4((bVz + pl), cij * 4u);
+        mraw = U2((d.mat + kbeg * pl), cij * 2u);
+        szz = F4((d.Szz + kbeg * pl), cij * 4u);
+        const bool fl = cl & BFD_CLS_FLUID, mem = !(cl & BFD_CLS_NOMEM) || !fl;
+        if (mem) rzz = F4((d.Rzz + kbeg * pl), cij * 4u);
+        if (!fl) {
+            sxx = F4((d.Sxx + kbeg * pl), cij * 4u); syy = F4((d.Syy + kbeg * pl), cij * 4u);
+            rxx = F4((d.Rxx + kbeg * pl), cij * 4u); ryy = F4((d.Ryy + kbeg * pl), cij * 4u);
+        }
+    }
+    float ha = ta.ok ? F4(baseA + kbeg * pl, offA) : 0.0f;
+    float hb = tb.ok ? F4(baseB + kbeg * pl, offB) : 0.0f;
+
+    for (int kl = kbeg; kl < kend; kl++) {
+        const int b = kl & 1;
+        const long ko = (long)__builtin_amdgcn_readfirstlane(kl) * pl;
+        const int k = d.k0 + kl;
+        const int bo = b * bufStride;
+        float nvx = 0, nvy = 0, nvz = 0, nha = 0, nhb = 0, nsxx = 0, nsyy = 0, nszz = 0, nrxx = 0, nryy = 0, nrzz = 0, npx = 0, npy = 0, npz = 0;
+        unsigned nmraw = 0, ncl2 = BFD_CLS_FLUID | BFD_CLS_NOMEM;
+        // the shear entries of THIS plane (own cell only, where the edge is updated here): issued with the prefetch, used at the end
+        float sxy = 0, rxy = 0, sxz = 0, rxz = 0, syz = 0, ryz = 0;
+        const bool shearHere = valid && !(cl & BFD_CLS_MIXED);
+        const bool eXY = shearHere && (cl & BFD_CLS_EXY), eXZ = shearHere && (cl & BFD_CLS_EXZ), eYZ = shearHere && (cl & BFD_CLS_EYZ);
+        auto prefetch_next = [&]() {
+            if (valid) ncl2 = U1((d.cls + ko + 2 * pl), cij);           // ghost planes make kl+2 addressable
+            if (eXY) { sxy = F4((d.Sxy + ko), cij * 4u); rxy = F4((d.Rxy + ko), cij * 4u); }
+            if (eXZ) { sxz = F4((d.Sxz + ko), cij * 4u); rxz = F4((d.Rxz + ko), cij * 4u); }
+            if (eYZ) { syz = F4((d.Syz + ko), cij * 4u); ryz = F4((d.Ryz + ko), cij * 4u); }
+            if (kl + 1 < kend) {
+                if (valid) {
+                    const bool nfl = cl1 & BFD_CLS_FLUID, nmem = !(cl1 & BFD_CLS_NOMEM) || !nfl;
+                    nvx = F4((d.Vx + ko + 3 * pl), cij * 4u); nvy = F4((d.Vy + ko + 3 * pl), cij * 4u); nvz = F4((d.Vz + ko + 2 * pl), cij * 4u);
+                    nmraw = U2((d.mat + ko + pl), cij * 2u);
+                    nszz = F4((d.Szz + ko + pl), cij * 4u);
+                    if (nmem) nrzz = F4((d.Rzz + ko + pl), cij * 4u);
+                    if (!nfl) {
+                        nsxx = F4((d.Sxx + ko + pl), cij * 4u); nsyy = F4((d.Syy + ko + pl), cij * 4u);
+                        nrxx = F4((d.Rxx + ko + pl), cij * 4u); nryy = F4((d.Ryy + ko + pl), cij * 4u);
+                    }
+                }
+                if (ta.ok) nha = F4(baseA + ko + pl, offA);
+                if (tb.ok) nhb = F4(baseB + ko + pl, offB);
+                if (zi) npx = F4(d.psi[0], (unsigned)(qx + dqx) * 4u);
+                if (zj) npy = F4(d.psi[1], (unsigned)(qy + dqy) * 4u);
+                const int kn = k + 1;
+                if (PML && valid && (kn < P || kn >= d.N3 - P)) npz = F4(d.psi[2], (unsigned)((unsigned)((kn < P ? kn : kn - (d.N3 - 2 * P)) * d.plane) + cij) * 4u);
+            }
+        };
+        sV[0][0][bo + own] = vx0; sV[0][1][bo + own] = vy0; sV[0][2][bo + own] = vz0;
+        la[bo] = ha;
+        if (hasB) lb[bo] = hb;
+        const int m = mraw & BFD_MAT_MASK;
+        const bool fl = cl & BFD_CLS_FLUID, mem = !(cl & BFD_CLS_NOMEM) || !fl;
+        float AP = 0, BP = 0, AS2 = 0, BS2 = 0, As = 0, Bs = 0;
+        if (valid) { AP = d.AP[m]; if (mem) BP = d.BP[m]; if (!fl) { AS2 = d.AS2[m]; BS2 = d.BS2[m]; } if (eXY || eXZ || eYZ) { As = shearTab[2 * m]; Bs = shearTab[2 * m + 1]; } }
+        __syncthreads();
+
+        prefetch_next();
+        if (valid) {
+            const float *sx = &sV[0][0][bo + own], *sy = &sV[0][1][bo + own], *sz = &sV[0][2][bo + own];
+            float dxVx = dminus4(sx[-2], sx[-1], vx0, sx[1]);
+            float dyVy = dminus4(sy[-2 * LW], sy[-LW], vy0, sy[LW]);
+            float dzVz = dminus4(vzm2, vzm1, vz0, vzp1);
+            if (cl & BFD_CLS_REFL) {
+                F4((d.Sxx + ko), cij * 4u) = 0.f; F4((d.Syy + ko), cij * 4u) = 0.f; F4((d.SzzW + ko), cij * 4u) = 0.f;
+                F4((d.Rxx + ko), cij * 4u) = 0.f; F4((d.Ryy + ko), cij * 4u) = 0.f; F4((d.RzzW + ko), cij * 4u) = 0.f;
+                F4((d.Sxy + ko), cij * 4u) = 0.f; F4((d.Sxz + ko), cij * 4u) = 0.f; F4((d.Syz + ko), cij * 4u) = 0.f;
+                F4((d.Rxy + ko), cij * 4u) = 0.f; F4((d.Rxz + ko), cij * 4u) = 0.f; F4((d.Ryz + ko), cij * 4u) = 0.f;
+            } else {
+                if (zi) { const float pn = bxc * px + ax * dxVx; F4(d.psi[0], (unsigned)(qx) * 4u) = pn; dxVx = dxVx + pn; }
+                if (zj) { const float pn = byc * py + ay * dyVy; F4(d.psi[1], (unsigned)(qy) * 4u) = pn; dyVy = dyVy + pn; }
+                if (PML && (k < P || k >= d.N3 - P)) {
+                    const float pn = d.bzI[k] * pz + d.azI[k] * dzVz;
+                    F4(d.psi[2], (unsigned)((unsigned)((k < P ? k : k - (d.N3 - 2 * P)) * d.plane) + cij) * 4u) = pn;
+                    dzVz = dzVz + pn;
+                }
+                const float sXY = dxVx + dyVy;
+                const float div = sXY + dzVz;
+                if (fl) {               // fluid cell: one copy of the identical normal stresses
+                    float val;
+                    if (!mem) val = szz + AP * div;
+                    else {
+                        const float rn = c1 * rzz - BP * div;
+                        val = szz + (AP * div + 0.5f * (rzz + rn));
+                        ST4((d.RzzW + ko), cij * 4u, rn);
+                    }
+                    ST4((d.SzzW + ko), cij * 4u, val);
+                } else {
+                    const float sYZ = dyVy + dzVz, sXZ = dxVx + dzVz;
+                    float rn;
+                    rn = c1 * rxx - (BP * div - BS2 * sYZ);
+                    ST4((d.Sxx + ko), cij * 4u, sxx + ((AP * div - AS2 * sYZ) + 0.5f * (rxx + rn))); ST4((d.Rxx + ko), cij * 4u, rn);
+                    rn = c1 * ryy - (BP * div - BS2 * sXZ);
+                    ST4((d.Syy + ko), cij * 4u, syy + ((AP * div - AS2 * sXZ) + 0.5f * (ryy + rn))); ST4((d.Ryy + ko), cij * 4u, rn);
+                    rn = c1 * rzz - (BP * div - BS2 * sXY);
+                    ST4((d.SzzW + ko), cij * 4u, szz + ((AP * div - AS2 * sXY) + 0.5f * (rzz + rn))); ST4((d.RzzW + ko), cij * 4u, rn);
+                }
+                // shear entries of this cell (same expressions as stress_v2 / stress_shear_sparse)
+                if (eXY) {
+                    float dyVx = dplus4(sx[-LW], vx0, sx[LW], sx[2 * LW]);
+                    float dxVy = dplus4(sy[-1], vy0, sy[1], sy[2]);
+                    if (zi) dxVy = cpml(d.psi[4], (unsigned)((kl * N2 + j) * (2 * P) + (i < P ? i : i - (N1 - 2 * P))), d.axH[i], d.bxH[i], dxVy);
+                    if (zj) dyVx = cpml(d.psi[3], (unsigned)((kl * (2 * P) + (j < P ? j : j - (N2 - 2 * P))) * N1 + i), d.ayH[j], d.byH[j], dyVx);
+                    const float e = dyVx + dxVy;
+                    const float rn = c1 * rxy - Bs * e;
+                    F4((d.Sxy + ko), cij * 4u) = sxy + (As * e + 0.5f * (rxy + rn)); F4((d.Rxy + ko), cij * 4u) = rn;
+                }
+                if (eXZ) {
+                    float dzVx = dplus4(vxm1, vx0, vxp1, vxp2);
+                    float dxVz = dplus4(sz[-1], vz0, sz[1], sz[2]);
+                    if (zi) dxVz = cpml(d.psi[6], (unsigned)((kl * N2 + j) * (2 * P) + (i < P ? i : i - (N1 - 2 * P))), d.axH[i], d.bxH[i], dxVz);
+                    if (PML && (k < P || k >= d.N3 - P)) dzVx = cpml(d.psi[5], (unsigned)((k < P ? k : k - (d.N3 - 2 * P)) * d.plane) + cij, d.azH[k], d.bzH[k], dzVx);
+                    const float e = dzVx + dxVz;
+                    const float rn = c1 * rxz - Bs * e;
+                    F4((d.Sxz + ko), cij * 4u) = sxz + (As * e + 0.5f * (rxz + rn)); F4((d.Rxz + ko), cij * 4u) = rn;
+                }
+                if (eYZ) {
+                    float dzVy = dplus4(vym1, vy0, vyp1, vyp2);
+                    float dyVz = dplus4(sz[-LW], vz0, sz[LW], sz[2 * LW]);
+                    if (zj) dyVz = cpml(d.psi[8], (unsigned)((kl * (2 * P) + (j < P ? j : j - (N2 - 2 * P))) * N1 + i), d.ayH[j], d.byH[j], dyVz);
+                    if (PML && (k < P || k >= d.N3 - P)) dzVy = cpml(d.psi[7], (unsigned)((k < P ? k : k - (d.N3 - 2 * P)) * d.plane) + cij, d.azH[k], d.bzH[k], dzVy);
+                    const float e = dzVy + dyVz;
+                    const float rn = c1 * ryz - Bs * e;
+                    F4((d.Syz + ko), cij * 4u) = syz + (As * e + 0.5f * (ryz + rn)); F4((d.Ryz + ko), cij * 4u) = rn;
+                }
+            }
+        }
+        vxm1 = vx0; vx0 = vxp1; vxp1 = vxp2; vxp2 = nvx;
+        vym1 = vy0; vy0 = vyp1; vyp1 = vyp2; vyp2 = nvy;
+        vzm2 = vzm1; vzm1 = vz0; vz0 = vzp1; vzp1 = nvz;
+        ha = nha; hb = nhb; mraw = nmraw; cl = cl1; cl1 = ncl2;
+        sxx = nsxx; syy = nsyy; szz = nszz; rxx = nrxx; ryy = nryy; rzz = nrzz;
+        px = npx; py = npy; pz = npz; qx += dqx; qy += dqy;
+    }
+}
+
+#ifndef SOLID_MERGED_WAVES_PER_SIMD
+#define SOLID_MERGED_WAVES_PER_SIMD 4
+#endif
+__global__ __launch_bounds__(NTHREADS, SOLID_MERGED_WAVES_PER_SIMD) void stress_solid_merged(bfd_dev d, int tilesX, int nblocks, const int4 *__restrict__ runs,
+                                                                                             const float *__restrict__ shearTab)
+{
+    __shared__ float sV[2][3][LH * LW];
+    const int4 run = runs[remap_block(blockIdx.x, nblocks)];
+    if (run.z & 8) stress_solid_merged_body<true>(d, run, tilesX, shearTab, sV);
+    else stress_solid_merged_body<false>(d, run, tilesX, shearTab, sV);
+}
+
 // one halo value of the solid velocity kernel: SUBST (Sxx / Syy halos): Szz where the halo cell is fluid; otherwise a
 // shear array, loaded only where its edge bit is set. base / alt are wave-uniform (SGPR) plane bases.
 __device__ __forceinline__ float halo_value(const float *__restrict__ base, const float *__restrict__ alt, bool subst, unsigned bit,
@@ -1181,9 +1395,11 @@ __global__ void cell_classes(bfd_dev d, const uint16_t *__restrict__ matBase, ui
             const long z0 = (long)k1 * pl + (long)j * N1, z1 = (long)k1 * pl + (long)j1 * N1;
             const bool sx = d.invMu[matBase[r0 + i1] & BFD_MAT_MASK] > 0.f, sy = d.invMu[matBase[r1 + i] & BFD_MAT_MASK] > 0.f;
             const bool sz = d.invMu[matBase[z0 + i] & BFD_MAT_MASK] > 0.f;
-            if (sx && sy && d.invMu[matBase[r1 + i1] & BFD_MAT_MASK] > 0.f) c |= BFD_CLS_EXY;
-            if (sx && sz && d.invMu[matBase[z0 + i1] & BFD_MAT_MASK] > 0.f) c |= BFD_CLS_EXZ;
-            if (sy && sz && d.invMu[matBase[z1 + i] & BFD_MAT_MASK] > 0.f) c |= BFD_CLS_EYZ;
+            const int mX = matBase[r0 + i1] & BFD_MAT_MASK, mY = matBase[r1 + i] & BFD_MAT_MASK, mZ = matBase[z0 + i] & BFD_MAT_MASK;
+            const int mXY = matBase[r1 + i1] & BFD_MAT_MASK, mXZ = matBase[z0 + i1] & BFD_MAT_MASK, mYZ = matBase[z1 + i] & BFD_MAT_MASK;
+            if (sx && sy && d.invMu[mXY] > 0.f) { c |= BFD_CLS_EXY; if (mX != m || mY != m || mXY != m) c |= BFD_CLS_MIXED; }
+            if (sx && sz && d.invMu[mXZ] > 0.f) { c |= BFD_CLS_EXZ; if (mX != m || mZ != m || mXZ != m) c |= BFD_CLS_MIXED; }
+            if (sy && sz && d.invMu[mYZ] > 0.f) { c |= BFD_CLS_EYZ; if (mY != m || mZ != m || mYZ != m) c |= BFD_CLS_MIXED; }
         }
         clsBase[v] = (uint8_t)c;
     }
@@ -1273,20 +1489,23 @@ __global__ __launch_bounds__(256) void stress_shear_sparse(bfd_dev d, const unsi
         dzVy = cpml(d.psi[7], q, d.azH[k], d.bzH[k], dzVy);
     }
     const float c1 = d.c1;
+    // memory variables: beside the list (Rc, list order) or, when the list only holds the cells the merged solid kernel leaves
+    // out (Rc == null), in the full-volume arrays
+    float *pRxy = Rc ? Rc + t : d.Rxy + c, *pRxz = Rc ? Rc + nTotal + t : d.Rxz + c, *pRyz = Rc ? Rc + 2 * nTotal + t : d.Ryz + c;
     if (Axy != 0.f) {
         const float e = dyVx + dxVy;
-        const float r = LDNT(Rc + t), rn = c1 * r - Bxy * e;
-        d.Sxy[c] = LDNT(d.Sxy + c) + (Axy * e + 0.5f * (r + rn)); Rc[t] = rn;
+        const float r = LDNT(pRxy), rn = c1 * r - Bxy * e;
+        d.Sxy[c] = LDNT(d.Sxy + c) + (Axy * e + 0.5f * (r + rn)); *pRxy = rn;
     }
     if (Axz != 0.f) {
         const float e = dzVx + dxVz;
-        const float r = LDNT(Rc + nTotal + t), rn = c1 * r - Bxz * e;
-        d.Sxz[c] = LDNT(d.Sxz + c) + (Axz * e + 0.5f * (r + rn)); Rc[nTotal + t] = rn;
+        const float r = LDNT(pRxz), rn = c1 * r - Bxz * e;
+        d.Sxz[c] = LDNT(d.Sxz + c) + (Axz * e + 0.5f * (r + rn)); *pRxz = rn;
     }
     if (Ayz != 0.f) {
         const float e = dzVy + dyVz;
-        const float r = LDNT(Rc + 2 * nTotal + t), rn = c1 * r - Byz * e;
-        d.Syz[c] = LDNT(d.Syz + c) + (Ayz * e + 0.5f * (r + rn)); Rc[2 * nTotal + t] = rn;
+        const float r = LDNT(pRyz), rn = c1 * r - Byz * e;
+        d.Syz[c] = LDNT(d.Syz + c) + (Ayz * e + 0.5f * (r + rn)); *pRyz = rn;
     }
 }
 
@@ -1309,11 +1528,12 @@ __global__ void gather_shear_memory(bfd_dev d, const unsigned *__restrict__ cell
 }
 
 // setup: flag cells with a solid, non-reflector centre; then the edge coefficients of the listed cells
-__global__ void mark_solid_cells(bfd_dev d, unsigned char *__restrict__ flag, long n)
+__global__ void mark_solid_cells(bfd_dev d, unsigned char *__restrict__ flag, long n, bool mixedOnly)
 {
     for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (long)gridDim.x * blockDim.x) {
         const unsigned raw = d.mat[v];
-        flag[v] = (!(raw & BFD_REFLECTOR_BIT) && d.invMu[raw & BFD_MAT_MASK] > 0.f) ? 1 : 0;
+        const bool solid = !(raw & BFD_REFLECTOR_BIT) && d.invMu[raw & BFD_MAT_MASK] > 0.f;
+        flag[v] = (solid && (!mixedOnly || (d.cls[v] & BFD_CLS_MIXED))) ? 1 : 0;
     }
 }
 // codes (may be null): one word per listed cell, a byte per edge (xy, xz, yz): 0 = the edge is never updated, 1 + m = its four
@@ -1524,9 +1744,9 @@ void bfd_launch_shear_order_keys(const bfd_dev &d, hipStream_t s, const unsigned
     if (n) hipLaunchKernelGGL(shear_order_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d, cells, keys, n, lowPlanes, hiStart, mode);
 }
 
-void bfd_launch_mark_solid(const bfd_dev &d, hipStream_t s, unsigned char *flag, long n)
+void bfd_launch_mark_solid(const bfd_dev &d, hipStream_t s, unsigned char *flag, long n, bool mixedOnly)
 {
-    hipLaunchKernelGGL(mark_solid_cells, dim3((unsigned)std::min<long>((n + 255) / 256, 8192)), dim3(256), 0, s, d, flag, n);
+    hipLaunchKernelGGL(mark_solid_cells, dim3((unsigned)std::min<long>((n + 255) / 256, 8192)), dim3(256), 0, s, d, flag, n, mixedOnly);
 }
 void bfd_launch_scatter_shear_memory(const bfd_dev &d, hipStream_t s, const bfd_tiles *t)
 {
@@ -1572,7 +1792,8 @@ void bfd_launch_stress_v2(const bfd_dev &d, hipStream_t s0, const bfd_tiles *t, 
     hipStream_t s = s0;
     if (nS) {
         BFD_KT(BFD_K_STRESS_SOLID, 0);
-        if (t->shearCells) BFD_LAUNCH(stress_solid, nS, t->runs + t->nFluid + offS);
+        if (t->shearCells && t->merged) BFD_LAUNCH(stress_solid_merged, nS, t->runs + t->nFluid + offS, (const float *)t->shearTab);
+        else if (t->shearCells) BFD_LAUNCH(stress_solid, nS, t->runs + t->nFluid + offS);
         else BFD_LAUNCH(stress_v2, nS, t->runs + t->nFluid + offS, (const unsigned short *)nullptr);     // variant 2: monolithic, dense
         BFD_KT(BFD_K_STRESS_SOLID, 1);
     }
@@ -1581,8 +1802,9 @@ void bfd_launch_stress_v2(const bfd_dev &d, hipStream_t s0, const bfd_tiles *t, 
         if (part == 1) { e0 = t->shearLowEnd; b1 = t->shearHighBeg; e1 = t->nShear; }
         else if (part == 2) { b0 = t->shearLowEnd; e0 = t->shearHighBeg; }
         BFD_KT(BFD_K_STRESS_SHEAR, 0);
-        if (e0 > b0) hipLaunchKernelGGL(stress_shear_sparse, dim3((unsigned)((e0 - b0 + 255) / 256)), dim3(256), 0, s, d, t->shearCells + b0, t->shearCodes + b0, t->shearTab, t->shearCoef + 6 * b0, t->shearR + b0, t->nShear, e0 - b0);
-        if (e1 > b1) hipLaunchKernelGGL(stress_shear_sparse, dim3((unsigned)((e1 - b1 + 255) / 256)), dim3(256), 0, s, d, t->shearCells + b1, t->shearCodes + b1, t->shearTab, t->shearCoef + 6 * b1, t->shearR + b1, t->nShear, e1 - b1);
+        float *R0 = t->shearR ? t->shearR + b0 : nullptr, *R1 = t->shearR ? t->shearR + b1 : nullptr;
+        if (e0 > b0) hipLaunchKernelGGL(stress_shear_sparse, dim3((unsigned)((e0 - b0 + 255) / 256)), dim3(256), 0, s, d, t->shearCells + b0, t->shearCodes + b0, t->shearTab, t->shearCoef + 6 * b0, R0, t->nShear, e0 - b0);
+        if (e1 > b1) hipLaunchKernelGGL(stress_shear_sparse, dim3((unsigned)((e1 - b1 + 255) / 256)), dim3(256), 0, s, d, t->shearCells + b1, t->shearCodes + b1, t->shearTab, t->shearCoef + 6 * b1, R1, t->nShear, e1 - b1);
         BFD_KT(BFD_K_STRESS_SHEAR, 1);
     }
     if (n) {
