@@ -139,3 +139,24 @@ def test_thermal_host_logic():
     R.set_devices(None)
     R._device = 0
     assert R._devices is None
+
+
+def test_benchmark_test_file_hook(tmp_path):
+    """The reference's synthetic-medium hook (BenchmarkTestFile, BASE:1253-1260, 1313-1321): a medium written in that layout and
+    read back gives make_problem the very inputs the in-code medium gives it."""
+    from babelbrain_amd import harness as H
+    from oracle import oracle as O
+    dt_fn = lambda ml, f, h, c: O.stable_dt(ml, f, True, h, c)
+    a, k, info = H.make_problem('C2', N=(48, 40, 56), steps=40, stable_dt_fn=dt_fn)
+    path = str(tmp_path / 'bench_medium.h5')
+    H.save_benchmark_medium(path, a[0], a[1], k['QCorrection'], TestType=1)
+    mm, ml, q, sos = H.benchmark_medium(path)
+    assert np.array_equal(mm, a[0]) and np.array_equal(ml, a[1]) and np.array_equal(q, np.asarray(k['QCorrection'], np.float64))
+    assert sos == min(ml[:, 1].min(), ml[ml[:, 2] > 0, 2].min())
+    a2, k2, info2 = H.make_problem('C2', steps=40, stable_dt_fn=dt_fn, benchmark_file=path)
+    assert info2['N'] == (48, 40, 56) and info2['medium'] == 'benchmark file'
+    for x, y in zip(a, a2):
+        assert np.array_equal(np.asarray(x), np.asarray(y))
+    assert k2['DT'] == k['DT'] and np.array_equal(k2['QCorrection'], k['QCorrection'])
+    with pytest.raises(ValueError):
+        H.save_benchmark_medium(path, np.zeros((4, 4, 4), np.uint32), a[1])      # a material that never occurs in the map
