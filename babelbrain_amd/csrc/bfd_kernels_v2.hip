@@ -903,6 +903,9 @@ __device__ __forceinline__ void stress_solid_body(const bfd_dev &d, const int4 &
 #ifndef SOLID_STRESS_WAVES_PER_SIMD
 #define SOLID_STRESS_WAVES_PER_SIMD 4
 #endif
+// (-DBFD_STRESS_SOLID_GLOBAL builds the GLOBAL / branch-free-prefetch body below instead: measured 1 % slower, 0.308-0.311 against
+// 0.305 ms at the shear medium 512^3 -- this kernel is at the rate of the bytes it moves; profiles/r4/experiment_solid_kernels_prefetch.txt)
+#ifndef BFD_STRESS_SOLID_GLOBAL
 __global__ __launch_bounds__(NTHREADS, SOLID_STRESS_WAVES_PER_SIMD) void stress_solid(bfd_dev d, int tilesX, int nblocks, const int4 *__restrict__ runs)
 {
     __shared__ float sV[2][2][LH * LW];
@@ -910,6 +913,7 @@ __global__ __launch_bounds__(NTHREADS, SOLID_STRESS_WAVES_PER_SIMD) void stress_
     if (run.z & 8) stress_solid_body<true>(d, run, tilesX, sV);
     else stress_solid_body<false>(d, run, tilesX, sV);
 }
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // SOLID runs, normal AND shear stresses in one pass (BFD_SOLID_MERGED=1): stress_solid_body plus the shear update of the
@@ -1332,10 +1336,394 @@ __device__ __forceinline__ void velocity_solid_body(const bfd_dev &d, const int4
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The solid-run kernels again with GLOBAL loads and a prefetch WITHOUT branches (round 4). In the bodies above every predicated
+// load of the next plane sits in its own basic block and the loads are FLAT: the first LDS wait of an iteration (lgkmcnt, which
+// flat loads count on) drains the whole prefetch, so an iteration is one memory round trip followed by the arithmetic, nothing
+// overlaps. Here a load whose class predicate is off reads the first dword of its plane instead (one line every lane shares:
+// an L1 hit, no traffic) and its result is replaced by 0, so every iteration issues the same loads in the same order, the
+// compiler counts them (vmcnt(n) waits) and the plane k+1 loads stay in flight across the arithmetic of plane k.
+// Same values, same arithmetic: bit-identical.
+// ------------------------------------------------------------------------------------------------
+#define BFD_GA __attribute__((address_space(1)))
+template <typename T> __device__ __forceinline__ BFD_GA T *gbase(const T *p)
+{
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (BFD_GA T *)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ unsigned gpin(unsigned v) { asm("" : "+v"(v)); return v; }
+__device__ __forceinline__ float gl4(const float *b, unsigned ofs) { return *(BFD_GA const float *)((BFD_GA const char *)gbase(b) + gpin(ofs)); }
+__device__ __forceinline__ float gl4nt(const float *b, unsigned ofs) { return __builtin_nontemporal_load((BFD_GA const float *)((BFD_GA const char *)gbase(b) + gpin(ofs))); }
+__device__ __forceinline__ unsigned gl2(const uint16_t *b, unsigned ofs) { return *(BFD_GA const uint16_t *)((BFD_GA const char *)gbase(b) + gpin(ofs)); }
+__device__ __forceinline__ unsigned gl1(const uint8_t *b, unsigned ofs) { return *(BFD_GA const uint8_t *)((BFD_GA const char *)gbase(b) + gpin(ofs)); }
+// predicated: lanes with c == false read dword 0 of the plane and get 0
+__device__ __forceinline__ float glp(const float *b, unsigned ofs, bool c) { const float v = gl4(b, c ? ofs : 0u); return c ? v : 0.0f; }
+__device__ __forceinline__ void gs4(float *b, unsigned ofs, float v) { *(BFD_GA float *)((BFD_GA char *)gbase(b) + gpin(ofs)) = v; }
+__device__ __forceinline__ void gs4nt(float *b, unsigned ofs, float v)
+{
+#ifndef BFD_NT_STORES_OFF
+    __builtin_nontemporal_store(v, (BFD_GA float *)((BFD_GA char *)gbase(b) + gpin(ofs)));
+#else
+    gs4(b, ofs, v);
+#endif
+}
+// one halo value: SUBST (Sxx / Syy halos): Szz where the halo cell is fluid, the array itself otherwise; else a shear array where its
+// edge bit is set, 0 elsewhere. One load on every path: the plane base is chosen per lane, the offset falls back to dword 0.
+__device__ __forceinline__ float halo_value_g(const float *base, const float *alt, bool subst, unsigned bit, unsigned hc, unsigned off4, bool ok)
+{
+    const bool fluid = (hc & BFD_CLS_FLUID) != 0;
+    const bool take = ok && (subst || (hc & bit));
+    const unsigned long long pb = (unsigned long long)gbase(base), pa = (unsigned long long)gbase(alt);
+    const unsigned long long pp = (subst && fluid) ? pa : pb;
+    const float v = *(BFD_GA const float *)(pp + (take ? off4 : 0u));
+    return take ? v : 0.0f;
+}
+
+template <bool PML>
+__device__ __forceinline__ void stress_solid_body_g(const bfd_dev &d, const int4 &run, int tilesX, float (*sV)[2][LH * LW])
+{
+    const int N1 = d.N1, N2 = d.N2;
+    const int bx = run.x % tilesX, by = run.x / tilesX, kbeg = run.y & 0xFFFF, kend = run.y >> 16;
+    const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * TX + tx;
+    const int i0 = bx * TX, j0 = by * TY;
+    const int i = i0 + tx, j = j0 + ty;
+    const bool valid = (i < N1) && (j < N2);
+    const long pl = d.plane;
+    const int P = d.P;
+    const int own = (ty + 2) * LW + tx + 2;
+    const unsigned cij = valid ? (unsigned)(j * N1 + i) : 0u;
+    const unsigned c4 = cij * 4u;
+
+    HaloTask t; t.lofs = -1; t.ok = false; t.arr = 0; t.gofs = 0;
+    if (tid < YT) ytask(tid, 1, i0, j0, N1, N2, t);
+    else if (tid < YT + XT) xtask(tid - YT, 0, i0, j0, N1, N2, t);
+    const bool has = t.lofs >= 0;
+    const float *ph = __builtin_amdgcn_readfirstlane(t.arr) == 0 ? d.Vx : d.Vy;
+    const unsigned hofs = t.ok ? (unsigned)t.gofs * 4u : 0u;
+    float *lh = &sV[0][t.arr][has ? t.lofs : 0];
+    const float c1 = d.c1;
+
+    const bool zi = PML && valid && (i < P || i >= N1 - P);
+    const bool zj = PML && valid && (j < P || j >= N2 - P);
+    float ax = 0, bxc = 0, ay = 0, byc = 0, px = 0, py = 0, pz = 0;
+    unsigned qx = 0, qy = 0;
+    const unsigned dqx = (unsigned)(N2 * 2 * P), dqy = (unsigned)(2 * P * N1);
+    if (zi) { ax = d.axI[i]; bxc = d.bxI[i]; qx = (unsigned)((kbeg * N2 + j) * (2 * P) + (i < P ? i : i - (N1 - 2 * P))); px = F4(d.psi[0], (unsigned)(qx) * 4u); }
+    if (zj) { ay = d.ayI[j]; byc = d.byI[j]; qy = (unsigned)((kbeg * (2 * P) + (j < P ? j : j - (N2 - 2 * P))) * N1 + i); py = F4(d.psi[1], (unsigned)(qy) * 4u); }
+    if (PML) {
+        const int kg = d.k0 + kbeg;
+        if (valid && (kg < P || kg >= d.N3 - P)) pz = F4(d.psi[2], (unsigned)((unsigned)((kg < P ? kg : kg - (d.N3 - 2 * P)) * d.plane) + cij) * 4u);
+    }
+
+    float vx0 = 0, vy0 = 0, vzm2 = 0, vzm1 = 0, vz0 = 0, vzp1 = 0;
+    float sxx = 0, syy = 0, szz = 0, rxx = 0, ryy = 0, rzz = 0;
+    unsigned mraw = 0, cl = BFD_CLS_FLUID | BFD_CLS_NOMEM, cl1 = BFD_CLS_FLUID | BFD_CLS_NOMEM;
+    if (valid) {
+        const float *bVz = d.Vz + kbeg * pl;
+        cl = gl1(d.cls + kbeg * pl, cij); cl1 = gl1(d.cls + kbeg * pl + pl, cij);
+        vx0 = gl4(d.Vx + kbeg * pl, c4); vy0 = gl4(d.Vy + kbeg * pl, c4);
+        vzm2 = gl4(bVz - 2 * pl, c4); vzm1 = gl4(bVz - pl, c4); vz0 = gl4(bVz, c4); vzp1 = gl4(bVz + pl, c4);
+        mraw = gl2(d.mat + kbeg * pl, cij * 2u);
+        szz = gl4(d.Szz + kbeg * pl, c4);
+        const bool fl = cl & BFD_CLS_FLUID, mem = !(cl & BFD_CLS_NOMEM) || !fl;
+        rzz = glp(d.Rzz + kbeg * pl, c4, mem);
+        sxx = glp(d.Sxx + kbeg * pl, c4, !fl); syy = glp(d.Syy + kbeg * pl, c4, !fl);
+        rxx = glp(d.Rxx + kbeg * pl, c4, !fl); ryy = glp(d.Ryy + kbeg * pl, c4, !fl);
+    }
+    float hv = glp(ph + kbeg * pl, hofs, t.ok);
+
+    for (int kl = kbeg; kl < kend; kl++) {
+        const int b = kl & 1;
+        const long ko = (long)__builtin_amdgcn_readfirstlane(kl) * pl;
+        const int k = d.k0 + kl;
+        sV[b][0][own] = vx0; sV[b][1][own] = vy0;
+        if (has) lh[b * (2 * LH * LW)] = hv;
+        const int m = mraw & BFD_MAT_MASK;
+        const bool fl = cl & BFD_CLS_FLUID, mem = !(cl & BFD_CLS_NOMEM) || !fl;
+        float AP = 0, BP = 0, AS2 = 0, BS2 = 0;
+        if (valid) { AP = d.AP[m]; if (mem) BP = d.BP[m]; if (!fl) { AS2 = d.AS2[m]; BS2 = d.BS2[m]; } }
+        __syncthreads();
+
+        // everything plane kl+1 needs: the same loads in every iteration (a predicate that is off reads dword 0 of the plane); the raw
+        // values are not touched before the end of the iteration
+        const bool more = kl + 1 < kend;
+        const long kn = more ? pl : 0;
+        const bool nfl = cl1 & BFD_CLS_FLUID, nmem = !(cl1 & BFD_CLS_NOMEM) || !nfl;
+        const bool pM = more && valid && nmem, pS = more && valid && !nfl, pH = more && t.ok;
+        const unsigned ncl2R = gl1(d.cls + ko + 2 * pl, cij);           // ghost planes make kl+2 addressable
+        const float nvxR = gl4(d.Vx + ko + kn, c4), nvyR = gl4(d.Vy + ko + kn, c4), nvzR = gl4(d.Vz + ko + pl + kn, c4);
+        const unsigned nmrawR = gl2(d.mat + ko + kn, cij * 2u);
+        const float nszzR = gl4(d.Szz + ko + kn, c4);
+        const float nrzzR = gl4(d.Rzz + ko + kn, pM ? c4 : 0u);
+        const float nsxxR = gl4(d.Sxx + ko + kn, pS ? c4 : 0u), nsyyR = gl4(d.Syy + ko + kn, pS ? c4 : 0u);
+        const float nrxxR = gl4(d.Rxx + ko + kn, pS ? c4 : 0u), nryyR = gl4(d.Ryy + ko + kn, pS ? c4 : 0u);
+        const float nhR = gl4(ph + ko + kn, pH ? hofs : 0u);
+        float npx = 0, npy = 0, npz = 0;
+        if (PML) {
+            if (more && zi) npx = F4(d.psi[0], (unsigned)(qx + dqx) * 4u);
+            if (more && zj) npy = F4(d.psi[1], (unsigned)(qy + dqy) * 4u);
+            const int kq = k + 1;
+            if (more && valid && (kq < P || kq >= d.N3 - P)) npz = F4(d.psi[2], (unsigned)((unsigned)((kq < P ? kq : kq - (d.N3 - 2 * P)) * d.plane) + cij) * 4u);
+        }
+
+        if (valid) {
+            const float *sx = &sV[b][0][own], *sy = &sV[b][1][own];
+            float dxVx = dminus4(sx[-2], sx[-1], vx0, sx[1]);
+            float dyVy = dminus4(sy[-2 * LW], sy[-LW], vy0, sy[LW]);
+            float dzVz = dminus4(vzm2, vzm1, vz0, vzp1);
+            if (cl & BFD_CLS_REFL) {
+                gs4(d.Sxx + ko, c4, 0.f); gs4(d.Syy + ko, c4, 0.f); gs4(d.SzzW + ko, c4, 0.f);
+                gs4(d.Rxx + ko, c4, 0.f); gs4(d.Ryy + ko, c4, 0.f); gs4(d.RzzW + ko, c4, 0.f);
+                gs4(d.Sxy + ko, c4, 0.f); gs4(d.Sxz + ko, c4, 0.f); gs4(d.Syz + ko, c4, 0.f);
+                gs4(d.Rxy + ko, c4, 0.f); gs4(d.Rxz + ko, c4, 0.f); gs4(d.Ryz + ko, c4, 0.f);
+            } else {
+                if (zi) { const float pn = bxc * px + ax * dxVx; F4(d.psi[0], (unsigned)(qx) * 4u) = pn; dxVx = dxVx + pn; }
+                if (zj) { const float pn = byc * py + ay * dyVy; F4(d.psi[1], (unsigned)(qy) * 4u) = pn; dyVy = dyVy + pn; }
+                if (PML && (k < P || k >= d.N3 - P)) {
+                    const float pn = d.bzI[k] * pz + d.azI[k] * dzVz;
+                    F4(d.psi[2], (unsigned)((unsigned)((k < P ? k : k - (d.N3 - 2 * P)) * d.plane) + cij) * 4u) = pn;
+                    dzVz = dzVz + pn;
+                }
+                const float sXY = dxVx + dyVy;
+                const float div = sXY + dzVz;
+                if (fl) {               // fluid cell: one copy of the identical normal stresses
+                    float val;
+                    if (!mem) val = szz + AP * div;
+                    else {
+                        const float rn = c1 * rzz - BP * div;
+                        val = szz + (AP * div + 0.5f * (rzz + rn));
+                        gs4nt(d.RzzW + ko, c4, rn);
+                    }
+                    gs4nt(d.SzzW + ko, c4, val);
+                } else {
+                    const float sYZ = dyVy + dzVz, sXZ = dxVx + dzVz;
+                    float rn;
+                    rn = c1 * rxx - (BP * div - BS2 * sYZ);
+                    gs4nt(d.Sxx + ko, c4, sxx + ((AP * div - AS2 * sYZ) + 0.5f * (rxx + rn))); gs4nt(d.Rxx + ko, c4, rn);
+                    rn = c1 * ryy - (BP * div - BS2 * sXZ);
+                    gs4nt(d.Syy + ko, c4, syy + ((AP * div - AS2 * sXZ) + 0.5f * (ryy + rn))); gs4nt(d.Ryy + ko, c4, rn);
+                    rn = c1 * rzz - (BP * div - BS2 * sXY);
+                    gs4nt(d.SzzW + ko, c4, szz + ((AP * div - AS2 * sXY) + 0.5f * (rzz + rn))); gs4nt(d.RzzW + ko, c4, rn);
+                }
+            }
+        }
+        // masks of the prefetched values, queues
+        const bool mv = more && valid;
+        vx0 = mv ? nvxR : 0.0f; vy0 = mv ? nvyR : 0.0f;
+        vzm2 = vzm1; vzm1 = vz0; vz0 = vzp1; vzp1 = mv ? nvzR : 0.0f;
+        hv = pH ? nhR : 0.0f; mraw = mv ? nmrawR : 0u; cl = cl1; cl1 = valid ? ncl2R : (unsigned)(BFD_CLS_FLUID | BFD_CLS_NOMEM);
+        sxx = pS ? nsxxR : 0.0f; syy = pS ? nsyyR : 0.0f; szz = mv ? nszzR : 0.0f; rxx = pS ? nrxxR : 0.0f; ryy = pS ? nryyR : 0.0f; rzz = pM ? nrzzR : 0.0f;
+        px = npx; py = npy; pz = npz; qx += dqx; qy += dqy;
+    }
+}
+
+template <bool ACC, bool PML>
+__device__ __forceinline__ void velocity_solid_body_g(const bfd_dev &d, const int4 &run, int tilesX, float (*sS)[5][LH * LW],
+                                                      float *__restrict__ accP, float *__restrict__ pkP)
+{
+    const int N1 = d.N1, N2 = d.N2;
+    const int bx = run.x % tilesX, by = run.x / tilesX;
+    const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * TX + tx;
+    const int wv = __builtin_amdgcn_readfirstlane(ty);      // wave index = tile row (uniform)
+    const int i0 = bx * TX, j0 = by * TY;
+    const int i = i0 + tx, j = j0 + ty;
+    const bool valid = (i < N1) && (j < N2);
+    const long pl = d.plane;
+    const int kbeg = run.y & 0xFFFF, kend = run.y >> 16;
+    const int P = d.P;
+    const int own = (ty + 2) * LW + tx + 2;
+    const unsigned cij = valid ? (unsigned)(j * N1 + i) : 0u;
+    const unsigned c4 = cij * 4u, c2 = cij * 2u;
+    const bool hasX = valid && i + 1 < N1, hasY = valid && j + 1 < N2;
+    const unsigned cx2 = c2 + (hasX ? 2u : 0u), cy2 = c2 + (hasY ? (unsigned)N1 * 2u : 0u);
+    const bool accA = ACC && accP != nullptr, accK = ACC && pkP != nullptr;
+
+    HaloTask ta, tb;
+    const int arrA = wv < 4 ? 1 : 2;
+    ytask(tid & 255, arrA, i0, j0, N1, N2, ta);
+    const int arrB = wv < 4 ? 4 : (wv == 4 ? 0 : (wv == 5 ? 2 : 3));
+    if (wv < 4) ytask(tid, 4, i0, j0, N1, N2, tb);
+    else if (wv < 7 && tx < XT) xtask(tx, arrB, i0, j0, N1, N2, tb);
+    else { tb.lofs = -1; tb.ok = false; tb.arr = arrB; tb.gofs = 0; }
+    const float *baseA = arrA == 1 ? d.Syy : d.Sxy;
+    const float *baseB = arrB == 4 ? d.Syz : (arrB == 0 ? d.Sxx : (arrB == 2 ? d.Sxy : d.Sxz));
+    const bool substA = arrA == 1, substB = arrB == 0;
+    const unsigned bitA = BFD_CLS_EXY, bitB = arrB == 4 ? BFD_CLS_EYZ : (arrB == 2 ? BFD_CLS_EXY : BFD_CLS_EXZ);
+    const unsigned offA = ta.ok ? (unsigned)ta.gofs : 0u, offB = tb.ok ? (unsigned)tb.gofs : 0u;
+    float *la = &sS[0][ta.arr][ta.lofs];
+    float *lb = &sS[0][tb.arr][tb.lofs < 0 ? 0 : tb.lofs];
+    const bool hasB = tb.lofs >= 0;
+    const int bufStride = 5 * LH * LW;
+
+    const bool zi = PML && valid && (i < P || i >= N1 - P);
+    const bool zj = PML && valid && (j < P || j >= N2 - P);
+    const bool inner = valid && i >= d.ND && i < N1 - d.ND && j >= d.ND && j < N2 - d.ND;
+
+    float zzm1 = 0, zz0 = 0, zzp1 = 0, zzp2 = 0, xzm2 = 0, xzm1 = 0, xz0 = 0, xzp1 = 0, yzm2 = 0, yzm1 = 0, yz0 = 0, yzp1 = 0;
+    unsigned cB = BFD_CLS_FLUID, cC = BFD_CLS_FLUID;
+    {
+        const float *bzz = d.Szz + kbeg * pl, *bxz = d.Sxz + kbeg * pl, *byz = d.Syz + kbeg * pl;
+        const uint8_t *bc = d.cls + kbeg * pl;
+        unsigned cm2 = BFD_CLS_FLUID, cm1 = BFD_CLS_FLUID, c0 = BFD_CLS_FLUID;
+        if (valid) { cm2 = gl1(bc - 2 * pl, cij); cm1 = gl1(bc - pl, cij); c0 = gl1(bc, cij); cB = gl1(bc + pl, cij); cC = gl1(bc + 2 * pl, cij); }
+        zzm1 = glp(bzz - pl, c4, valid); zz0 = glp(bzz, c4, valid); zzp1 = glp(bzz + pl, c4, valid); zzp2 = glp(bzz + 2 * pl, c4, valid);
+        xzm2 = glp(bxz - 2 * pl, c4, valid && (cm2 & BFD_CLS_EXZ)); xzm1 = glp(bxz - pl, c4, valid && (cm1 & BFD_CLS_EXZ));
+        xz0 = glp(bxz, c4, valid && (c0 & BFD_CLS_EXZ)); xzp1 = glp(bxz + pl, c4, valid && (cB & BFD_CLS_EXZ));
+        yzm2 = glp(byz - 2 * pl, c4, valid && (cm2 & BFD_CLS_EYZ)); yzm1 = glp(byz - pl, c4, valid && (cm1 & BFD_CLS_EYZ));
+        yz0 = glp(byz, c4, valid && (c0 & BFD_CLS_EYZ)); yzp1 = glp(byz + pl, c4, valid && (cB & BFD_CLS_EYZ));
+        const bool fl0 = (c0 & BFD_CLS_FLUID) != 0;
+        float sxx = glp(d.Sxx + kbeg * pl, c4, valid && !fl0), syy = glp(d.Syy + kbeg * pl, c4, valid && !fl0);
+        if (valid && fl0) { sxx = zz0; syy = zz0; }
+        const float sxy = glp(d.Sxy + kbeg * pl, c4, valid && (c0 & BFD_CLS_EXY));
+        const int bo0 = (kbeg & 1) * bufStride;
+        sS[0][0][bo0 + own] = sxx; sS[0][1][bo0 + own] = syy; sS[0][2][bo0 + own] = sxy; sS[0][3][bo0 + own] = xz0; sS[0][4][bo0 + own] = yz0;
+    }
+    float r0 = 0;
+    unsigned mraw = 0, mraw1 = 0, mx = 0, my = 0;
+    if (valid) {
+        const uint16_t *bM = d.mat + kbeg * pl;
+        mraw = gl2(bM, c2); mraw1 = gl2(bM + pl, c2); mx = gl2(bM, cx2); my = gl2(bM, cy2);
+        r0 = d.invRho[mraw & BFD_MAT_MASK];
+    }
+    unsigned hcA = 0, hcB = 0;
+    {
+        unsigned h0A = 0, h0B = 0;
+        if (ta.ok) { h0A = gl1(d.cls + kbeg * pl, offA); hcA = gl1(d.cls + kbeg * pl + pl, offA); }
+        if (tb.ok) { h0B = gl1(d.cls + kbeg * pl, offB); hcB = gl1(d.cls + kbeg * pl + pl, offB); }
+        const float ha = halo_value_g(baseA + kbeg * pl, d.Szz + kbeg * pl, substA, bitA, h0A, offA * 4u, ta.ok);
+        const float hb = halo_value_g(baseB + kbeg * pl, d.Szz + kbeg * pl, substB, bitB, h0B, offB * 4u, tb.ok);
+        la[(kbeg & 1) * bufStride] = ha;
+        if (hasB) lb[(kbeg & 1) * bufStride] = hb;
+    }
+
+    for (int kl = kbeg; kl < kend; kl++) {
+        const int b = kl & 1;
+        const long ko = (long)__builtin_amdgcn_readfirstlane(kl) * pl;
+        const int k = d.k0 + kl;
+        const int bn = (b ^ 1) * bufStride;     // buffer of plane kl+1
+        // own V and sums of this plane (before the barrier), then, after it, everything plane kl+1 needs: always the same loads
+        const float vx = gl4nt(d.Vx + ko, c4), vy = gl4nt(d.Vy + ko, c4), vz = gl4nt(d.Vz + ko, c4);
+        float av = 0, pv = 0;
+        if (accA) av = gl4nt(accP + ko, c4);
+        if (accK) pv = gl4(pkP + ko, c4);
+        float r1 = 0, rx = 0, ry = 0;
+        if (valid) {
+            r1 = d.invRho[mraw1 & BFD_MAT_MASK];       // plane kl+1, becomes r0 of the next iteration
+            rx = d.invRho[mx & BFD_MAT_MASK];
+            ry = d.invRho[my & BFD_MAT_MASK];
+        }
+        __syncthreads();
+
+        // The raw values are not touched before the end of the iteration (their class masks are applied there): nothing between
+        // here and the staging waits for them.
+        const bool more = kl + 1 < kend;                // uniform
+        const unsigned nm2 = gl2(d.mat + ko + 2 * pl, c2);                       // ghost planes make kl+2 addressable
+        const unsigned nc3raw = gl1(d.cls + ko + (kl + 2 < kend ? 3 : 2) * pl, cij);
+        const bool bfl = (cB & BFD_CLS_FLUID) != 0;
+        const bool pXZ = more && valid && (cC & BFD_CLS_EXZ), pYZ = more && valid && (cC & BFD_CLS_EYZ);
+        const bool pNN = more && valid && !bfl, pXY = more && valid && (cB & BFD_CLS_EXY);
+        const bool takeA = more && ta.ok && (substA || (hcA & bitA)), takeB = more && tb.ok && (substB || (hcB & bitB));
+        const long kn = more ? pl : 0;                  // the last iteration reads its own plane again (addressable, unused)
+        const float nzzR = gl4(d.Szz + ko + 2 * pl + kn, c4);
+        const float nxzR = gl4(d.Sxz + ko + pl + kn, pXZ ? c4 : 0u);
+        const float nyzR = gl4(d.Syz + ko + pl + kn, pYZ ? c4 : 0u);
+        const float nxxR = gl4(d.Sxx + ko + kn, pNN ? c4 : 0u);
+        const float nyyR = gl4(d.Syy + ko + kn, pNN ? c4 : 0u);
+        const float nxyR = gl4(d.Sxy + ko + kn, pXY ? c4 : 0u);
+        const unsigned nmx = gl2(d.mat + ko + kn, cx2), nmy = gl2(d.mat + ko + kn, cy2);
+        float nhaR, nhbR;
+        {
+            const unsigned long long pbA = (unsigned long long)gbase(baseA + ko + kn), paA = (unsigned long long)gbase(d.Szz + ko + kn);
+            const unsigned long long pbB = (unsigned long long)gbase(baseB + ko + kn);
+            nhaR = *(BFD_GA const float *)(((substA && (hcA & BFD_CLS_FLUID)) ? paA : pbA) + (takeA ? offA * 4u : 0u));
+            nhbR = *(BFD_GA const float *)(((substB && (hcB & BFD_CLS_FLUID)) ? paA : pbB) + (takeB ? offB * 4u : 0u));
+        }
+        const unsigned nhcA = gl1(d.cls + ko + pl + kn, offA), nhcB = gl1(d.cls + ko + pl + kn, offB);
+
+        float *wVx = d.VxW + ko, *wVy = d.VyW + ko, *wVz = d.VzW + ko;
+        if (valid) {
+            const float sxx = sS[b][0][own], syy = sS[b][1][own], sxy = sS[b][2][own];
+            if (ACC) {
+                if (inner && k >= d.ND && k < d.N3 - d.ND) {
+                    const float s = (sxx + syy) + zz0;
+                    const float p = -s * (1.0f / 3.0f);
+                    if (accA) gs4(accP + ko, c4, av + p * p);
+                    if (accK) { const float ap = fabsf(p); if (ap > pv) gs4(pkP + ko, c4, ap); }
+                }
+            }
+            if (mraw & BFD_REFLECTOR_BIT) {
+                gs4(wVx, c4, 0.f); gs4(wVy, c4, 0.f); gs4(wVz, c4, 0.f);
+            } else {
+                const float *pxx = &sS[b][0][own], *pyy = &sS[b][1][own], *pxy = &sS[b][2][own];
+                const float *pxz = &sS[b][3][own], *pyz = &sS[b][4][own];
+                float dxSxx = dplus4(pxx[-1], sxx, pxx[1], pxx[2]);
+                float dySxy = dminus4(pxy[-2 * LW], pxy[-LW], sxy, pxy[LW]);
+                float dzSxz = dminus4(xzm2, xzm1, xz0, xzp1);
+                float dxSxy = dminus4(pxy[-2], pxy[-1], sxy, pxy[1]);
+                float dySyy = dplus4(pyy[-LW], syy, pyy[LW], pyy[2 * LW]);
+                float dzSyz = dminus4(yzm2, yzm1, yz0, yzp1);
+                float dxSxz = dminus4(pxz[-2], pxz[-1], xz0, pxz[1]);
+                float dySyz = dminus4(pyz[-2 * LW], pyz[-LW], yz0, pyz[LW]);
+                float dzSzz = dplus4(zzm1, zz0, zzp1, zzp2);
+                if (zi) {
+                    const int xi = i < P ? i : i - (N1 - 2 * P);
+                    const unsigned q = (unsigned)((kl * N2 + j) * (2 * P) + xi);
+                    dxSxx = cpml(d.psi[9], q, d.axH[i], d.bxH[i], dxSxx);
+                    dxSxy = cpml(d.psi[12], q, d.axI[i], d.bxI[i], dxSxy);
+                    dxSxz = cpml(d.psi[15], q, d.axI[i], d.bxI[i], dxSxz);
+                }
+                if (zj) {
+                    const int yj = j < P ? j : j - (N2 - 2 * P);
+                    const unsigned q = (unsigned)((kl * (2 * P) + yj) * N1 + i);
+                    dySxy = cpml(d.psi[10], q, d.ayI[j], d.byI[j], dySxy);
+                    dySyy = cpml(d.psi[13], q, d.ayH[j], d.byH[j], dySyy);
+                    dySyz = cpml(d.psi[16], q, d.ayI[j], d.byI[j], dySyz);
+                }
+                if (PML && (k < P || k >= d.N3 - P)) {
+                    const int zk = k < P ? k : k - (d.N3 - 2 * P);
+                    const unsigned q = (unsigned)(zk * d.plane) + cij;
+                    dzSxz = cpml(d.psi[11], q, d.azI[k], d.bzI[k], dzSxz);
+                    dzSyz = cpml(d.psi[14], q, d.azI[k], d.bzI[k], dzSyz);
+                    dzSzz = cpml(d.psi[17], q, d.azH[k], d.bzH[k], dzSzz);
+                }
+                const float bxv = 0.5f * (r0 + rx), byv = 0.5f * (r0 + ry), bzv = 0.5f * (r0 + r1);
+                gs4nt(wVx, c4, vx + bxv * ((dxSxx + dySxy) + dzSxz));
+                gs4nt(wVy, c4, vy + byv * ((dxSxy + dySyy) + dzSyz));
+                gs4nt(wVz, c4, vz + bzv * ((dxSxz + dySyz) + dzSzz));
+            }
+        }
+        // masks of the prefetched values, queues, staging of plane kl+1
+        const float nzz = (more && valid) ? nzzR : 0.0f, nxz = pXZ ? nxzR : 0.0f, nyz = pYZ ? nyzR : 0.0f;
+        const float nxx = pNN ? nxxR : ((more && valid && bfl) ? zzp1 : 0.0f), nyy = pNN ? nyyR : ((more && valid && bfl) ? zzp1 : 0.0f);
+        const float nxy = pXY ? nxyR : 0.0f, nha = takeA ? nhaR : 0.0f, nhb = takeB ? nhbR : 0.0f;
+        const unsigned nc3 = (kl + 2 < kend && valid) ? nc3raw : (unsigned)BFD_CLS_FLUID;
+        zzm1 = zz0; zz0 = zzp1; zzp1 = zzp2; zzp2 = nzz;
+        xzm2 = xzm1; xzm1 = xz0; xz0 = xzp1; xzp1 = nxz;
+        yzm2 = yzm1; yzm1 = yz0; yz0 = yzp1; yzp1 = nyz;
+        sS[0][0][bn + own] = nxx; sS[0][1][bn + own] = nyy; sS[0][2][bn + own] = nxy; sS[0][3][bn + own] = xz0; sS[0][4][bn + own] = yz0;
+        la[bn] = nha;
+        if (hasB) lb[bn] = nhb;
+        hcA = nhcA; hcB = nhcB;
+        r0 = r1; mraw = mraw1; mraw1 = nm2; mx = nmx; my = nmy;
+        cB = cC; cC = nc3;
+    }
+}
+
+#ifdef BFD_STRESS_SOLID_GLOBAL
+__global__ __launch_bounds__(NTHREADS, SOLID_STRESS_WAVES_PER_SIMD) void stress_solid(bfd_dev d, int tilesX, int nblocks, const int4 *__restrict__ runs)
+{
+    __shared__ float sV[2][2][LH * LW];
+    const int4 run = runs[remap_block(blockIdx.x, nblocks)];
+    if (run.z & 8) stress_solid_body_g<true>(d, run, tilesX, sV);
+    else stress_solid_body_g<false>(d, run, tilesX, sV);
+}
+#endif
+
 // two kernels (the absorbing-layer flavour needs ~18 registers more and would spill inside a common one); the solid run
 // list keeps the runs that touch the layer at its two ends (bfd_tiles::nSolidBP / nSolidIP)
 #ifndef SOLID_VELOCITY_WAVES_PER_SIMD
-#define SOLID_VELOCITY_WAVES_PER_SIMD 4      // of the plain flavour; the absorbing-layer flavour needs 108 registers and always gets 4
+#define SOLID_VELOCITY_WAVES_PER_SIMD 4      // lower bound of the plain flavour (78-80 VGPRs since round 4: 6 waves); the absorbing-layer flavour needs 105 registers and gets 4
 #endif
 template <bool ACC, bool PML>
 __global__ __launch_bounds__(NTHREADS, PML ? 4 : SOLID_VELOCITY_WAVES_PER_SIMD) void velocity_solid(bfd_dev d, int tilesX, int nblocks,
@@ -1348,7 +1736,11 @@ __global__ __launch_bounds__(NTHREADS, PML ? 4 : SOLID_VELOCITY_WAVES_PER_SIMD) 
     if (nblocks < 0) { sPad[threadIdx.x] = 1.f; sS[0][0][0] = sPad[(threadIdx.x + 1) & 511]; }
 #endif
     const int4 run = runs[remap_block(blockIdx.x, nblocks)];
+#ifndef BFD_VELOCITY_SOLID_FLAT      // default since round 4: GLOBAL loads, prefetch without branches (0.405 -> 0.378 ms at the shear medium 512^3)
+    velocity_solid_body_g<ACC, PML>(d, run, tilesX, sS, accP, pkP);
+#else
     velocity_solid_body<ACC, PML>(d, run, tilesX, sS, accP, pkP);
+#endif
 }
 
 // placement probe (bfd_api.hip, choose_placement): two float32 arrays updated in place at the same cell offset along the
