@@ -263,7 +263,8 @@ class SlabRunner:
             self.step()
 
 
-def create_hip_slab(args, kwargs, rank, world, device, kernelVariant=0, local=None, host_staging=False, rmsFirstStep=0):
+def create_hip_slab(args, kwargs, rank, world, device, kernelVariant=0, local=None, host_staging=False, rmsFirstStep=0,
+                    placement_search_bytes=None):
     """Build the engine for this rank's slab from the same arguments the reference passes to
     StaggeredFDTD_3D_with_relaxation (BASE:2338-2365). Returns (HipSlab, info).
     local=(N3, k0, nk, gl, gh): the volumes in `args` are already this rank's slab (MaterialMap with
@@ -289,6 +290,8 @@ def create_hip_slab(args, kwargs, rank, world, device, kernelVariant=0, local=No
                          selMapsSensors=kwargs.get('SelMapsSensorsList', ('Pressure',)),
                          qfactorCorrection=kwargs.get('QfactorCorrection', True), device=device,
                          kernelVariant=kernelVariant, rmsFirstStep=rmsFirstStep)
+    if placement_search_bytes is not None:      # a caller that owns the device may let the placement search further (bfd_set_placement)
+        eng.set_placement(1, int(placement_search_bytes))
     eng.set_materials(ml, kwargs.get('QCorrection', 1.0))
     if local is None:
         view, gl, gh = material_slab(np.asarray(MaterialMap), k0, nk)

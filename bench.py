@@ -67,6 +67,7 @@ def parse():
     ap.add_argument('--lean-host', action='store_true', help='build the inputs slab-style (size-1 Ox/Oy/Oz) also at N=1')
     ap.add_argument('--cpu-sample', type=int, nargs=4, default=None, help='N1 N2 N3 steps of the oracle sample (default: the grid of the config itself, 56 steps, when the host has the memory; else 384 384 256 224)')
     ap.add_argument('--group-child', nargs=4, default=None, metavar=('CONFIG', 'N1', 'N2', 'N3'), help='internal: run ONE volume through bfd_group over --gpus devices and print its block (the parent bench starts this as a child process with a timeout)')
+    ap.add_argument('--placement-search-gib', type=float, default=190.0, help='throw-away device memory the placement of the arrays may hold while it looks for a buffer in another memory region (the bench owns the device; the library default is 64 GiB / half of the free memory / nothing on a shared device); < 0 = library default')
     ap.add_argument('--no-group', action='store_true', help='skip the one-process bfd_group figures (group_one_slab at N=1, group_strong_c3 under torchrun)')
     ap.add_argument('--no-next-rows', action='store_true', help='skip the Rayleigh / BHTE kernel rates (N=1, default workload only)')
     ap.add_argument('--no-extra-strong', action='store_true', help='N > 1: skip the extra block that splits ONE C5 volume (1024^3, 1 MHz) over the ranks')
@@ -211,8 +212,9 @@ class Workload:
         self.a, self.k, self.info, self.local = a, k, info, local
         # rmsFirstStep=1: the Pressure RMS accumulates in EVERY step (warm-up included); a production call accumulates
         # only over the last 2 periods (the sensors keep that window here)
+        search = None if (args.placement_search_gib < 0 or shared) else int(args.placement_search_gib * 2 ** 30)
         self.slab, self.sinfo = slab.create_hip_slab(a, k, rank, world, local_rank, kernelVariant=variant, local=local,
-                                                     host_staging=shared, rmsFirstStep=1)
+                                                     host_staging=shared, rmsFirstStep=1, placement_search_bytes=search)
         self.eng = self.slab.eng
         self._shared = shared
         self.runner = None
@@ -402,6 +404,8 @@ def group_run(args, config, N, ndev, dt_fn, steps, warmup, windows, variant, lab
         g.set_material_map(MaterialMap)
         g.set_sources(lin, row, wx, wy, wz, Pulse)
         g.set_sensor_map(SensorMap)
+        if args.placement_search_gib >= 0 and not emulated:       # every slab alone on its device: the search may go as far as at N = 1
+            g.set_placement(1, int(args.placement_search_gib * 2 ** 30))
         g.prepare()
         setup = time.time() - t0
         g.run(warmup)
@@ -470,7 +474,7 @@ def group_in_child(args, config, N, ndev, steps, warmup, timeout=900):
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'LOCAL_WORLD_SIZE', 'GROUP_RANK', 'ROLE_RANK',
                                                              'MASTER_ADDR', 'MASTER_PORT', 'TORCHELASTIC_RUN_ID', 'TORCH_NCCL_HIGH_PRIORITY')}
     cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(ndev), '--steps', str(steps), '--warmup', str(warmup), '--windows', '1',
-           '--variant', str(args.variant), '--group-child', config, str(N[0]), str(N[1]), str(N[2])]
+           '--variant', str(args.variant), '--placement-search-gib', str(args.placement_search_gib), '--group-child', config, str(N[0]), str(N[1]), str(N[2])]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
     if r.returncode != 0:
         return {'value': None, 'error': 'child exit code %d: %s' % (r.returncode, r.stderr[-400:])}
