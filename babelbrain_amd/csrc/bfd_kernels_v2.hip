@@ -1825,9 +1825,14 @@ __device__ __forceinline__ float ldv(const float *__restrict__ a, int N1, int N2
     return (i >= 0 && i < N1 && j >= 0 && j < N2) ? a[kofs + (long)j * N1 + i] : 0.0f;
 }
 
+// x / d for x < 2^31 and d >= 2 as a multiply-high and a shift (M = ceil(2^(31+L) / d), L = ceil(log2 d)): the three run-time integer
+// divisions of the cell index cost ~100 of this kernel's ~310 VALU instructions per thread
+struct FastDiv { unsigned M, s; };
+__device__ __forceinline__ unsigned fdiv(unsigned x, FastDiv f) { return __umulhi(x, f.M) >> f.s; }
+
 __global__ __launch_bounds__(256) void stress_shear_sparse(bfd_dev d, const unsigned *__restrict__ cells, const unsigned *__restrict__ codes,
                                                            const float *__restrict__ tab, const float *__restrict__ coef,
-                                                           float *__restrict__ Rc, long nTotal, long n)
+                                                           float *__restrict__ Rc, long nTotal, long n, FastDiv divN1, FastDiv divPlane)
 {
     // XCD e works through the e-th contiguous eighth of the list (order: shear_order_keys): the V values a cell gathers from its
     // row / plane neighbours were fetched by blocks just before it on the SAME XCD (its own L2)
@@ -1836,7 +1841,8 @@ __global__ __launch_bounds__(256) void stress_shear_sparse(bfd_dev d, const unsi
     const int N1 = d.N1, N2 = d.N2, P = d.P;
     const long pl = d.plane;
     const unsigned c = LDNT(cells + t);
-    const int i = (int)(c % (unsigned)N1), j = (int)((c / (unsigned)N1) % (unsigned)N2), kl = (int)(c / (unsigned)d.plane);
+    const unsigned ukl = fdiv(c, divPlane), rem = c - ukl * (unsigned)d.plane, uj = fdiv(rem, divN1);
+    const int i = (int)(rem - uj * (unsigned)N1), j = (int)uj, kl = (int)ukl;
     const long ko = (long)kl * pl;
     const int k = d.k0 + kl;
     // edge coefficients: from the per-material table where the four cells of the edge hold one material (most of a bone's
@@ -1855,13 +1861,24 @@ __global__ __launch_bounds__(256) void stress_shear_sparse(bfd_dev d, const unsi
         const unsigned q = (cw >> 16) & 255u;
         if (q == 255u) { Ayz = LDNT(coef + 6 * t + 4); Byz = LDNT(coef + 6 * t + 5); } else if (q) { Ayz = tab[2 * (q - 1)]; Byz = tab[2 * (q - 1) + 1]; }
     }
-    const float vx0 = d.Vx[c], vy0 = d.Vy[c], vz0 = d.Vz[c];
-    float dyVx = dplus4(ldv(d.Vx, N1, N2, i, j - 1, ko), vx0, ldv(d.Vx, N1, N2, i, j + 1, ko), ldv(d.Vx, N1, N2, i, j + 2, ko));
-    float dxVy = dplus4(ldv(d.Vy, N1, N2, i - 1, j, ko), vy0, ldv(d.Vy, N1, N2, i + 1, j, ko), ldv(d.Vy, N1, N2, i + 2, j, ko));
-    float dzVx = dplus4(d.Vx[c - pl], vx0, d.Vx[c + pl], d.Vx[c + 2 * pl]);
-    float dxVz = dplus4(ldv(d.Vz, N1, N2, i - 1, j, ko), vz0, ldv(d.Vz, N1, N2, i + 1, j, ko), ldv(d.Vz, N1, N2, i + 2, j, ko));
-    float dzVy = dplus4(d.Vy[c - pl], vy0, d.Vy[c + pl], d.Vy[c + 2 * pl]);
-    float dyVz = dplus4(ldv(d.Vz, N1, N2, i, j - 1, ko), vz0, ldv(d.Vz, N1, N2, i, j + 1, ko), ldv(d.Vz, N1, N2, i, j + 2, ko));
+    // the 21 velocities: wave-uniform bases + one 32-bit byte offset (c < 2^30); a cell whose stencil stays inside the domain in x and y
+    // (all but the cells on the outermost two rows / columns) takes them without a test per value
+    const unsigned c4 = c * 4u, r4 = (unsigned)N1 * 4u;
+    const float vx0 = F4(d.Vx, c4), vy0 = F4(d.Vy, c4), vz0 = F4(d.Vz, c4);
+    float dyVx, dxVy, dxVz, dyVz;
+    if (i >= 1 && i + 2 < N1 && j >= 1 && j + 2 < N2) {
+        dyVx = dplus4(F4(d.Vx, c4 - r4), vx0, F4(d.Vx, c4 + r4), F4(d.Vx, c4 + 2 * r4));
+        dxVy = dplus4(F4(d.Vy, c4 - 4u), vy0, F4(d.Vy, c4 + 4u), F4(d.Vy, c4 + 8u));
+        dxVz = dplus4(F4(d.Vz, c4 - 4u), vz0, F4(d.Vz, c4 + 4u), F4(d.Vz, c4 + 8u));
+        dyVz = dplus4(F4(d.Vz, c4 - r4), vz0, F4(d.Vz, c4 + r4), F4(d.Vz, c4 + 2 * r4));
+    } else {
+        dyVx = dplus4(ldv(d.Vx, N1, N2, i, j - 1, ko), vx0, ldv(d.Vx, N1, N2, i, j + 1, ko), ldv(d.Vx, N1, N2, i, j + 2, ko));
+        dxVy = dplus4(ldv(d.Vy, N1, N2, i - 1, j, ko), vy0, ldv(d.Vy, N1, N2, i + 1, j, ko), ldv(d.Vy, N1, N2, i + 2, j, ko));
+        dxVz = dplus4(ldv(d.Vz, N1, N2, i - 1, j, ko), vz0, ldv(d.Vz, N1, N2, i + 1, j, ko), ldv(d.Vz, N1, N2, i + 2, j, ko));
+        dyVz = dplus4(ldv(d.Vz, N1, N2, i, j - 1, ko), vz0, ldv(d.Vz, N1, N2, i, j + 1, ko), ldv(d.Vz, N1, N2, i, j + 2, ko));
+    }
+    float dzVx = dplus4(F4(d.Vx - pl, c4), vx0, F4(d.Vx + pl, c4), F4(d.Vx + 2 * pl, c4));
+    float dzVy = dplus4(F4(d.Vy - pl, c4), vy0, F4(d.Vy + pl, c4), F4(d.Vy + 2 * pl, c4));
     if (i < P || i >= N1 - P) {
         const int xi = i < P ? i : i - (N1 - 2 * P);
         const unsigned q = (unsigned)((kl * N2 + j) * (2 * P) + xi);
@@ -2195,8 +2212,11 @@ void bfd_launch_stress_v2(const bfd_dev &d, hipStream_t s0, const bfd_tiles *t, 
         else if (part == 2) { b0 = t->shearLowEnd; e0 = t->shearHighBeg; }
         BFD_KT(BFD_K_STRESS_SHEAR, 0);
         float *R0 = t->shearR ? t->shearR + b0 : nullptr, *R1 = t->shearR ? t->shearR + b1 : nullptr;
-        if (e0 > b0) hipLaunchKernelGGL(stress_shear_sparse, dim3((unsigned)((e0 - b0 + 255) / 256)), dim3(256), 0, s, d, t->shearCells + b0, t->shearCodes + b0, t->shearTab, t->shearCoef + 6 * b0, R0, t->nShear, e0 - b0);
-        if (e1 > b1) hipLaunchKernelGGL(stress_shear_sparse, dim3((unsigned)((e1 - b1 + 255) / 256)), dim3(256), 0, s, d, t->shearCells + b1, t->shearCodes + b1, t->shearTab, t->shearCoef + 6 * b1, R1, t->nShear, e1 - b1);
+        auto magic = [](unsigned dv) { FastDiv f; unsigned L = 0; while ((1ull << L) < dv) L++; if (L == 0) L = 1;
+                                       f.M = (unsigned)(((1ull << (31 + L)) + dv - 1) / dv); f.s = L - 1; return f; };
+        const FastDiv dN1 = magic((unsigned)d.N1), dPl = magic((unsigned)d.plane);
+        if (e0 > b0) hipLaunchKernelGGL(stress_shear_sparse, dim3((unsigned)((e0 - b0 + 255) / 256)), dim3(256), 0, s, d, t->shearCells + b0, t->shearCodes + b0, t->shearTab, t->shearCoef + 6 * b0, R0, t->nShear, e0 - b0, dN1, dPl);
+        if (e1 > b1) hipLaunchKernelGGL(stress_shear_sparse, dim3((unsigned)((e1 - b1 + 255) / 256)), dim3(256), 0, s, d, t->shearCells + b1, t->shearCodes + b1, t->shearTab, t->shearCoef + 6 * b1, R1, t->nShear, e1 - b1, dN1, dPl);
         BFD_KT(BFD_K_STRESS_SHEAR, 1);
     }
     if (n) {
