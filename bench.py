@@ -663,13 +663,24 @@ def main():
     if world > 1 and not args.no_group:
         # the path the reference's caller gets (one process, one call): ONE 512^3 C3 volume split over the N devices through
         # bfd_group_*, run by rank 0 after every rank has released its slabs; the other ranks wait at the barrier below
+        # the other ranks wait on a CPU-side (gloo) barrier: a rank waiting in an RCCL barrier keeps a kernel spinning on its GPU,
+        # beside the child's measurement
+        cpu_group = None
+        try:
+            os.environ.setdefault('GLOO_SOCKET_IFNAME', 'lo')
+            cpu_group = dist.new_group(backend='gloo') if dist.get_backend() != 'gloo' else dist.group.WORLD
+        except Exception:
+            cpu_group = None
         dist.barrier()
+        torch.cuda.synchronize()
         if rank == 0:
             try:
-                line['group_strong_c3'] = group_in_child(args, 'C3', H.CONFIGS['C3']['N'], world, args.steps, min(args.warmup, 20))
+                line['group_strong_c3'] = group_in_child(args, 'C3', H.CONFIGS['C3']['N'], world, args.steps, min(args.warmup, 20), timeout=420)
                 line['group_strong_c3']['label'] = 'strong scaling of the metric config through the drop-in path: a child process of rank 0 drives all devices'
             except Exception as e:
                 line['group_strong_c3'] = {'value': None, 'error': repr(e)}
+        if cpu_group is not None:
+            dist.barrier(group=cpu_group)
     if world == 1 and not args.no_group and args.config == 'C3' and not args.size:
         try:       # the same workload through the one-process group path with one slab: SCALE N=1 on both paths
             line['group_one_slab'] = group_run(args, 'C3', dims, 1, dt_fn, args.steps, args.warmup, 1, args.variant, 'one slab through bfd_group_*')
