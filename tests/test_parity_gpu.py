@@ -289,7 +289,7 @@ def test_graph_replay_equals_direct_launches(monkeypatch):
                 assert np.array_equal(x, y)
 
 
-@pytest.mark.parametrize('config', ['C1', 'C1-lossy', 'C2', 'C3', 'C3-lossless'])
+@pytest.mark.parametrize('config', ['C1', 'C1-lossy', 'C2', 'C3', 'C3-lossless', 'C3-peak', 'C1-rms'])
 def test_fused_fluid_step_variant4(config):
     """kernelVariant 4: eligible fluid runs (64 x 24 cells, bfd_kernels_fused.hip) advance both half-steps in one pass over
     two copies of V, Szz, Rzz; everything else runs the variant-3 kernels out of place. Outputs and raw fields must equal
@@ -307,9 +307,9 @@ def test_fused_fluid_step_variant4(config):
         a = list(a); ml = np.array(a[1], np.float64); ml[:, 3:] = 0.0; a[1] = ml; a = tuple(a)
     k['SelMapsRMSPeakList'] = ['Pressure', 'Vx', 'Vz']
     k['SelMapsSensorsList'] = ['Pressure', 'Vy']
-    k['SelRMSorPeak'] = 3
+    k['SelRMSorPeak'] = {'C3-peak': 2, 'C1-rms': 1}.get(config, 3)      # the fused body has a flavour per accumulation mode (sums / peaks / both)
     oh, orf = run_both(a, k, 4)
-    compare_runs(oh, orf, TOL, both=True)
+    compare_runs(oh, orf, TOL, both=(k['SelRMSorPeak'] == 3))
     assert orf[2]['Pressure'].max() > 0
     mm, ml, f, smap, pulse, h, T, sensor = a
     N1, N2, N3 = mm.shape
