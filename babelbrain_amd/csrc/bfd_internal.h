@@ -37,7 +37,9 @@
 #define BFD_SUBZ 8
 #endif
 // output rows of a workgroup of the fused time step (bfd_kernels_fused.hip): three tiles of the classification grid
+#ifndef BFD_FUSED_ROWS
 #define BFD_FUSED_ROWS 24
+#endif
 // multi-material runs of the fused time step keep AP, BP, 1/rho of every material in LDS: media with more materials fuse only their one-material runs
 #define BFD_FUSED_MAX_MATERIALS 1024
 

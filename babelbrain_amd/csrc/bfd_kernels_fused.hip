@@ -35,7 +35,10 @@ constexpr int FR_W = FT_X + 3, FR_H = FT_Y + 3;         // region of the new str
 constexpr int FP = FR_W + 3;                            // LDS pitch 70: column t <-> x = i0-3+t (Vx needs x-2 .. x+1 of every region cell)
 constexpr int FS_N = FR_H * FP;                         // Vx, new-stress and 1/rho tiles: region rows
 constexpr int FVY_N = (FR_H + 3) * FP;                  // Vy tile: rows u <-> y = j0-3+u
-constexpr int NT = 512, CPT = 4;
+#ifndef FUSED_CPT
+#define FUSED_CPT 4
+#endif
+constexpr int NT = 512, CPT = FUSED_CPT;       // region cells per thread
 constexpr int RSTEP = (FR_H + CPT - 1) / CPT;           // 7: thread (r, col) owns the region cells (r + 7 c, col), c = 0 .. 3
 constexpr int NCELLT = RSTEP * FR_W;                    // 469 threads hold cells
 static_assert(NCELLT <= NT && RSTEP * CPT >= FR_H, "four region cells per thread");
