@@ -60,6 +60,7 @@ def parse():
     ap.add_argument('--variant', type=int, default=0, help='kernel variant (0 default, 1 simple, 2 LDS-tiled dense, 4 fused fluid step)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-shear-workload', action='store_true', help='skip the C2-medium (viscoelastic) block at N=1')
+    ap.add_argument('--no-production-schedule', action='store_true', help='skip the block that times the steps before the RMS window (N=1)')
     ap.add_argument('--no-kernel-pass', action='store_true', help='skip the per-kernel timing pass (roofline then covers half-steps only)')
     ap.add_argument('--dense-reference', action='store_true', help='also time the dense kernels (variant 2) at N=1')
     ap.add_argument('--no-steady-warmup', action='store_true', help='do exactly W warm-up steps (default: at least W, and enough for %.2f s of load)' % STEADY_SECONDS)
@@ -180,7 +181,7 @@ class Workload:
     """One slab engine per rank for a config, with the two timing passes of the bench."""
 
     def __init__(self, args, config, dims, scaling, rank, world, local_rank, dist, dt_fn, steps, warmup, variant, full_sensors=True,
-                 connect=True):
+                 connect=True, rms_first_step=1):
         import torch
         from babelbrain_amd import harness as H, slab, RayleighAndBHTE
         self.torch, self.dist, self.rank, self.world = torch, dist, rank, world
@@ -211,10 +212,10 @@ class Workload:
         self.host_build_s = time.time() - t0
         self.a, self.k, self.info, self.local = a, k, info, local
         # rmsFirstStep=1: the Pressure RMS accumulates in EVERY step (warm-up included); a production call accumulates
-        # only over the last 2 periods (the sensors keep that window here)
+        # only over the last 2 periods (the sensors keep that window here; `production_schedule` times the steps before it)
         search = None if (args.placement_search_gib < 0 or shared) else int(args.placement_search_gib * 2 ** 30)
         self.slab, self.sinfo = slab.create_hip_slab(a, k, rank, world, local_rank, kernelVariant=variant, local=local,
-                                                     host_staging=shared, rmsFirstStep=1, placement_search_bytes=search)
+                                                     host_staging=shared, rmsFirstStep=rms_first_step, placement_search_bytes=search)
         self.eng = self.slab.eng
         self._shared = shared
         self.runner = None
@@ -698,6 +699,25 @@ def main():
             ws.close()
         except Exception as e:
             line['shear_workload'] = {'value': None, 'error': repr(e)}
+    if world == 1 and not args.no_production_schedule and args.variant in (0, 3) and args.config == 'C3' and not args.size:
+        # what ONE production call of the reference's caller spends its steps on: nt steps of the config's time plan
+        # (BASE:2082-2109), the Pressure RMS accumulated over the last 2 periods only. `value` above prices every step as an
+        # accumulating one; here the steps before the window are timed too and the two rates are weighted by the plan.
+        try:
+            wp = Workload(args, args.config, dims, 'weak', 0, 1, local_rank, None, dt_fn, args.steps, args.warmup, args.variant,
+                          rms_first_step=2 ** 30)
+            wall, tm = wp.timed()
+            nt_plan, n_acc = wp.info['plan_nt'], wp.info['plan_accumulating_steps']
+            t_acc, t_no = res['ms_per_step'], wall / wp.steps * 1e3
+            mix = wp.total_vox * nt_plan / ((n_acc * t_acc + (nt_plan - n_acc) * t_no) * 1e-3) / 1e6
+            line['production_schedule'] = {'note': 'one call of the reference\'s caller at this config: %d steps, Pressure RMS accumulated in the last %d '
+                                                   '(2 periods); `value` above accumulates in every step' % (nt_plan, n_acc),
+                                           'steps_before_the_window': {'value': wp.total_vox * wp.steps / wall / 1e6, 'unit': 'Mvoxel-steps/s', 'ms_per_step': t_no,
+                                                                       'windows_ms_per_step': [x / wp.steps * 1e3 for x in wp.window_walls]},
+                                           'whole_call_weighted': {'value': mix, 'unit': 'Mvoxel-steps/s'}}
+            wp.close()
+        except Exception as e:
+            line['production_schedule'] = {'value': None, 'error': repr(e)}
     if world == 1 and args.dense_reference and args.variant in (0, 3):
         try:
             wd = Workload(args, args.config, dims, args.scaling, 0, 1, local_rank, None, dt_fn, args.steps, args.warmup, 2)
