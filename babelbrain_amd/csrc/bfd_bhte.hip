@@ -175,6 +175,171 @@ __global__ __launch_bounds__(B2_T) void bhte_step2(B2_ARGS)
     }
     bhte_step2_body<REV>(b, Tin, Tout, dose, qa, qb, mat, cd, cp, nMat, N1, N2, N3, Tcore, dtMin, zrun, tilesX, tilesY, nBlocks, xcdOrder);
 }
+
+// ---- round 4: the same two steps with loads that stay in flight (bhte_step2g, the default; BFD_BHTE_KERNEL=1 selects bhte_step2) ----
+// What the ISA of bhte_step2 shows: its loads are FLAT instructions -- they count on lgkmcnt as well, so every wait for an LDS read
+// drains them -- and the material id and heat source of every cell are loaded inside that cell's branch and waited for at once:
+// five to eight exposed memory round trips per plane, 71 VALU instructions per cell of which a third is address arithmetic, flag tests
+// and queue rotation. Here:
+//   * GLOBAL (saddr) loads: wave-uniform plane base in SGPRs + ONE 32-bit byte offset per thread. The region is 68 x 28 (outputs
+//     64 x 24) so that a thread's four cells are rows r, r+7, r+14, r+21 of one column: the same offset register serves all of them
+//     (the row stride goes into the scalar base), one LDS index with constant displacements;
+//   * no branch around a load: the arrays carry pads in front and behind (bhte_run_core), so every cell of the region is
+//     addressable whether it lies in the volume or not; what must not be used is masked by the per-cell flags when it is USED;
+//   * T(n) of plane p+2, id and heat source of plane p+1 are issued in the MIDDLE of iteration p, after the first update has
+//     consumed the registers they replace (no extra registers), and fly through the second update, the stores and the barrier; the
+//     dose of plane p-1 is issued at the top and flies through the first update;
+//   * the plane loop is unrolled three times with the queue slots as compile-time constants (no register moves).
+constexpr int G2_W = 68, G2_H = 28, G2_TY = G2_H - 4, G2_T = 512, G2_NC = 4, G2_ROWS = 7, G2_ACT = G2_ROWS * G2_W, G2_CELLS = G2_W * G2_H;
+#define BFD_GA __attribute__((address_space(1)))
+template <typename T> __device__ __forceinline__ BFD_GA const T *gbase(const T *p)
+{
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (BFD_GA const T *)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ unsigned gpin(unsigned v) { asm("" : "+v"(v)); return v; }
+__device__ __forceinline__ float gl4(const float *b, unsigned ofs) { return *(BFD_GA const float *)((BFD_GA const char *)gbase(b) + ofs); }
+__device__ __forceinline__ unsigned gl1(const unsigned char *b, unsigned ofs) { return *(BFD_GA const unsigned char *)((BFD_GA const unsigned char *)gbase(b) + ofs); }
+__device__ __forceinline__ void gs4(float *b, unsigned ofs, float v) { *(BFD_GA float *)((BFD_GA char *)gbase((const float *)b) + ofs) = v; }
+template <int K> struct Ph3 { static constexpr int v = K; };
+
+// QM: 0 no heating in either step, 1 the same heat source in both, 2 anything else (qa / qb independent, either may be null)
+template <bool REV, int QM>
+__device__ __forceinline__ void bhte_step2g_body(int b, B2_ARGS)
+{
+    // one row of margin before and behind each tile: the ring cells read "neighbours" there (never used)
+    __shared__ float A[2][G2_CELLS + 2 * G2_W], B[2][G2_CELLS + 2 * G2_W];
+    __shared__ float2 sC[256];
+    for (int m = threadIdx.x; m < nMat; m += G2_T) sC[m] = make_float2(cd[m], cp[m]);
+#ifdef G2_EXP_LDS_PAD      // experiment: fewer workgroups per CU
+    __shared__ float sPad[G2_EXP_LDS_PAD];
+    if (nMat < 0) { sPad[threadIdx.x] = 1.f; sC[0].x = sPad[(threadIdx.x + 1) % 512]; }
+#endif
+    // 476 threads own the 4 x 476 region cells; the last 36 repeat the work of threads 0..35 without storing (same LDS values)
+    const bool mirror = threadIdx.x >= G2_ACT;
+    const int tid = mirror ? threadIdx.x - G2_ACT : threadIdx.x;
+    const int bx = b % tilesX, by = (b / tilesX) % tilesY, bz = b / (tilesX * tilesY);
+    const int x0 = bx * 64 - 2, y0 = by * G2_TY - 2, z0 = bz * zrun, z1 = min(z0 + zrun, N3);
+    const long pl = (long)N1 * N2;
+    const int r = tid / G2_W, rx = tid - r * G2_W, e0 = tid + G2_W;
+    // byte offsets of the thread's cells from the region's corner: one VGPR per cell, so that an array needs one scalar base per plane
+    unsigned g[G2_NC];
+    #pragma unroll
+    for (int n = 0; n < G2_NC; n++) g[n] = 4u * (unsigned)((r + G2_ROWS * n) * N1 + rx);
+    // scalar address parts (cells): the region's corner inside a plane (may lie in the pads) and the row stride between a thread's cells
+    const int corner = __builtin_amdgcn_readfirstlane(y0 * N1 + x0);
+    // per cell: inside the volume / T(n+1) computed here / output cell / on an x or y face (loop-invariant lane masks)
+    bool fC1[G2_NC], fOut[G2_NC], fFace[G2_NC];
+    #pragma unroll
+    for (int n = 0; n < G2_NC; n++) {
+        const int ry = r + G2_ROWS * n, gi = x0 + rx, gj = y0 + ry;
+        const bool in = gi >= 0 && gi < N1 && gj >= 0 && gj < N2;
+        const bool face = gi == 0 || gi == N1 - 1 || gj == 0 || gj == N2 - 1;
+        fC1[n] = in && !face && rx >= 1 && rx <= G2_W - 2 && ry >= 1 && ry <= G2_H - 2;
+        fOut[n] = in && !mirror && rx >= 2 && rx <= G2_W - 3 && ry >= 2 && ry <= G2_H - 3;
+        fFace[n] = in && face;
+    }
+    auto clampz = [&](int k) { return (long)__builtin_amdgcn_readfirstlane(min(max(k, 0), N3 - 1)) * pl + corner; };
+    const bool heatA = QM == 1 || (QM == 2 && qa != nullptr), heatB = QM == 1 || (QM == 2 && qb != nullptr);
+    const float *qaE = heatA ? qa : Tin, *qbE = heatB ? qb : Tin;                 // a valid address whatever the mode
+
+    // queues, slot = (plane + const) mod 3: t0 = T(n) of planes p-1, p, p+1; t1 = T(n+1) of planes p-2, p-1, p; mi / qv = id and heat
+    // source of planes p-1, p, p+1
+    float t0[G2_NC][3], t1[G2_NC][3], qv[G2_NC][3];
+    unsigned mi[G2_NC][3];
+    const int p0 = z0 - 1;
+    #pragma unroll
+    for (int n = 0; n < G2_NC; n++) {
+        asm volatile("" : "+v"(g[n]));
+        const unsigned gp = g[n];
+        // phase 0 of the first iteration: planes p0-1, p0, p0+1 in slots 2, 0, 1
+        t0[n][2] = gl4(Tin + clampz(p0 - 1), gp);
+        t0[n][0] = gl4(Tin + clampz(p0), gp);
+        t0[n][1] = gl4(Tin + clampz(p0 + 1), gp);
+        mi[n][0] = gl1(mat + clampz(p0), gp >> 2);
+        qv[n][0] = QM ? gl4(qaE + clampz(p0), gp) : 0.0f;
+        t1[n][0] = t1[n][1] = t1[n][2] = 0.0f; mi[n][1] = mi[n][2] = 0u; qv[n][1] = qv[n][2] = 0.0f;
+    }
+    __syncthreads();                                  // the coefficient table
+
+    auto plane = [&](auto PH, const int p) {
+        constexpr int c = decltype(PH)::v, m1 = (c + 2) % 3, p1 = (c + 1) % 3;      // slots of planes p, p-1, p+1 (t1: p-2 lives in p1)
+        const int par = p & 1;
+        float *Ap = A[par], *Bp = B[par]; const float *Bq = B[par ^ 1];
+        const bool outs = p - 1 >= z0 && p - 1 < z1;
+        const bool inner = p > 0 && p < N3 - 1, innerOut = p - 1 > 0 && p - 1 < N3 - 1;
+        const long kO = clampz(p - 1);                                              // the plane of this iteration's outputs
+        float dz[G2_NC], q2[G2_NC];
+        // the offsets become values of THIS block (asm on the loop-carried registers themselves, no copy): hoisted out of the loop
+        // their zero-extensions would turn into 64-bit VGPR addresses
+        #pragma unroll
+        for (int n = 0; n < G2_NC; n++) asm volatile("" : "+v"(g[n]));
+        #pragma unroll
+        for (int n = 0; n < G2_NC; n++) {
+            dz[n] = gl4(dose + kO, g[n]);
+            q2[n] = QM == 2 ? gl4(qbE + kO, g[n]) : 0.0f;
+            Ap[e0 + n * G2_ACT] = t0[n][c];
+        }
+        __syncthreads();
+        // ---- first update: T(n+1) of plane p ----
+        #pragma unroll
+        for (int n = 0; n < G2_NC; n++) {
+            const int e = e0 + n * G2_ACT;
+            const float2 cc = sC[mi[n][c]];
+            float T1 = bhte_update<REV>(t0[n][c], Ap[e - 1], Ap[e + 1], Ap[e - G2_W], Ap[e + G2_W], t0[n][m1], t0[n][p1], cc.x, cc.y, Tcore, heatA, qv[n][c]);
+#ifndef G2_BRANCHY
+            asm volatile("" : "+v"(T1));            // computed by every lane: no branch around the update (the select below masks it)
+#endif
+            t1[n][c] = (inner && fC1[n]) ? T1 : t0[n][c];
+            Bp[e] = t1[n][c];
+        }
+        // ---- what the next iteration's first update needs: T(n) of plane p+2 replaces plane p-1, id and heat source of plane p+1 ----
+        const long kN = clampz(p + 1), kNN = clampz(p + 2);
+        #pragma unroll
+        for (int n = 0; n < G2_NC; n++) {
+            mi[n][p1] = gl1(mat + kN, g[n] >> 2);
+            if (QM) qv[n][p1] = gl4(qaE + kN, g[n]);
+            t0[n][m1] = gl4(Tin + kNN, g[n]);
+        }
+        // ---- second update: T(n+2) of plane p-1, dose ----
+        if (outs) {
+            #pragma unroll
+            for (int n = 0; n < G2_NC; n++) {
+                const int e = e0 + n * G2_ACT;
+                const float2 cc = sC[mi[n][m1]];
+                const float qq = QM == 1 ? qv[n][m1] : q2[n];
+                float U = bhte_update<REV>(t1[n][m1], Bq[e - 1], Bq[e + 1], Bq[e - G2_W], Bq[e + G2_W], t1[n][p1], t1[n][c], cc.x, cc.y, Tcore, heatB, qq);
+#ifndef G2_BRANCHY
+                asm volatile("" : "+v"(U));
+#endif
+                const float T2 = (innerOut && !fFace[n]) ? U : t1[n][m1];
+                if (fOut[n]) {
+                    gs4(Tout + kO, g[n], T2);
+                    gs4(dose + kO, g[n], __fadd_rn(__fadd_rn(dz[n], bhte_dose_rate(t1[n][m1], dtMin)), bhte_dose_rate(T2, dtMin)));
+                }
+            }
+        }
+    };
+    int p = p0;
+    for (; p + 2 <= z1; p += 3) { plane(Ph3<0>(), p); plane(Ph3<1>(), p + 1); plane(Ph3<2>(), p + 2); }
+    if (p <= z1) plane(Ph3<0>(), p);
+    if (p + 1 <= z1) plane(Ph3<1>(), p + 1);
+}
+
+#ifndef G2_WAVES
+#define G2_WAVES 6           // waves per SIMD the register budget is held to (6: 80 VGPRs, three workgroups per CU)
+#endif
+template <bool REV, int QM>
+__global__ __launch_bounds__(G2_T, G2_WAVES) void bhte_step2g(B2_ARGS)
+{
+    int b = blockIdx.x;
+    if (xcdOrder) {
+        const int per = nBlocks >> 3, rem = nBlocks & 7, x = b & 7, slot = b >> 3;
+        b = x * per + (x < rem ? x : rem) + slot;
+    }
+    bhte_step2g_body<REV, QM>(b, Tin, Tout, dose, qa, qb, mat, cd, cp, nMat, N1, N2, N3, Tcore, dtMin, zrun, tilesX, tilesY, nBlocks, xcdOrder);
+}
 // Monitors of the first of two fused steps: T(n+1) at the listed voxels / on the monitored plane, computed from T(n)
 template <bool REV>
 __global__ void step_points(const float *__restrict__ Tin, const float *__restrict__ q, const unsigned char *__restrict__ mat,
@@ -259,11 +424,18 @@ static int bhte_run_core(int32_t device, int32_t F, int32_t M, int32_t S, int32_
     unsigned char *dmat = nullptr; unsigned *dIdx = nullptr;
     std::vector<void *> allocs;
     auto A = [&](void **p, size_t bytes) { hipError_t e = hipMalloc(p, bytes ? bytes : 1); if (e == hipSuccess) allocs.push_back(*p); return e; };
-    hipError_t e = A((void **)&dT[0], n * 4);
-    if (e == hipSuccess) e = A((void **)&dT[1], n * 4);
-    if (e == hipSuccess) e = A((void **)&dDose, n * 4);
-    if (e == hipSuccess) e = A((void **)&dq, n * 4 * (size_t)nFields);
-    if (e == hipSuccess) e = A((void **)&dmat, n);
+    // the volumes carry pads (elements): bhte_step2g addresses every cell of its 68 x 28 regions, also those that hang over the faces
+    const size_t padF = (((size_t)2 * N1 + 64 + 255) / 256) * 256, padB = (size_t)49 * N1 + 256;
+    auto AP = [&](void **p, size_t elems, size_t elemBytes) {
+        void *raw = nullptr; const hipError_t e = A(&raw, (padF + elems + padB) * elemBytes);
+        if (e == hipSuccess) *p = (char *)raw + padF * elemBytes;
+        return e;
+    };
+    hipError_t e = AP((void **)&dT[0], n, 4);
+    if (e == hipSuccess) e = AP((void **)&dT[1], n, 4);
+    if (e == hipSuccess) e = AP((void **)&dDose, n, 4);
+    if (e == hipSuccess) e = AP((void **)&dq, n * (size_t)nFields, 4);
+    if (e == hipSuccess) e = AP((void **)&dmat, n, 1);
     if (e == hipSuccess) e = A((void **)&dcd, nMat * 4);
     if (e == hipSuccess) e = A((void **)&dcp, nMat * 4);
     if (e == hipSuccess) e = A((void **)&dqf, nMat * 4);
@@ -304,10 +476,23 @@ static int bhte_run_core(int32_t device, int32_t F, int32_t M, int32_t S, int32_
         // ~2900 workgroups (768 fit the chip at once). Measured at 384^3 (profiles/r3/bhte_two_steps_per_launch.txt): runs of 8 / 12 /
         // 16 / 24 planes -> 381 / 400 / 372 / 365 Gvoxel-steps/s; 372-378 -> 386-389 with the XCD-contiguous order; not kept: loads
         // issued a plane ahead, 8 waves/SIMD, items handed out at run time to resident workgroups (81 VGPRs: 320)
-        const int tilesX = (N1 + 63) / 64, tilesY = (N2 + B2_TY - 1) / B2_TY;
+        ev = getenv("BFD_BHTE_KERNEL");
+        const bool gform = !(ev && atoi(ev) == 1);                               // 1: the round-3 kernel (bhte_step2, 64 x 26 tiles)
+        const int tileY = gform ? G2_TY : B2_TY;
+        const int tilesX = (N1 + 63) / 64, tilesY = (N2 + tileY - 1) / tileY;
         ev = getenv("BFD_BHTE_ZRUN");
         int zrun = (ev && atoi(ev) > 0) ? atoi(ev) : 0;
-        if (!zrun) { const int runs = (2880 + tilesX * tilesY - 1) / (tilesX * tilesY); zrun = (N3 + runs - 1) / runs; zrun = zrun < 8 ? 8 : zrun > 24 ? 24 : zrun; }
+        if (!zrun && !gform) { const int runs = (2880 + tilesX * tilesY - 1) / (tilesX * tilesY); zrun = (N3 + runs - 1) / runs; zrun = zrun < 8 ? 8 : zrun > 24 ? 24 : zrun; }
+        // bhte_step2g runs at the memory system's rate with one to three workgroups per CU alike (profiles/r4/bhte_two_step_kernel_rewrite.txt),
+        // so a CU's time is the number of workgroups it gets times the planes each of them marches (its run + 2): pick the run length
+        // that minimises ceil(workgroups / 256) x (zrun + 2). The measured order of run lengths follows this count at 256^3, 384^3 and 512^3.
+        if (!zrun) {
+            long best = -1;
+            for (int z = 8; z <= 64; z++) {
+                const long w = (long)tilesX * tilesY * ((N3 + z - 1) / z), cost = ((w + 255) / 256) * (z + 2);
+                if (best < 0 || cost <= best) { best = cost; zrun = z; }
+            }
+        }
         ev = getenv("BFD_BHTE_XCD_ORDER");
         const int xcdOrder = (ev && atoi(ev) == 0) ? 0 : 1;
         const int runsZ = (N3 + zrun - 1) / zrun;
@@ -322,8 +507,11 @@ static int bhte_run_core(int32_t device, int32_t F, int32_t M, int32_t S, int32_
                 const float *qa = Q(fieldOfStep[s]), *qb = Q(fieldOfStep[s + 1]);
                 if (dPts) hipLaunchKernelGGL(step_points<REV>, dim3((unsigned)((nPoints + 255) / 256)), dim3(256), 0, 0, dT[cur], qa, dmat, dcd, dcp, N1, N2, N3, Tcore, dIdx, dPts, (long)nPoints, (long)nSteps, (long)s);
                 if (dSlice && s % fm == 0) hipLaunchKernelGGL(step_slice<REV>, dim3(256), dim3(256), 0, 0, dT[cur], qa, dmat, dcd, dcp, N1, N2, N3, Tcore, dSlice, sliceJ, (long)(s / fm), nSamples);
-                hipLaunchKernelGGL(bhte_step2<REV>, dim3((unsigned)nBlocks2), dim3(B2_T), 0, 0, dT[cur], dT[1 - cur], dDose, qa, qb, dmat, dcd, dcp, nMat, N1, N2, N3, Tcore, dtMin,
-                                   zrun, tilesX, tilesY, (int)nBlocks2, xcdOrder);
+#define B2G_LAUNCH(QM) hipLaunchKernelGGL((bhte_step2g<REV, QM>), dim3((unsigned)nBlocks2), dim3(G2_T), 0, 0, dT[cur], dT[1 - cur], dDose, qa, qb, dmat, dcd, dcp, nMat, N1, N2, N3, \
+                                          Tcore, dtMin, zrun, tilesX, tilesY, (int)nBlocks2, xcdOrder)
+                if (gform) { if (!qa && !qb) B2G_LAUNCH(0); else if (qa == qb) B2G_LAUNCH(1); else B2G_LAUNCH(2); }
+                else hipLaunchKernelGGL(bhte_step2<REV>, dim3((unsigned)nBlocks2), dim3(B2_T), 0, 0, dT[cur], dT[1 - cur], dDose, qa, qb, dmat, dcd, dcp, nMat, N1, N2, N3, Tcore, dtMin,
+                                        zrun, tilesX, tilesY, (int)nBlocks2, xcdOrder);
                 cur = 1 - cur; s += 2;
                 monitors(s - 1);
             } else {

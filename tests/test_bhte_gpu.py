@@ -130,9 +130,10 @@ def test_multiple_pressure_fields_schedule_and_oracle():
 
 
 def test_two_steps_per_launch_equal_one_step_per_launch(monkeypatch):
-    """The default path takes two steps per launch (bhte_step2: z-marching tiles of 64 x 26 cells with two rings); the
-    temperature, the dose and every monitor must have the bits of the one-step kernel, on grids that do not fill the tiles,
-    with odd step counts, with the field changing between the two fused steps, and with monitors on intermediate steps."""
+    """The default path takes two steps per launch (bhte_step2g: z-marching tiles of 64 x 24 cells with two rings, loads in
+    flight across the plane; BFD_BHTE_KERNEL=1: the round-3 kernel bhte_step2 on 64 x 26 tiles); the temperature, the dose and
+    every monitor must have the bits of the one-step kernel, on grids that do not fill the tiles, with odd step counts, with
+    the field changing between the two fused steps, and with monitors on intermediate steps."""
     from babelbrain_amd import RayleighAndBHTE as R
     rng = np.random.default_rng(11)
     ml = _materials()
@@ -143,14 +144,17 @@ def test_two_steps_per_launch_equal_one_step_per_launch(monkeypatch):
         mpm = np.zeros(N, np.uint32); mpm[1, 1, 1] = 1; mpm[N[0] // 2, N[1] // 2, N[2] // 2] = 2; mpm[N[0] - 1, N[1] - 2, 0] = 3
         T0 = (37.0 + 8.0 * rng.random(N)).astype(np.float32)                 # some cells above 43: both dose bases
         out = {}
-        for fuse in ('1', '0'):
+        for fuse, kernel in (('1', '0'), ('1', '1'), ('0', '0')):
             monkeypatch.setenv('BFD_BHTE_FUSE', fuse)
+            monkeypatch.setenv('BFD_BHTE_KERNEL', kernel)
             if zrun: monkeypatch.setenv('BFD_BHTE_ZRUN', zrun)
             else: monkeypatch.delenv('BFD_BHTE_ZRUN', raising=False)
-            out[fuse] = R.BHTEMultiplePressureFields(fields, mm, ml, 4e-4, nS, onoff, N[1] // 2, nFactorMonitoring=3, dt=0.02, initT0=T0, MonitoringPointsMap=mpm)
-        for a, b in zip(out['1'], out['0']):
-            assert np.array_equal(a, b)
-        assert out['1'][0].max() > 44.0 and out['1'][1].max() > 0
+            out[fuse + kernel] = R.BHTEMultiplePressureFields(fields, mm, ml, 4e-4, nS, onoff, N[1] // 2, nFactorMonitoring=3, dt=0.02, initT0=T0, MonitoringPointsMap=mpm)
+        for k in ('10', '11'):
+            for a, b in zip(out[k], out['00']):
+                assert np.array_equal(a, b)
+        assert out['10'][0].max() > 44.0 and out['10'][1].max() > 0
+    monkeypatch.delenv('BFD_BHTE_KERNEL', raising=False)
     # and the oracle, bit for bit on the temperature now that the roundings are pinned (the dose goes through exp2f against numpy's power)
     N = (70, 30, 35)
     mm = rng.integers(0, 5, N).astype(np.uint8)
