@@ -10,7 +10,7 @@
 //   cd = dt k/(rho c dx^2),  cp = dt rho_b c_b w / (6e7 c)  (w in mL/min/kg),  q = dt * duty * a_abs p^2/(rho c_s) / (rho c)
 //   dose += dt/60 * R^(43 - T'),  R = 0.5 for T' >= 43 else 0.25 (evaluated as exp2).   Faces of the volume keep their temperature.
 // Bound: HBM. One step moves T read + write, q read, dose RMW, uint8 ids: ~21 B per voxel; the default path takes TWO steps per
-// launch (bhte_step2) and moves those 21 B once for both. x-fastest layout.
+// launch (bhte_step2g; bhte_step2 is its round-3 form) and moves those 21 B once for both. x-fastest layout.
 #include "bfd_internal.h"
 #include <math.h>
 #include <vector>
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void bhte_step(const float *__restrict__ Tin, 
     dose[c] = __fadd_rn(dose[c], bhte_dose_rate(Tn, dtMin));
 }
 
-// Two steps per launch. One step moves 21 B per voxel (T in, T out, dose in and out, heat source, material id) for ~12
+// Two steps per launch, round-3 form (BFD_BHTE_KERNEL=1; the default is bhte_step2g below). One step moves 21 B per voxel (T in, T out, dose in and out, heat source, material id) for ~12
 // flops; two steps in one pass move the same 21 B: T(n) in, T(n+2) out, the dose read once and written once with both
 // increments, heat source and id read once. A workgroup marches a z-run over a tile of 64 x 26 output cells: the region it
 // keeps is 68 x 30 cells (two rings: T(n+1) is needed one cell around the outputs, T(n) one cell around that), 2040 cells =
