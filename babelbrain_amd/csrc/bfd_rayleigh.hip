@@ -35,7 +35,9 @@ constexpr int SUB = 16;      // sources summed in float32 before the sum goes to
 // PPL = field points per lane: every source record read from LDS serves that many pairs. 4 for large point sets (899-905
 // against 845-855 Gpairs/s with 2 at 6.5 M points; 128 VGPRs), 2 below a million points, 1 where even that leaves CUs without a
 // workgroup (a 488 x 488 source plane is 465 workgroups at 2)
-template <int PPL>
+// ATT: complex wavenumber (Im k != 0). A template parameter, not a run-time test: as a uniform condition inside the pair loop the
+// compiler turned it into exp + multiply + select for EVERY pair (v_exp_f32 is a quarter-rate instruction), 10 % of the loop in water.
+template <int PPL, bool ATT>
 __global__ __launch_bounds__(RB) void rayleigh_forward(const float *__restrict__ cen, const float *__restrict__ ds,
                                                        const float *__restrict__ u0, long nSrc, double kr, double ki,
                                                        const float *__restrict__ rf, long nPts, float *__restrict__ out)
@@ -73,9 +75,15 @@ __global__ __launch_bounds__(RB) void rayleigh_forward(const float *__restrict__
 #pragma unroll
             for (int p = 0; p < PPL; p++) {
                 const double dx = px[p] - (double)s.x, dy = py[p] - (double)s.y, dz = pz[p] - (double)s.z;
+#ifdef BFD_RAYLEIGH_NO_FMA
                 const double r2 = dx * dx + dy * dy + dz * dz;
                 double inv = (double)rsqrtf((float)r2);
                 inv = inv * (1.5 - 0.5 * r2 * inv * inv);
+#else           // explicit fused multiply-adds (the build contracts nothing by itself): 11 float64 operations per pair instead of 15
+                const double r2 = __builtin_fma(dx, dx, __builtin_fma(dy, dy, dz * dz));
+                double inv = (double)rsqrtf((float)r2);
+                inv = __builtin_fma(inv, __builtin_fma(-0.5 * r2, inv * inv, 0.5), inv);          // y + y (1 - r2 y^2) / 2
+#endif
                 const double R = r2 * inv;
                 const double rev = R * krev;
                 // hardware sine / cosine: v_sin_f32 / v_cos_f32 take their argument in revolutions (a float32 Taylor polynomial on
@@ -87,11 +95,16 @@ __global__ __launch_bounds__(RB) void rayleigh_forward(const float *__restrict__
                 const float fr = (float)__builtin_amdgcn_fract(rev);   // phase / 2 pi in [0,1)
                 const float sn = __builtin_amdgcn_sinf(fr), cs = __builtin_amdgcn_cosf(fr);
                 float amp = (float)inv;
-                if (ki != 0.0) amp *= __expf(kif * (float)R);        // exp(-i k R) with complex k: Im k < 0 attenuates
+                if (ATT) amp *= __expf(kif * (float)R);              // exp(-i k R) with complex k: Im k < 0 attenuates
                 // (re + i im) * amp * (cos - i sin)
                 const float er = amp * cs, ei = amp * sn;
+#ifdef BFD_RAYLEIGH_NO_FMA
                 br[p] += s.w * er + sim * ei;
                 bi[p] += sim * er - s.w * ei;
+#else
+                br[p] = __builtin_fmaf(s.w, er, __builtin_fmaf(sim, ei, br[p]));
+                bi[p] = __builtin_fmaf(sim, er, __builtin_fmaf(-s.w, ei, bi[p]));
+#endif
             }
         }
 #pragma unroll
@@ -140,9 +153,11 @@ extern "C" int bfd_rayleigh_forward(int32_t device, int64_t nSrc, const float *c
         int ppl = nPts >= (1 << 20) ? 4 : nPts >= (1 << 18) ? 2 : 1;
         if (const char *ev = getenv("BFD_RAYLEIGH_PPL")) { const int v = atoi(ev); if (v == 1 || v == 2 || v == 4) ppl = v; }
         const dim3 grid((unsigned)((nPts + RB * ppl - 1) / (RB * ppl)));
-        if (ppl == 4) hipLaunchKernelGGL(rayleigh_forward<4>, grid, dim3(RB), 0, 0, dc, dd, du, (long)nSrc, kReal, kImag, dr, (long)nPts, dout);
-        else if (ppl == 2) hipLaunchKernelGGL(rayleigh_forward<2>, grid, dim3(RB), 0, 0, dc, dd, du, (long)nSrc, kReal, kImag, dr, (long)nPts, dout);
-        else hipLaunchKernelGGL(rayleigh_forward<1>, grid, dim3(RB), 0, 0, dc, dd, du, (long)nSrc, kReal, kImag, dr, (long)nPts, dout);
+#define RAYLEIGH_LAUNCH(P, A) hipLaunchKernelGGL((rayleigh_forward<P, A>), grid, dim3(RB), 0, 0, dc, dd, du, (long)nSrc, kReal, kImag, dr, (long)nPts, dout)
+        const bool att = kImag != 0.0;
+        if (ppl == 4) { if (att) RAYLEIGH_LAUNCH(4, true); else RAYLEIGH_LAUNCH(4, false); }
+        else if (ppl == 2) { if (att) RAYLEIGH_LAUNCH(2, true); else RAYLEIGH_LAUNCH(2, false); }
+        else { if (att) RAYLEIGH_LAUNCH(1, true); else RAYLEIGH_LAUNCH(1, false); }
         e = hipGetLastError();
     }
     if (e == hipSuccess) { hipEventRecord(e1, 0); e = hipEventSynchronize(e1); }
