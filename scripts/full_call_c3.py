@@ -20,6 +20,8 @@ for series in (True, False):      # the reference's return values; then without 
           % (series, t3 - t2, tm['total_ms'] / 1e3, N * info['nt'], out[-1]['device_bytes'] / 1e9))
     print('   device-only %.0f Mvoxel-steps/s; PCIe-inclusive (whole call) %.0f Mvoxel-steps/s'
           % (N * info['nt'] / tm['total_ms'] / 1e3, N * info['nt'] / (t3 - t2) / 1e6))
+    print('   placement:', out[-1].get('placement'))
+    print('   timing:', {k: (round(v, 2) if isinstance(v, float) else v) for k, v in tm.items()})
     if series:
         print('   sensor block', out[0]['Pressure'].shape, '%.1f GB' % (out[0]['Pressure'].nbytes / 1e9), 'RMS max', float(out[2]['Pressure'].max()))
         ref = out[-1]['SensorDFT']['Pressure']
