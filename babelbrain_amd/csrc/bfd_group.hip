@@ -40,6 +40,7 @@ struct bfd_group {
     std::vector<HaloPtr> halo;            // device pointers of every slab's halo regions, taken once in group_prepare
     bool threads;                         // one host thread per slab queues its work (BFD_GROUP_THREADS=0: one thread for all)
     bool prepared, overlap;
+    bool forcePeer = false;               // BFD_GROUP_FORCE_PEER_COPY: hipMemcpyPeerAsync also between slabs on one device
     std::vector<int64_t> nSens;
     double issueSeconds; int64_t issueSteps;    // host time spent queueing work in bfd_group_run
     double haloBytesPerStep;
@@ -121,6 +122,9 @@ int group_prepare(bfd_group *g)
             const int rc = bfd_halo_region(g->sim[r], grp, f, side, send, &g->halo[r].ptr[grp][f][side][send], &g->halo[r].bytes);
             if (rc) return rc;
         }
+    // BFD_GROUP_FORCE_PEER_COPY=1 (tests on a 1-GPU box): the halo planes go through hipMemcpyPeerAsync also between slabs that share a
+    // device, so that the call the multi-GPU path makes is exercised with the same arguments
+    if (const char *ev = getenv("BFD_GROUP_FORCE_PEER_COPY")) g->forcePeer = atoi(ev) != 0;
     g->threads = g->n > 1;
     if (const char *ev = getenv("BFD_GROUP_THREADS")) g->threads = g->n > 1 && atoi(ev) != 0;
     g->prepared = true;
@@ -171,7 +175,7 @@ int issue_copies(bfd_group *g, int r, long n)
             void *dst = g->halo[r].ptr[grp][f][side][0];                        // my ghost planes on that side
             void *src = g->halo[s].ptr[grp][f][side ^ 1][1];                    // the neighbour's boundary planes facing me
             const size_t nb = g->halo[r].bytes;
-            if (g->dev[r] == g->dev[s]) BFD_HIP(hipMemcpyAsync(dst, src, nb, hipMemcpyDeviceToDevice, X));
+            if (g->dev[r] == g->dev[s] && !g->forcePeer) BFD_HIP(hipMemcpyAsync(dst, src, nb, hipMemcpyDeviceToDevice, X));
             else BFD_HIP(hipMemcpyPeerAsync(dst, g->dev[r], src, g->dev[s], nb, X));
         }
     }

@@ -106,6 +106,20 @@ def test_group_c_abi_with_x_fastest_views_and_reset():
         g.close()
 
 
+def test_group_halo_planes_through_the_peer_copy_call(monkeypatch):
+    """BFD_GROUP_FORCE_PEER_COPY=1: the halo planes of slabs that share the device move through hipMemcpyPeerAsync, the call
+    (and argument order) the path over distinct GPUs makes, in both step orders and with the per-slab host threads."""
+    monkeypatch.setenv('BFD_GROUP_FORCE_PEER_COPY', '1')
+    a, k, info = _problem('C2', (64, 56, 96), 520)
+    ref = PropagationModel(device=0).StaggeredFDTD_3D_with_relaxation(*a, SILENT=True, **k)
+    for overlap, threads in (('1', '1'), ('0', '1'), ('1', '0')):
+        monkeypatch.setenv('BFD_GROUP_OVERLAP', overlap)
+        monkeypatch.setenv('BFD_GROUP_THREADS', threads)
+        out = PropagationModel(devices=[0, 0, 0]).StaggeredFDTD_3D_with_relaxation(*a, SILENT=True, **k)
+        _same(out, ref)
+    assert ref[2]['Pressure'][:, :, 64:].max() > 0
+
+
 def test_group_over_distinct_devices():
     """the same call over >= 2 GPUs (peer copies over xGMI); skips on the 1-GPU box"""
     devs = [d for d, _ in _engine.list_devices()]
