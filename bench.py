@@ -706,21 +706,29 @@ def main():
         # what ONE production call of the reference's caller spends its steps on: nt steps of the config's time plan
         # (BASE:2082-2109), the Pressure RMS accumulated over the last 2 periods only. `value` above prices every step as an
         # accumulating one; here the steps before the window are timed too and the two rates are weighted by the plan.
+        def production(config, t_acc):
+            wp = Workload(args, config, dims, 'weak', 0, 1, local_rank, None, dt_fn, args.steps, args.warmup, args.variant, rms_first_step=2 ** 30)
+            try:
+                wall, tm = wp.timed()
+                nt_plan, n_acc = wp.info['plan_nt'], wp.info['plan_accumulating_steps']
+                t_no = wall / wp.steps * 1e3
+                mix = wp.total_vox * nt_plan / ((n_acc * t_acc + (nt_plan - n_acc) * t_no) * 1e-3) / 1e6
+                return {'note': 'one call of the reference\'s caller at this config: %d steps, Pressure RMS accumulated in the last %d '
+                                '(2 periods); the headline of this workload accumulates in every step' % (nt_plan, n_acc),
+                        'steps_before_the_window': {'value': wp.total_vox * wp.steps / wall / 1e6, 'unit': 'Mvoxel-steps/s', 'ms_per_step': t_no,
+                                                    'windows_ms_per_step': [x / wp.steps * 1e3 for x in wp.window_walls]},
+                        'whole_call_weighted': {'value': mix, 'unit': 'Mvoxel-steps/s'}}
+            finally:
+                wp.close()
         try:
-            wp = Workload(args, args.config, dims, 'weak', 0, 1, local_rank, None, dt_fn, args.steps, args.warmup, args.variant,
-                          rms_first_step=2 ** 30)
-            wall, tm = wp.timed()
-            nt_plan, n_acc = wp.info['plan_nt'], wp.info['plan_accumulating_steps']
-            t_acc, t_no = res['ms_per_step'], wall / wp.steps * 1e3
-            mix = wp.total_vox * nt_plan / ((n_acc * t_acc + (nt_plan - n_acc) * t_no) * 1e-3) / 1e6
-            line['production_schedule'] = {'note': 'one call of the reference\'s caller at this config: %d steps, Pressure RMS accumulated in the last %d '
-                                                   '(2 periods); `value` above accumulates in every step' % (nt_plan, n_acc),
-                                           'steps_before_the_window': {'value': wp.total_vox * wp.steps / wall / 1e6, 'unit': 'Mvoxel-steps/s', 'ms_per_step': t_no,
-                                                                       'windows_ms_per_step': [x / wp.steps * 1e3 for x in wp.window_walls]},
-                                           'whole_call_weighted': {'value': mix, 'unit': 'Mvoxel-steps/s'}}
-            wp.close()
+            line['production_schedule'] = production(args.config, res['ms_per_step'])
         except Exception as e:
             line['production_schedule'] = {'value': None, 'error': repr(e)}
+        if (line.get('shear_workload') or {}).get('value'):
+            try:
+                line['shear_workload']['production_schedule'] = production('C2', line['shear_workload']['ms_per_step'])
+            except Exception as e:
+                line['shear_workload']['production_schedule'] = {'value': None, 'error': repr(e)}
     if world == 1 and args.dense_reference and args.variant in (0, 3):
         try:
             wd = Workload(args, args.config, dims, args.scaling, 0, 1, local_rank, None, dt_fn, args.steps, args.warmup, 2)
