@@ -7,7 +7,9 @@ from oracle import oracle as O
 from babelbrain_amd import PropagationModel
 bad = []
 t0 = time.time()
-for seed in range(14, 214):
+# usage: random_media_hunt.py [first_seed count]  -> only the single-domain hunt over that range (default: every section with its fixed seeds)
+RANGE = range(int(sys.argv[1]), int(sys.argv[1]) + int(sys.argv[2])) if len(sys.argv) > 2 else range(14, 214)
+for seed in RANGE:
     try:
         a, k = random_case(seed)
         oh = PropagationModel().StaggeredFDTD_3D_with_relaxation(*a, SILENT=True, **k)
@@ -17,7 +19,9 @@ for seed in range(14, 214):
         bad.append((seed, str(e)[:200])); print('MISMATCH seed', seed, str(e)[:200], flush=True)
     except Exception as e:
         bad.append((seed, repr(e)[:200])); print('ERROR seed', seed, repr(e)[:300], flush=True)
-print('%d seeds in %.0f s, %d bad' % (200, time.time() - t0, len(bad)))
+print('%d seeds (%d..%d) in %.0f s, %d bad' % (len(RANGE), RANGE[0], RANGE[-1], time.time() - t0, len(bad)))
+if len(sys.argv) > 2:
+    sys.exit(1 if bad else 0)
 
 # the same media cut into 2-4 slabs (both step orders)
 import torch
