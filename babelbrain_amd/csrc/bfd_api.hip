@@ -1091,9 +1091,14 @@ static int build_tile_lists(bfd_sim *s)
         } else if (mode == 0) {     // column order
             for (int txy = 0; txy < tx * ty; txy++) for (int c = 0; c < nChunks; c++) seq.push_back({txy, c});
         } else {                    // 8 y-bands (one per XCD part), inside a band z-chunk slowest
+            // mode 3 (experiment): the two z-chunks of the absorbing layer first, the interior chunks after them -- the cheapest
+            // workgroups at the end of every XCD's part of the list
+            std::vector<int> corder;
+            if (mode == 3 && nChunks > 2) { corder.push_back(0); corder.push_back(nChunks - 1); for (int c = 1; c + 1 < nChunks; c++) corder.push_back(c); }
+            else for (int c = 0; c < nChunks; c++) corder.push_back(c);
             for (int e = 0; e < 8; e++) {
                 const int y0 = (int)((long)ty * e / 8), y1 = (int)((long)ty * (e + 1) / 8);
-                for (int c = 0; c < nChunks; c++) for (int by = y0; by < y1; by++) for (int bx = 0; bx < tx; bx++) seq.push_back({by * tx + bx, c});
+                for (int c : corder) for (int by = y0; by < y1; by++) for (int bx = 0; bx < tx; bx++) seq.push_back({by * tx + bx, c});
             }
         }
     }
