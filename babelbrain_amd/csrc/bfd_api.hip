@@ -952,7 +952,7 @@ static int build_tile_lists(bfd_sim *s)
     // full-volume arrays
     const bool carryShearMemory = s->step > 0 && s->tilesReady == false && s->tiles.shearR && s->tiles.nShear > 0;
     if (carryShearMemory) { bfd_launch_scatter_shear_memory(s->d, s->stream, &s->tiles); BFD_HIP(hipStreamSynchronize(s->stream)); }
-    dev_release(s, &s->tiles.runs); dev_release(s, &s->tiles.shearCells); dev_release(s, &s->tiles.shearCoef); dev_release(s, &s->tiles.shearR);    // lists of an earlier build
+    dev_release(s, &s->tiles.runs); dev_release(s, &s->tiles.xmap); dev_release(s, &s->tiles.shearCells); dev_release(s, &s->tiles.shearCoef); dev_release(s, &s->tiles.shearR);    // lists of an earlier build
     dev_release(s, &s->tiles.shearCodes); dev_release(s, &s->tiles.shearTab);
     const int SUB = bfd_tile_subz();
     // longest run one workgroup marches: 16 planes; 8 on small grids so that the launch still has a few thousand
@@ -1148,6 +1148,72 @@ static int build_tile_lists(bfd_sim *s)
     int rc = dev_alloc(s, &s->tiles.runs, all.size(), false);
     if (rc) return rc;
     BFD_HIP(hipMemcpy(s->tiles.runs, all.data(), all.size() * sizeof(int4), hipMemcpyHostToDevice));
+    // Cost-balanced block -> run maps (experiment, BFD_XCD_BALANCE=1; default off). A launch's blocks go to the 8 XCDs round-robin and every
+    // XCD works through its own blocks at its own pace (-DBFD_EXP_XCD_CLOCK build: block b always runs on XCD (x0 + b) mod 8). With equal
+    // COUNTS per XCD (remap_block) the XCD that holds the short boundary runs is idle for the last fifth of every fluid launch and the bands
+    // with more tissue finish last. Here the contiguous parts of the list are cut by estimated cost instead (planes + prologue, weighted by
+    // the bytes per cell of the run's class), the launch gets 8 x (longest part) blocks and a block beyond its part returns at once.
+    // Measured: the ends of the XCDs move together (spread 19 % -> 13 % of a launch) and the step time does not -- C3 +1.2 %, shear medium
+    // -0.4 %, other weightings +-2 % either way: an XCD that runs dry leaves its share of the memory system to the others.
+    // profiles/r4/xcd_balance.txt.
+    {
+        bool on = false;
+        if (const char *ev = getenv("BFD_XCD_BALANCE")) on = atoi(ev) != 0 && s->cfg.kernelVariant != 2 && s->cfg.kernelVariant != 1;
+        s->tiles.xmap = nullptr;
+        memset(s->tiles.xmapH, 0, sizeof s->tiles.xmapH);
+        if (on) {
+            double wPml = 0.25, wLossy = 8, wMulti = 2, wRun = 2.0;
+            if (const char *ev = getenv("BFD_XCD_WEIGHTS")) sscanf(ev, "%lf,%lf,%lf,%lf", &wPml, &wLossy, &wMulti, &wRun);
+            // cost of run r for kernel class c: 0 fluid stress, 1 fluid velocity, 2 solid stress, 3 solid velocity
+            auto cost = [&](const int4 &r, int c) {
+                const double planes = (double)((r.y >> 16) - (r.y & 0xFFFF)) + wRun;
+                const int f = r.z;
+                double w;
+                if (c == 0) w = 20 + ((f & 2) ? wLossy : 0) + ((f & 4) ? 0 : wMulti);
+                else if (c == 1) w = 36 + ((f & 4) ? 0 : wMulti);
+                else w = 40;
+                if (f & 8) w *= 1.0 + wPml;
+                return planes * w;
+            };
+            auto make = [&](int m, size_t a0, size_t a1, int c) {
+                int *seg = s->tiles.xmapH[m];
+                const size_t n = a1 > a0 ? a1 - a0 : 0;
+                std::vector<double> cum(n + 1, 0.0);
+                for (size_t i = 0; i < n; i++) cum[i + 1] = cum[i] + cost(all[a0 + i], c);
+                int maxcnt = 0;
+                seg[0] = 0;
+                for (int x = 1; x <= 8; x++) {
+                    const double target = cum[n] * x / 8.0;
+                    size_t j = std::lower_bound(cum.begin(), cum.end(), target) - cum.begin();
+                    if (j > n || x == 8) j = n;
+                    if ((int)j < seg[x - 1]) j = seg[x - 1];
+                    seg[x] = (int)j;
+                    maxcnt = std::max(maxcnt, seg[x] - seg[x - 1]);
+                }
+                seg[9] = std::max(maxcnt, 1);
+            };
+            const size_t F = T.nFluid, FB = T.nFluidB, S0 = F, SB = T.nSolidB, SN = T.nSolid;
+            for (int c = 0; c < 2; c++) {            // fluid stress (c = 0), fluid velocity (c = 1): parts 0, 1, 2
+                const int m = c == 0 ? BFD_XM_SF : BFD_XM_VF;
+                make(m + 0, 0, F, c); make(m + 1, 0, FB, c); make(m + 2, FB, F, c);
+            }
+            make(BFD_XM_SS + 0, S0, S0 + SN, 2); make(BFD_XM_SS + 1, S0, S0 + SB, 2); make(BFD_XM_SS + 2, S0 + SB, S0 + SN, 2);
+            const size_t bp = T.nSolidBP, ip = T.nSolidIP;          // solid list = [boundary: PML | plain][interior: plain | PML]
+            make(BFD_XM_VS + 0, S0 + bp, S0 + SN - ip, 3); make(BFD_XM_VS + 1, S0 + bp, S0 + SB, 3); make(BFD_XM_VS + 2, S0 + SB, S0 + SN - ip, 3);
+            make(BFD_XM_VSP_LO, S0, S0 + bp, 3); make(BFD_XM_VSP_HI, S0 + SN - ip, S0 + SN, 3);
+            make(BFD_XM_FUSED, S0 + SN, S0 + SN + T.nFused, 0);
+            if (getenv("BFD_XCD_VERBOSE"))
+                for (int m = 0; m < BFD_XMAP_COUNT; m++) {
+                    const int *g = s->tiles.xmapH[m];
+                    fprintf(stderr, "xcd map %2d: runs %d, parts", m, g[8]);
+                    for (int x = 0; x < 8; x++) fprintf(stderr, " %d", g[x + 1] - g[x]);
+                    fprintf(stderr, " (longest %d)\n", g[9]);
+                }
+            rc = dev_alloc(s, &s->tiles.xmap, (size_t)BFD_XMAP_COUNT * 10, false);
+            if (rc) return rc;
+            BFD_HIP(hipMemcpy(s->tiles.xmap, s->tiles.xmapH, sizeof s->tiles.xmapH, hipMemcpyHostToDevice));
+        }
+    }
     s->tiles.shearCells = nullptr; s->tiles.shearCoef = nullptr; s->tiles.shearR = nullptr; s->tiles.shearCodes = nullptr; s->tiles.shearTab = nullptr;
     s->tiles.nShearExplicit = 0;
     s->tiles.nShear = s->tiles.shearLowEnd = s->tiles.shearHighBeg = 0;

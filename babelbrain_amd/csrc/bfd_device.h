@@ -134,4 +134,18 @@ __device__ __forceinline__ int remap_block(int bid, int nblocks)
     return (bid & 7) * per + (bid >> 3);
 }
 
+// Cost-balanced form (bfd_tiles::xmap): slot b & 7 = one XCD; its k-th block takes run seg[slot] + k of the launched range, -1 = nothing left
+// for this block. The eighths are equal in estimated cost, not in count (profiles/r4/xcd_balance.txt).
+__device__ __forceinline__ int xcd_run_index(const int *__restrict__ xmap)
+{
+    const int slot = __builtin_amdgcn_readfirstlane(blockIdx.x & 7), k = blockIdx.x >> 3;
+    const int idx = xmap[slot] + k;
+    return idx < xmap[slot + 1] ? idx : -1;
+}
+// the run of this block: cost-balanced map if the launch has one, otherwise equal counts per XCD; -1 = no run for this block
+__device__ __forceinline__ int run_index(int nblocks, const int *__restrict__ xmap)
+{
+    return xmap ? xcd_run_index(xmap) : remap_block(blockIdx.x, nblocks);
+}
+
 }  // namespace

@@ -84,12 +84,19 @@ struct bfd_sim;
 // records an event before (end = 0) / after (end = 1) a launch of class cls (bfd_api.hip); t->ktimer != null while class timing is on
 void bfd_kmark(bfd_sim *sim, int cls, int end, hipStream_t st);
 
+// maps of bfd_tiles::xmap: fluid stress / fluid velocity / solid stress / solid velocity (plain runs) by part 0, 1, 2; the two pieces of solid
+// runs in the absorbing layer; the fused runs
+enum { BFD_XM_SF = 0, BFD_XM_VF = 3, BFD_XM_SS = 6, BFD_XM_VS = 9, BFD_XM_VSP_LO = 12, BFD_XM_VSP_HI = 13, BFD_XM_FUSED = 14, BFD_XMAP_COUNT = 15 };
 struct bfd_tiles { bfd_sim *ktimer; int nMat; bool merged /* solid runs: normal and shear stresses in one kernel, the sparse list holds the MIXED cells only */; int4 *runs;
                    unsigned *shearCells; float *shearCoef; long nShear, shearLowEnd, shearHighBeg;   /* sparse shear list */
                    unsigned *shearCodes; float *shearTab; long nShearExplicit;   /* per listed cell a byte per edge: 0 inactive, 1 + m = one material around the edge (coefficients from shearTab[2 m ..]), 255 = explicit coefficients in shearCoef; number of explicit edges */
                    float *shearR;   /* memory variables Rxy, Rxz, Ryz of the listed cells, [3][nShear] in list order: only the sparse kernel uses them, so they live beside the list (dense, coalesced) instead of in the full-volume arrays, which are filled from here on demand (bfd_get_field) */
                    int nFluid, nFluidB, nSolid, nSolidB, nSolidBP /* leading boundary runs that touch the absorbing layer */, nSolidIP /* trailing interior ones */, nFused /* runs of the fused kernel, after the solid runs */;
-                   int nLossless, nLossy, nSolidSub, nUni, nPml, nLean, nFusedSub; };
+                   int nLossless, nLossy, nSolidSub, nUni, nPml, nLean, nFusedSub;
+                   /* cost-balanced block -> run maps (round 4): block b of a launch runs on XCD slot b & 7 and takes run seg[slot] + (b >> 3) of
+                      the launched range if that is below seg[slot + 1]; the launch has 8 x maxcnt blocks. One map of 10 ints (seg[0..8], maxcnt)
+                      per launched range and kernel class, on the device in xmap, on the host in xmapH. */
+                   int *xmap; int xmapH[BFD_XMAP_COUNT][10]; };
 
 struct bfd_sim {
     bfd_config cfg;

@@ -906,10 +906,12 @@ __device__ __forceinline__ void stress_solid_body(const bfd_dev &d, const int4 &
 // (-DBFD_STRESS_SOLID_GLOBAL builds the GLOBAL / branch-free-prefetch body below instead: measured 1 % slower, 0.308-0.311 against
 // 0.305 ms at the shear medium 512^3 -- this kernel is at the rate of the bytes it moves; profiles/r4/experiment_solid_kernels_prefetch.txt)
 #ifndef BFD_STRESS_SOLID_GLOBAL
-__global__ __launch_bounds__(NTHREADS, SOLID_STRESS_WAVES_PER_SIMD) void stress_solid(bfd_dev d, int tilesX, int nblocks, const int4 *__restrict__ runs)
+__global__ __launch_bounds__(NTHREADS, SOLID_STRESS_WAVES_PER_SIMD) void stress_solid(bfd_dev d, int tilesX, int nblocks, const int *__restrict__ xmap, const int4 *__restrict__ runs)
 {
     __shared__ float sV[2][2][LH * LW];
-    const int4 run = runs[remap_block(blockIdx.x, nblocks)];
+    const int ri = run_index(nblocks, xmap);
+    if (ri < 0) return;
+    const int4 run = runs[ri];
     if (run.z & 8) stress_solid_body<true>(d, run, tilesX, sV);
     else stress_solid_body<false>(d, run, tilesX, sV);
 }
@@ -1120,11 +1122,13 @@ __device__ __forceinline__ void stress_solid_merged_body(const bfd_dev &d, const
 #ifndef SOLID_MERGED_WAVES_PER_SIMD
 #define SOLID_MERGED_WAVES_PER_SIMD 4
 #endif
-__global__ __launch_bounds__(NTHREADS, SOLID_MERGED_WAVES_PER_SIMD) void stress_solid_merged(bfd_dev d, int tilesX, int nblocks, const int4 *__restrict__ runs,
+__global__ __launch_bounds__(NTHREADS, SOLID_MERGED_WAVES_PER_SIMD) void stress_solid_merged(bfd_dev d, int tilesX, int nblocks, const int *__restrict__ xmap, const int4 *__restrict__ runs,
                                                                                              const float *__restrict__ shearTab)
 {
     __shared__ float sV[2][3][LH * LW];
-    const int4 run = runs[remap_block(blockIdx.x, nblocks)];
+    const int ri = run_index(nblocks, xmap);
+    if (ri < 0) return;
+    const int4 run = runs[ri];
     if (run.z & 8) stress_solid_merged_body<true>(d, run, tilesX, shearTab, sV);
     else stress_solid_merged_body<false>(d, run, tilesX, shearTab, sV);
 }
@@ -1711,10 +1715,12 @@ __device__ __forceinline__ void velocity_solid_body_g(const bfd_dev &d, const in
 }
 
 #ifdef BFD_STRESS_SOLID_GLOBAL
-__global__ __launch_bounds__(NTHREADS, SOLID_STRESS_WAVES_PER_SIMD) void stress_solid(bfd_dev d, int tilesX, int nblocks, const int4 *__restrict__ runs)
+__global__ __launch_bounds__(NTHREADS, SOLID_STRESS_WAVES_PER_SIMD) void stress_solid(bfd_dev d, int tilesX, int nblocks, const int *__restrict__ xmap, const int4 *__restrict__ runs)
 {
     __shared__ float sV[2][2][LH * LW];
-    const int4 run = runs[remap_block(blockIdx.x, nblocks)];
+    const int ri = run_index(nblocks, xmap);
+    if (ri < 0) return;
+    const int4 run = runs[ri];
     if (run.z & 8) stress_solid_body_g<true>(d, run, tilesX, sV);
     else stress_solid_body_g<false>(d, run, tilesX, sV);
 }
@@ -1726,7 +1732,7 @@ __global__ __launch_bounds__(NTHREADS, SOLID_STRESS_WAVES_PER_SIMD) void stress_
 #define SOLID_VELOCITY_WAVES_PER_SIMD 4      // lower bound of the plain flavour (78-80 VGPRs since round 4: 6 waves); the absorbing-layer flavour needs 105 registers and gets 4
 #endif
 template <bool ACC, bool PML>
-__global__ __launch_bounds__(NTHREADS, PML ? 4 : SOLID_VELOCITY_WAVES_PER_SIMD) void velocity_solid(bfd_dev d, int tilesX, int nblocks,
+__global__ __launch_bounds__(NTHREADS, PML ? 4 : SOLID_VELOCITY_WAVES_PER_SIMD) void velocity_solid(bfd_dev d, int tilesX, int nblocks, const int *__restrict__ xmap,
                                                         float *__restrict__ accP, float *__restrict__ pkP,
                                                         const int4 *__restrict__ runs)
 {
@@ -1735,7 +1741,9 @@ __global__ __launch_bounds__(NTHREADS, PML ? 4 : SOLID_VELOCITY_WAVES_PER_SIMD) 
     __shared__ float sPad[VELOCITY_SOLID_LDS_PAD];
     if (nblocks < 0) { sPad[threadIdx.x] = 1.f; sS[0][0][0] = sPad[(threadIdx.x + 1) & 511]; }
 #endif
-    const int4 run = runs[remap_block(blockIdx.x, nblocks)];
+    const int ri = run_index(nblocks, xmap);
+    if (ri < 0) return;
+    const int4 run = runs[ri];
 #ifndef BFD_VELOCITY_SOLID_FLAT      // default since round 4: GLOBAL loads, prefetch without branches (0.405 -> 0.378 ms at the shear medium 512^3)
     velocity_solid_body_g<ACC, PML>(d, run, tilesX, sS, accP, pkP);
 #else
@@ -2029,32 +2037,61 @@ __device__ __forceinline__ void stress_fluid_switch(const bfd_dev &d, const int4
     }
 }
 
+#ifdef BFD_EXP_XCD_CLOCK
+// Experiment build: when does each XCD finish its part of a fluid launch? Every block leaves the wall clock (100 MHz) of its start and of
+// its end in its own slot (plain stores: atomics on a few shared addresses serialise in one L2 channel and triple the launch time), the
+// end together with the XCC_ID hardware register, so that the assumption remap_block rests on (block b runs on XCD b & 7) can be checked.
+// kind 0 / 1 = stress_fluid / velocity_fluid. bfd_debug_xcd_clock() copies the slots out.
+constexpr int XCLK_MAX = 1 << 17;
+__device__ unsigned long long g_blkStart[2][XCLK_MAX], g_blkEnd[2][XCLK_MAX];
+__device__ __forceinline__ void xcd_clock_begin(int kind) { if (threadIdx.x == 0 && blockIdx.x < XCLK_MAX) g_blkStart[kind][blockIdx.x] = wall_clock64(); }
+__device__ __forceinline__ void xcd_clock_end(int kind)
+{
+    __syncthreads();
+    if (threadIdx.x == 0 && blockIdx.x < XCLK_MAX) {
+        const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u;          // HW_REG_XCC_ID, bits 3:0
+        g_blkEnd[kind][blockIdx.x] = (wall_clock64() << 4) | xcc;
+    }
+}
+#else
+__device__ __forceinline__ void xcd_clock_begin(int) {}
+__device__ __forceinline__ void xcd_clock_end(int) {}
+#endif
+
 // COLLAPSED = true: all-fluid slab, every run keeps only Szz/Rzz. false: slab with solid tiles; runs flagged LEAN
 // (bit4) still take the collapsed bodies, the others write all three normal stresses.
 template <bool COLLAPSED>
-__global__ __launch_bounds__(NTHREADS, FLUID_WAVES_PER_SIMD) void stress_fluid(bfd_dev d, int tilesX, int nblocks,
+__global__ __launch_bounds__(NTHREADS, FLUID_WAVES_PER_SIMD) void stress_fluid(bfd_dev d, int tilesX, int nblocks, const int *__restrict__ xmap,
                                                                                const int4 *__restrict__ runs)
 {
     __shared__ float sV[2][2][LH * LW];
-    const int4 run = runs[remap_block(blockIdx.x, nblocks)];
+    const int ri = run_index(nblocks, xmap);
+    if (ri < 0) return;
+    const int4 run = runs[ri];
+    xcd_clock_begin(0);
     if (COLLAPSED || (run.z & 16)) stress_fluid_switch<true>(d, run, tilesX, sV);
     else stress_fluid_switch<false>(d, run, tilesX, sV);
+    xcd_clock_end(0);
 }
 
 template <bool ACC>
-__global__ __launch_bounds__(NTHREADS, VELOCITY_FLUID_WAVES_PER_SIMD) void velocity_fluid(bfd_dev d, int tilesX, int nblocks,
+__global__ __launch_bounds__(NTHREADS, VELOCITY_FLUID_WAVES_PER_SIMD) void velocity_fluid(bfd_dev d, int tilesX, int nblocks, const int *__restrict__ xmap,
                                                                                  const int4 *__restrict__ runs,
                                                                                  float *__restrict__ accP, float *__restrict__ pkP)
 {
     __shared__ float sS[2][LH * LW];
-    const int4 run = runs[remap_block(blockIdx.x, nblocks)];
+    const int ri = run_index(nblocks, xmap);
+    if (ri < 0) return;
+    const int4 run = runs[ri];
     const int bx = run.x % tilesX, by = run.x / tilesX, kbeg = run.y & 0xFFFF, kend = run.y >> 16, tm = run.w;
+    xcd_clock_begin(1);
     switch ((run.z >> 2) & 3) {
     case 0: velocity_fluid_body<ACC, false, false>(d, bx, by, kbeg, kend, tm, sS, accP, pkP); break;
     case 1: velocity_fluid_body<ACC, true, false>(d, bx, by, kbeg, kend, tm, sS, accP, pkP); break;
     case 2: velocity_fluid_body<ACC, false, true>(d, bx, by, kbeg, kend, tm, sS, accP, pkP); break;
     default: velocity_fluid_body<ACC, true, true>(d, bx, by, kbeg, kend, tm, sS, accP, pkP); break;
     }
+    xcd_clock_end(1);
 }
 
 // one workgroup per 64 x 8 x SUBZ sub-tile. flags: bit0 = a solid cell within the sub-tile grown by 2 cells;
@@ -2180,6 +2217,9 @@ void bfd_launch_classify(const bfd_dev &d, hipStream_t s, int *flagsDev, int *ti
 }
 
 #define BFD_LAUNCH(K, n, ...) hipLaunchKernelGGL(K, dim3(n), dim3(TX, TY, 1), 0, s, d, tilesX, n, __VA_ARGS__)
+// launch over a range that has a cost-balanced map (bfd_tiles::xmap, index m): 8 x maxcnt blocks, those without a run return at once
+#define BFD_LAUNCH_X(K, n, m, ...) do { const int *xm_ = t->xmap ? t->xmap + 10 * (m) : nullptr; \
+        hipLaunchKernelGGL(K, dim3(xm_ ? 8 * t->xmapH[m][9] : (n)), dim3(TX, TY, 1), 0, s, d, tilesX, n, xm_, __VA_ARGS__); } while (0)
 #define BFD_KT(cls, end) do { if (t->ktimer) bfd_kmark(t->ktimer, cls, end, s); } while (0)
 
 // run list layout: [fluid boundary | fluid interior | solid boundary | solid interior]; "boundary" = runs
@@ -2201,8 +2241,8 @@ void bfd_launch_stress_v2(const bfd_dev &d, hipStream_t s0, const bfd_tiles *t, 
     hipStream_t s = s0;
     if (nS) {
         BFD_KT(BFD_K_STRESS_SOLID, 0);
-        if (t->shearCells && t->merged) BFD_LAUNCH(stress_solid_merged, nS, t->runs + t->nFluid + offS, (const float *)t->shearTab);
-        else if (t->shearCells) BFD_LAUNCH(stress_solid, nS, t->runs + t->nFluid + offS);
+        if (t->shearCells && t->merged) BFD_LAUNCH_X(stress_solid_merged, nS, BFD_XM_SS + part, t->runs + t->nFluid + offS, (const float *)t->shearTab);
+        else if (t->shearCells) BFD_LAUNCH_X(stress_solid, nS, BFD_XM_SS + part, t->runs + t->nFluid + offS);
         else BFD_LAUNCH(stress_v2, nS, t->runs + t->nFluid + offS, (const unsigned short *)nullptr);     // variant 2: monolithic, dense
         BFD_KT(BFD_K_STRESS_SOLID, 1);
     }
@@ -2221,7 +2261,7 @@ void bfd_launch_stress_v2(const bfd_dev &d, hipStream_t s0, const bfd_tiles *t, 
     }
     if (n) {
         BFD_KT(BFD_K_STRESS_FLUID, 0);
-        BFD_LAUNCH((stress_fluid<true>), n, t->runs + off);      // fluid cells keep one copy of their normal stresses (bfd_dev::cls)
+        BFD_LAUNCH_X((stress_fluid<true>), n, BFD_XM_SF + part, t->runs + off);      // fluid cells keep one copy of their normal stresses (bfd_dev::cls)
         BFD_KT(BFD_K_STRESS_FLUID, 1);
     }
 }
@@ -2243,13 +2283,13 @@ void bfd_launch_velocity_v2(const bfd_dev &d, hipStream_t s0, float *accP, float
             if (part != 2) { pb = 0; pe = t->nSolidBP; }
             if (part != 1) { qb = t->nSolid - t->nSolidIP; qe = t->nSolid; }
             const int nb = part == 2 ? t->nSolidB : t->nSolidBP, ne = part == 1 ? t->nSolidB : t->nSolid - t->nSolidIP;
-            auto go = [&](bool pml, int a0, int a1) {
+            auto go = [&](bool pml, int a0, int a1, int m) {
                 const int cnt = a1 - a0;
                 if (cnt <= 0) return;
-                if (pml) { if (acc) BFD_LAUNCH((velocity_solid<true, true>), cnt, accP, pkP, base + a0); else BFD_LAUNCH((velocity_solid<false, true>), cnt, accP, pkP, base + a0); }
-                else { if (acc) BFD_LAUNCH((velocity_solid<true, false>), cnt, accP, pkP, base + a0); else BFD_LAUNCH((velocity_solid<false, false>), cnt, accP, pkP, base + a0); }
+                if (pml) { if (acc) BFD_LAUNCH_X((velocity_solid<true, true>), cnt, m, accP, pkP, base + a0); else BFD_LAUNCH_X((velocity_solid<false, true>), cnt, m, accP, pkP, base + a0); }
+                else { if (acc) BFD_LAUNCH_X((velocity_solid<true, false>), cnt, m, accP, pkP, base + a0); else BFD_LAUNCH_X((velocity_solid<false, false>), cnt, m, accP, pkP, base + a0); }
             };
-            go(false, nb, ne); go(true, pb, pe); go(true, qb, qe);
+            go(false, nb, ne, BFD_XM_VS + part); go(true, pb, pe, BFD_XM_VSP_LO); go(true, qb, qe, BFD_XM_VSP_HI);
         } else {                                                     // variant 2: dense
             if (acc) BFD_LAUNCH((velocity_v2<true>), n, accP, pkP, t->runs + t->nFluid + off);
             else BFD_LAUNCH((velocity_v2<false>), n, accP, pkP, t->runs + t->nFluid + off);
@@ -2258,8 +2298,18 @@ void bfd_launch_velocity_v2(const bfd_dev &d, hipStream_t s0, float *accP, float
     }
     if (nF) {
         BFD_KT(BFD_K_VELOCITY_FLUID, 0);
-        if (acc) BFD_LAUNCH((velocity_fluid<true>), nF, t->runs + offF, accP, pkP);
-        else BFD_LAUNCH((velocity_fluid<false>), nF, t->runs + offF, accP, pkP);
+        if (acc) BFD_LAUNCH_X((velocity_fluid<true>), nF, BFD_XM_VF + part, t->runs + offF, accP, pkP);
+        else BFD_LAUNCH_X((velocity_fluid<false>), nF, BFD_XM_VF + part, t->runs + offF, accP, pkP);
         BFD_KT(BFD_K_VELOCITY_FLUID, 1);
     }
 }
+
+#ifdef BFD_EXP_XCD_CLOCK
+// experiment build only: copies the first n block slots of a kind out: start[n], end[n] (end << 4 | xcc id)
+extern "C" int bfd_debug_xcd_clock(int kind, int n, unsigned long long *start, unsigned long long *end)
+{
+    if (kind < 0 || kind > 1 || n < 0 || n > XCLK_MAX) return -1;
+    if (hipMemcpyFromSymbol(start, HIP_SYMBOL(g_blkStart), (size_t)n * 8, (size_t)kind * XCLK_MAX * 8) != hipSuccess) return -1;
+    return hipMemcpyFromSymbol(end, HIP_SYMBOL(g_blkEnd), (size_t)n * 8, (size_t)kind * XCLK_MAX * 8) == hipSuccess ? 0 : -1;
+}
+#endif
