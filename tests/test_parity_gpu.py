@@ -410,3 +410,40 @@ def test_placement_choice_does_not_change_results(monkeypatch):
     for idx in range(4):
         for name in ref[idx]:
             assert np.array_equal(ref[idx][name], out4[idx][name]), (idx, name)
+
+
+def test_cost_balanced_run_maps_do_not_change_results(monkeypatch):
+    """BFD_XCD_BALANCE=1 (experiment): the run lists are cut among the 8 XCDs by estimated cost instead of by count
+    and the launches carry surplus blocks that return at once. Which block takes which run must not matter: same bits, on a
+    medium with solid runs in and outside the absorbing layer, also as the boundary / interior parts of a Z-slab."""
+    from babelbrain_amd import slab
+    from tests.test_slab_gpu import _exchange
+    a, k, info = H.make_problem('C2', N=(192, 96, 96), steps=90, stable_dt_fn=oracle_dt)
+    k['SelMapsRMSPeakList'] = ['Pressure', 'Vz', 'Sigmaxy']
+    k['SelRMSorPeak'] = 3
+    monkeypatch.setenv('BFD_XCD_BALANCE', '0')
+    ref = hip_model().StaggeredFDTD_3D_with_relaxation(*a, SILENT=True, **k)
+    monkeypatch.setenv('BFD_XCD_BALANCE', '1')
+    out = hip_model().StaggeredFDTD_3D_with_relaxation(*a, SILENT=True, **k)
+    for idx in range(4):
+        for name in ref[idx]:
+            assert np.array_equal(ref[idx][name], out[idx][name]), (idx, name)
+    assert np.abs(ref[1]['Sigmaxy']).max() > 0
+    # two slabs, split half-steps (parts 1 and 2 have their own maps)
+    import torch
+    from babelbrain_amd._engine import HALO_STRESS, HALO_VELOCITY
+    slabs, infos = zip(*[slab.create_hip_slab(a, k, r, 2, 0, kernelVariant=0) for r in range(2)])
+    for _ in range(info['nt']):
+        for s in slabs: s.half_step_stress(1)
+        _exchange(slabs, HALO_STRESS)
+        for s in slabs: s.half_step_stress(2)
+        for s in slabs: s.half_step_velocity(1)
+        _exchange(slabs, HALO_VELOCITY)
+        for s in slabs: s.half_step_velocity(2)
+    torch.cuda.synchronize()
+    merged = slab.merge_slab_outputs([slab.collect_slab_outputs(s.eng, k, i) for s, i in zip(slabs, infos)])
+    for n in ref[2]:
+        assert np.array_equal(merged['RMS'][n], ref[2][n]), n
+        assert np.array_equal(merged['Peak'][n], ref[3][n]), n
+    for s in slabs:
+        s.eng.close()
