@@ -36,6 +36,18 @@ def test_n_steps_matches_the_callers_time_plan():
         assert n_steps(nt * dt, dt) == nt                         # TimeSimulation = nt*dt (BASE:2089)
 
 
+def test_make_problem_keeps_the_callers_plan_beside_an_overridden_step_count():
+    """bench.py's production_schedule weights its two rates by the caller's own time plan (BASE:2082-2109): info['plan_nt'] steps, of
+    which the last 2 periods accumulate, whatever `steps` the bench asks for."""
+    from tests.util import oracle_dt
+    from babelbrain_amd import harness as H
+    a, k, info = H.make_problem('C1', N=(48, 48, 64), steps=30, stable_dt_fn=oracle_dt)
+    a2, k2, info2 = H.make_problem('C1', N=(48, 48, 64), stable_dt_fn=oracle_dt)
+    assert info['nt'] == 30 and info2['nt'] == info2['plan_nt'] == info['plan_nt']
+    assert info['plan_accumulating_steps'] == info2['plan_nt'] - k2['SensorStart'] * k2['SensorSubSampling']
+    assert info['plan_accumulating_steps'] == 2 * info['ppp'] and info['plan_nt'] % info['ppp'] == 0
+
+
 @given(st.integers(0, 2 ** 32 - 1))
 @settings(max_examples=50, deadline=None)
 def test_compact_sources_per_slab_union_is_the_whole(seed):
