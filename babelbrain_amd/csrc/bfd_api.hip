@@ -175,21 +175,33 @@ __device__ __forceinline__ bool normal_collapsed(const bfd_dev &d, long c)
     return (d.cls[c] & BFD_CLS_FLUID) != 0;
 }
 
+// a value that exists only at solid cells: from the compact arrays when the solid state is compact (0 where the cell is not listed:
+// a reflector, or a fluid cell asked for a shear stress), else from the full-volume array
+__device__ __forceinline__ float solid_value(const bfd_dev &d, const float *full, const float *comp, long c)
+{
+    if (!d.cssRow) return full[c];
+    const long e = css_index(d, c);
+    return e >= 0 ? comp[e] : 0.0f;
+}
 __device__ __forceinline__ float map_value(const bfd_dev &d, int sel, long c)
 {
     switch (sel) {
     case BFD_MAP_VX: return d.Vx[c];
     case BFD_MAP_VY: return d.Vy[c];
     case BFD_MAP_VZ: return d.Vz[c];
-    case BFD_MAP_SIGMAXX: return normal_collapsed(d, c) ? d.Szz[c] : d.Sxx[c];     // a fluid cell keeps one copy of its normal stresses
-    case BFD_MAP_SIGMAYY: return normal_collapsed(d, c) ? d.Szz[c] : d.Syy[c];
+    case BFD_MAP_SIGMAXX: return normal_collapsed(d, c) ? d.Szz[c] : solid_value(d, d.Sxx, d.cSxx, c);     // a fluid cell keeps one copy of its normal stresses
+    case BFD_MAP_SIGMAYY: return normal_collapsed(d, c) ? d.Szz[c] : solid_value(d, d.Syy, d.cSyy, c);
     case BFD_MAP_SIGMAZZ: return d.Szz[c];
-    case BFD_MAP_SIGMAXY: return d.Sxy[c];
-    case BFD_MAP_SIGMAXZ: return d.Sxz[c];
-    case BFD_MAP_SIGMAYZ: return d.Syz[c];
+    case BFD_MAP_SIGMAXY: return solid_value(d, d.Sxy, d.cSxy, c);
+    case BFD_MAP_SIGMAXZ: return solid_value(d, d.Sxz, d.cSxz, c);
+    case BFD_MAP_SIGMAYZ: return solid_value(d, d.Syz, d.cSyz, c);
     case BFD_MAP_PRESSURE: {
         const float zz = d.Szz[c];
-        const float s = normal_collapsed(d, c) ? (zz + zz) + zz : (d.Sxx[c] + d.Syy[c]) + zz;
+        if (normal_collapsed(d, c)) return -((zz + zz) + zz) * (1.0f / 3.0f);
+        float xx, yy;
+        if (d.cssRow) { const long e = css_index(d, c); xx = e >= 0 ? d.cSxx[e] : 0.0f; yy = e >= 0 ? d.cSyy[e] : 0.0f; }
+        else { xx = d.Sxx[c]; yy = d.Syy[c]; }
+        const float s = (xx + yy) + zz;
         return -s * (1.0f / 3.0f);
     }
     default: return 0.0f;
@@ -329,8 +341,13 @@ __global__ void inject_sources(bfd_dev d, int typeSource, const uint32_t *__rest
         const float x = wx ? wx[s] : 1.0f;
         if (typeSource >= 2) {
             const float v = val * x;
-            if (typeSource == 2) { d.Sxx[c] = d.Sxx[c] + v; d.Syy[c] = d.Syy[c] + v; d.Szz[c] = d.Szz[c] + v; }
-            else { d.Sxx[c] = v; d.Syy[c] = v; d.Szz[c] = v; }
+            float *pxx = d.Sxx + c, *pyy = d.Syy + c;
+            if (d.cssRow) {         // compact solid state: a listed cell's Sxx, Syy live in the list; elsewhere nobody reads them (fluid cells keep Szz only)
+                const long e = css_index(d, c);
+                if (e >= 0) { pxx = d.cSxx + e; pyy = d.cSyy + e; }
+            }
+            if (typeSource == 2) { *pxx = *pxx + v; *pyy = *pyy + v; d.Szz[c] = d.Szz[c] + v; }
+            else { *pxx = v; *pyy = v; d.Szz[c] = v; }
         } else {
             const float y = wy ? wy[s] : 1.0f, z = wz ? wz[s] : 1.0f;
             if (typeSource == 0) { d.Vx[c] = d.Vx[c] + val * x; d.Vy[c] = d.Vy[c] + val * y; d.Vz[c] = d.Vz[c] + val * z; }
@@ -353,8 +370,13 @@ __global__ void inject_sources_at(bfd_dev d, int typeSource, const uint32_t *__r
         const float x = wx ? wx[s] : 1.0f;
         if (typeSource >= 2) {
             const float v = val * x;
-            if (typeSource == 2) { d.Sxx[c] = d.Sxx[c] + v; d.Syy[c] = d.Syy[c] + v; d.Szz[c] = d.Szz[c] + v; }
-            else { d.Sxx[c] = v; d.Syy[c] = v; d.Szz[c] = v; }
+            float *pxx = d.Sxx + c, *pyy = d.Syy + c;
+            if (d.cssRow) {         // compact solid state: a listed cell's Sxx, Syy live in the list; elsewhere nobody reads them (fluid cells keep Szz only)
+                const long e = css_index(d, c);
+                if (e >= 0) { pxx = d.cSxx + e; pyy = d.cSyy + e; }
+            }
+            if (typeSource == 2) { *pxx = *pxx + v; *pyy = *pyy + v; d.Szz[c] = d.Szz[c] + v; }
+            else { *pxx = v; *pyy = v; d.Szz[c] = v; }
         } else {
             const float y = wy ? wy[s] : 1.0f, z = wz ? wz[s] : 1.0f;
             if (typeSource == 0) { d.Vx[c] = d.Vx[c] + val * x; d.Vy[c] = d.Vy[c] + val * y; d.Vz[c] = d.Vz[c] + val * z; }
@@ -621,6 +643,12 @@ int bfd_create(const bfd_config *cfg, bfd_sim **out)
     memset(s->algBytes, 0, sizeof s->algBytes); s->tiles.ktimer = nullptr;
     if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) { delete s; BFD_FAIL(-10, "hipStreamCreate failed"); }
     s->ownStream = true;
+    if (const char *ev = getenv("BFD_CONCURRENT")) if (atoi(ev) != 0) {     // experiment: solid-run kernels beside the fluid kernel (bfd_tiles::sideStream)
+        bfd_tiles &T = s->tiles;
+        bool ok = hipEventCreateWithFlags(&T.sideFork, hipEventDisableTiming) == hipSuccess;
+        for (int q = 0; q < 2 && ok; q++) ok = hipStreamCreateWithFlags(&T.sideStream[q], hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&T.sideJoin[q], hipEventDisableTiming) == hipSuccess;
+        if (!ok) { T.sideStream[0] = T.sideStream[1] = nullptr; (void)hipGetLastError(); }
+    }
     if (hipEventCreate(&s->evBegin) != hipSuccess) { hipStreamDestroy(s->stream); delete s; BFD_FAIL(-10, "hipEventCreate failed"); }
     if (hipEventCreate(&s->evEnd) != hipSuccess) { hipEventDestroy(s->evBegin); hipStreamDestroy(s->stream); delete s; BFD_FAIL(-10, "hipEventCreate failed"); }
 
@@ -695,6 +723,8 @@ void bfd_destroy(bfd_sim *s)
     for (hipEvent_t e : s->evVelocity) hipEventDestroy(e);
     for (auto &v : s->evK) for (hipEvent_t e : v) hipEventDestroy(e);
     hipEventDestroy(s->evBegin); hipEventDestroy(s->evEnd);
+    for (int q = 0; q < 2; q++) { if (s->tiles.sideStream[q]) hipStreamDestroy(s->tiles.sideStream[q]); if (s->tiles.sideJoin[q]) hipEventDestroy(s->tiles.sideJoin[q]); }
+    if (s->tiles.sideFork) hipEventDestroy(s->tiles.sideFork);
     if (s->ownStream) hipStreamDestroy(s->stream);
     delete s;
 }
@@ -951,7 +981,13 @@ static int build_tile_lists(bfd_sim *s)
     // a list rebuilt in the middle of a run (inputs set again at step > 0): the shear memory variables travel through the
     // full-volume arrays
     const bool carryShearMemory = s->step > 0 && s->tilesReady == false && s->tiles.shearR && s->tiles.nShear > 0;
+    const bool hadList = s->tiles.shearCells != nullptr, hadListR = s->tiles.shearR != nullptr, wasMerged = s->tiles.merged;
     if (carryShearMemory) { bfd_launch_scatter_shear_memory(s->d, s->stream, &s->tiles); BFD_HIP(hipStreamSynchronize(s->stream)); }
+    // the same for a compact solid state: back into the full-volume arrays, from which the new list is filled again
+    const bool carryCompact = s->step > 0 && s->d.cssRow && s->tiles.nShear > 0;
+    if (carryCompact) { bfd_launch_css_copy(s->d, s->stream, &s->tiles, 0x7Fu, true); BFD_HIP(hipStreamSynchronize(s->stream)); }
+    s->d.cssRow = nullptr; s->d.cSxx = s->d.cSyy = s->d.cSxy = s->d.cSxz = s->d.cSyz = s->d.cRxx = s->d.cRyy = nullptr;
+    dev_release(s, &s->tiles.cssRow); dev_release(s, &s->tiles.css); s->tiles.cssCap = 0;
     dev_release(s, &s->tiles.runs); dev_release(s, &s->tiles.xmap); dev_release(s, &s->tiles.shearCells); dev_release(s, &s->tiles.shearCoef); dev_release(s, &s->tiles.shearR);    // lists of an earlier build
     dev_release(s, &s->tiles.shearCodes); dev_release(s, &s->tiles.shearTab);
     const int SUB = bfd_tile_subz();
@@ -984,7 +1020,7 @@ static int build_tile_lists(bfd_sim *s)
     // different solids. BFD_SOLID_MERGED=0 selects the two-kernel form (stress_solid + stress_shear_sparse over every solid cell).
     T.merged = BFD_SOLID_MERGED_DEFAULT != 0;
     if (const char *ev = getenv("BFD_SOLID_MERGED")) T.merged = atoi(ev) != 0;
-    if (s->step > 0 && s->tiles.shearR) T.merged = false;       // a list rebuilt in the middle of a run keeps the form it started with
+    if (s->step > 0 && hadList) T.merged = hadListR ? false : wasMerged;       // a list rebuilt in the middle of a run keeps the form it started with (where its shear memory variables live)
     T.nFluid = T.nFluidB = T.nSolid = T.nSolidB = T.nSolidBP = T.nSolidIP = T.nFused = T.nLossless = T.nLossy = T.nSolidSub = T.nUni = T.nPml = T.nLean = T.nFusedSub = 0;
     s->d.tilesX = tx; s->d.tilesY = ty;
     // Every fluid sub-tile is LEAN (bit4): fluid cells keep a single copy of their identical normal stresses, whatever
@@ -1122,7 +1158,7 @@ static int build_tile_lists(bfd_sim *s)
                 }
                 const int kbeg = q * SUB, kend = std::min(r * SUB, s->d.nk);
                 // solid runs: bit0 + bit3 (a sub-tile of the run touches the absorbing layer)
-                int4 run; run.x = txy; run.y = kbeg | (kend << 16); run.z = solid ? (1 | pmlAny) : (f & ~(32 | 128 | 256)); run.w = m;
+                int4 run; run.x = txy; run.y = kbeg | (kend << 16); run.z = solid ? (1 | pmlAny | (getenv("BFD_EXP_SOLID_AS_FLUID") ? 2 : 0)) : (f & ~(32 | 128 | 256)); run.w = m;
                 lists[(solid ? 2 : 0) + (bnd ? 0 : 1)].push_back(run);
                 for (int u = q; u < r; u++) {
                     taken[(size_t)u * tx * ty + txy] = 1;
@@ -1271,6 +1307,25 @@ static int build_tile_lists(bfd_sim *s)
         if (rc) return rc;
         s->tiles.nShear = count;
         if (s->step > 0 && s->tiles.shearR) { bfd_launch_gather_shear_memory(s->d, s->stream, &s->tiles); BFD_HIP(hipStreamSynchronize(s->stream)); }
+        // Compact solid state (bfd_dev::cssRow): Sxx, Syy, the shear stresses, Rxx, Ryy of the listed cells in list order. Needs the row-contiguous
+        // list order (mode 2) and the two-kernel form; whole domains only so far (a Z-slab's neighbours read Sxz / Syz ghost planes out of the
+        // full-volume arrays). BFD_COMPACT_SOLID=0 keeps the full-volume arrays.
+        bool compact = count > 0 && orderMode == 2 && !T.merged && s->d.k0 == 0 && s->d.nk == s->d.N3 && s->d.N1 <= 4095 && bfd_css_supported();
+        if (const char *ev = getenv("BFD_COMPACT_SOLID")) compact = compact && atoi(ev) != 0;
+        if (compact) {
+            const int stride = tx + 1;
+            rc = dev_alloc(s, &s->tiles.cssRow, (size_t)(s->d.nk + 4) * s->d.N2 * stride, false);
+            if (!rc) rc = dev_alloc(s, &s->tiles.css, 7 * (size_t)count, true);
+            if (rc) return rc;
+            s->tiles.cssCap = count;
+            bfd_launch_css_row_table(s->d, s->stream, s->tiles.shearCells, count, s->tiles.cssRow, stride, lowPlanes, hiStart);
+            float *c = s->tiles.css;
+            s->d.cssRow = s->tiles.cssRow; s->d.cssStride = stride;
+            s->d.cSxx = c; s->d.cSyy = c + (size_t)count; s->d.cSxy = c + 2 * (size_t)count; s->d.cSxz = c + 3 * (size_t)count; s->d.cSyz = c + 4 * (size_t)count;
+            s->d.cRxx = c + 5 * (size_t)count; s->d.cRyy = c + 6 * (size_t)count;
+            if (s->step > 0) bfd_launch_css_copy(s->d, s->stream, &s->tiles, 0x7Fu, false);
+            BFD_HIP(hipStreamSynchronize(s->stream));
+        }
         s->tiles.shearLowEnd = std::lower_bound(hostCells.begin(), hostCells.end(), (unsigned)lowPlanes * (unsigned)s->d.plane) - hostCells.begin();
         s->tiles.shearHighBeg = std::lower_bound(hostCells.begin(), hostCells.end(), (unsigned)hiStart * (unsigned)s->d.plane) - hostCells.begin();
     }
@@ -1971,6 +2026,7 @@ int bfd_reset(bfd_sim *s)
         if (n) BFD_HIP(hipMemsetAsync(d.psi[a], 0, n * sizeof(float), s->stream));
     }
     if (s->tiles.shearR && s->tiles.nShear) BFD_HIP(hipMemsetAsync(s->tiles.shearR, 0, 3 * (size_t)s->tiles.nShear * sizeof(float), s->stream));
+    if (s->tiles.css && s->tiles.cssCap) BFD_HIP(hipMemsetAsync(s->tiles.css, 0, 7 * (size_t)s->tiles.cssCap * sizeof(float), s->stream));
     if (s->acc) BFD_HIP(hipMemsetAsync(s->acc, 0, (size_t)s->nSelR * s->nloc * sizeof(float), s->stream));
     if (s->pk) BFD_HIP(hipMemsetAsync(s->pk, 0, (size_t)s->nSelR * s->nloc * sizeof(float), s->stream));
     if (s->sensOut) BFD_HIP(hipMemsetAsync(s->sensOut, 0, (size_t)s->nSelS * s->nTs * (size_t)s->nSensors * sizeof(float), s->stream));
@@ -2085,6 +2141,10 @@ int bfd_get_field(bfd_sim *s, int32_t a, float *out, int64_t s1, int64_t s2, int
     BFD_HIP(hipSetDevice(s->cfg.device));
     expand_if_collapsed(s);
     if (a >= 12 && s->tilesReady && s->cfg.kernelVariant != 1) bfd_launch_scatter_shear_memory(s->d, s->stream, &s->tiles);   // Rxy, Rxz, Ryz live beside the sparse list
+    {   // so do Sxx, Syy, Sxy, Sxz, Syz, Rxx, Ryy of the listed cells when the solid state is compact: into the full-volume array asked for
+        static const int cssOf[15] = {-1, -1, -1, 0, 1, -1, 2, 3, 4, 5, 6, -1, -1, -1, -1};
+        if (cssOf[a] >= 0 && s->tilesReady) bfd_launch_css_copy(s->d, s->stream, &s->tiles, 1u << cssOf[a], true);
+    }
     const bfd_dev &d = s->d;
     float *cur[15] = {d.Vx, d.Vy, d.Vz, d.Sxx, d.Syy, d.Szz, d.Sxy, d.Sxz, d.Syz, d.Rxx, d.Ryy, d.Rzz, d.Rxy, d.Rxz, d.Ryz};
     return download_volume(s, cur[a], out, s1, s2, s3);

@@ -71,7 +71,38 @@ struct bfd_dev {
     // write targets of the fields that variant 4 keeps in two copies (V, Szz, Rzz); equal to the read pointers in
     // every other variant (in-place update). Kernels read d.X and write d.XW.
     float *VxW, *VyW, *VzW, *SzzW, *RzzW;
+    // Compact solid state (round 5; bfd_tiles::css). cssRow != null: the values that exist only at solid cells -- Sxx, Syy, the three
+    // shear stresses and the memory variables Rxx, Ryy -- live in the order of the sparse shear list ("listed" cells: solid centre,
+    // no reflector) instead of the full-volume arrays, which are then not maintained. cssRow[((kl + 2) * N2 + j) * cssStride + bx] =
+    // list index of the first listed cell of row (kl, j) with i >= 64 bx (bx = tilesX: one past the row's last entry); a row of the
+    // list is contiguous in x, so the entry of cell i is that base + the number of listed cells of the row in [64 bx, i).
+    // 0xFFFFFFFF marks planes without compact values (ghost planes: every value there is 0).
+    const unsigned *cssRow; int cssStride;
+    float *cSxx, *cSyy, *cSxy, *cSxz, *cSyz, *cRxx, *cRyy;
 };
+#define BFD_CSS_NONE 0xFFFFFFFFu
+// a cell has compact values ("listed") when its class byte says solid centre, no reflector
+static __device__ __forceinline__ bool css_listed(unsigned c) { return (c & (BFD_CLS_FLUID | BFD_CLS_REFL)) == 0u; }
+// number of lanes below this one whose predicate is set (all lanes of the wave must get here)
+static __device__ __forceinline__ unsigned css_rank(bool listed)
+{
+    const unsigned long long b = __ballot(listed);
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u));
+}
+// list index of owned cell c (local linear index) or -1 when it has no compact values; for the readers outside the marching kernels
+// (sensors, maps, sources): walks the class bytes of the row from the tile edge
+static __device__ __forceinline__ long css_index(const bfd_dev &d, long c)
+{
+    if (!css_listed(d.cls[c])) return -1;
+    const int kl = (int)(c / d.plane);
+    const int r = (int)(c - (long)kl * d.plane);
+    const int j = r / d.N1, i = r - j * d.N1;
+    const unsigned rb = d.cssRow[((long)(kl + 2) * d.N2 + j) * d.cssStride + (i >> 6)];
+    if (rb == BFD_CSS_NONE) return -1;
+    unsigned n = 0;
+    for (long q = c - (i & 63); q < c; q++) n += css_listed(d.cls[q]) ? 1u : 0u;
+    return (long)rb + n;
+}
 
 // tile lists of the class-specialised path (variant 3): device array
 // runs [fluid boundary | fluid interior | solid boundary | solid interior] (boundary = inside the first/last
@@ -90,13 +121,17 @@ enum { BFD_XM_SF = 0, BFD_XM_VF = 3, BFD_XM_SS = 6, BFD_XM_VS = 9, BFD_XM_VSP_LO
 struct bfd_tiles { bfd_sim *ktimer; int nMat; bool merged /* solid runs: normal and shear stresses in one kernel, the sparse list holds the MIXED cells only */; int4 *runs;
                    unsigned *shearCells; float *shearCoef; long nShear, shearLowEnd, shearHighBeg;   /* sparse shear list */
                    unsigned *shearCodes; float *shearTab; long nShearExplicit;   /* per listed cell a byte per edge: 0 inactive, 1 + m = one material around the edge (coefficients from shearTab[2 m ..]), 255 = explicit coefficients in shearCoef; number of explicit edges */
+                   unsigned *cssRow; float *css; long cssCap;   /* compact solid state (bfd_dev::cssRow): row table, [7][cssCap] values Sxx Syy Sxy Sxz Syz Rxx Ryy in list order */
                    float *shearR;   /* memory variables Rxy, Rxz, Ryz of the listed cells, [3][nShear] in list order: only the sparse kernel uses them, so they live beside the list (dense, coalesced) instead of in the full-volume arrays, which are filled from here on demand (bfd_get_field) */
                    int nFluid, nFluidB, nSolid, nSolidB, nSolidBP /* leading boundary runs that touch the absorbing layer */, nSolidIP /* trailing interior ones */, nFused /* runs of the fused kernel, after the solid runs */;
                    int nLossless, nLossy, nSolidSub, nUni, nPml, nLean, nFusedSub;
                    /* cost-balanced block -> run maps (round 4): block b of a launch runs on XCD slot b & 7 and takes run seg[slot] + (b >> 3) of
                       the launched range if that is below seg[slot + 1]; the launch has 8 x maxcnt blocks. One map of 10 ints (seg[0..8], maxcnt)
                       per launched range and kernel class, on the device in xmap, on the host in xmapH. */
-                   int *xmap; int xmapH[BFD_XMAP_COUNT][10]; };
+                   int *xmap; int xmapH[BFD_XMAP_COUNT][10];
+                   /* experiment (BFD_CONCURRENT=1): the solid-run kernels of a half-step on side streams beside the fluid kernel (they write
+                      disjoint cells); fork / join through events. Null = everything on the engine's stream. */
+                   hipStream_t sideStream[2]; hipEvent_t sideFork, sideJoin[2]; };
 
 struct bfd_sim {
     bfd_config cfg;
@@ -173,6 +208,7 @@ void bfd_launch_fused(const bfd_dev &d, hipStream_t s, float *accP, float *pkP, 
 int bfd_fused_rows(void);
 int bfd_fused_max_materials(void);
 int bfd_tile_subz(void);
+bool bfd_css_supported(void);     // false in the experiment builds whose solid-run kernels have no compact form
 void bfd_launch_classify(const bfd_dev &d, hipStream_t s, int *flagsDev, int *tileMatDev);
 // flags the cells of the sparse shear list: solid, non-reflector centre; mixedOnly: only those with BFD_CLS_MIXED (merged solid stress kernel)
 void bfd_launch_mark_solid(const bfd_dev &d, hipStream_t s, unsigned char *flag, long n, bool mixedOnly);
@@ -181,6 +217,10 @@ void bfd_launch_shear_coefficients(const bfd_dev &d, hipStream_t s, const unsign
 // copies the list-ordered shear memory variables into the full-volume arrays Rxy, Rxz, Ryz (outputs only)
 void bfd_launch_scatter_shear_memory(const bfd_dev &d, hipStream_t s, const bfd_tiles *t);
 void bfd_launch_gather_shear_memory(const bfd_dev &d, hipStream_t s, const bfd_tiles *t);
+// compact solid state: the row table of a list in order mode 2 (lowPlanes / hiStart as for bfd_launch_shear_order_keys); copies between the
+// compact arrays and the full-volume ones (mask: bit a = array a of Sxx Syy Sxy Sxz Syz Rxx Ryy; toFull = compact -> full volume)
+void bfd_launch_css_row_table(const bfd_dev &d, hipStream_t s, const unsigned *cells, long n, unsigned *rowTable, int stride, int lowPlanes, int hiStart);
+void bfd_launch_css_copy(const bfd_dev &d, hipStream_t s, const bfd_tiles *t, unsigned mask, bool toFull);
 void bfd_launch_cell_classes(const bfd_dev &d, hipStream_t s, uint8_t *clsBase, long nalloc);
 // counts over the cells of the solid runs: [0] fluid no-memory, [1] fluid with memory, [2] solid no-memory, [3] solid with memory,
 // [4] active shear edges, [5] reflector cells

@@ -21,6 +21,12 @@
 
 namespace {
 
+#ifdef BFD_EXP_ALL_FLUID_CLASSES
+// experiment build (wrong results): the solid-run kernels see every cell as a fluid cell -- what they cost without their solid-only streams
+#define EXPCL(x) (((x) | BFD_CLS_FLUID) & ~(BFD_CLS_EXY | BFD_CLS_EXZ | BFD_CLS_EYZ | BFD_CLS_REFL | BFD_CLS_MIXED))
+#else
+#define EXPCL(x) (x)
+#endif
 constexpr int TX = BFD_TILE_X;
 constexpr int TY = BFD_TILE_Y;
 constexpr int LW = TX + 4;          // LDS row length (floats)
@@ -758,12 +764,15 @@ __device__ __forceinline__ void velocity_fluid_body(const bfd_dev &d, int bx, in
 // canonical sequence for every lane (zeros / substituted values make it equal to the dense kernels' bit for bit, up
 // to the sign of an exact zero). Class bytes run two planes ahead of the state loads they steer.
 // ------------------------------------------------------------------------------------------------
-template <bool PML>
+// CSS: the solid-only values (Sxx, Syy, Rxx, Ryy) of a listed cell live in the compact arrays (bfd_dev::cssRow): a wave = one tile row,
+// entry of a lane = row base (one scalar per row and plane) + the number of listed lanes below it
+template <bool PML, bool CSS>
 __device__ __forceinline__ void stress_solid_body(const bfd_dev &d, const int4 &run, int tilesX, float (*sV)[2][LH * LW])
 {
     const int N1 = d.N1, N2 = d.N2;
     const int bx = run.x % tilesX, by = run.x / tilesX, kbeg = run.y & 0xFFFF, kend = run.y >> 16;
     const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * TX + tx;
+    const int wv = __builtin_amdgcn_readfirstlane(ty);
     const int i0 = bx * TX, j0 = by * TY;
     const int i = i0 + tx, j = j0 + ty;
     const bool valid = (i < N1) && (j < N2);
@@ -799,19 +808,30 @@ __device__ __forceinline__ void stress_solid_body(const bfd_dev &d, const int4 &
     unsigned mraw = 0, cl = BFD_CLS_FLUID | BFD_CLS_NOMEM, cl1 = BFD_CLS_FLUID | BFD_CLS_NOMEM;
     if (valid) {
         const float *bVz = d.Vz + kbeg * pl;
-        cl = U1((d.cls + kbeg * pl), cij); cl1 = U1((d.cls + kbeg * pl + pl), cij);
+        cl = EXPCL(U1((d.cls + kbeg * pl), cij)); cl1 = EXPCL(U1((d.cls + kbeg * pl + pl), cij));
         vx0 = F4((d.Vx + kbeg * pl), cij * 4u); vy0 = F4((d.Vy + kbeg * pl), cij * 4u);
         vzm2 = F4((bVz - 2 * pl), cij * 4u); vzm1 = F4((bVz - pl), cij * 4u); vz0 = F4(bVz, cij * 4u); vzp1 = F4((bVz + pl), cij * 4u);
         mraw = U2((d.mat + kbeg * pl), cij * 2u);
         szz = F4((d.Szz + kbeg * pl), cij * 4u);
         const bool fl = cl & BFD_CLS_FLUID, mem = !(cl & BFD_CLS_NOMEM) || !fl;
         if (mem) rzz = F4((d.Rzz + kbeg * pl), cij * 4u);
-        if (!fl) {
+        if (!CSS && !fl) {
             sxx = F4((d.Sxx + kbeg * pl), cij * 4u); syy = F4((d.Syy + kbeg * pl), cij * 4u);
             rxx = F4((d.Rxx + kbeg * pl), cij * 4u); ryy = F4((d.Ryy + kbeg * pl), cij * 4u);
         }
     }
     float hv = t.ok ? F4(ph + kbeg * pl, hofs) : 0.0f;
+    // compact entries: ix = entry of this lane's cell in the plane whose values sit in sxx .. ryy (meaningful where the cell is listed)
+    const unsigned *rowp = nullptr;
+    long rs = 0;
+    unsigned ix = 0;
+    if (CSS) {
+        rowp = d.cssRow + ((long)2 * N2 + min(j0 + wv, N2 - 1)) * d.cssStride + bx;
+        rs = (long)N2 * d.cssStride;
+        const bool li = css_listed(cl);
+        ix = (unsigned)__builtin_amdgcn_readfirstlane((int)rowp[kbeg * rs]) + css_rank(li);
+        if (li) { sxx = F4(d.cSxx, ix * 4u); syy = F4(d.cSyy, ix * 4u); rxx = F4(d.cRxx, ix * 4u); ryy = F4(d.cRyy, ix * 4u); }
+    }
 
     for (int kl = kbeg; kl < kend; kl++) {
         const int b = kl & 1;
@@ -820,9 +840,9 @@ __device__ __forceinline__ void stress_solid_body(const bfd_dev &d, const int4 &
         const long ko = (long)__builtin_amdgcn_readfirstlane(kl) * pl;
         const int k = d.k0 + kl;
         float nvx = 0, nvy = 0, nvz = 0, nh = 0, nsxx = 0, nsyy = 0, nszz = 0, nrxx = 0, nryy = 0, nrzz = 0, npx = 0, npy = 0, npz = 0;
-        unsigned nmraw = 0, ncl2 = BFD_CLS_FLUID | BFD_CLS_NOMEM;
+        unsigned nmraw = 0, ncl2 = BFD_CLS_FLUID | BFD_CLS_NOMEM, nix = 0;
         auto prefetch_next = [&]() {
-        if (valid) ncl2 = U1((d.cls + ko + 2 * pl), cij);           // ghost planes make kl+2 addressable
+        if (valid) ncl2 = EXPCL(U1((d.cls + ko + 2 * pl), cij));           // ghost planes make kl+2 addressable
             if (kl + 1 < kend) {
                 if (valid) {
                     const bool nfl = cl1 & BFD_CLS_FLUID, nmem = !(cl1 & BFD_CLS_NOMEM) || !nfl;
@@ -830,10 +850,15 @@ __device__ __forceinline__ void stress_solid_body(const bfd_dev &d, const int4 &
                     nmraw = U2((d.mat + ko + pl), cij * 2u);
                     nszz = F4((d.Szz + ko + pl), cij * 4u);
                     if (nmem) nrzz = F4((d.Rzz + ko + pl), cij * 4u);
-                    if (!nfl) {
+                    if (!CSS && !nfl) {
                         nsxx = F4((d.Sxx + ko + pl), cij * 4u); nsyy = F4((d.Syy + ko + pl), cij * 4u);
                         nrxx = F4((d.Rxx + ko + pl), cij * 4u); nryy = F4((d.Ryy + ko + pl), cij * 4u);
                     }
+                }
+                if (CSS) {
+                    const bool nli = css_listed(cl1);
+                    nix = (unsigned)__builtin_amdgcn_readfirstlane((int)rowp[(kl + 1) * rs]) + css_rank(nli);
+                    if (nli) { nsxx = F4(d.cSxx, nix * 4u); nsyy = F4(d.cSyy, nix * 4u); nrxx = F4(d.cRxx, nix * 4u); nryy = F4(d.cRyy, nix * 4u); }
                 }
                 if (t.ok) nh = F4(ph + ko + pl, hofs);
                 if (zi) npx = F4(d.psi[0], (unsigned)(qx + dqx) * 4u);
@@ -884,9 +909,11 @@ __device__ __forceinline__ void stress_solid_body(const bfd_dev &d, const int4 &
                     const float sYZ = dyVy + dzVz, sXZ = dxVx + dzVz;
                     float rn;
                     rn = c1 * rxx - (BP * div - BS2 * sYZ);
-                    ST4((d.Sxx + ko), cij * 4u, sxx + ((AP * div - AS2 * sYZ) + 0.5f * (rxx + rn))); ST4((d.Rxx + ko), cij * 4u, rn);
+                    if (CSS) { ST4(d.cSxx, ix * 4u, sxx + ((AP * div - AS2 * sYZ) + 0.5f * (rxx + rn))); ST4(d.cRxx, ix * 4u, rn); }
+                    else { ST4((d.Sxx + ko), cij * 4u, sxx + ((AP * div - AS2 * sYZ) + 0.5f * (rxx + rn))); ST4((d.Rxx + ko), cij * 4u, rn); }
                     rn = c1 * ryy - (BP * div - BS2 * sXZ);
-                    ST4((d.Syy + ko), cij * 4u, syy + ((AP * div - AS2 * sXZ) + 0.5f * (ryy + rn))); ST4((d.Ryy + ko), cij * 4u, rn);
+                    if (CSS) { ST4(d.cSyy, ix * 4u, syy + ((AP * div - AS2 * sXZ) + 0.5f * (ryy + rn))); ST4(d.cRyy, ix * 4u, rn); }
+                    else { ST4((d.Syy + ko), cij * 4u, syy + ((AP * div - AS2 * sXZ) + 0.5f * (ryy + rn))); ST4((d.Ryy + ko), cij * 4u, rn); }
                     rn = c1 * rzz - (BP * div - BS2 * sXY);
                     ST4((d.SzzW + ko), cij * 4u, szz + ((AP * div - AS2 * sXY) + 0.5f * (rzz + rn))); ST4((d.RzzW + ko), cij * 4u, rn);
                 }
@@ -895,7 +922,7 @@ __device__ __forceinline__ void stress_solid_body(const bfd_dev &d, const int4 &
         vx0 = nvx; vy0 = nvy;
         vzm2 = vzm1; vzm1 = vz0; vz0 = vzp1; vzp1 = nvz;
         hv = nh; mraw = nmraw; cl = cl1; cl1 = ncl2;
-        sxx = nsxx; syy = nsyy; szz = nszz; rxx = nrxx; ryy = nryy; rzz = nrzz;
+        sxx = nsxx; syy = nsyy; szz = nszz; rxx = nrxx; ryy = nryy; rzz = nrzz; ix = nix;
         px = npx; py = npy; pz = npz; qx += dqx; qy += dqy;
     }
 }
@@ -906,14 +933,15 @@ __device__ __forceinline__ void stress_solid_body(const bfd_dev &d, const int4 &
 // (-DBFD_STRESS_SOLID_GLOBAL builds the GLOBAL / branch-free-prefetch body below instead: measured 1 % slower, 0.308-0.311 against
 // 0.305 ms at the shear medium 512^3 -- this kernel is at the rate of the bytes it moves; profiles/r4/experiment_solid_kernels_prefetch.txt)
 #ifndef BFD_STRESS_SOLID_GLOBAL
+template <bool CSS>
 __global__ __launch_bounds__(NTHREADS, SOLID_STRESS_WAVES_PER_SIMD) void stress_solid(bfd_dev d, int tilesX, int nblocks, const int *__restrict__ xmap, const int4 *__restrict__ runs)
 {
     __shared__ float sV[2][2][LH * LW];
     const int ri = run_index(nblocks, xmap);
     if (ri < 0) return;
     const int4 run = runs[ri];
-    if (run.z & 8) stress_solid_body<true>(d, run, tilesX, sV);
-    else stress_solid_body<false>(d, run, tilesX, sV);
+    if (run.z & 8) stress_solid_body<true, CSS>(d, run, tilesX, sV);
+    else stress_solid_body<false, CSS>(d, run, tilesX, sV);
 }
 #endif
 
@@ -1384,6 +1412,17 @@ __device__ __forceinline__ float halo_value_g(const float *base, const float *al
     return take ? v : 0.0f;
 }
 
+// compact form: the halo cell's value comes from Szz (SUBST and fluid), from the compact array at byte offset e4 (SUBST: listed cell, else: edge bit
+// set), or is 0
+__device__ __forceinline__ float halo_value_c(const float *cbase, const float *alt, bool subst, unsigned bit, unsigned hc, unsigned off4, unsigned e4, bool ok)
+{
+    const bool fromAlt = subst && (hc & BFD_CLS_FLUID) != 0;
+    const bool take = ok && (fromAlt || (subst ? css_listed(hc) : (hc & bit) != 0));
+    const unsigned long long pp = fromAlt ? (unsigned long long)gbase(alt) : (unsigned long long)gbase(cbase);
+    const float v = *(BFD_GA const float *)(pp + (take ? (fromAlt ? off4 : e4) : 0u));
+    return take ? v : 0.0f;
+}
+
 template <bool PML>
 __device__ __forceinline__ void stress_solid_body_g(const bfd_dev &d, const int4 &run, int tilesX, float (*sV)[2][LH * LW])
 {
@@ -1522,7 +1561,10 @@ __device__ __forceinline__ void stress_solid_body_g(const bfd_dev &d, const int4
     }
 }
 
-template <bool ACC, bool PML>
+// CSS: Sxx, Syy and the three shear stresses of listed cells come from the compact arrays (bfd_dev::cssRow). Entry of a cell = base of its
+// row (per plane; own row and halo row: one scalar each, the halo columns: one table word per lane) + the listed cells before it in the row;
+// the bases a plane needs are fetched one iteration ahead, so the prefetch still issues without waiting for anything.
+template <bool ACC, bool PML, bool CSS>
 __device__ __forceinline__ void velocity_solid_body_g(const bfd_dev &d, const int4 &run, int tilesX, float (*sS)[5][LH * LW],
                                                       float *__restrict__ accP, float *__restrict__ pkP)
 {
@@ -1564,22 +1606,64 @@ __device__ __forceinline__ void velocity_solid_body_g(const bfd_dev &d, const in
     const bool zj = PML && valid && (j < P || j >= N2 - P);
     const bool inner = valid && i >= d.ND && i < N1 - d.ND && j >= d.ND && j < N2 - d.ND;
 
+    // compact solid state: row table of the own row and of the halo row of task A (waves 0-3: also of task B), planes as a scalar stride;
+    // the halo-column lanes (waves 4-6, lanes 0..31) read their table word themselves: cells i0-2, i0-1 count back from the base of this
+    // tile's row, cells i0+64, i0+65 count on from the base of the next tile's
+    const long rs = CSS ? (long)N2 * d.cssStride : 0;
+    const unsigned *rowp = nullptr, *rowpA = nullptr;
+    const float *cbaseA = nullptr, *cbaseB = nullptr;
+    unsigned rtOfs = 0;
+    const int cc = tx & 3;
+    if (CSS) {
+        rowp = d.cssRow + ((long)2 * N2 + min(j0 + wv, N2 - 1)) * d.cssStride + bx;
+        const int rA = wv & 3, gjA = j0 - 2 + (rA < 2 ? rA : TY + rA);
+        rowpA = d.cssRow + ((long)2 * N2 + min(max(gjA, 0), N2 - 1)) * d.cssStride + bx;
+        cbaseA = arrA == 1 ? d.cSyy : d.cSxy;
+        cbaseB = arrB == 4 ? d.cSyz : (arrB == 0 ? d.cSxx : (arrB == 2 ? d.cSxy : d.cSxz));
+        if (wv >= 4 && wv < 7 && tx < XT) rtOfs = (unsigned)(((2 * N2 + min(j0 + (tx >> 2), N2 - 1)) * d.cssStride + bx + (cc >= 2 ? 1 : 0)) * 4);
+    }
+    auto rowbase = [&](const unsigned *rp, int plane) { return (unsigned)__builtin_amdgcn_readfirstlane((int)rp[plane * rs]); };
+    // entry of this lane's halo cell of task B: waves 0-3 a row like task A, waves 4-6 the columns
+    auto entryB = [&](unsigned rbRow, unsigned rbx, unsigned hc) {
+        const bool li = tb.ok && css_listed(hc);
+        if (wv < 4) return rbRow + css_rank(li);
+        const unsigned long long lb = __ballot(li);
+        const unsigned pb = (unsigned)(lb >> ((cc == 0 ? tx + 1 : tx - 1) & 63)) & 1u;
+        return cc < 2 ? rbx - 1u - (cc == 0 ? pb : 0u) : rbx + (cc == 3 ? pb : 0u);
+    };
+    unsigned rbB = BFD_CSS_NONE, rbC = BFD_CSS_NONE, rbA = 0, rbx = 0;      // row bases: own row at planes kl+1 / kl+2, halo row and column word at plane kl+1
+
     float zzm1 = 0, zz0 = 0, zzp1 = 0, zzp2 = 0, xzm2 = 0, xzm1 = 0, xz0 = 0, xzp1 = 0, yzm2 = 0, yzm1 = 0, yz0 = 0, yzp1 = 0;
     unsigned cB = BFD_CLS_FLUID, cC = BFD_CLS_FLUID;
     {
         const float *bzz = d.Szz + kbeg * pl, *bxz = d.Sxz + kbeg * pl, *byz = d.Syz + kbeg * pl;
         const uint8_t *bc = d.cls + kbeg * pl;
         unsigned cm2 = BFD_CLS_FLUID, cm1 = BFD_CLS_FLUID, c0 = BFD_CLS_FLUID;
-        if (valid) { cm2 = gl1(bc - 2 * pl, cij); cm1 = gl1(bc - pl, cij); c0 = gl1(bc, cij); cB = gl1(bc + pl, cij); cC = gl1(bc + 2 * pl, cij); }
+        if (valid) { cm2 = EXPCL(gl1(bc - 2 * pl, cij)); cm1 = EXPCL(gl1(bc - pl, cij)); c0 = EXPCL(gl1(bc, cij)); cB = EXPCL(gl1(bc + pl, cij)); cC = EXPCL(gl1(bc + 2 * pl, cij)); }
         zzm1 = glp(bzz - pl, c4, valid); zz0 = glp(bzz, c4, valid); zzp1 = glp(bzz + pl, c4, valid); zzp2 = glp(bzz + 2 * pl, c4, valid);
-        xzm2 = glp(bxz - 2 * pl, c4, valid && (cm2 & BFD_CLS_EXZ)); xzm1 = glp(bxz - pl, c4, valid && (cm1 & BFD_CLS_EXZ));
-        xz0 = glp(bxz, c4, valid && (c0 & BFD_CLS_EXZ)); xzp1 = glp(bxz + pl, c4, valid && (cB & BFD_CLS_EXZ));
-        yzm2 = glp(byz - 2 * pl, c4, valid && (cm2 & BFD_CLS_EYZ)); yzm1 = glp(byz - pl, c4, valid && (cm1 & BFD_CLS_EYZ));
-        yz0 = glp(byz, c4, valid && (c0 & BFD_CLS_EYZ)); yzp1 = glp(byz + pl, c4, valid && (cB & BFD_CLS_EYZ));
         const bool fl0 = (c0 & BFD_CLS_FLUID) != 0;
-        float sxx = glp(d.Sxx + kbeg * pl, c4, valid && !fl0), syy = glp(d.Syy + kbeg * pl, c4, valid && !fl0);
+        float sxx, syy, sxy;
+        if (CSS) {
+            const unsigned rm2 = rowbase(rowp, kbeg - 2), rm1 = rowbase(rowp, kbeg - 1), rb0 = rowbase(rowp, kbeg);
+            rbB = rowbase(rowp, kbeg + 1); rbC = rowbase(rowp, kbeg + 2);
+            const unsigned em2 = (rm2 + css_rank(css_listed(cm2))) * 4u, em1 = (rm1 + css_rank(css_listed(cm1))) * 4u;
+            const unsigned e0 = (rb0 + css_rank(css_listed(c0))) * 4u, e1 = (rbB + css_rank(css_listed(cB))) * 4u;
+            const bool gm2 = rm2 != BFD_CSS_NONE, gm1 = rm1 != BFD_CSS_NONE, g1 = rbB != BFD_CSS_NONE;       // ghost planes hold no compact values: 0
+            xzm2 = glp(d.cSxz, em2, gm2 && (cm2 & BFD_CLS_EXZ)); xzm1 = glp(d.cSxz, em1, gm1 && (cm1 & BFD_CLS_EXZ));
+            xz0 = glp(d.cSxz, e0, (c0 & BFD_CLS_EXZ) != 0); xzp1 = glp(d.cSxz, e1, g1 && (cB & BFD_CLS_EXZ));
+            yzm2 = glp(d.cSyz, em2, gm2 && (cm2 & BFD_CLS_EYZ)); yzm1 = glp(d.cSyz, em1, gm1 && (cm1 & BFD_CLS_EYZ));
+            yz0 = glp(d.cSyz, e0, (c0 & BFD_CLS_EYZ) != 0); yzp1 = glp(d.cSyz, e1, g1 && (cB & BFD_CLS_EYZ));
+            sxx = glp(d.cSxx, e0, css_listed(c0)); syy = glp(d.cSyy, e0, css_listed(c0));
+            sxy = glp(d.cSxy, e0, (c0 & BFD_CLS_EXY) != 0);
+        } else {
+            xzm2 = glp(bxz - 2 * pl, c4, valid && (cm2 & BFD_CLS_EXZ)); xzm1 = glp(bxz - pl, c4, valid && (cm1 & BFD_CLS_EXZ));
+            xz0 = glp(bxz, c4, valid && (c0 & BFD_CLS_EXZ)); xzp1 = glp(bxz + pl, c4, valid && (cB & BFD_CLS_EXZ));
+            yzm2 = glp(byz - 2 * pl, c4, valid && (cm2 & BFD_CLS_EYZ)); yzm1 = glp(byz - pl, c4, valid && (cm1 & BFD_CLS_EYZ));
+            yz0 = glp(byz, c4, valid && (c0 & BFD_CLS_EYZ)); yzp1 = glp(byz + pl, c4, valid && (cB & BFD_CLS_EYZ));
+            sxx = glp(d.Sxx + kbeg * pl, c4, valid && !fl0); syy = glp(d.Syy + kbeg * pl, c4, valid && !fl0);
+            sxy = glp(d.Sxy + kbeg * pl, c4, valid && (c0 & BFD_CLS_EXY));
+        }
         if (valid && fl0) { sxx = zz0; syy = zz0; }
-        const float sxy = glp(d.Sxy + kbeg * pl, c4, valid && (c0 & BFD_CLS_EXY));
         const int bo0 = (kbeg & 1) * bufStride;
         sS[0][0][bo0 + own] = sxx; sS[0][1][bo0 + own] = syy; sS[0][2][bo0 + own] = sxy; sS[0][3][bo0 + own] = xz0; sS[0][4][bo0 + own] = yz0;
     }
@@ -1593,10 +1677,21 @@ __device__ __forceinline__ void velocity_solid_body_g(const bfd_dev &d, const in
     unsigned hcA = 0, hcB = 0;
     {
         unsigned h0A = 0, h0B = 0;
-        if (ta.ok) { h0A = gl1(d.cls + kbeg * pl, offA); hcA = gl1(d.cls + kbeg * pl + pl, offA); }
-        if (tb.ok) { h0B = gl1(d.cls + kbeg * pl, offB); hcB = gl1(d.cls + kbeg * pl + pl, offB); }
-        const float ha = halo_value_g(baseA + kbeg * pl, d.Szz + kbeg * pl, substA, bitA, h0A, offA * 4u, ta.ok);
-        const float hb = halo_value_g(baseB + kbeg * pl, d.Szz + kbeg * pl, substB, bitB, h0B, offB * 4u, tb.ok);
+        if (ta.ok) { h0A = EXPCL(gl1(d.cls + kbeg * pl, offA)); hcA = EXPCL(gl1(d.cls + kbeg * pl + pl, offA)); }
+        if (tb.ok) { h0B = EXPCL(gl1(d.cls + kbeg * pl, offB)); hcB = EXPCL(gl1(d.cls + kbeg * pl + pl, offB)); }
+        float ha, hb;
+        if (CSS) {
+            const unsigned ra0 = rowbase(rowpA, kbeg);
+            const unsigned rx0 = *(BFD_GA const unsigned *)((BFD_GA const char *)gbase(d.cssRow + kbeg * rs) + gpin(rtOfs));
+            rbA = rowbase(rowpA, kbeg + 1);
+            rbx = *(BFD_GA const unsigned *)((BFD_GA const char *)gbase(d.cssRow + (kbeg + 1) * rs) + gpin(rtOfs));
+            const unsigned ea = ra0 + css_rank(ta.ok && css_listed(h0A)), eb = entryB(ra0, rx0, h0B);
+            ha = halo_value_c(cbaseA, d.Szz + kbeg * pl, substA, bitA, h0A, offA * 4u, ea * 4u, ta.ok);
+            hb = halo_value_c(cbaseB, d.Szz + kbeg * pl, substB, bitB, h0B, offB * 4u, eb * 4u, tb.ok);
+        } else {
+            ha = halo_value_g(baseA + kbeg * pl, d.Szz + kbeg * pl, substA, bitA, h0A, offA * 4u, ta.ok);
+            hb = halo_value_g(baseB + kbeg * pl, d.Szz + kbeg * pl, substB, bitB, h0B, offB * 4u, tb.ok);
+        }
         la[(kbeg & 1) * bufStride] = ha;
         if (hasB) lb[(kbeg & 1) * bufStride] = hb;
     }
@@ -1623,27 +1718,48 @@ __device__ __forceinline__ void velocity_solid_body_g(const bfd_dev &d, const in
         // here and the staging waits for them.
         const bool more = kl + 1 < kend;                // uniform
         const unsigned nm2 = gl2(d.mat + ko + 2 * pl, c2);                       // ghost planes make kl+2 addressable
-        const unsigned nc3raw = gl1(d.cls + ko + (kl + 2 < kend ? 3 : 2) * pl, cij);
+        const unsigned nc3raw = EXPCL(gl1(d.cls + ko + (kl + 2 < kend ? 3 : 2) * pl, cij));
         const bool bfl = (cB & BFD_CLS_FLUID) != 0;
-        const bool pXZ = more && valid && (cC & BFD_CLS_EXZ), pYZ = more && valid && (cC & BFD_CLS_EYZ);
-        const bool pNN = more && valid && !bfl, pXY = more && valid && (cB & BFD_CLS_EXY);
-        const bool takeA = more && ta.ok && (substA || (hcA & bitA)), takeB = more && tb.ok && (substB || (hcB & bitB));
         const long kn = more ? pl : 0;                  // the last iteration reads its own plane again (addressable, unused)
         const float nzzR = gl4(d.Szz + ko + 2 * pl + kn, c4);
-        const float nxzR = gl4(d.Sxz + ko + pl + kn, pXZ ? c4 : 0u);
-        const float nyzR = gl4(d.Syz + ko + pl + kn, pYZ ? c4 : 0u);
-        const float nxxR = gl4(d.Sxx + ko + kn, pNN ? c4 : 0u);
-        const float nyyR = gl4(d.Syy + ko + kn, pNN ? c4 : 0u);
-        const float nxyR = gl4(d.Sxy + ko + kn, pXY ? c4 : 0u);
-        const unsigned nmx = gl2(d.mat + ko + kn, cx2), nmy = gl2(d.mat + ko + kn, cy2);
-        float nhaR, nhbR;
-        {
+        bool pXZ, pYZ, pNN, pXY, takeA, takeB;
+        float nxzR, nyzR, nxxR, nyyR, nxyR, nhaR, nhbR;
+        unsigned nrb = BFD_CSS_NONE, nrbA = 0, nrbx = 0;
+        if (CSS) {
+            // entries of the own cell in planes kl+1 (in-plane values) and kl+2 (Sxz, Syz); the bases of the next iteration
+            const bool lB = css_listed(cB);
+            const unsigned eB = (rbB + css_rank(lB)) * 4u, eC = (rbC + css_rank(css_listed(cC))) * 4u;
+            nrb = rowbase(rowp, kl + (kl + 2 < kend ? 3 : 2));
+            nrbA = rowbase(rowpA, kl + (more ? 2 : 1));
+            nrbx = *(BFD_GA const unsigned *)((BFD_GA const char *)gbase(d.cssRow + (kl + (more ? 2 : 1)) * rs) + gpin(rtOfs));
+            const bool gC = rbC != BFD_CSS_NONE;        // plane kl+2 may be the ghost plane nk: no compact values, every value 0
+            pXZ = more && gC && (cC & BFD_CLS_EXZ); pYZ = more && gC && (cC & BFD_CLS_EYZ);
+            pNN = more && lB; pXY = more && (cB & BFD_CLS_EXY);
+            nxzR = gl4(d.cSxz, pXZ ? eC : 0u); nyzR = gl4(d.cSyz, pYZ ? eC : 0u);
+            nxxR = gl4(d.cSxx, pNN ? eB : 0u); nyyR = gl4(d.cSyy, pNN ? eB : 0u); nxyR = gl4(d.cSxy, pXY ? eB : 0u);
+            const unsigned eA = (rbA + css_rank(ta.ok && css_listed(hcA))) * 4u, eH = entryB(rbA, rbx, hcB) * 4u;
+            const bool flA = substA && (hcA & BFD_CLS_FLUID), flB = substB && (hcB & BFD_CLS_FLUID);
+            takeA = more && ta.ok && (flA || (substA ? css_listed(hcA) : (hcA & bitA) != 0));
+            takeB = more && tb.ok && (flB || (substB ? css_listed(hcB) : (hcB & bitB) != 0));
+            const unsigned long long paA = (unsigned long long)gbase(d.Szz + ko + kn);
+            nhaR = *(BFD_GA const float *)((flA ? paA : (unsigned long long)gbase(cbaseA)) + (takeA ? (flA ? offA * 4u : eA) : 0u));
+            nhbR = *(BFD_GA const float *)((flB ? paA : (unsigned long long)gbase(cbaseB)) + (takeB ? (flB ? offB * 4u : eH) : 0u));
+        } else {
+            pXZ = more && valid && (cC & BFD_CLS_EXZ); pYZ = more && valid && (cC & BFD_CLS_EYZ);
+            pNN = more && valid && !bfl; pXY = more && valid && (cB & BFD_CLS_EXY);
+            takeA = more && ta.ok && (substA || (hcA & bitA)); takeB = more && tb.ok && (substB || (hcB & bitB));
+            nxzR = gl4(d.Sxz + ko + pl + kn, pXZ ? c4 : 0u);
+            nyzR = gl4(d.Syz + ko + pl + kn, pYZ ? c4 : 0u);
+            nxxR = gl4(d.Sxx + ko + kn, pNN ? c4 : 0u);
+            nyyR = gl4(d.Syy + ko + kn, pNN ? c4 : 0u);
+            nxyR = gl4(d.Sxy + ko + kn, pXY ? c4 : 0u);
             const unsigned long long pbA = (unsigned long long)gbase(baseA + ko + kn), paA = (unsigned long long)gbase(d.Szz + ko + kn);
             const unsigned long long pbB = (unsigned long long)gbase(baseB + ko + kn);
             nhaR = *(BFD_GA const float *)(((substA && (hcA & BFD_CLS_FLUID)) ? paA : pbA) + (takeA ? offA * 4u : 0u));
             nhbR = *(BFD_GA const float *)(((substB && (hcB & BFD_CLS_FLUID)) ? paA : pbB) + (takeB ? offB * 4u : 0u));
         }
-        const unsigned nhcA = gl1(d.cls + ko + pl + kn, offA), nhcB = gl1(d.cls + ko + pl + kn, offB);
+        const unsigned nmx = gl2(d.mat + ko + kn, cx2), nmy = gl2(d.mat + ko + kn, cy2);
+        const unsigned nhcA = EXPCL(gl1(d.cls + ko + pl + kn, offA)), nhcB = EXPCL(gl1(d.cls + ko + pl + kn, offB));
 
         float *wVx = d.VxW + ko, *wVy = d.VyW + ko, *wVz = d.VzW + ko;
         if (valid) {
@@ -1711,6 +1827,7 @@ __device__ __forceinline__ void velocity_solid_body_g(const bfd_dev &d, const in
         hcA = nhcA; hcB = nhcB;
         r0 = r1; mraw = mraw1; mraw1 = nm2; mx = nmx; my = nmy;
         cB = cC; cC = nc3;
+        if (CSS) { rbB = rbC; rbC = nrb; rbA = nrbA; rbx = nrbx; }
     }
 }
 
@@ -1731,7 +1848,7 @@ __global__ __launch_bounds__(NTHREADS, SOLID_STRESS_WAVES_PER_SIMD) void stress_
 #ifndef SOLID_VELOCITY_WAVES_PER_SIMD
 #define SOLID_VELOCITY_WAVES_PER_SIMD 4      // lower bound of the plain flavour (78-80 VGPRs since round 4: 6 waves); the absorbing-layer flavour needs 105 registers and gets 4
 #endif
-template <bool ACC, bool PML>
+template <bool ACC, bool PML, bool CSS>
 __global__ __launch_bounds__(NTHREADS, PML ? 4 : SOLID_VELOCITY_WAVES_PER_SIMD) void velocity_solid(bfd_dev d, int tilesX, int nblocks, const int *__restrict__ xmap,
                                                         float *__restrict__ accP, float *__restrict__ pkP,
                                                         const int4 *__restrict__ runs)
@@ -1745,8 +1862,9 @@ __global__ __launch_bounds__(NTHREADS, PML ? 4 : SOLID_VELOCITY_WAVES_PER_SIMD) 
     if (ri < 0) return;
     const int4 run = runs[ri];
 #ifndef BFD_VELOCITY_SOLID_FLAT      // default since round 4: GLOBAL loads, prefetch without branches (0.405 -> 0.378 ms at the shear medium 512^3)
-    velocity_solid_body_g<ACC, PML>(d, run, tilesX, sS, accP, pkP);
+    velocity_solid_body_g<ACC, PML, CSS>(d, run, tilesX, sS, accP, pkP);
 #else
+    static_assert(!CSS, "the FLAT body has no compact form");
     velocity_solid_body<ACC, PML>(d, run, tilesX, sS, accP, pkP);
 #endif
 }
@@ -1840,7 +1958,8 @@ __device__ __forceinline__ unsigned fdiv(unsigned x, FastDiv f) { return __umulh
 
 __global__ __launch_bounds__(256) void stress_shear_sparse(bfd_dev d, const unsigned *__restrict__ cells, const unsigned *__restrict__ codes,
                                                            const float *__restrict__ tab, const float *__restrict__ coef,
-                                                           float *__restrict__ Rc, long nTotal, long n, FastDiv divN1, FastDiv divPlane)
+                                                           float *__restrict__ Rc, long nTotal, long n, FastDiv divN1, FastDiv divPlane,
+                                                           float *__restrict__ cSxy, float *__restrict__ cSxz, float *__restrict__ cSyz)
 {
     // XCD e works through the e-th contiguous eighth of the list (order: shear_order_keys): the V values a cell gathers from its
     // row / plane neighbours were fetched by blocks just before it on the SAME XCD (its own L2)
@@ -1909,20 +2028,22 @@ __global__ __launch_bounds__(256) void stress_shear_sparse(bfd_dev d, const unsi
     // memory variables: beside the list (Rc, list order) or, when the list only holds the cells the merged solid kernel leaves
     // out (Rc == null), in the full-volume arrays
     float *pRxy = Rc ? Rc + t : d.Rxy + c, *pRxz = Rc ? Rc + nTotal + t : d.Rxz + c, *pRyz = Rc ? Rc + 2 * nTotal + t : d.Ryz + c;
+    // shear stresses: in list order too when the solid state is compact (cSxy .. = the entries of this launch's part of the list)
+    float *pSxy = cSxy ? cSxy + t : d.Sxy + c, *pSxz = cSxz ? cSxz + t : d.Sxz + c, *pSyz = cSyz ? cSyz + t : d.Syz + c;
     if (Axy != 0.f) {
         const float e = dyVx + dxVy;
         const float r = LDNT(pRxy), rn = c1 * r - Bxy * e;
-        d.Sxy[c] = LDNT(d.Sxy + c) + (Axy * e + 0.5f * (r + rn)); *pRxy = rn;
+        *pSxy = LDNT(pSxy) + (Axy * e + 0.5f * (r + rn)); *pRxy = rn;
     }
     if (Axz != 0.f) {
         const float e = dzVx + dxVz;
         const float r = LDNT(pRxz), rn = c1 * r - Bxz * e;
-        d.Sxz[c] = LDNT(d.Sxz + c) + (Axz * e + 0.5f * (r + rn)); *pRxz = rn;
+        *pSxz = LDNT(pSxz) + (Axz * e + 0.5f * (r + rn)); *pRxz = rn;
     }
     if (Ayz != 0.f) {
         const float e = dzVy + dyVz;
         const float r = LDNT(pRyz), rn = c1 * r - Byz * e;
-        d.Syz[c] = LDNT(d.Syz + c) + (Ayz * e + 0.5f * (r + rn)); *pRyz = rn;
+        *pSyz = LDNT(pSyz) + (Ayz * e + 0.5f * (r + rn)); *pRyz = rn;
     }
 }
 
@@ -2145,6 +2266,14 @@ void bfd_tile_grid(const bfd_dev &d, int *tilesX, int *tilesY, int *subZ)
 }
 int bfd_tile_zchunk(void) { return ZCHUNK; }
 int bfd_tile_subz(void) { return SUBZ; }
+bool bfd_css_supported(void)
+{
+#if defined(BFD_VELOCITY_SOLID_FLAT) || defined(BFD_STRESS_SOLID_GLOBAL)
+    return false;
+#else
+    return true;
+#endif
+}
 
 void bfd_launch_probe_pair(const bfd_dev &d, hipStream_t s, const bfd_tiles *t, float *a, float *b, int kmax)
 {
@@ -2171,6 +2300,13 @@ void bfd_launch_count_solid_cells(const bfd_dev &d, hipStream_t s, const int4 *s
 // slower). Mode 1 cuts the rows at the 64-wide tiles as well: same bytes, 3 % slower.
 // The three plane ranges the split half-steps launch separately (first / middle / last planes of a slab) stay contiguous: their
 // number leads the key. profiles/r3/shear_list_order.txt
+// mode 2: rows keep their whole length in x: (part of the slab, z-chunk, band of 8 rows, plane, row, i)
+__device__ __forceinline__ unsigned long long shear_key2(unsigned i, unsigned j, unsigned k, int lowPlanes, int hiStart)
+{
+    const unsigned long long seg = (int)k < lowPlanes ? 0ull : ((int)k >= hiStart ? 2ull : 1ull);
+    return (seg << 44) | ((unsigned long long)(k >> 4) << 32) | ((unsigned long long)(j >> 3) << 19) |
+           ((unsigned long long)(k & 15u) << 15) | ((unsigned long long)(j & 7u) << 12) | (unsigned long long)(i & 4095u);
+}
 __global__ void shear_order_keys(bfd_dev d, const unsigned *__restrict__ cells, unsigned long long *__restrict__ keys, long n, int lowPlanes, int hiStart, int mode)
 {
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2178,13 +2314,57 @@ __global__ void shear_order_keys(bfd_dev d, const unsigned *__restrict__ cells, 
     const unsigned c = cells[t];
     const unsigned i = c % (unsigned)d.N1, j = (c / (unsigned)d.N1) % (unsigned)d.N2, k = c / (unsigned)d.plane;
     const unsigned long long seg = (int)k < lowPlanes ? 0ull : ((int)k >= hiStart ? 2ull : 1ull);
-    if (mode == 2)       // rows keep their whole length in x: (z-chunk, band of 8 rows, plane, row, i)
-        keys[t] = (seg << 44) | ((unsigned long long)(k >> 4) << 32) | ((unsigned long long)(j >> 3) << 19) |
-                  ((unsigned long long)(k & 15u) << 15) | ((unsigned long long)(j & 7u) << 12) | (unsigned long long)(i & 4095u);
+    if (mode == 2)
+        keys[t] = shear_key2(i, j, k, lowPlanes, hiStart);
     else
         keys[t] = (seg << 44) | ((unsigned long long)(k >> 4) << 32) | ((unsigned long long)(j >> 3) << 19) | ((unsigned long long)(i >> 6) << 13) |
                   ((unsigned long long)(k & 15u) << 9) | ((unsigned long long)(j & 7u) << 6) | (unsigned long long)(i & 63u);
 }
+// Row table of the compact solid state (bfd_dev::cssRow) for a list in order mode 2: entry (plane kk = kl + 2, row j, tile bx) = number of listed
+// cells that precede cell (64 bx, j, kl) in list order = lower bound of its key in the sorted list (the keys are recomputed from the cells). A
+// row of the list is contiguous and ascending in i, so this is the entry of the row's first listed cell at or after x = 64 bx; bx = tilesX
+// (the key's i field carries into the row bits: still the next key in order) gives one past the row. Ghost planes: BFD_CSS_NONE.
+__global__ void css_row_table(bfd_dev d, const unsigned *__restrict__ cells, long n, unsigned *__restrict__ table, int stride, int lowPlanes, int hiStart)
+{
+    const long total = (long)(d.nk + 4) * d.N2 * stride;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int bx = (int)(e % stride);
+        const long r = e / stride;
+        const int j = (int)(r % d.N2), kl = (int)(r / d.N2) - 2;
+        if (kl < 0 || kl >= d.nk) { table[e] = BFD_CSS_NONE; continue; }
+        const unsigned long long probe = shear_key2(0u, (unsigned)j, (unsigned)kl, lowPlanes, hiStart) + (unsigned long long)(64 * bx);
+        long lo = 0, hi = n;
+        while (lo < hi) {
+            const long mid = (lo + hi) >> 1;
+            const unsigned c = cells[mid];
+            const unsigned ci = c % (unsigned)d.N1, cj = (c / (unsigned)d.N1) % (unsigned)d.N2, ck = c / (unsigned)d.plane;
+            if (shear_key2(ci, cj, ck, lowPlanes, hiStart) < probe) lo = mid + 1; else hi = mid;
+        }
+        table[e] = (unsigned)lo;
+    }
+}
+void bfd_launch_css_row_table(const bfd_dev &d, hipStream_t s, const unsigned *cells, long n, unsigned *rowTable, int stride, int lowPlanes, int hiStart)
+{
+    const long total = (long)(d.nk + 4) * d.N2 * stride;
+    hipLaunchKernelGGL(css_row_table, dim3((unsigned)std::min<long>((total + 255) / 256, 65536)), dim3(256), 0, s, d, cells, n, rowTable, stride, lowPlanes, hiStart);
+}
+// compact arrays <-> full-volume arrays at the listed cells (outputs; a list rebuilt in the middle of a run)
+__global__ void css_copy(bfd_dev d, const unsigned *__restrict__ cells, long n, unsigned mask, int toFull)
+{
+    float *full[7] = {d.Sxx, d.Syy, d.Sxy, d.Sxz, d.Syz, d.Rxx, d.Ryy};
+    float *comp[7] = {d.cSxx, d.cSyy, d.cSxy, d.cSxz, d.cSyz, d.cRxx, d.cRyy};
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x) {
+        const unsigned c = cells[t];
+        for (int a = 0; a < 7; a++)
+            if (mask & (1u << a)) { if (toFull) full[a][c] = comp[a][t]; else comp[a][t] = full[a][c]; }
+    }
+}
+void bfd_launch_css_copy(const bfd_dev &d, hipStream_t s, const bfd_tiles *t, unsigned mask, bool toFull)
+{
+    if (d.cssRow && t->shearCells && t->nShear && mask)
+        hipLaunchKernelGGL(css_copy, dim3((unsigned)std::min<long>((t->nShear + 255) / 256, 8192)), dim3(256), 0, s, d, t->shearCells, t->nShear, mask, toFull ? 1 : 0);
+}
+
 void bfd_launch_shear_order_keys(const bfd_dev &d, hipStream_t s, const unsigned *cells, unsigned long long *keys, long n, int lowPlanes, int hiStart, int mode)
 {
     if (n) hipLaunchKernelGGL(shear_order_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d, cells, keys, n, lowPlanes, hiStart, mode);
@@ -2239,13 +2419,24 @@ void bfd_launch_stress_v2(const bfd_dev &d, hipStream_t s0, const bfd_tiles *t, 
     part_range(t->nFluid, t->nFluidB, part, &off, &n);
     part_range(t->nSolid, t->nSolidB, part, &offS, &nS);
     hipStream_t s = s0;
-    if (nS) {
+    const bool conc = t->sideStream[0] && !t->ktimer && (nS || (t->shearCells && t->nShear)) && n;
+    if (conc) { hipEventRecord(t->sideFork, s0); hipStreamWaitEvent(t->sideStream[0], t->sideFork, 0); hipStreamWaitEvent(t->sideStream[1], t->sideFork, 0); s = t->sideStream[0]; }
+    // experiment (wrong results): the FLUID kernels on the solid run list, as a separate launch -- what the list itself costs (scattered runs whose
+    // neighbours belong to another launch), apart from the solid-run kernels' own code
+    static const bool expSolidAsFluid = getenv("BFD_EXP_SOLID_AS_FLUID") != nullptr;
+    if (nS && expSolidAsFluid) {
+        BFD_KT(BFD_K_STRESS_SOLID, 0);
+        BFD_LAUNCH_X((stress_fluid<true>), nS, BFD_XM_SS + part, t->runs + t->nFluid + offS);
+        BFD_KT(BFD_K_STRESS_SOLID, 1);
+    } else if (nS) {
         BFD_KT(BFD_K_STRESS_SOLID, 0);
         if (t->shearCells && t->merged) BFD_LAUNCH_X(stress_solid_merged, nS, BFD_XM_SS + part, t->runs + t->nFluid + offS, (const float *)t->shearTab);
-        else if (t->shearCells) BFD_LAUNCH_X(stress_solid, nS, BFD_XM_SS + part, t->runs + t->nFluid + offS);
+        else if (t->shearCells && d.cssRow) BFD_LAUNCH_X((stress_solid<true>), nS, BFD_XM_SS + part, t->runs + t->nFluid + offS);
+        else if (t->shearCells) BFD_LAUNCH_X((stress_solid<false>), nS, BFD_XM_SS + part, t->runs + t->nFluid + offS);
         else BFD_LAUNCH(stress_v2, nS, t->runs + t->nFluid + offS, (const unsigned short *)nullptr);     // variant 2: monolithic, dense
         BFD_KT(BFD_K_STRESS_SOLID, 1);
     }
+    if (conc) s = t->sideStream[1];
     if (t->shearCells && t->nShear) {     // sparse shear: cells sorted by index; [0,lowEnd) and [highBeg,n) are the boundary chunks
         long b0 = 0, e0 = t->nShear, b1 = 0, e1 = 0;
         if (part == 1) { e0 = t->shearLowEnd; b1 = t->shearHighBeg; e1 = t->nShear; }
@@ -2255,15 +2446,20 @@ void bfd_launch_stress_v2(const bfd_dev &d, hipStream_t s0, const bfd_tiles *t, 
         auto magic = [](unsigned dv) { FastDiv f; unsigned L = 0; while ((1ull << L) < dv) L++; if (L == 0) L = 1;
                                        f.M = (unsigned)(((1ull << (31 + L)) + dv - 1) / dv); f.s = L - 1; return f; };
         const FastDiv dN1 = magic((unsigned)d.N1), dPl = magic((unsigned)d.plane);
-        if (e0 > b0) hipLaunchKernelGGL(stress_shear_sparse, dim3((unsigned)((e0 - b0 + 255) / 256)), dim3(256), 0, s, d, t->shearCells + b0, t->shearCodes + b0, t->shearTab, t->shearCoef + 6 * b0, R0, t->nShear, e0 - b0, dN1, dPl);
-        if (e1 > b1) hipLaunchKernelGGL(stress_shear_sparse, dim3((unsigned)((e1 - b1 + 255) / 256)), dim3(256), 0, s, d, t->shearCells + b1, t->shearCodes + b1, t->shearTab, t->shearCoef + 6 * b1, R1, t->nShear, e1 - b1, dN1, dPl);
+        const bool cs = d.cssRow != nullptr;
+        if (e0 > b0) hipLaunchKernelGGL(stress_shear_sparse, dim3((unsigned)((e0 - b0 + 255) / 256)), dim3(256), 0, s, d, t->shearCells + b0, t->shearCodes + b0, t->shearTab, t->shearCoef + 6 * b0, R0, t->nShear, e0 - b0, dN1, dPl,
+                                        cs ? d.cSxy + b0 : nullptr, cs ? d.cSxz + b0 : nullptr, cs ? d.cSyz + b0 : nullptr);
+        if (e1 > b1) hipLaunchKernelGGL(stress_shear_sparse, dim3((unsigned)((e1 - b1 + 255) / 256)), dim3(256), 0, s, d, t->shearCells + b1, t->shearCodes + b1, t->shearTab, t->shearCoef + 6 * b1, R1, t->nShear, e1 - b1, dN1, dPl,
+                                        cs ? d.cSxy + b1 : nullptr, cs ? d.cSxz + b1 : nullptr, cs ? d.cSyz + b1 : nullptr);
         BFD_KT(BFD_K_STRESS_SHEAR, 1);
     }
+    s = s0;
     if (n) {
         BFD_KT(BFD_K_STRESS_FLUID, 0);
         BFD_LAUNCH_X((stress_fluid<true>), n, BFD_XM_SF + part, t->runs + off);      // fluid cells keep one copy of their normal stresses (bfd_dev::cls)
         BFD_KT(BFD_K_STRESS_FLUID, 1);
     }
+    if (conc) for (int q = 0; q < 2; q++) { hipEventRecord(t->sideJoin[q], t->sideStream[q]); hipStreamWaitEvent(s0, t->sideJoin[q], 0); }
 }
 
 void bfd_launch_velocity_v2(const bfd_dev &d, hipStream_t s0, float *accP, float *pkP, const bfd_tiles *t, int part)
@@ -2274,7 +2470,15 @@ void bfd_launch_velocity_v2(const bfd_dev &d, hipStream_t s0, float *accP, float
     part_range(t->nFluid, t->nFluidB, part, &offF, &nF);
     part_range(t->nSolid, t->nSolidB, part, &off, &n);
     hipStream_t s = s0;
-    if (n) {
+    const bool conc = t->sideStream[0] && !t->ktimer && n && nF && t->shearCells;
+    if (conc) { hipEventRecord(t->sideFork, s0); hipStreamWaitEvent(t->sideStream[0], t->sideFork, 0); s = t->sideStream[0]; }
+    static const bool expSolidAsFluid = getenv("BFD_EXP_SOLID_AS_FLUID") != nullptr;
+    if (n && expSolidAsFluid) {
+        BFD_KT(BFD_K_VELOCITY_SOLID, 0);
+        if (acc) BFD_LAUNCH_X((velocity_fluid<true>), n, BFD_XM_VS + part, t->runs + t->nFluid + off, accP, pkP);
+        else BFD_LAUNCH_X((velocity_fluid<false>), n, BFD_XM_VS + part, t->runs + t->nFluid + off, accP, pkP);
+        BFD_KT(BFD_K_VELOCITY_SOLID, 1);
+    } else if (n) {
         BFD_KT(BFD_K_VELOCITY_SOLID, 0);
         if (t->shearCells) {
             // solid list = [boundary: PML | plain][interior: plain | PML]: the plain runs of the requested part are contiguous
@@ -2286,8 +2490,15 @@ void bfd_launch_velocity_v2(const bfd_dev &d, hipStream_t s0, float *accP, float
             auto go = [&](bool pml, int a0, int a1, int m) {
                 const int cnt = a1 - a0;
                 if (cnt <= 0) return;
-                if (pml) { if (acc) BFD_LAUNCH_X((velocity_solid<true, true>), cnt, m, accP, pkP, base + a0); else BFD_LAUNCH_X((velocity_solid<false, true>), cnt, m, accP, pkP, base + a0); }
-                else { if (acc) BFD_LAUNCH_X((velocity_solid<true, false>), cnt, m, accP, pkP, base + a0); else BFD_LAUNCH_X((velocity_solid<false, false>), cnt, m, accP, pkP, base + a0); }
+#ifndef BFD_VELOCITY_SOLID_FLAT
+                if (d.cssRow) {
+                    if (pml) { if (acc) BFD_LAUNCH_X((velocity_solid<true, true, true>), cnt, m, accP, pkP, base + a0); else BFD_LAUNCH_X((velocity_solid<false, true, true>), cnt, m, accP, pkP, base + a0); }
+                    else { if (acc) BFD_LAUNCH_X((velocity_solid<true, false, true>), cnt, m, accP, pkP, base + a0); else BFD_LAUNCH_X((velocity_solid<false, false, true>), cnt, m, accP, pkP, base + a0); }
+                    return;
+                }
+#endif
+                if (pml) { if (acc) BFD_LAUNCH_X((velocity_solid<true, true, false>), cnt, m, accP, pkP, base + a0); else BFD_LAUNCH_X((velocity_solid<false, true, false>), cnt, m, accP, pkP, base + a0); }
+                else { if (acc) BFD_LAUNCH_X((velocity_solid<true, false, false>), cnt, m, accP, pkP, base + a0); else BFD_LAUNCH_X((velocity_solid<false, false, false>), cnt, m, accP, pkP, base + a0); }
             };
             go(false, nb, ne, BFD_XM_VS + part); go(true, pb, pe, BFD_XM_VSP_LO); go(true, qb, qe, BFD_XM_VSP_HI);
         } else {                                                     // variant 2: dense
@@ -2296,12 +2507,14 @@ void bfd_launch_velocity_v2(const bfd_dev &d, hipStream_t s0, float *accP, float
         }
         BFD_KT(BFD_K_VELOCITY_SOLID, 1);
     }
+    s = s0;
     if (nF) {
         BFD_KT(BFD_K_VELOCITY_FLUID, 0);
         if (acc) BFD_LAUNCH_X((velocity_fluid<true>), nF, BFD_XM_VF + part, t->runs + offF, accP, pkP);
         else BFD_LAUNCH_X((velocity_fluid<false>), nF, BFD_XM_VF + part, t->runs + offF, accP, pkP);
         BFD_KT(BFD_K_VELOCITY_FLUID, 1);
     }
+    if (conc) { hipEventRecord(t->sideJoin[0], t->sideStream[0]); hipStreamWaitEvent(s0, t->sideJoin[0], 0); }
 }
 
 #ifdef BFD_EXP_XCD_CLOCK
