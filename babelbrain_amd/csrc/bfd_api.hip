@@ -988,6 +988,7 @@ static int build_tile_lists(bfd_sim *s)
     if (carryCompact) { bfd_launch_css_copy(s->d, s->stream, &s->tiles, 0x7Fu, true); BFD_HIP(hipStreamSynchronize(s->stream)); }
     s->d.cssRow = nullptr; s->d.cSxx = s->d.cSyy = s->d.cSxy = s->d.cSxz = s->d.cSyz = s->d.cRxx = s->d.cRyy = nullptr;
     dev_release(s, &s->tiles.cssRow); dev_release(s, &s->tiles.css); s->tiles.cssCap = 0;
+    dev_release(s, &s->tiles.runsAll); s->tiles.nAll = s->tiles.nAllB = 0;
     dev_release(s, &s->tiles.runs); dev_release(s, &s->tiles.xmap); dev_release(s, &s->tiles.shearCells); dev_release(s, &s->tiles.shearCoef); dev_release(s, &s->tiles.shearR);    // lists of an earlier build
     dev_release(s, &s->tiles.shearCodes); dev_release(s, &s->tiles.shearTab);
     const int SUB = bfd_tile_subz();
@@ -1033,6 +1034,7 @@ static int build_tile_lists(bfd_sim *s)
     const int hiStart = std::max(((nkl - 2) / SUB) * SUB, lowPlanes);
     auto subBnd = [&](int q) { return q * SUB < lowPlanes || std::min((q + 1) * SUB, nkl) > hiStart; };
     std::vector<int4> lists[5];      // fluid boundary, fluid interior, solid boundary, solid interior, fused fluid
+    std::vector<int4> listsAll[2];   // every run of the two-kernel path in list order: boundary, interior (bfd_tiles::runsAll)
     std::vector<char> taken((size_t)n, 0);
     // Runs of the fused time step (variant 4, bfd_kernels_fused.hip): 64 x 24 cells = three tiles of this grid in y, a z-run of
     // 2 .. fusedSub sub-tiles. A sub-tile qualifies (bit5) when it is fluid, has nothing of the absorbing layer or the domain
@@ -1158,8 +1160,9 @@ static int build_tile_lists(bfd_sim *s)
                 }
                 const int kbeg = q * SUB, kend = std::min(r * SUB, s->d.nk);
                 // solid runs: bit0 + bit3 (a sub-tile of the run touches the absorbing layer)
-                int4 run; run.x = txy; run.y = kbeg | (kend << 16); run.z = solid ? (1 | pmlAny | (getenv("BFD_EXP_SOLID_AS_FLUID") ? 2 : 0)) : (f & ~(32 | 128 | 256)); run.w = m;
+                int4 run; run.x = txy; run.y = kbeg | (kend << 16); run.z = solid ? (1 | pmlAny) : (f & ~(32 | 128 | 256)); run.w = m;
                 lists[(solid ? 2 : 0) + (bnd ? 0 : 1)].push_back(run);
+                listsAll[bnd ? 0 : 1].push_back(run);
                 for (int u = q; u < r; u++) {
                     taken[(size_t)u * tx * ty + txy] = 1;
                     if (solid) T.nSolidSub++;
@@ -1308,9 +1311,10 @@ static int build_tile_lists(bfd_sim *s)
         s->tiles.nShear = count;
         if (s->step > 0 && s->tiles.shearR) { bfd_launch_gather_shear_memory(s->d, s->stream, &s->tiles); BFD_HIP(hipStreamSynchronize(s->stream)); }
         // Compact solid state (bfd_dev::cssRow): Sxx, Syy, the shear stresses, Rxx, Ryy of the listed cells in list order. Needs the row-contiguous
-        // list order (mode 2) and the two-kernel form; whole domains only so far (a Z-slab's neighbours read Sxz / Syz ghost planes out of the
-        // full-volume arrays). BFD_COMPACT_SOLID=0 keeps the full-volume arrays.
-        bool compact = count > 0 && orderMode == 2 && !T.merged && s->d.k0 == 0 && s->d.nk == s->d.N3 && s->d.N1 <= 4095 && bfd_css_supported();
+        // list order (mode 2) and the two-kernel form. In a Z-slab the ghost planes of Sxz / Syz stay in the full-volume arrays (the sparse kernel
+        // keeps full-volume copies of the planes a neighbour reads, the velocity kernel takes ghost planes from there): the halo exchange is
+        // unchanged. BFD_COMPACT_SOLID=0 keeps the full-volume arrays.
+        bool compact = count > 0 && orderMode == 2 && !T.merged && s->d.N1 <= 4095 && bfd_css_supported();
         if (const char *ev = getenv("BFD_COMPACT_SOLID")) compact = compact && atoi(ev) != 0;
         if (compact) {
             const int stride = tx + 1;
@@ -1325,6 +1329,12 @@ static int build_tile_lists(bfd_sim *s)
             s->d.cRxx = c + 5 * (size_t)count; s->d.cRyy = c + 6 * (size_t)count;
             if (s->step > 0) bfd_launch_css_copy(s->d, s->stream, &s->tiles, 0x7Fu, false);
             BFD_HIP(hipStreamSynchronize(s->stream));
+            std::vector<int4> ra(listsAll[0]);
+            ra.insert(ra.end(), listsAll[1].begin(), listsAll[1].end());
+            rc = dev_alloc(s, &s->tiles.runsAll, ra.size(), false);
+            if (rc) return rc;
+            BFD_HIP(hipMemcpy(s->tiles.runsAll, ra.data(), ra.size() * sizeof(int4), hipMemcpyHostToDevice));
+            s->tiles.nAllB = (int)listsAll[0].size(); s->tiles.nAll = (int)ra.size();
         }
         s->tiles.shearLowEnd = std::lower_bound(hostCells.begin(), hostCells.end(), (unsigned)lowPlanes * (unsigned)s->d.plane) - hostCells.begin();
         s->tiles.shearHighBeg = std::lower_bound(hostCells.begin(), hostCells.end(), (unsigned)hiStart * (unsigned)s->d.plane) - hostCells.begin();
@@ -1385,7 +1395,10 @@ static int build_tile_lists(bfd_sim *s)
             const double all = nF0 + nF1 + nS + nR;
             const double bs = 15.0 * all + 8.0 * nF0 + 16.0 * nF1 + 48.0 * nS + 48.0 * nR;
             const double bv = 31.0 * all + 8.0 * (nS + nR) + 4.0 * nE;
-            for (int a = 0; a < 2; a++) { B[a][BFD_K_STRESS_SOLID] += bs; B[a][BFD_K_VELOCITY_SOLID] += bv; }
+            // compact solid state: the fluid kernel takes Szz / Rzz of the solid runs too (V 12 + id 2, + Szz r/w 8 (+ Rzz r/w 8); no class byte), the
+            // sparse kernel Sxx, Syy, Rxx, Ryy of its cells (+ 32 + id 2 per listed cell, below)
+            const double bsf = 14.0 * all + 8.0 * nF0 + 16.0 * nF1 + 16.0 * nS + 8.0 * nR;
+            for (int a = 0; a < 2; a++) { if (s->d.cssRow) B[a][BFD_K_STRESS_FLUID] += bsf; else B[a][BFD_K_STRESS_SOLID] += bs; B[a][BFD_K_VELOCITY_SOLID] += bv; }
         }
         if (s->tiles.nShear) {       // sparse shear: cell index + 6 coefficients + V of the cell + read-modify-write of S and R per active edge
             unsigned long long *dc = nullptr, hc[2] = {0, 0};
@@ -1398,7 +1411,7 @@ static int build_tile_lists(bfd_sim *s)
             if (e != hipSuccess) BFD_FAIL(-10, std::string("shear edge count: ") + hipGetErrorString(e));
             s->tiles.nShearExplicit = (long)hc[1];
             // per listed cell: index 4 + edge codes 4 + V 12; per edge with explicit coefficients 8; per active edge S and R r/w 16
-            for (int a = 0; a < 2; a++) B[a][BFD_K_STRESS_SHEAR] = 20.0 * (double)s->tiles.nShear + 8.0 * (double)hc[1] + 16.0 * (double)hc[0];
+            for (int a = 0; a < 2; a++) B[a][BFD_K_STRESS_SHEAR] = (s->d.cssRow ? 54.0 : 20.0) * (double)s->tiles.nShear + 8.0 * (double)hc[1] + 16.0 * (double)hc[0];
             if (T.merged) for (int a = 0; a < 2; a++) B[a][BFD_K_STRESS_SOLID] -= 16.0 * (double)hc[0];      // those edges are the sparse kernel's
         }
         if (T.merged && T.nSolid && s->cfg.kernelVariant != 2) for (int a = 0; a < 2; a++) B[a][BFD_K_STRESS_SOLID] += 16.0 * (double)cnt[4];   // S and R of every active edge, read and written

@@ -121,6 +121,7 @@ enum { BFD_XM_SF = 0, BFD_XM_VF = 3, BFD_XM_SS = 6, BFD_XM_VS = 9, BFD_XM_VSP_LO
 struct bfd_tiles { bfd_sim *ktimer; int nMat; bool merged /* solid runs: normal and shear stresses in one kernel, the sparse list holds the MIXED cells only */; int4 *runs;
                    unsigned *shearCells; float *shearCoef; long nShear, shearLowEnd, shearHighBeg;   /* sparse shear list */
                    unsigned *shearCodes; float *shearTab; long nShearExplicit;   /* per listed cell a byte per edge: 0 inactive, 1 + m = one material around the edge (coefficients from shearTab[2 m ..]), 255 = explicit coefficients in shearCoef; number of explicit edges */
+                   int4 *runsAll; int nAll, nAllB;   /* compact solid state: every run, fluid and solid, in list order [boundary | interior] -- the stress half-step's one launch of the fluid kernel */
                    unsigned *cssRow; float *css; long cssCap;   /* compact solid state (bfd_dev::cssRow): row table, [7][cssCap] values Sxx Syy Sxy Sxz Syz Rxx Ryy in list order */
                    float *shearR;   /* memory variables Rxy, Rxz, Ryz of the listed cells, [3][nShear] in list order: only the sparse kernel uses them, so they live beside the list (dense, coalesced) instead of in the full-volume arrays, which are filled from here on demand (bfd_get_field) */
                    int nFluid, nFluidB, nSolid, nSolidB, nSolidBP /* leading boundary runs that touch the absorbing layer */, nSolidIP /* trailing interior ones */, nFused /* runs of the fused kernel, after the solid runs */;

@@ -493,7 +493,11 @@ __global__ __launch_bounds__(NTHREADS, VELOCITY_WAVES_PER_SIMD) void velocity_v2
 // switches on its tile's flags (block-uniform) into the matching instantiation.
 // All bodies are software pipelined: every value plane kl needs is in registers when its iteration starts
 // and the iteration issues the loads for plane kl+1 (CPML memory variables included).
-template <bool LOSSY, bool COLLAPSED, bool UNI, bool PML>
+// SOLID (round 5, compact solid state): the run may hold solid cells. Their Szz / Rzz take the solid formula (AS2, BS2 of the cell's material, 0 in
+// a fluid: the same expression serves every lane, equal to the fluid one up to the sign of an exact zero); everything else a solid cell has --
+// Sxx, Syy, the shear stresses and their memory variables -- is the sparse kernel's (stress_shear_sparse, which runs after this one and reads
+// the absorbing-layer memory variables this kernel has just advanced).
+template <bool LOSSY, bool COLLAPSED, bool UNI, bool PML, bool SOLID = false>
 __device__ __forceinline__ void stress_fluid_body(const bfd_dev &d, int bx, int by, int kbeg, int kend, int tm,
                                                   float (*sV)[2][LH * LW])
 {
@@ -555,8 +559,8 @@ __device__ __forceinline__ void stress_fluid_body(const bfd_dev &d, int bx, int 
         sV[b][0][own] = vx0; sV[b][1][own] = vy0;
         if (has) lh[b * (2 * LH * LW)] = hv;
         // table rows of this plane (cache-resident; short latency, overlaps the barrier)
-        float AP = APu, BP = BPu;
-        if (!UNI && valid) { const int m = mraw & BFD_MAT_MASK; AP = d.AP[m]; if (LOSSY) BP = d.BP[m]; }
+        float AP = APu, BP = BPu, AS2 = 0.f, BS2 = 0.f;
+        if (!UNI && valid) { const int m = mraw & BFD_MAT_MASK; AP = d.AP[m]; if (LOSSY) BP = d.BP[m]; if (SOLID) { AS2 = d.AS2[m]; BS2 = d.BS2[m]; } }
         __syncthreads();
 
         float nvx = 0, nvy = 0, nvz = 0, nh = 0, nszz = 0, nrzz = 0, npx = 0, npy = 0, npz = 0;
@@ -592,8 +596,12 @@ __device__ __forceinline__ void stress_fluid_body(const bfd_dev &d, int bx, int 
                         dzVz = dzVz + pn;
                     }
                 }
-                const float div = (dxVx + dyVy) + dzVz;
-                if (LOSSY) {
+                const float sXY = dxVx + dyVy;
+                const float div = sXY + dzVz;
+                if (SOLID) {
+                    rn = c1 * rzz - (BP * div - BS2 * sXY);
+                    val = szz + ((AP * div - AS2 * sXY) + 0.5f * (rzz + rn));
+                } else if (LOSSY) {
                     rn = c1 * rzz - BP * div;
                     val = szz + (AP * div + 0.5f * (rzz + rn));
                 } else {
@@ -764,15 +772,12 @@ __device__ __forceinline__ void velocity_fluid_body(const bfd_dev &d, int bx, in
 // canonical sequence for every lane (zeros / substituted values make it equal to the dense kernels' bit for bit, up
 // to the sign of an exact zero). Class bytes run two planes ahead of the state loads they steer.
 // ------------------------------------------------------------------------------------------------
-// CSS: the solid-only values (Sxx, Syy, Rxx, Ryy) of a listed cell live in the compact arrays (bfd_dev::cssRow): a wave = one tile row,
-// entry of a lane = row base (one scalar per row and plane) + the number of listed lanes below it
-template <bool PML, bool CSS>
+template <bool PML>
 __device__ __forceinline__ void stress_solid_body(const bfd_dev &d, const int4 &run, int tilesX, float (*sV)[2][LH * LW])
 {
     const int N1 = d.N1, N2 = d.N2;
     const int bx = run.x % tilesX, by = run.x / tilesX, kbeg = run.y & 0xFFFF, kend = run.y >> 16;
     const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * TX + tx;
-    const int wv = __builtin_amdgcn_readfirstlane(ty);
     const int i0 = bx * TX, j0 = by * TY;
     const int i = i0 + tx, j = j0 + ty;
     const bool valid = (i < N1) && (j < N2);
@@ -815,23 +820,12 @@ __device__ __forceinline__ void stress_solid_body(const bfd_dev &d, const int4 &
         szz = F4((d.Szz + kbeg * pl), cij * 4u);
         const bool fl = cl & BFD_CLS_FLUID, mem = !(cl & BFD_CLS_NOMEM) || !fl;
         if (mem) rzz = F4((d.Rzz + kbeg * pl), cij * 4u);
-        if (!CSS && !fl) {
+        if (!fl) {
             sxx = F4((d.Sxx + kbeg * pl), cij * 4u); syy = F4((d.Syy + kbeg * pl), cij * 4u);
             rxx = F4((d.Rxx + kbeg * pl), cij * 4u); ryy = F4((d.Ryy + kbeg * pl), cij * 4u);
         }
     }
     float hv = t.ok ? F4(ph + kbeg * pl, hofs) : 0.0f;
-    // compact entries: ix = entry of this lane's cell in the plane whose values sit in sxx .. ryy (meaningful where the cell is listed)
-    const unsigned *rowp = nullptr;
-    long rs = 0;
-    unsigned ix = 0;
-    if (CSS) {
-        rowp = d.cssRow + ((long)2 * N2 + min(j0 + wv, N2 - 1)) * d.cssStride + bx;
-        rs = (long)N2 * d.cssStride;
-        const bool li = css_listed(cl);
-        ix = (unsigned)__builtin_amdgcn_readfirstlane((int)rowp[kbeg * rs]) + css_rank(li);
-        if (li) { sxx = F4(d.cSxx, ix * 4u); syy = F4(d.cSyy, ix * 4u); rxx = F4(d.cRxx, ix * 4u); ryy = F4(d.cRyy, ix * 4u); }
-    }
 
     for (int kl = kbeg; kl < kend; kl++) {
         const int b = kl & 1;
@@ -840,7 +834,7 @@ __device__ __forceinline__ void stress_solid_body(const bfd_dev &d, const int4 &
         const long ko = (long)__builtin_amdgcn_readfirstlane(kl) * pl;
         const int k = d.k0 + kl;
         float nvx = 0, nvy = 0, nvz = 0, nh = 0, nsxx = 0, nsyy = 0, nszz = 0, nrxx = 0, nryy = 0, nrzz = 0, npx = 0, npy = 0, npz = 0;
-        unsigned nmraw = 0, ncl2 = BFD_CLS_FLUID | BFD_CLS_NOMEM, nix = 0;
+        unsigned nmraw = 0, ncl2 = BFD_CLS_FLUID | BFD_CLS_NOMEM;
         auto prefetch_next = [&]() {
         if (valid) ncl2 = EXPCL(U1((d.cls + ko + 2 * pl), cij));           // ghost planes make kl+2 addressable
             if (kl + 1 < kend) {
@@ -850,15 +844,10 @@ __device__ __forceinline__ void stress_solid_body(const bfd_dev &d, const int4 &
                     nmraw = U2((d.mat + ko + pl), cij * 2u);
                     nszz = F4((d.Szz + ko + pl), cij * 4u);
                     if (nmem) nrzz = F4((d.Rzz + ko + pl), cij * 4u);
-                    if (!CSS && !nfl) {
+                    if (!nfl) {
                         nsxx = F4((d.Sxx + ko + pl), cij * 4u); nsyy = F4((d.Syy + ko + pl), cij * 4u);
                         nrxx = F4((d.Rxx + ko + pl), cij * 4u); nryy = F4((d.Ryy + ko + pl), cij * 4u);
                     }
-                }
-                if (CSS) {
-                    const bool nli = css_listed(cl1);
-                    nix = (unsigned)__builtin_amdgcn_readfirstlane((int)rowp[(kl + 1) * rs]) + css_rank(nli);
-                    if (nli) { nsxx = F4(d.cSxx, nix * 4u); nsyy = F4(d.cSyy, nix * 4u); nrxx = F4(d.cRxx, nix * 4u); nryy = F4(d.cRyy, nix * 4u); }
                 }
                 if (t.ok) nh = F4(ph + ko + pl, hofs);
                 if (zi) npx = F4(d.psi[0], (unsigned)(qx + dqx) * 4u);
@@ -909,11 +898,9 @@ __device__ __forceinline__ void stress_solid_body(const bfd_dev &d, const int4 &
                     const float sYZ = dyVy + dzVz, sXZ = dxVx + dzVz;
                     float rn;
                     rn = c1 * rxx - (BP * div - BS2 * sYZ);
-                    if (CSS) { ST4(d.cSxx, ix * 4u, sxx + ((AP * div - AS2 * sYZ) + 0.5f * (rxx + rn))); ST4(d.cRxx, ix * 4u, rn); }
-                    else { ST4((d.Sxx + ko), cij * 4u, sxx + ((AP * div - AS2 * sYZ) + 0.5f * (rxx + rn))); ST4((d.Rxx + ko), cij * 4u, rn); }
+                    ST4((d.Sxx + ko), cij * 4u, sxx + ((AP * div - AS2 * sYZ) + 0.5f * (rxx + rn))); ST4((d.Rxx + ko), cij * 4u, rn);
                     rn = c1 * ryy - (BP * div - BS2 * sXZ);
-                    if (CSS) { ST4(d.cSyy, ix * 4u, syy + ((AP * div - AS2 * sXZ) + 0.5f * (ryy + rn))); ST4(d.cRyy, ix * 4u, rn); }
-                    else { ST4((d.Syy + ko), cij * 4u, syy + ((AP * div - AS2 * sXZ) + 0.5f * (ryy + rn))); ST4((d.Ryy + ko), cij * 4u, rn); }
+                    ST4((d.Syy + ko), cij * 4u, syy + ((AP * div - AS2 * sXZ) + 0.5f * (ryy + rn))); ST4((d.Ryy + ko), cij * 4u, rn);
                     rn = c1 * rzz - (BP * div - BS2 * sXY);
                     ST4((d.SzzW + ko), cij * 4u, szz + ((AP * div - AS2 * sXY) + 0.5f * (rzz + rn))); ST4((d.RzzW + ko), cij * 4u, rn);
                 }
@@ -922,7 +909,7 @@ __device__ __forceinline__ void stress_solid_body(const bfd_dev &d, const int4 &
         vx0 = nvx; vy0 = nvy;
         vzm2 = vzm1; vzm1 = vz0; vz0 = vzp1; vzp1 = nvz;
         hv = nh; mraw = nmraw; cl = cl1; cl1 = ncl2;
-        sxx = nsxx; syy = nsyy; szz = nszz; rxx = nrxx; ryy = nryy; rzz = nrzz; ix = nix;
+        sxx = nsxx; syy = nsyy; szz = nszz; rxx = nrxx; ryy = nryy; rzz = nrzz;
         px = npx; py = npy; pz = npz; qx += dqx; qy += dqy;
     }
 }
@@ -933,15 +920,14 @@ __device__ __forceinline__ void stress_solid_body(const bfd_dev &d, const int4 &
 // (-DBFD_STRESS_SOLID_GLOBAL builds the GLOBAL / branch-free-prefetch body below instead: measured 1 % slower, 0.308-0.311 against
 // 0.305 ms at the shear medium 512^3 -- this kernel is at the rate of the bytes it moves; profiles/r4/experiment_solid_kernels_prefetch.txt)
 #ifndef BFD_STRESS_SOLID_GLOBAL
-template <bool CSS>
 __global__ __launch_bounds__(NTHREADS, SOLID_STRESS_WAVES_PER_SIMD) void stress_solid(bfd_dev d, int tilesX, int nblocks, const int *__restrict__ xmap, const int4 *__restrict__ runs)
 {
     __shared__ float sV[2][2][LH * LW];
     const int ri = run_index(nblocks, xmap);
     if (ri < 0) return;
     const int4 run = runs[ri];
-    if (run.z & 8) stress_solid_body<true, CSS>(d, run, tilesX, sV);
-    else stress_solid_body<false, CSS>(d, run, tilesX, sV);
+    if (run.z & 8) stress_solid_body<true>(d, run, tilesX, sV);
+    else stress_solid_body<false>(d, run, tilesX, sV);
 }
 #endif
 
@@ -1622,7 +1608,9 @@ __device__ __forceinline__ void velocity_solid_body_g(const bfd_dev &d, const in
         cbaseB = arrB == 4 ? d.cSyz : (arrB == 0 ? d.cSxx : (arrB == 2 ? d.cSxy : d.cSxz));
         if (wv >= 4 && wv < 7 && tx < XT) rtOfs = (unsigned)(((2 * N2 + min(j0 + (tx >> 2), N2 - 1)) * d.cssStride + bx + (cc >= 2 ? 1 : 0)) * 4);
     }
-    auto rowbase = [&](const unsigned *rp, int plane) { return (unsigned)__builtin_amdgcn_readfirstlane((int)rp[plane * rs]); };
+    // a scalar load (constant address space, wave-uniform address): it returns on lgkmcnt, so nothing in the prefetch below waits for it -- as a vector
+    // load + readfirstlane the compiler put an s_waitcnt vmcnt in the middle of the prefetch section (a second memory round trip per plane)
+    auto rowbase = [&](const unsigned *rp, int plane) { return *(const __attribute__((address_space(4))) unsigned *)(unsigned long long)(rp + plane * rs); };
     // entry of this lane's halo cell of task B: waves 0-3 a row like task A, waves 4-6 the columns
     auto entryB = [&](unsigned rbRow, unsigned rbx, unsigned hc) {
         const bool li = tb.ok && css_listed(hc);
@@ -1648,11 +1636,13 @@ __device__ __forceinline__ void velocity_solid_body_g(const bfd_dev &d, const in
             rbB = rowbase(rowp, kbeg + 1); rbC = rowbase(rowp, kbeg + 2);
             const unsigned em2 = (rm2 + css_rank(css_listed(cm2))) * 4u, em1 = (rm1 + css_rank(css_listed(cm1))) * 4u;
             const unsigned e0 = (rb0 + css_rank(css_listed(c0))) * 4u, e1 = (rbB + css_rank(css_listed(cB))) * 4u;
-            const bool gm2 = rm2 != BFD_CSS_NONE, gm1 = rm1 != BFD_CSS_NONE, g1 = rbB != BFD_CSS_NONE;       // ghost planes hold no compact values: 0
-            xzm2 = glp(d.cSxz, em2, gm2 && (cm2 & BFD_CLS_EXZ)); xzm1 = glp(d.cSxz, em1, gm1 && (cm1 & BFD_CLS_EXZ));
-            xz0 = glp(d.cSxz, e0, (c0 & BFD_CLS_EXZ) != 0); xzp1 = glp(d.cSxz, e1, g1 && (cB & BFD_CLS_EXZ));
-            yzm2 = glp(d.cSyz, em2, gm2 && (cm2 & BFD_CLS_EYZ)); yzm1 = glp(d.cSyz, em1, gm1 && (cm1 & BFD_CLS_EYZ));
-            yz0 = glp(d.cSyz, e0, (c0 & BFD_CLS_EYZ) != 0); yzp1 = glp(d.cSyz, e1, g1 && (cB & BFD_CLS_EYZ));
+            // a ghost plane (row base BFD_CSS_NONE) has no compact values: its Sxz / Syz come out of the full-volume arrays, where a Z-neighbour's
+            // planes arrive (the sparse kernel keeps full-volume copies of the planes a neighbour reads); zeros at the ends of the domain
+            const bool gm2 = rm2 != BFD_CSS_NONE, gm1 = rm1 != BFD_CSS_NONE, g1 = rbB != BFD_CSS_NONE;
+            xzm2 = glp(gm2 ? d.cSxz : bxz - 2 * pl, gm2 ? em2 : c4, (cm2 & BFD_CLS_EXZ) != 0); xzm1 = glp(gm1 ? d.cSxz : bxz - pl, gm1 ? em1 : c4, (cm1 & BFD_CLS_EXZ) != 0);
+            xz0 = glp(d.cSxz, e0, (c0 & BFD_CLS_EXZ) != 0); xzp1 = glp(g1 ? d.cSxz : bxz + pl, g1 ? e1 : c4, (cB & BFD_CLS_EXZ) != 0);
+            yzm2 = glp(gm2 ? d.cSyz : byz - 2 * pl, gm2 ? em2 : c4, (cm2 & BFD_CLS_EYZ) != 0); yzm1 = glp(gm1 ? d.cSyz : byz - pl, gm1 ? em1 : c4, (cm1 & BFD_CLS_EYZ) != 0);
+            yz0 = glp(d.cSyz, e0, (c0 & BFD_CLS_EYZ) != 0); yzp1 = glp(g1 ? d.cSyz : byz + pl, g1 ? e1 : c4, (cB & BFD_CLS_EYZ) != 0);
             sxx = glp(d.cSxx, e0, css_listed(c0)); syy = glp(d.cSyy, e0, css_listed(c0));
             sxy = glp(d.cSxy, e0, (c0 & BFD_CLS_EXY) != 0);
         } else {
@@ -1732,10 +1722,11 @@ __device__ __forceinline__ void velocity_solid_body_g(const bfd_dev &d, const in
             nrb = rowbase(rowp, kl + (kl + 2 < kend ? 3 : 2));
             nrbA = rowbase(rowpA, kl + (more ? 2 : 1));
             nrbx = *(BFD_GA const unsigned *)((BFD_GA const char *)gbase(d.cssRow + (kl + (more ? 2 : 1)) * rs) + gpin(rtOfs));
-            const bool gC = rbC != BFD_CSS_NONE;        // plane kl+2 may be the ghost plane nk: no compact values, every value 0
-            pXZ = more && gC && (cC & BFD_CLS_EXZ); pYZ = more && gC && (cC & BFD_CLS_EYZ);
+            const bool gC = rbC != BFD_CSS_NONE;        // plane kl+2 may be the ghost plane nk: full-volume arrays there (uniform choice)
+            pXZ = more && (cC & BFD_CLS_EXZ); pYZ = more && (cC & BFD_CLS_EYZ);
             pNN = more && lB; pXY = more && (cB & BFD_CLS_EXY);
-            nxzR = gl4(d.cSxz, pXZ ? eC : 0u); nyzR = gl4(d.cSyz, pYZ ? eC : 0u);
+            const unsigned eZ = gC ? eC : c4;
+            nxzR = gl4(gC ? d.cSxz : d.Sxz + ko + pl + kn, pXZ ? eZ : 0u); nyzR = gl4(gC ? d.cSyz : d.Syz + ko + pl + kn, pYZ ? eZ : 0u);
             nxxR = gl4(d.cSxx, pNN ? eB : 0u); nyyR = gl4(d.cSyy, pNN ? eB : 0u); nxyR = gl4(d.cSxy, pXY ? eB : 0u);
             const unsigned eA = (rbA + css_rank(ta.ok && css_listed(hcA))) * 4u, eH = entryB(rbA, rbx, hcB) * 4u;
             const bool flA = substA && (hcA & BFD_CLS_FLUID), flB = substB && (hcB & BFD_CLS_FLUID);
@@ -1956,10 +1947,21 @@ __device__ __forceinline__ float ldv(const float *__restrict__ a, int N1, int N2
 struct FastDiv { unsigned M, s; };
 __device__ __forceinline__ unsigned fdiv(unsigned x, FastDiv f) { return __umulhi(x, f.M) >> f.s; }
 
-__global__ __launch_bounds__(256) void stress_shear_sparse(bfd_dev d, const unsigned *__restrict__ cells, const unsigned *__restrict__ codes,
+#ifndef SPARSE_WAVES_PER_SIMD
+#define SPARSE_WAVES_PER_SIMD 5
+#endif
+#ifndef SPARSE_HOIST
+#define SPARSE_HOIST 1
+#endif
+// NORMAL (compact solid state): the kernel also updates Sxx, Syy and their memory variables of its cell (compact arrays, entry t of this launch's
+// part of the list) -- Szz / Rzz of the cell were written by the fluid stress kernel, which ran before and has advanced the absorbing-layer
+// memory variables of dxVx, dyVy, dzVz: they are read here, not advanced.
+template <bool NORMAL>
+__global__ __launch_bounds__(256, SPARSE_WAVES_PER_SIMD) void stress_shear_sparse(bfd_dev d, const unsigned *__restrict__ cells, const unsigned *__restrict__ codes,
                                                            const float *__restrict__ tab, const float *__restrict__ coef,
                                                            float *__restrict__ Rc, long nTotal, long n, FastDiv divN1, FastDiv divPlane,
-                                                           float *__restrict__ cSxy, float *__restrict__ cSxz, float *__restrict__ cSyz)
+                                                           float *__restrict__ cSxy, float *__restrict__ cSxz, float *__restrict__ cSyz,
+                                                           float *__restrict__ cSxx, float *__restrict__ cSyy, float *__restrict__ cRxx, float *__restrict__ cRyy)
 {
     // XCD e works through the e-th contiguous eighth of the list (order: shear_order_keys): the V values a cell gathers from its
     // row / plane neighbours were fetched by blocks just before it on the SAME XCD (its own L2)
@@ -1968,6 +1970,13 @@ __global__ __launch_bounds__(256) void stress_shear_sparse(bfd_dev d, const unsi
     const int N1 = d.N1, N2 = d.N2, P = d.P;
     const long pl = d.plane;
     const unsigned c = LDNT(cells + t);
+    // compact solid state: the ten values of the cell are dense streams in list order and depend on nothing -- in flight before the gathers start
+    float oSxx = 0.f, oSyy = 0.f, oRxx = 0.f, oRyy = 0.f, oSxy = 0.f, oSxz = 0.f, oSyz = 0.f, oRxy = 0.f, oRxz = 0.f, oRyz = 0.f;
+    if (NORMAL && SPARSE_HOIST) {
+        oSxx = LDNT(cSxx + t); oSyy = LDNT(cSyy + t); oRxx = LDNT(cRxx + t); oRyy = LDNT(cRyy + t);
+        oSxy = LDNT(cSxy + t); oSxz = LDNT(cSxz + t); oSyz = LDNT(cSyz + t);
+        oRxy = LDNT(Rc + t); oRxz = LDNT(Rc + nTotal + t); oRyz = LDNT(Rc + 2 * nTotal + t);
+    }
     const unsigned ukl = fdiv(c, divPlane), rem = c - ukl * (unsigned)d.plane, uj = fdiv(rem, divN1);
     const int i = (int)(rem - uj * (unsigned)N1), j = (int)uj, kl = (int)ukl;
     const long ko = (long)kl * pl;
@@ -1991,40 +2000,64 @@ __global__ __launch_bounds__(256) void stress_shear_sparse(bfd_dev d, const unsi
     // the 21 velocities: wave-uniform bases + one 32-bit byte offset (c < 2^30); a cell whose stencil stays inside the domain in x and y
     // (all but the cells on the outermost two rows / columns) takes them without a test per value
     const unsigned c4 = c * 4u, r4 = (unsigned)N1 * 4u;
-    const float vx0 = F4(d.Vx, c4), vy0 = F4(d.Vy, c4), vz0 = F4(d.Vz, c4);
-    float dyVx, dxVy, dxVz, dyVz;
-    if (i >= 1 && i + 2 < N1 && j >= 1 && j + 2 < N2) {
+    float vx0, vy0, vz0;
+    float dyVx, dxVy, dxVz, dyVz, dxVx = 0.f, dyVy = 0.f, dzVz = 0.f;
+    const bool inside = i >= 2 && i + 2 < N1 && j >= 2 && j + 2 < N2;
+    if (inside) {
+        vx0 = F4(d.Vx, c4); vy0 = F4(d.Vy, c4); vz0 = F4(d.Vz, c4);
         dyVx = dplus4(F4(d.Vx, c4 - r4), vx0, F4(d.Vx, c4 + r4), F4(d.Vx, c4 + 2 * r4));
         dxVy = dplus4(F4(d.Vy, c4 - 4u), vy0, F4(d.Vy, c4 + 4u), F4(d.Vy, c4 + 8u));
         dxVz = dplus4(F4(d.Vz, c4 - 4u), vz0, F4(d.Vz, c4 + 4u), F4(d.Vz, c4 + 8u));
         dyVz = dplus4(F4(d.Vz, c4 - r4), vz0, F4(d.Vz, c4 + r4), F4(d.Vz, c4 + 2 * r4));
+        if (NORMAL) { dxVx = dminus4(F4(d.Vx, c4 - 8u), F4(d.Vx, c4 - 4u), vx0, F4(d.Vx, c4 + 4u)); dyVy = dminus4(F4(d.Vy, c4 - 2 * r4), F4(d.Vy, c4 - r4), vy0, F4(d.Vy, c4 + r4)); }
     } else {
+        vx0 = F4(d.Vx, c4); vy0 = F4(d.Vy, c4); vz0 = F4(d.Vz, c4);
         dyVx = dplus4(ldv(d.Vx, N1, N2, i, j - 1, ko), vx0, ldv(d.Vx, N1, N2, i, j + 1, ko), ldv(d.Vx, N1, N2, i, j + 2, ko));
         dxVy = dplus4(ldv(d.Vy, N1, N2, i - 1, j, ko), vy0, ldv(d.Vy, N1, N2, i + 1, j, ko), ldv(d.Vy, N1, N2, i + 2, j, ko));
         dxVz = dplus4(ldv(d.Vz, N1, N2, i - 1, j, ko), vz0, ldv(d.Vz, N1, N2, i + 1, j, ko), ldv(d.Vz, N1, N2, i + 2, j, ko));
         dyVz = dplus4(ldv(d.Vz, N1, N2, i, j - 1, ko), vz0, ldv(d.Vz, N1, N2, i, j + 1, ko), ldv(d.Vz, N1, N2, i, j + 2, ko));
+        if (NORMAL) {
+            dxVx = dminus4(ldv(d.Vx, N1, N2, i - 2, j, ko), ldv(d.Vx, N1, N2, i - 1, j, ko), vx0, ldv(d.Vx, N1, N2, i + 1, j, ko));
+            dyVy = dminus4(ldv(d.Vy, N1, N2, i, j - 2, ko), ldv(d.Vy, N1, N2, i, j - 1, ko), vy0, ldv(d.Vy, N1, N2, i, j + 1, ko));
+        }
     }
     float dzVx = dplus4(F4(d.Vx - pl, c4), vx0, F4(d.Vx + pl, c4), F4(d.Vx + 2 * pl, c4));
     float dzVy = dplus4(F4(d.Vy - pl, c4), vy0, F4(d.Vy + pl, c4), F4(d.Vy + 2 * pl, c4));
+    if (NORMAL) dzVz = dminus4(F4(d.Vz - 2 * pl, c4), F4(d.Vz - pl, c4), vz0, F4(d.Vz + pl, c4));
     if (i < P || i >= N1 - P) {
         const int xi = i < P ? i : i - (N1 - 2 * P);
         const unsigned q = (unsigned)((kl * N2 + j) * (2 * P) + xi);
         dxVy = cpml(d.psi[4], q, d.axH[i], d.bxH[i], dxVy);
         dxVz = cpml(d.psi[6], q, d.axH[i], d.bxH[i], dxVz);
+        if (NORMAL) dxVx = dxVx + d.psi[0][q];          // advanced by the fluid stress kernel in this half-step
     }
     if (j < P || j >= N2 - P) {
         const int yj = j < P ? j : j - (N2 - 2 * P);
         const unsigned q = (unsigned)((kl * (2 * P) + yj) * N1 + i);
         dyVx = cpml(d.psi[3], q, d.ayH[j], d.byH[j], dyVx);
         dyVz = cpml(d.psi[8], q, d.ayH[j], d.byH[j], dyVz);
+        if (NORMAL) dyVy = dyVy + d.psi[1][q];
     }
     if (k < P || k >= d.N3 - P) {
         const int zk = k < P ? k : k - (d.N3 - 2 * P);
         const unsigned q = (unsigned)(zk * d.plane) + (unsigned)(j * N1 + i);
         dzVx = cpml(d.psi[5], q, d.azH[k], d.bzH[k], dzVx);
         dzVy = cpml(d.psi[7], q, d.azH[k], d.bzH[k], dzVy);
+        if (NORMAL) dzVz = dzVz + d.psi[2][q];
     }
     const float c1 = d.c1;
+    if (NORMAL) {       // Sxx, Syy of the cell: the canonical expressions of stress_v2 / stress_solid
+        const int m = d.mat[c] & BFD_MAT_MASK;
+        const float AP = d.AP[m], BP = d.BP[m], AS2 = d.AS2[m], BS2 = d.BS2[m];
+        const float sXY = dxVx + dyVy;
+        const float div = sXY + dzVz;
+        const float sYZ = dyVy + dzVz, sXZ = dxVx + dzVz;
+        if (!SPARSE_HOIST) { oSxx = LDNT(cSxx + t); oSyy = LDNT(cSyy + t); oRxx = LDNT(cRxx + t); oRyy = LDNT(cRyy + t); }
+        float rn = c1 * oRxx - (BP * div - BS2 * sYZ);
+        __builtin_nontemporal_store(oSxx + ((AP * div - AS2 * sYZ) + 0.5f * (oRxx + rn)), cSxx + t); __builtin_nontemporal_store(rn, cRxx + t);
+        rn = c1 * oRyy - (BP * div - BS2 * sXZ);
+        __builtin_nontemporal_store(oSyy + ((AP * div - AS2 * sXZ) + 0.5f * (oRyy + rn)), cSyy + t); __builtin_nontemporal_store(rn, cRyy + t);
+    }
     // memory variables: beside the list (Rc, list order) or, when the list only holds the cells the merged solid kernel leaves
     // out (Rc == null), in the full-volume arrays
     float *pRxy = Rc ? Rc + t : d.Rxy + c, *pRxz = Rc ? Rc + nTotal + t : d.Rxz + c, *pRyz = Rc ? Rc + 2 * nTotal + t : d.Ryz + c;
@@ -2032,18 +2065,25 @@ __global__ __launch_bounds__(256) void stress_shear_sparse(bfd_dev d, const unsi
     float *pSxy = cSxy ? cSxy + t : d.Sxy + c, *pSxz = cSxz ? cSxz + t : d.Sxz + c, *pSyz = cSyz ? cSyz + t : d.Syz + c;
     if (Axy != 0.f) {
         const float e = dyVx + dxVy;
-        const float r = LDNT(pRxy), rn = c1 * r - Bxy * e;
-        *pSxy = LDNT(pSxy) + (Axy * e + 0.5f * (r + rn)); *pRxy = rn;
+        const float r = (NORMAL && SPARSE_HOIST) ? oRxy : LDNT(pRxy), rn = c1 * r - Bxy * e;
+        *pSxy = ((NORMAL && SPARSE_HOIST) ? oSxy : LDNT(pSxy)) + (Axy * e + 0.5f * (r + rn)); *pRxy = rn;
     }
+    // compact solid state in a Z-slab: the planes a neighbour reads (its ghost planes: my plane 0 and my last two) also go to the full-volume
+    // Sxz / Syz, which is where the halo exchange takes them from
+    const bool shared = NORMAL && (kl == 0 || kl >= d.nk - 2);
     if (Axz != 0.f) {
         const float e = dzVx + dxVz;
-        const float r = LDNT(pRxz), rn = c1 * r - Bxz * e;
-        *pSxz = LDNT(pSxz) + (Axz * e + 0.5f * (r + rn)); *pRxz = rn;
+        const float r = (NORMAL && SPARSE_HOIST) ? oRxz : LDNT(pRxz), rn = c1 * r - Bxz * e;
+        const float v = ((NORMAL && SPARSE_HOIST) ? oSxz : LDNT(pSxz)) + (Axz * e + 0.5f * (r + rn));
+        *pSxz = v; *pRxz = rn;
+        if (shared) d.Sxz[c] = v;
     }
     if (Ayz != 0.f) {
         const float e = dzVy + dyVz;
-        const float r = LDNT(pRyz), rn = c1 * r - Byz * e;
-        *pSyz = LDNT(pSyz) + (Ayz * e + 0.5f * (r + rn)); *pRyz = rn;
+        const float r = (NORMAL && SPARSE_HOIST) ? oRyz : LDNT(pRyz), rn = c1 * r - Byz * e;
+        const float v = ((NORMAL && SPARSE_HOIST) ? oSyz : LDNT(pSyz)) + (Ayz * e + 0.5f * (r + rn));
+        *pSyz = v; *pRyz = rn;
+        if (shared) d.Syz[c] = v;
     }
 }
 
@@ -2146,6 +2186,11 @@ template <bool COLLAPSED>
 __device__ __forceinline__ void stress_fluid_switch(const bfd_dev &d, const int4 &run, int tilesX, float (*sV)[2][LH * LW])
 {
     const int bx = run.x % tilesX, by = run.x / tilesX, kbeg = run.y & 0xFFFF, kend = run.y >> 16, tm = run.w;
+    if (run.z & 1) {          // a solid run in the fluid launch (compact solid state): memory variables, several materials
+        if (run.z & 8) stress_fluid_body<true, true, false, true, true>(d, bx, by, kbeg, kend, tm, sV);
+        else stress_fluid_body<true, true, false, false, true>(d, bx, by, kbeg, kend, tm, sV);
+        return;
+    }
     switch ((run.z >> 1) & 7) {
     case 0: stress_fluid_body<false, COLLAPSED, false, false>(d, bx, by, kbeg, kend, tm, sV); break;
     case 1: stress_fluid_body<true, COLLAPSED, false, false>(d, bx, by, kbeg, kend, tm, sV); break;
@@ -2419,20 +2464,26 @@ void bfd_launch_stress_v2(const bfd_dev &d, hipStream_t s0, const bfd_tiles *t, 
     part_range(t->nFluid, t->nFluidB, part, &off, &n);
     part_range(t->nSolid, t->nSolidB, part, &offS, &nS);
     hipStream_t s = s0;
+    // Compact solid state: Szz / Rzz of EVERY run, solid ones included, in one launch of the fluid kernel over the combined list (natural order:
+    // a solid run sits between its fluid neighbours, their ring lines are shared in L2), then the sparse kernel with everything that exists
+    // only at solid cells. It must come second: it reads the absorbing-layer memory variables the fluid kernel advances.
+    const bool all = d.cssRow && t->runsAll;
+    if (all) {
+        int offA, nA;
+        part_range(t->nAll, t->nAllB, part, &offA, &nA);
+        if (nA) {
+            BFD_KT(BFD_K_STRESS_FLUID, 0);
+            BFD_LAUNCH((stress_fluid<true>), nA, (const int *)nullptr, t->runsAll + offA);
+            BFD_KT(BFD_K_STRESS_FLUID, 1);
+        }
+        n = 0; nS = 0;
+    }
     const bool conc = t->sideStream[0] && !t->ktimer && (nS || (t->shearCells && t->nShear)) && n;
     if (conc) { hipEventRecord(t->sideFork, s0); hipStreamWaitEvent(t->sideStream[0], t->sideFork, 0); hipStreamWaitEvent(t->sideStream[1], t->sideFork, 0); s = t->sideStream[0]; }
-    // experiment (wrong results): the FLUID kernels on the solid run list, as a separate launch -- what the list itself costs (scattered runs whose
-    // neighbours belong to another launch), apart from the solid-run kernels' own code
-    static const bool expSolidAsFluid = getenv("BFD_EXP_SOLID_AS_FLUID") != nullptr;
-    if (nS && expSolidAsFluid) {
-        BFD_KT(BFD_K_STRESS_SOLID, 0);
-        BFD_LAUNCH_X((stress_fluid<true>), nS, BFD_XM_SS + part, t->runs + t->nFluid + offS);
-        BFD_KT(BFD_K_STRESS_SOLID, 1);
-    } else if (nS) {
+    if (nS) {
         BFD_KT(BFD_K_STRESS_SOLID, 0);
         if (t->shearCells && t->merged) BFD_LAUNCH_X(stress_solid_merged, nS, BFD_XM_SS + part, t->runs + t->nFluid + offS, (const float *)t->shearTab);
-        else if (t->shearCells && d.cssRow) BFD_LAUNCH_X((stress_solid<true>), nS, BFD_XM_SS + part, t->runs + t->nFluid + offS);
-        else if (t->shearCells) BFD_LAUNCH_X((stress_solid<false>), nS, BFD_XM_SS + part, t->runs + t->nFluid + offS);
+        else if (t->shearCells) BFD_LAUNCH_X(stress_solid, nS, BFD_XM_SS + part, t->runs + t->nFluid + offS);
         else BFD_LAUNCH(stress_v2, nS, t->runs + t->nFluid + offS, (const unsigned short *)nullptr);     // variant 2: monolithic, dense
         BFD_KT(BFD_K_STRESS_SOLID, 1);
     }
@@ -2446,11 +2497,15 @@ void bfd_launch_stress_v2(const bfd_dev &d, hipStream_t s0, const bfd_tiles *t, 
         auto magic = [](unsigned dv) { FastDiv f; unsigned L = 0; while ((1ull << L) < dv) L++; if (L == 0) L = 1;
                                        f.M = (unsigned)(((1ull << (31 + L)) + dv - 1) / dv); f.s = L - 1; return f; };
         const FastDiv dN1 = magic((unsigned)d.N1), dPl = magic((unsigned)d.plane);
-        const bool cs = d.cssRow != nullptr;
-        if (e0 > b0) hipLaunchKernelGGL(stress_shear_sparse, dim3((unsigned)((e0 - b0 + 255) / 256)), dim3(256), 0, s, d, t->shearCells + b0, t->shearCodes + b0, t->shearTab, t->shearCoef + 6 * b0, R0, t->nShear, e0 - b0, dN1, dPl,
-                                        cs ? d.cSxy + b0 : nullptr, cs ? d.cSxz + b0 : nullptr, cs ? d.cSyz + b0 : nullptr);
-        if (e1 > b1) hipLaunchKernelGGL(stress_shear_sparse, dim3((unsigned)((e1 - b1 + 255) / 256)), dim3(256), 0, s, d, t->shearCells + b1, t->shearCodes + b1, t->shearTab, t->shearCoef + 6 * b1, R1, t->nShear, e1 - b1, dN1, dPl,
-                                        cs ? d.cSxy + b1 : nullptr, cs ? d.cSxz + b1 : nullptr, cs ? d.cSyz + b1 : nullptr);
+        auto sparse = [&](long b, long e, float *R) {
+            if (e <= b) return;
+            const dim3 g((unsigned)((e - b + 255) / 256));
+            if (d.cssRow) hipLaunchKernelGGL(stress_shear_sparse<true>, g, dim3(256), 0, s, d, t->shearCells + b, t->shearCodes + b, t->shearTab, t->shearCoef + 6 * b, R, t->nShear, e - b, dN1, dPl,
+                                             d.cSxy + b, d.cSxz + b, d.cSyz + b, d.cSxx + b, d.cSyy + b, d.cRxx + b, d.cRyy + b);
+            else hipLaunchKernelGGL(stress_shear_sparse<false>, g, dim3(256), 0, s, d, t->shearCells + b, t->shearCodes + b, t->shearTab, t->shearCoef + 6 * b, R, t->nShear, e - b, dN1, dPl,
+                                    (float *)nullptr, (float *)nullptr, (float *)nullptr, (float *)nullptr, (float *)nullptr, (float *)nullptr, (float *)nullptr);
+        };
+        sparse(b0, e0, R0); sparse(b1, e1, R1);
         BFD_KT(BFD_K_STRESS_SHEAR, 1);
     }
     s = s0;
@@ -2472,13 +2527,7 @@ void bfd_launch_velocity_v2(const bfd_dev &d, hipStream_t s0, float *accP, float
     hipStream_t s = s0;
     const bool conc = t->sideStream[0] && !t->ktimer && n && nF && t->shearCells;
     if (conc) { hipEventRecord(t->sideFork, s0); hipStreamWaitEvent(t->sideStream[0], t->sideFork, 0); s = t->sideStream[0]; }
-    static const bool expSolidAsFluid = getenv("BFD_EXP_SOLID_AS_FLUID") != nullptr;
-    if (n && expSolidAsFluid) {
-        BFD_KT(BFD_K_VELOCITY_SOLID, 0);
-        if (acc) BFD_LAUNCH_X((velocity_fluid<true>), n, BFD_XM_VS + part, t->runs + t->nFluid + off, accP, pkP);
-        else BFD_LAUNCH_X((velocity_fluid<false>), n, BFD_XM_VS + part, t->runs + t->nFluid + off, accP, pkP);
-        BFD_KT(BFD_K_VELOCITY_SOLID, 1);
-    } else if (n) {
+    if (n) {
         BFD_KT(BFD_K_VELOCITY_SOLID, 0);
         if (t->shearCells) {
             // solid list = [boundary: PML | plain][interior: plain | PML]: the plain runs of the requested part are contiguous

@@ -170,3 +170,44 @@ def test_random_media_with_the_placement_choice_forced(seed, monkeypatch):
     oh = PropagationModel().StaggeredFDTD_3D_with_relaxation(*a, SILENT=True, **k)
     orf = O.StaggeredFDTD_3D_with_relaxation(*a, **k)
     assert compare_runs(oh, orf, 0.0, both=(k['SelRMSorPeak'] == 3)) == 0.0
+
+
+@pytest.mark.parametrize('seed', [1, 4, 6])
+def test_compact_solid_state_equals_full_volume_arrays(seed, monkeypatch):
+    """Round 5: with the compact solid state (default) Sxx, Syy, the shear stresses and Rxx, Ryy of the solid cells live in sparse-list
+    order, the fluid stress kernel takes Szz / Rzz of the solid runs and the sparse kernel everything else a solid cell has. All 15
+    state arrays, read back through bfd_get_field (which fills the full-volume arrays from the compact ones), must equal those of a
+    run with BFD_COMPACT_SOLID=0 (full-volume arrays, stress_solid + stress_shear_sparse) -- also after a reset and a second run."""
+    from babelbrain_amd import _engine
+    from babelbrain_amd.PropagationModel import compact_sources
+    a, k = random_case(seed)
+    mm, ml, f, smap, pulse, h, T, sensor = a
+    nt = int(round(T / k['DT']))
+
+    def fields(env):
+        monkeypatch.setenv('BFD_COMPACT_SOLID', env)
+        eng = _engine.Engine(*mm.shape, len(ml), h, k['DT'], f, nt, NDelta=k['NDelta'], typeSource=k['TypeSource'], sensorSub=k['SensorSubSampling'],
+                             sensorStart=k['SensorStart'], selMapsRMS=['Pressure'], selMapsSensors=['Pressure', 'Sigmaxx', 'Sigmaxz'], selRMSorPeak=1)
+        eng.set_materials(ml, k['QCorrection'])
+        eng.set_material_map(mm, 0, 0)
+        if k['ReflectorMask'] is not None:
+            eng.set_reflector(k['ReflectorMask'])
+        eng.set_sources(*compact_sources(smap, k['Ox'], k['Oy'], k['Oz']), pulse)
+        eng.set_sensor_map(sens_map)
+        out = []
+        for rep in range(2):
+            eng.run(nt // 2)
+            out.append({n: eng.get_field(n).copy() for n in _engine.FIELD_NAMES})
+            out[-1]['sensors'] = eng.sensors().copy()
+            eng.run(nt - nt // 2)             # get_field in the middle of a run must not disturb it
+            out.append({n: eng.get_field(n).copy() for n in _engine.FIELD_NAMES})
+            eng.reset()
+        eng.close()
+        return out
+
+    sens_map = sensor
+    full, comp = fields('0'), fields('1')
+    assert any(np.abs(full[1][n]).max() > 0 for n in ('Sxy', 'Sxz', 'Syz', 'Rxx', 'Rxy'))
+    for q, (x, y) in enumerate(zip(full, comp)):
+        for n in x:
+            assert np.array_equal(x[n], y[n]), (q, n)
