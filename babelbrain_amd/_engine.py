@@ -33,6 +33,7 @@ ABI_SYMBOLS = [
     'bfd_group_set_reflector', 'bfd_group_set_sources', 'bfd_group_set_sensor_map', 'bfd_group_prepare', 'bfd_group_run', 'bfd_group_sync',
     'bfd_group_reset', 'bfd_group_timing_begin', 'bfd_group_timing_end', 'bfd_group_num_sensors', 'bfd_group_num_sensor_steps',
     'bfd_group_get_sensor_index', 'bfd_group_get_sensors', 'bfd_group_get_sensor_dft', 'bfd_group_get_map', 'bfd_group_device_bytes',
+    'bfd_group_peer_status', 'bfd_placement_cache_release',
 ]
 
 
@@ -174,7 +175,10 @@ def load_library():
     lib.bfd_group_get_map.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_int64, C.c_int64]
     lib.bfd_group_device_bytes.argtypes = [C.c_void_p]
     lib.bfd_group_device_bytes.restype = C.c_int64
-    if lib.bfd_abi_version() != 5:
+    lib.bfd_group_peer_status.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+    lib.bfd_placement_cache_release.argtypes = []
+    lib.bfd_placement_cache_release.restype = C.c_int64
+    if lib.bfd_abi_version() != 6:
         raise EngineError('libbabelfdtd_hip.so ABI version mismatch')
     _lib = lib
     return lib
@@ -489,6 +493,26 @@ class _SlabView(Engine):
         pass
 
 
+PEER_PATHS = {0: 'same device (device copy)', 1: 'peer access both ways (direct hipMemcpyPeerAsync)', 2: 'STAGED through the host (peer access missing)'}
+
+
+def decode_peer_status(codes, devices=None):
+    """Status words of bfd_group_peer_status -> one dict per interface r | r+1: path, can_access / enabled in each direction."""
+    out = []
+    for r, c in enumerate(np.asarray(codes, np.int64).tolist()):
+        e = {'interface': r, 'path': PEER_PATHS.get(c & 15, 'unknown'), 'direct': (c & 15) != 2,
+             'can_access': [bool(c & 16), bool(c & 64)], 'enabled': [bool(c & 32), bool(c & 128)]}
+        if devices is not None and r + 1 < len(devices):
+            e['devices'] = [int(devices[r]), int(devices[r + 1])]
+        out.append(e)
+    return out
+
+
+def placement_cache_release():
+    """Frees the device buffers kept between solver calls for the placement of the arrays; returns the bytes freed."""
+    return int(load_library().bfd_placement_cache_release())
+
+
 class Group:
     """One solver call split into Z-slabs over several HIP devices of this process (bfd_group_*): whole-domain inputs and
     outputs, step loop and halo copies inside the library."""
@@ -600,7 +624,16 @@ class Group:
         ov = C.c_int32()
         _check(self.lib.bfd_group_timing_end(self.h, *[C.byref(x) for x in d], C.byref(ov)), 'bfd_group_timing_end')
         return {'total_ms': d[0].value, 'max_device_ms': d[1].value, 'host_issue_ms': d[2].value, 'halo_bytes_per_step': d[3].value,
-                'overlapped': bool(ov.value), 'slabs': self.size}
+                'overlapped': bool(ov.value), 'slabs': self.size, 'peer': self.peer_status()}
+
+    def peer_status(self):
+        """How the halo planes cross each interface (bfd_group_peer_status), decoded: one dict per interface."""
+        n = max(self.size - 1, 0)
+        codes = np.zeros(max(n, 1), np.int32)
+        got = self.lib.bfd_group_peer_status(self.h, _ptr(codes), n)
+        if got < 0:
+            _check(got, 'bfd_group_peer_status')
+        return decode_peer_status(codes[:n], self.devices)
 
     # ---- outputs (whole domain) ----
     @property

@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <array>
 #include <chrono>
+#include <mutex>
 #include <thread>
 #include <hipcub/hipcub.hpp>
 
@@ -708,6 +709,7 @@ int bfd_create(const bfd_config *cfg, bfd_sim **out)
     return 0;
 }
 
+static bool placement_cache_put(int device, size_t bytes, void *p);
 void bfd_destroy(bfd_sim *s)
 {
     if (!s) return;
@@ -717,7 +719,11 @@ void bfd_destroy(bfd_sim *s)
     if (s->captureStream) hipStreamDestroy(s->captureStream);
     release_streaming(s);
     for (int b = 0; b < 2; b++) { if (s->evTile[b]) hipEventDestroy(s->evTile[b]); for (int q = 0; q < 2; q++) if (s->evRead[b][q]) hipEventDestroy(s->evRead[b][q]); }
-    for (void *p : s->allocs) hipFree(p);
+    for (void *p : s->allocs) {
+        const bool searched = std::find(s->searched.begin(), s->searched.end(), p) != s->searched.end();
+        if (searched && placement_cache_put(s->cfg.device, s->nalloc * sizeof(float), p)) continue;
+        hipFree(p);
+    }
     for (hipEvent_t e : s->evPool) hipEventDestroy(e);
     for (hipEvent_t e : s->evStress) hipEventDestroy(e);
     for (hipEvent_t e : s->evVelocity) hipEventDestroy(e);
@@ -1439,6 +1445,46 @@ static int build_tile_lists(bfd_sim *s)
 // allocator moves on; bounded by the free memory). The Pressure accumulators are re-allocated likewise when they fall on
 // the wrong side. A few dozen probes of well under a millisecond; results do not depend on it.
 // BFD_PLACEMENT=0 (or BFD_PLACEMENT_TRIALS=0, the round-2 name) switches it off; BFD_PLACEMENT_VERBOSE=1 prints what it does.
+// Buffers that a search found in another memory region are kept when their engine is destroyed and offered to the next engine of this
+// process that wants arrays of the same size on the same device (re-probed there: region classes are relative): the two or three solver calls
+// of one RunCases (BASE:2338, 2374, 2401) pay the search once. Bounded (BABELFDTD_PLACEMENT_CACHE_GIB, default 48, 0 = off);
+// bfd_placement_cache_release() frees it.
+struct CachedBuf { int device; size_t bytes; void *p; };
+static std::mutex g_cacheMutex;
+static std::vector<CachedBuf> g_cache;
+static size_t placement_cache_cap()
+{
+    double gib = 48.0;
+    if (const char *ev = getenv("BABELFDTD_PLACEMENT_CACHE_GIB")) gib = atof(ev);
+    return gib > 0 ? (size_t)(gib * 1073741824.0) : 0;
+}
+static std::vector<void *> placement_cache_take(int device, size_t bytes)
+{
+    std::lock_guard<std::mutex> lk(g_cacheMutex);
+    std::vector<void *> out;
+    for (size_t q = 0; q < g_cache.size();) {
+        if (g_cache[q].device == device && g_cache[q].bytes == bytes) { out.push_back(g_cache[q].p); g_cache.erase(g_cache.begin() + q); }
+        else q++;
+    }
+    return out;
+}
+// true if the cache took the buffer (the caller must not free it)
+static bool placement_cache_put(int device, size_t bytes, void *p)
+{
+    std::lock_guard<std::mutex> lk(g_cacheMutex);
+    const size_t cap = placement_cache_cap();
+    // buffers of another size on this device are of no use to the caller that is coming: they make room first
+    for (size_t q = 0; q < g_cache.size();) {
+        if (g_cache[q].device == device && g_cache[q].bytes != bytes) { hipSetDevice(device); hipFree(g_cache[q].p); g_cache.erase(g_cache.begin() + q); }
+        else q++;
+    }
+    size_t held = 0;
+    for (const CachedBuf &c : g_cache) held += c.bytes;
+    if (held + bytes > cap) return false;
+    g_cache.push_back({device, bytes, p});
+    return true;
+}
+
 static void bind_state_views(bfd_sim *s)
 {
     bfd_dev &d = s->d;
@@ -1576,9 +1622,23 @@ static int choose_placement(bfd_sim *s)
     size_t heldCap = std::min((size_t)64 << 30, free0 / 2);
     std::string capNote;
     if (others > ((size_t)6 << 30)) { heldCap = 0; char q[96]; snprintf(q, sizeof q, "; device shared (%.0f GiB of other allocations): no search beyond the own buffers", others / 1073741824.0); capNote = q; }
+    if (const char *ev = getenv("BABELFDTD_PLACEMENT_SEARCH_GIB")) {           // the owner of the device raises (or lowers) the default bound without code
+        const double gib = atof(ev);
+        if (gib >= 0 && others <= ((size_t)6 << 30)) heldCap = std::min((size_t)(gib * 1073741824.0), free0 > (free0 / 8) ? free0 - free0 / 8 : 0);
+    }
     if (s->placementLimit >= 0) { heldCap = (size_t)s->placementLimit; capNote.clear(); }
     if (const char *ev = getenv("BFD_PLACEMENT_SEARCH_MB")) { probeTells = true; heldCap = (size_t)atol(ev) << 20; capNote.clear(); }   // tests: walk a little on any grid
     if (heldCap == 0) probeTells = false;
+    int nCached = 0;
+    if ((need[0] > 0 || need[1] > 0) && tSame >= 0.05f) {                      // first what an earlier engine of this process found
+        for (void *cp : placement_cache_take(s->cfg.device, bytes)) {
+            float *c = (float *)cp;
+            int sd = -1;
+            if (hipMemsetAsync(c, 0, bytes, s->stream) == hipSuccess) { const float t = pair(repOf[M], c + g); if (t > 0) sd = t >= thr ? 0 : 1; }
+            if (sd >= 0 && need[sd] > 0) { pool.push_back({c, sd == 0 ? M : 100 + nFresh, true}); need[sd]--; nFresh++; nCached++; }
+            else { hipStreamSynchronize(s->stream); hipFree(c); }
+        }
+    }
     while ((need[0] > 0 || need[1] > 0) && !gaveUp && probeTells) {            // draw candidates until both sides have enough
         size_t freeB = 0, totalB = 0;
         if (hipMemGetInfo(&freeB, &totalB) != hipSuccess || freeB < 2 * bytes + totalB / 8 || heldBytes + bytes > heldCap) { gaveUp = true; break; }
@@ -1622,7 +1682,7 @@ static int choose_placement(bfd_sim *s)
     }
     BFD_HIP(hipStreamSynchronize(s->stream));
     for (size_t q = 0; q < pool.size(); q++) {
-        if (taken[q]) { if (pool[q].fresh) s->allocs.push_back(pool[q].base); continue; }
+        if (taken[q]) { if (pool[q].fresh) { s->allocs.push_back(pool[q].base); s->searched.push_back(pool[q].base); } continue; }
         if (!pool[q].fresh) {                                                 // an original buffer displaced by a fresh one
             auto it = std::find(s->allocs.begin(), s->allocs.end(), (void *)pool[q].base);
             if (it != s->allocs.end()) s->allocs.erase(it);
@@ -1682,7 +1742,7 @@ static int choose_placement(bfd_sim *s)
     snprintf(buf, sizeof buf, "arrays placed by memory region (pair probe on the zero state: %d probes, within-region %.3f ms, threshold %.3f ms, gap between the levels %.0f %%; %zu regions seen): "
              "regions of %s %s -> %s (m / n = fresh allocation in / outside the most populated region),%s %d fresh, %zu candidates / spacers (%.1f GiB) released%s; %.2f s", nProbes, tSame, thr, 100.0 * widest, repOf.size(),
              (std::string("Vx Vy Vz Szz Rzz") + (s->pingpong ? " + their second copies" : "") + (solids ? " Sxx Rxx Syy Ryy Sxy Rxy Sxz Rxz Syz Ryz" : "")).c_str(), before.c_str(), after.c_str(), accNote.c_str(), nFresh, held.size(), heldBytes / 1073741824.0,
-             (std::string(gaveUp ? "; search for another region given up (limit / memory)" : "") + capNote).c_str(), std::chrono::duration<double>(std::chrono::steady_clock::now() - tStart).count());
+             (std::string(gaveUp ? "; search for another region given up (limit / memory)" : "") + capNote + (nCached ? "; " + std::to_string(nCached) + " of the fresh buffers came from an earlier search of this process" : "")).c_str(), std::chrono::duration<double>(std::chrono::steady_clock::now() - tStart).count());
     s->placementNote = buf;
     if (verbose) fprintf(stderr, "placement: %s\nplacement: probe times, array:ms against Vx, array/class:ms against the other representatives:%s\n", buf, times.c_str());
     return 0;
@@ -1932,6 +1992,19 @@ int bfd_halo_region(bfd_sim *s, int32_t group, int32_t f, int32_t side, int32_t 
     *devPtr = a + kl * (long)d.plane;
     *bytes = 2 * (size_t)d.plane * sizeof(float);
     return 0;
+}
+
+int64_t bfd_placement_cache_release(void)
+{
+    std::lock_guard<std::mutex> lk(g_cacheMutex);
+    int64_t freed = 0;
+    int cur = 0;
+    const bool haveCur = hipGetDevice(&cur) == hipSuccess;
+    for (const CachedBuf &c : g_cache) { hipSetDevice(c.device); hipFree(c.p); freed += (int64_t)c.bytes; }
+    g_cache.clear();
+    if (haveCur) hipSetDevice(cur);
+    (void)hipGetLastError();
+    return freed;
 }
 
 int bfd_set_placement(bfd_sim *s, int32_t mode, int64_t searchLimitBytes)

@@ -41,6 +41,7 @@ struct bfd_group {
     bool threads;                         // one host thread per slab queues its work (BFD_GROUP_THREADS=0: one thread for all)
     bool prepared, overlap;
     bool forcePeer = false;               // BFD_GROUP_FORCE_PEER_COPY: hipMemcpyPeerAsync also between slabs on one device
+    std::vector<int32_t> peer;            // per interface r | r+1: BFD_PEER_* code + detail bits (bfd_group_peer_status)
     std::vector<int64_t> nSens;
     double issueSeconds; int64_t issueSteps;    // host time spent queueing work in bfd_group_run
     double haloBytesPerStep;
@@ -256,13 +257,25 @@ int bfd_group_create(const bfd_config *cfg, int32_t nSlabs, const int32_t *devic
     g->evMain.assign(nSlabs, nullptr); g->evPart1.assign(nSlabs, nullptr); g->evPart1b.assign(nSlabs, nullptr); g->evHalo.assign(nSlabs, nullptr);
     g->threads = false;
     g->reads[0].assign(nSlabs, 7u); g->reads[1].assign(nSlabs, 7u); g->nSens.assign(nSlabs, 0);
-    // peer access between the devices of neighbouring slabs (hipMemcpyPeerAsync falls back to staging without it)
+    // peer access between the devices of neighbouring slabs. Without it hipMemcpyPeerAsync still works, but the runtime stages every halo plane
+    // through the host: nothing fails, the curve is just bad -- so what happened is kept per interface (bfd_group_peer_status)
+    g->peer.assign(nSlabs > 1 ? nSlabs - 1 : 0, BFD_PEER_SAME_DEVICE);
     for (int r = 0; r + 1 < nSlabs; r++) {
         const int a = devices[r], b = devices[r + 1];
         if (a == b) continue;
-        int can = 0;
-        if (hipDeviceCanAccessPeer(&can, a, b) == hipSuccess && can) { hipSetDevice(a); if (hipDeviceEnablePeerAccess(b, 0) != hipSuccess) (void)hipGetLastError(); }
-        if (hipDeviceCanAccessPeer(&can, b, a) == hipSuccess && can) { hipSetDevice(b); if (hipDeviceEnablePeerAccess(a, 0) != hipSuccess) (void)hipGetLastError(); }
+        int32_t bits = 0;
+        const int from[2] = {a, b}, to[2] = {b, a};
+        for (int q = 0; q < 2; q++) {
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, from[q], to[q]) != hipSuccess) { can = 0; (void)hipGetLastError(); }
+            if (!can) continue;
+            bits |= 16 << (2 * q);
+            hipSetDevice(from[q]);
+            const hipError_t e = hipDeviceEnablePeerAccess(to[q], 0);
+            if (e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled) bits |= 32 << (2 * q);
+            (void)hipGetLastError();
+        }
+        g->peer[r] = ((bits & 0xF0) == 0xF0 ? BFD_PEER_DIRECT : BFD_PEER_STAGED) | bits;
     }
     int rc = 0;
     for (int r = 0; r < nSlabs && !rc; r++) {
@@ -440,6 +453,14 @@ int bfd_group_timing_begin(bfd_group *g)
     for (int r = 0; r < g->n; r++) { rc = bfd_timing_begin(g->sim[r], 0); if (rc) return rc; }
     g->issueSeconds = 0; g->issueSteps = 0; g->timing = true; g->t0 = std::chrono::steady_clock::now();
     return 0;
+}
+
+int bfd_group_peer_status(bfd_group *g, int32_t *status, int32_t n)
+{
+    if (!g || (!status && n > 0)) GRP_FAIL(-1, "bfd_group_peer_status: null argument");
+    if (n < g->n - 1) GRP_FAIL(-2, "bfd_group_peer_status: room for nSlabs - 1 interfaces needed");
+    for (int r = 0; r + 1 < g->n; r++) status[r] = g->peer[r];
+    return g->n - 1;
 }
 
 int bfd_group_timing_end(bfd_group *g, double *wallMs, double *maxDeviceMs, double *hostIssueMs, double *haloBytesPerStep, int32_t *overlapped)

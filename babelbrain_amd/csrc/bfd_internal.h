@@ -146,6 +146,7 @@ struct bfd_sim {
     uint8_t *clsBase; bool classesReady;
     bool placementDone, haloHandedOut;   // bfd_prepare: the per-voxel arrays may be moved until a halo pointer has been given out
     std::string placementNote;           // what choose_placement found and did (bfd_placement_note)
+    std::vector<void *> searched;        // state buffers that a search found in another memory region: kept for the next engine of this process when this one is destroyed
     int placementMode; int64_t placementLimit;   // bfd_set_placement: 0 = off; bytes the search may hold at a time (-1 = default rule)
     float *tables;                  // 7*nMat
     float *profiles;                // 4*(N1+N2+N3)

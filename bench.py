@@ -46,6 +46,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 BYTES_STEP_DENSE = 172.0       # every array of every voxel, full viscoelastic everywhere (secondary figure)
 STEADY_SECONDS = 0.35          # GPU load before the timed window (clocks settle; short bursts read a few % high)
+PROFILE_STALE_TOL = 0.03       # a committed PMC profile describes the running binary while its kernel's live launch average stays within 3 % of the profiled one
 
 
 def parse():
@@ -68,7 +69,11 @@ def parse():
     ap.add_argument('--lean-host', action='store_true', help='build the inputs slab-style (size-1 Ox/Oy/Oz) also at N=1')
     ap.add_argument('--cpu-sample', type=int, nargs=4, default=None, help='N1 N2 N3 steps of the oracle sample (default: the grid of the config itself, 56 steps, when the host has the memory; else 384 384 256 224)')
     ap.add_argument('--group-child', nargs=4, default=None, metavar=('CONFIG', 'N1', 'N2', 'N3'), help='internal: run ONE volume through bfd_group over --gpus devices and print its block (the parent bench starts this as a child process with a timeout)')
-    ap.add_argument('--placement-search-gib', type=float, default=190.0, help='throw-away device memory the placement of the arrays may hold while it looks for a buffer in another memory region (the bench owns the device; the library default is 64 GiB / half of the free memory / nothing on a shared device); < 0 = library default')
+    ap.add_argument('--placement-search-gib', type=float, default=-1.0, help='throw-away device memory the placement of the arrays may hold while it looks for a buffer in another memory region; < 0 (default) = the library\'s own rule, i.e. what a PropagationModel() call gets: 64 GiB / half of the free memory / nothing on a shared device')
+    ap.add_argument('--wide-placement-gib', type=float, default=190.0, help='N=1: search bound of the extra block `wide_placement_search` (the headline uses the library default)')
+    ap.add_argument('--no-wide-placement', action='store_true', help='N=1: skip the extra block that times the headline workload again under the wide search bound')
+    ap.add_argument('--no-strong-c5', action='store_true', help='skip the block that times ONE C5 volume (1024^3) through the one-process path (N=1: the anchor of the 1/2/4/8 curve)')
+    ap.add_argument('--strong-c5-steps', type=int, default=30, help='timed steps of the strong_c5 block (14 ms each on one device)')
     ap.add_argument('--no-group', action='store_true', help='skip the one-process bfd_group figures (group_one_slab at N=1, group_strong_c3 under torchrun)')
     ap.add_argument('--no-next-rows', action='store_true', help='skip the Rayleigh / BHTE kernel rates (N=1, default workload only)')
     ap.add_argument('--no-extra-strong', action='store_true', help='N > 1: skip the extra block that splits ONE C5 volume (1024^3, 1 MHz) over the ranks')
@@ -317,7 +322,10 @@ class Workload:
                        'launches': n, 'traffic_from_profile': traffic.get(c)}
             if traffic.get(c) and traffic.get('_profile'):
                 pr = traffic['_profile']
-                rows[c]['profile_ref'] = {'pmc': pr.get('pmc'), 'kernel_stats': pr.get('kernel_stats'), 'kernel_avg_us_in_profile': (pr.get('kernel_avg_us') or {}).get(c)}
+                ref_us = (pr.get('kernel_avg_us') or {}).get(c)
+                rows[c]['profile_ref'] = {'pmc': pr.get('pmc'), 'kernel_stats': pr.get('kernel_stats'), 'kernel_avg_us_in_profile': ref_us}
+                # the committed counters describe this binary only while the kernel still takes what it took under the profiler
+                rows[c]['profile_stale'] = (ref_us is None) or abs(avg * 1e6 / ref_us - 1.0) > PROFILE_STALE_TOL
             if traffic.get(c):
                 rows[c]['frac_of_peak_by_profile_traffic'] = traffic[c] / avg / 1e9 / HBM_PEAK_GBS
         return rows, alg
@@ -436,6 +444,8 @@ def group_run(args, config, N, ndev, dt_fn, steps, warmup, windows, variant, lab
                'windows_ms_per_step': [r['total_ms'] / steps for r in rows], 'steps': steps, 'warmup': warmup,
                'max_device_ms_per_step': tm['max_device_ms'] / steps, 'host_issue_ms_per_step': tm['host_issue_ms'] / steps,
                'halo_MB_per_step': tm['halo_bytes_per_step'] / 1e6, 'overlapped': tm['overlapped'], 'devices': devices, 'emulated': emulated,
+               'distinct_devices': len(set(devices)), 'peer': tm.get('peer'),
+               'halo_path_ok': all(p['direct'] for p in (tm.get('peer') or [])),
                'slabs': [[k0, nk, dev] for k0, nk, dev, _ in slabs], 'device_bytes': int(g.device_bytes), 'host_build_s': host_build, 'setup_s': setup,
                'dt': info['dt'], 'ppp': info['ppp'], 'n_sources': info['n_sources'], 'medium': info['medium'], 'tx': info['tx'], 'n_mat': info['n_mat'],
                'array_placement_slab0': slabs[0][3].placement_note()}
@@ -487,8 +497,37 @@ def group_in_child(args, config, N, ndev, steps, warmup, timeout=900):
     return json.loads(r.stdout.strip().splitlines()[-1])
 
 
+def strong_c5(args, ndev, dt_fn, variant):
+    """The curve north_star names: ONE C5 volume (1024^3, 1 MHz, water / cortical bone with shear / brain) over `ndev` devices through
+    the one-process path behind the drop-in call -- with its own anchor: the same host arrays on device 0 alone, timed in the same
+    run, so that every line carries scaling_efficiency = value / (ndev x anchor) by itself. At ndev = 1 the block IS the anchor."""
+    from babelbrain_amd import harness as H
+    c5 = H.CONFIGS['C5']['N']
+    steps, warmup = max(args.strong_c5_steps, 10), min(args.warmup, 8)
+    anchor = None
+    if ndev > 1:
+        try:
+            anchor = group_run(args, 'C5', c5, 1, dt_fn, steps, warmup, 1, variant, 'anchor: the same volume on device 0 alone')
+        except Exception as e:
+            anchor = {'value': None, 'error': repr(e)}
+    try:
+        head = group_run(args, 'C5', c5, ndev, dt_fn, steps, warmup, 1, variant, 'strong scaling of ONE 1024^3 volume')
+    except Exception as e:
+        return {'value': None, 'error': repr(e), 'one_device_same_volume': anchor}
+    if ndev == 1:
+        anchor = {'value': head['value'], 'ms_per_step': head['ms_per_step']}
+    head['scaling'] = 'strong'
+    head['one_device_same_volume'] = {k: anchor.get(k) for k in ('value', 'ms_per_step', 'error', 'array_placement_slab0') if k in anchor} if anchor else None
+    av = (anchor or {}).get('value')
+    head['scaling_efficiency'] = (head['value'] / (head['distinct_devices'] * av)) if av else None
+    head['scaling_efficiency_note'] = 'value / (distinct devices x one_device_same_volume.value), both timed in this run'
+    return head
+
+
 def main_group(args):
-    """`--gpus N` (N > 1) without a launcher: the one-process split (bfd_group_*) over devices 0 .. N-1."""
+    """`--gpus N` (N > 1) without a launcher: the one-process split (bfd_group_*) over devices 0 .. N-1. The headline is the SAME quantity
+    as at N = 1 and as under torchrun -- the metric's config, one 512^3 C3 grid per device (weak scaling: a 512 x 512 x 512 N domain
+    in N slabs) -- and the block `strong_c5` carries the 1024^3 curve with its own one-device anchor."""
     from babelbrain_amd import _engine, harness as H
     ndev = args.gpus
     if _engine.load_library().bfd_device_count() <= 0:
@@ -497,37 +536,50 @@ def main_group(args):
     def dt_fn(ml, f, h, acfl):
         return _engine.stable_dt(ml, f, True, h, acfl)
 
-    strong_cfg = args.config if (args.scaling == 'strong' and args.config != 'C3') else 'C5'
-    dims = tuple(args.size) if (args.size and args.scaling == 'strong') else H.CONFIGS[strong_cfg]['N']
-    head = group_run(args, strong_cfg, dims, ndev, dt_fn, args.steps, args.warmup, args.windows, args.variant, 'strong scaling of ONE volume')
-    line = {'metric': 'Mvoxel-steps/sec, 512^3 skull FDTD (achieved HBM GB/s in roofline)', 'value': head['value'], 'unit': 'Mvoxel-steps/s',
-            'n_gpus': ndev, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': head['ms_per_step'], 'higher_is_better': True,
-            'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic', 'emulated': head['emulated'],
-            'config': {'workload': head['workload'] + ', %s medium, %s source, PML 12, %d materials, Pressure RMS accumulated in every step' % (head['medium'], head['tx'], head['n_mat']),
-                       'parallelism': 'z-slab x%d, one process' % ndev, 'kernel_variant': args.variant, 'launcher': 'none (bfd_group_*)',
-                       'devices': head['devices'], 'slabs': head['slabs'], 'dt': head['dt'], 'ppp': head['ppp'], 'n_sources': head['n_sources'],
-                       'array_placement_slab0': head['array_placement_slab0'], 'untimed_steps_before_window': args.warmup},
-            'windows_ms_per_step': head['windows_ms_per_step'], 'max_device_ms_per_step': head['max_device_ms_per_step'],
-            'host_issue_ms_per_step': head['host_issue_ms_per_step'], 'halo_MB_per_step': head['halo_MB_per_step'],
-            'halo_exchange': 'overlapped' if head['overlapped'] else 'blocking', 'device_bytes': head['device_bytes'], 'host_build_s': head['host_build_s']}
-    if 'roofline_step' in head:
-        r = head['roofline_step']
-        line['roofline'] = dict(bound='hbm', kernel='whole time step, all slabs', achieved=r['achieved'], peak=r['peak'], unit='GB/s', frac=r['frac'], traffic=None,
-                                note='algorithmic bytes of the slabs per step / wall time per step; peak = 8 TB/s x distinct devices; the per-kernel figures are in the N=1 line')
-        line['roofline_step'] = r
+    cfgname = args.config
+    c = tuple(args.size) if args.size else H.CONFIGS[cfgname]['N']
+    dims = (c[0], c[1], c[2] * ndev) if args.scaling == 'weak' else c
+    what = ('weak scaling: one %dx%dx%d grid of %s per device' % (c[0], c[1], c[2], cfgname)) if args.scaling == 'weak' else 'strong scaling of ONE %s volume' % cfgname
+    line = {'metric': 'Mvoxel-steps/sec, 512^3 skull FDTD per device (achieved HBM GB/s in roofline)', 'value': None, 'unit': 'Mvoxel-steps/s',
+            'n_gpus': ndev, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': None, 'higher_is_better': True,
+            'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': '%s, %s: %dx%dx%d in %d Z-slabs, one process (bfd_group_*)' % (cfgname, what, dims[0], dims[1], dims[2], ndev),
+                       'parallelism': 'z-slab x%d, one process' % ndev, 'kernel_variant': args.variant, 'launcher': 'none (bfd_group_*)'}}
+    try:
+        head = group_run(args, cfgname, dims, ndev, dt_fn, args.steps, args.warmup, args.windows, args.variant, what)
+    except Exception as e:          # a first-ever failure on real hardware (peer access, memory) must still leave a line
+        head = None
+        line['error'] = repr(e)
+    if head is not None:
+        line.update({'value': head['value'], 'ms_per_step': head['ms_per_step'], 'emulated': head['emulated'],
+                     # a box with fewer devices than slabs repeats its ordinals: that is a 1-device figure, and it says so
+                     'n_gpus': head['distinct_devices'], 'slabs': ndev,
+                     'windows_ms_per_step': head['windows_ms_per_step'], 'max_device_ms_per_step': head['max_device_ms_per_step'],
+                     'host_issue_ms_per_step': head['host_issue_ms_per_step'], 'halo_MB_per_step': head['halo_MB_per_step'],
+                     'halo_exchange': 'overlapped' if head['overlapped'] else 'blocking', 'halo_path': head['peer'], 'halo_path_ok': head['halo_path_ok'],
+                     'device_bytes': head['device_bytes'], 'host_build_s': head['host_build_s']})
+        line['config'].update({'workload': line['config']['workload'] + ', %s medium, %s source, PML 12, %d materials, Pressure RMS accumulated in every step' % (head['medium'], head['tx'], head['n_mat']),
+                               'devices': head['devices'], 'slabs': head['slabs'], 'dt': head['dt'], 'ppp': head['ppp'], 'n_sources': head['n_sources'],
+                               'array_placement_slab0': head['array_placement_slab0'], 'untimed_steps_before_window': args.warmup,
+                               'placement_rule': placement_rule(args)})
+        if 'roofline_step' in head:
+            r = head['roofline_step']
+            line['roofline'] = dict(bound='hbm', kernel='whole time step, all slabs', achieved=r['achieved'], peak=r['peak'], unit='GB/s', frac=r['frac'], traffic=None,
+                                    note='algorithmic bytes of the slabs per step / wall time per step; peak = 8 TB/s x distinct devices; the per-kernel figures are in the N=1 line')
+            line['roofline_step'] = r
     line['cpu_baseline'] = {'value': None, 'note': 'timed at N=1 only'}
     try:
         line['group_check'] = group_equals_single(args, ndev, dt_fn, args.variant)
     except Exception as e:
         line['group_check'] = {'equals_single_domain': None, 'error': repr(e)}
-    if not args.no_extra_strong:
-        try:       # the weak-scaling companion: N grids of the metric's config as one 512 x 512 x (512 N) domain
-            c3 = H.CONFIGS['C3']['N']
-            line['secondary_weak_c3'] = group_run(args, 'C3', (c3[0], c3[1], c3[2] * ndev), ndev, dt_fn, args.steps, args.warmup, 1, args.variant,
-                                                  'weak scaling: one 512^3 grid of the metric config per device')
-        except Exception as e:
-            line['secondary_weak_c3'] = {'value': None, 'error': repr(e)}
+    if not args.no_strong_c5 and not args.no_extra_strong:
+        line['strong_c5'] = strong_c5(args, ndev, dt_fn, args.variant)
     print(json.dumps(line))
+
+
+def placement_rule(args):
+    return ('library default (what a PropagationModel() call gets: at most 64 GiB and half of the free memory held while searching, nothing on a shared device)'
+            if args.placement_search_gib < 0 else 'explicit bound of %g GiB (--placement-search-gib)' % args.placement_search_gib)
 
 
 def measure(w, args, traffic):
@@ -616,7 +668,8 @@ def main():
                        'n_sources': info['n_sources'], 'n_sensors_rank0': int(eng.num_sensors), 'tiles_rank0': eng.tile_counts() if args.variant != 1 else None,
                        'halo_exchange': 'overlapped' if w.runner.overlap else ('none' if world == 1 else 'blocking'),
                        'halo_exchange_check': res['exchange_check'], 'halo_exchange_vs_single_domain': sd_check,
-                       'array_placement': eng.placement_note(), 'untimed_steps_before_window': args.warmup + w.extra_warmup},
+                       'array_placement': eng.placement_note(), 'placement_rule': placement_rule(args),
+                       'untimed_steps_before_window': args.warmup + w.extra_warmup},
             'windows': res['windows'], 'device_ms_per_step': res['device_ms_per_step'], 'half_steps_ms': res['half_steps'],
             'host_issue_ms_per_step': res['host_issue_ms_per_step'],
             'device_bytes': int(eng.device_bytes), 'host_build_s': w.host_build_s,
@@ -630,7 +683,8 @@ def main():
             r = rows[dom]
             line['roofline'] = dict(bound='hbm', kernel=dom, achieved=r['achieved'], peak=HBM_PEAK_GBS, unit='GB/s', frac=r['frac'],
                                     traffic=r['traffic_from_profile'], traffic_from_profile=r['traffic_from_profile'], profile_ref=r.get('profile_ref'),
-                                    algorithmic_bytes_per_launch=r['algorithmic_bytes_per_launch'], avg_launch_ms=r['avg_launch_ms'], note=note)
+                                    algorithmic_bytes_per_launch=r['algorithmic_bytes_per_launch'], avg_launch_ms=r['avg_launch_ms'],
+                                    profile_stale=r.get('profile_stale'), note=note)
             line['roofline_kernels'] = rows
         elif 'roofline_step' in res:
             s = res['roofline_step']
@@ -656,14 +710,14 @@ def main():
             wx.connect()
             sx = measure(wx, argparse.Namespace(**dict(vars(args), no_kernel_pass=True, windows=1)), {})
             if rank == 0:
-                line['extra_strong_c5'] = {'workload': 'C5 1024^3 (1 MHz, water / cortical bone with shear / brain), ONE volume split into %d Z-slabs of %d planes' % (world, wx.sinfo['nk']),
+                line['strong_c5'] = {'workload': 'C5 1024^3 (1 MHz, water / cortical bone with shear / brain), ONE volume split into %d Z-slabs of %d planes, one rank per GPU (RCCL halo exchange)' % (world, wx.sinfo['nk']),
                                            'scaling': 'strong', 'value': sx['value'], 'unit': 'Mvoxel-steps/s', 'steps': wx.steps, 'warmup': wx.warmup + wx.extra_warmup,
                                            'ms_per_step': sx['ms_per_step'], 'device_ms_per_step': sx['device_ms_per_step'],
                                            'host_issue_ms_per_step': sx['host_issue_ms_per_step'], 'halo_exchange': 'overlapped' if wx.runner.overlap else 'blocking',
                                            'halo_exchange_check': sx['exchange_check'], 'halo_bytes_sent_rank0_per_step': wx.runner.bytes_per_step(),
                                            'roofline_step': sx.get('roofline_step'), 'array_placement': wx.eng.placement_note()}
         elif rank == 0:
-            line['extra_strong_c5'] = {'value': None, 'error': err or 'another rank failed to build its slab'}
+            line['strong_c5'] = {'value': None, 'error': err or 'another rank failed to build its slab'}
         if wx is not None:
             wx.close()
     if world > 1 and not args.no_group:
@@ -673,20 +727,52 @@ def main():
         # beside the child's measurement
         cpu_group = None
         try:
-            os.environ.setdefault('GLOO_SOCKET_IFNAME', 'lo')
+            if os.environ.get('LOCAL_WORLD_SIZE', str(world)) == str(world):      # one node: the loopback interface always resolves
+                os.environ.setdefault('GLOO_SOCKET_IFNAME', 'lo')
             cpu_group = dist.new_group(backend='gloo') if dist.get_backend() != 'gloo' else dist.group.WORLD
         except Exception:
             cpu_group = None
+        # every rank or none: a rank without the group would skip the barrier the others wait in
+        have_cpu_group = all_ok(dist, cpu_group is not None)
         dist.barrier()
         torch.cuda.synchronize()
-        if rank == 0:
+        if rank == 0 and have_cpu_group:
             try:
                 line['group_strong_c3'] = group_in_child(args, 'C3', H.CONFIGS['C3']['N'], world, args.steps, min(args.warmup, 20), timeout=420)
                 line['group_strong_c3']['label'] = 'strong scaling of the metric config through the drop-in path: a child process of rank 0 drives all devices'
             except Exception as e:
                 line['group_strong_c3'] = {'value': None, 'error': repr(e)}
-        if cpu_group is not None:
+            if (line.get('strong_c5') or {}).get('value') and not args.no_strong_c5:
+                try:        # the anchor of the 1024^3 curve: the same volume on ONE device, from a child process as well
+                    an = group_in_child(args, 'C5', H.CONFIGS['C5']['N'], 1, max(args.strong_c5_steps, 10), min(args.warmup, 8), timeout=600)
+                    line['strong_c5']['one_device_same_volume'] = {k: an.get(k) for k in ('value', 'ms_per_step', 'error') if k in an}
+                    if an.get('value'):
+                        line['strong_c5']['scaling_efficiency'] = line['strong_c5']['value'] / (world * an['value'])
+                        line['strong_c5']['scaling_efficiency_note'] = 'value / (N x one_device_same_volume.value), both timed in this run'
+                except Exception as e:
+                    line['strong_c5']['one_device_same_volume'] = {'value': None, 'error': repr(e)}
+        elif rank == 0:
+            line['group_strong_c3'] = {'value': None, 'error': 'no CPU-side (gloo) group on every rank: the child would be measured beside ranks spinning in an RCCL barrier'}
+        if have_cpu_group:
             dist.barrier(group=cpu_group)
+    if world == 1 and not args.no_wide_placement and args.placement_search_gib < 0 and args.config == 'C3' and not args.size:
+        # the same workload, same engine, with the wide search bound the bench used as its default until round 4: what the library's
+        # bound costs on THIS box (on most boxes nothing: exchanging the buffers suffices)
+        try:
+            wargs = argparse.Namespace(**dict(vars(args), placement_search_gib=args.wide_placement_gib, windows=1))
+            ww = Workload(wargs, args.config, dims, args.scaling, 0, 1, local_rank, None, dt_fn, args.steps, args.warmup, args.variant)
+            wall, _ = ww.timed()
+            line['wide_placement_search'] = {'search_gib': args.wide_placement_gib, 'value': ww.total_vox * ww.steps / wall / 1e6, 'unit': 'Mvoxel-steps/s',
+                                             'ms_per_step': wall / ww.steps * 1e3, 'array_placement': ww.eng.placement_note(),
+                                             'note': 'one window; `value` of the line is measured under the library default rule (config.placement_rule)'}
+            ww.close()
+        except Exception as e:
+            line['wide_placement_search'] = {'value': None, 'error': repr(e)}
+    if world == 1 and not args.no_strong_c5 and not args.no_group and args.config == 'C3' and not args.size:
+        try:       # the first point of the 1024^3 strong-scaling curve, in the line the driver records at N = 1
+            line['strong_c5'] = strong_c5(args, 1, dt_fn, args.variant)
+        except Exception as e:
+            line['strong_c5'] = {'value': None, 'error': repr(e)}
     if world == 1 and not args.no_group and args.config == 'C3' and not args.size:
         try:       # the same workload through the one-process group path with one slab: SCALE N=1 on both paths
             line['group_one_slab'] = group_run(args, 'C3', dims, 1, dt_fn, args.steps, args.warmup, 1, args.variant, 'one slab through bfd_group_*')

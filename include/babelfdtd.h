@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define BFD_ABI_VERSION 5
+#define BFD_ABI_VERSION 6
 
 enum {
     BFD_MAP_VX = 0, BFD_MAP_VY = 1, BFD_MAP_VZ = 2,
@@ -166,6 +166,12 @@ const char *bfd_placement_note(bfd_sim *sim);
  * device carries other allocations than this engine's (another process, the other slabs of a group): the engine's own buffers
  * are then only exchanged among themselves. bfd_prepare never fails for lack of memory where mode 0 succeeds. */
 int bfd_set_placement(bfd_sim *sim, int32_t mode, int64_t searchLimitBytes);
+/* The default rule can be moved without code by whoever owns the device: BABELFDTD_PLACEMENT_SEARCH_GIB=<GiB> replaces the 64 GiB of the
+ * default rule (the shared-device rule stays). Buffers a search found in another region are kept when their engine is destroyed and
+ * offered to the next engine of this process with arrays of the same size on the same device, so that the two or three solver calls of
+ * one RUN_SIMULATION (BabelIntegrationBASE.py:2338, 2374, 2401) pay the search once; at most BABELFDTD_PLACEMENT_CACHE_GIB (default
+ * 48, 0 = keep nothing) are held between calls. bfd_placement_cache_release frees them now and returns the bytes freed. */
+int64_t bfd_placement_cache_release(void);
 
 /* device pointer/bytes of a halo region: field f (0..2 within the group), side 0 = low-k face,
  * 1 = high-k face; send = 1: the 2 owned boundary planes, send = 0: the 2 ghost planes.
@@ -263,6 +269,16 @@ int bfd_group_reset(bfd_group *g);
 int bfd_group_timing_begin(bfd_group *g);
 int bfd_group_timing_end(bfd_group *g, double *wallMs, double *maxDeviceMs, double *hostIssueMs, double *haloBytesPerStep,
                          int32_t *overlapped);
+/* How the halo planes travel across each interface (slab r | slab r+1), decided in bfd_group_create -- the reference has no counterpart
+ * (one device per call, BabelIntegrationBASE.py:2358); here a silently missing peer path (IOMMU, HIP_VISIBLE_DEVICES, topology) would
+ * only show as a bad scaling curve. status[r] & 15 = BFD_PEER_SAME_DEVICE (both slabs on one device: a device copy), BFD_PEER_DIRECT
+ * (peer access enabled both ways: hipMemcpyPeerAsync moves the planes device to device) or BFD_PEER_STAGED (not available in at least
+ * one direction: the runtime stages the copies through the host). Detail bits: 16 / 32 = can access / enabled from slab r's device to
+ * slab r+1's, 64 / 128 = the other way. Returns the number of interfaces (nSlabs - 1); status needs room for that many. */
+#define BFD_PEER_SAME_DEVICE 0
+#define BFD_PEER_DIRECT 1
+#define BFD_PEER_STAGED 2
+int bfd_group_peer_status(bfd_group *g, int32_t *status, int32_t n);
 /* results over the whole domain: sensors of all slabs in ascending GLOBAL index (BASE:2369, 2503), volumes into a
  * strided (N1,N2,N3) view */
 int64_t bfd_group_num_sensors(bfd_group *g);

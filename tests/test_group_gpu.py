@@ -130,3 +130,15 @@ def test_group_over_distinct_devices():
     out = PropagationModel(devices=devs).StaggeredFDTD_3D_with_relaxation(*a, SILENT=True, **k)
     _same(out, ref)
     assert ref[2]['Pressure'][:, :, out[-1]['slabs'][-1][0]:].max() > 0
+    # every interface must have gone device to device: a missing peer path (staged through the host) fails nothing but the curve
+    peer = out[-1]['timing']['peer']
+    assert len(peer) == len(devs) - 1 and all(p['direct'] and all(p['can_access']) and all(p['enabled']) for p in peer), peer
+
+
+def test_group_reports_how_halo_planes_travel():
+    """bfd_group_peer_status through the drop-in call: slabs that share a device report a device copy on every interface."""
+    a, k, info = _problem('C2', (64, 56, 128), 40)
+    out = PropagationModel(devices=[0, 0, 0]).StaggeredFDTD_3D_with_relaxation(*a, SILENT=True, **k)
+    peer = out[-1]['timing']['peer']
+    assert [p['interface'] for p in peer] == [0, 1] and all(p['path'].startswith('same device') and p['direct'] for p in peer), peer
+    assert all(p['devices'] == [0, 0] for p in peer)

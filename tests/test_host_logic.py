@@ -172,3 +172,17 @@ def test_benchmark_test_file_hook(tmp_path):
     assert k2['DT'] == k['DT'] and np.array_equal(k2['QCorrection'], k['QCorrection'])
     with pytest.raises(ValueError):
         H.save_benchmark_medium(path, np.zeros((4, 4, 4), np.uint32), a[1])      # a material that never occurs in the map
+
+
+def test_peer_status_words_decode():
+    """bfd_group_peer_status packs, per interface, the path (low 4 bits: 0 same device, 1 direct, 2 staged through the host) and
+    can-access / enabled bits for each direction; the decoder must flag a staged interface and keep the order of the interfaces."""
+    from babelbrain_amd._engine import decode_peer_status
+    words = [0, 1 | 16 | 32 | 64 | 128, 2 | 16 | 32, 2]
+    d = decode_peer_status(words, devices=[0, 0, 1, 2, 3])
+    assert [e['interface'] for e in d] == [0, 1, 2, 3]
+    assert d[0]['path'].startswith('same device') and d[0]['direct'] and d[0]['devices'] == [0, 0]
+    assert d[1]['direct'] and d[1]['can_access'] == [True, True] and d[1]['enabled'] == [True, True] and d[1]['devices'] == [0, 1]
+    assert not d[2]['direct'] and d[2]['path'].startswith('STAGED') and d[2]['can_access'] == [True, False] and d[2]['enabled'] == [True, False]
+    assert not d[3]['direct'] and d[3]['can_access'] == [False, False]
+    assert decode_peer_status([]) == []
