@@ -668,14 +668,13 @@ __device__ __forceinline__ void velocity_fluid_body(const bfd_dev &d, int bx, in
 
     // own material id runs two planes ahead because the z face needs 1/rho of plane kl+1; neighbour ids
     // one plane ahead; table rows at the top of the iteration
-    float sm1 = 0, s0 = 0, sp1 = 0, sp2 = 0, vx = 0, vy = 0, vz = 0, av = 0, pv = 0, r0 = ru;
+    float sm1 = 0, s0 = 0, sp1 = 0, sp2 = 0, vx = 0, vy = 0, vz = 0, av = 0, r0 = ru;
     unsigned mraw = 0, mraw1 = 0, mx = 0, my = 0;
     if (valid) {
         const float *bS = d.Szz + kbeg * pl;
         sm1 = F4((bS - pl), cij * 4u); s0 = F4(bS, cij * 4u); sp1 = F4((bS + pl), cij * 4u); sp2 = F4((bS + 2 * pl), cij * 4u);
         vx = LD4((d.Vx + kbeg * pl), cij * 4u); vy = LD4((d.Vy + kbeg * pl), cij * 4u); vz = LD4((d.Vz + kbeg * pl), cij * 4u);
         if (accA) av = LD4((accP + kbeg * pl), cij * 4u);
-        if (accK) pv = F4((pkP + kbeg * pl), cij * 4u);
         if (!UNI) {
             const uint16_t *bM = d.mat + kbeg * pl;
             mraw = U2(bM, cij * 2u); mraw1 = U2((bM + pl), cij * 2u); mx = U2(bM, cx * 2u); my = U2(bM, cy * 2u);
@@ -698,7 +697,7 @@ __device__ __forceinline__ void velocity_fluid_body(const bfd_dev &d, int bx, in
         }
         __syncthreads();
 
-        float ns = 0, nh = 0, nvx = 0, nvy = 0, nvz = 0, nav = 0, npv = 0, npx = 0, npy = 0, npz = 0;
+        float ns = 0, nh = 0, nvx = 0, nvy = 0, nvz = 0, nav = 0, npx = 0, npy = 0, npz = 0;
         unsigned nm2 = 0, nmx = 0, nmy = 0;
         if (!UNI && valid) nm2 = U2((d.mat + ko + 2 * pl), cij * 2u);     // ghost planes make kl+2 addressable
         if (kl + 1 < kend) {
@@ -707,7 +706,6 @@ __device__ __forceinline__ void velocity_fluid_body(const bfd_dev &d, int bx, in
                 nvx = LD4((d.Vx + ko + pl), cij * 4u); nvy = LD4((d.Vy + ko + pl), cij * 4u); nvz = LD4((d.Vz + ko + pl), cij * 4u);
                 if (!UNI) { nmx = U2((d.mat + ko + pl), cx * 2u); nmy = U2((d.mat + ko + pl), cy * 2u); }
                 if (accA) nav = LD4((accP + ko + pl), cij * 4u);
-                if (accK) npv = F4((pkP + ko + pl), cij * 4u);
             }
             if (t.ok) nh = F4(ph + ko + pl, hofs);
             if (PML) {
@@ -723,7 +721,8 @@ __device__ __forceinline__ void velocity_fluid_body(const bfd_dev &d, int bx, in
                     const float s = (s0 + s0) + s0;
                     const float p = -s * (1.0f / 3.0f);
                     if (accA) ST4((accP + ko), cij * 4u, av + p * p);
-                    if (accK) { const float ap = fabsf(p); if (ap > pv) F4((pkP + ko), cij * 4u) = ap; }
+                    // the running peak is read here, not a plane ahead: one live register fewer (the accumulating flavour spilled one at 8 waves)
+                    if (accK) { const float ap = fabsf(p); if (ap > F4((pkP + ko), cij * 4u)) F4((pkP + ko), cij * 4u) = ap; }
                 }
             }
             if (!UNI && (mraw & BFD_REFLECTOR_BIT)) {
@@ -748,7 +747,7 @@ __device__ __forceinline__ void velocity_fluid_body(const bfd_dev &d, int bx, in
             }
         }
         sm1 = s0; s0 = sp1; sp1 = sp2; sp2 = ns;
-        hv = nh; vx = nvx; vy = nvy; vz = nvz; av = nav; pv = npv;
+        hv = nh; vx = nvx; vy = nvy; vz = nvz; av = nav;
         r0 = r1; mraw = mraw1; mraw1 = nm2; mx = nmx; my = nmy;
         px = npx; py = npy; pz = npz; qx += dqx; qy += dqy;
     }
