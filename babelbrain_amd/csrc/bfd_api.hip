@@ -217,6 +217,12 @@ __global__ void expand_normal(bfd_dev d, long n)
         d.Sxx[v] = s; d.Syy[v] = s; d.Rxx[v] = r; d.Ryy[v] = r;
     }
 }
+// output assembly (bfd_get_field, compact solid state): out = src at the cells that keep one copy of their normal stresses
+__global__ void copy_at_fluid_cells(bfd_dev d, const float *__restrict__ src, float *__restrict__ out, long n)
+{
+    for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (long)gridDim.x * blockDim.x)
+        if (normal_collapsed(d, v)) out[v] = src[v];
+}
 __device__ __forceinline__ float map_sq(const bfd_dev &d, int sel, long c)
 {
     if (sel == BFD_MAP_ALLV) {
@@ -343,12 +349,12 @@ __global__ void inject_sources(bfd_dev d, int typeSource, const uint32_t *__rest
         if (typeSource >= 2) {
             const float v = val * x;
             float *pxx = d.Sxx + c, *pyy = d.Syy + c;
-            if (d.cssRow) {         // compact solid state: a listed cell's Sxx, Syy live in the list; elsewhere nobody reads them (fluid cells keep Szz only)
-                const long e = css_index(d, c);
-                if (e >= 0) { pxx = d.cSxx + e; pyy = d.cSyy + e; }
+            if (d.cssRow) {         // compact solid state: a listed cell's Sxx, Syy live in the list; elsewhere nobody reads them (fluid cells keep Szz only) and
+                const long e = css_index(d, c);      // the full-volume arrays are not to be written: they may host the compact ones
+                pxx = e >= 0 ? d.cSxx + e : nullptr; pyy = e >= 0 ? d.cSyy + e : nullptr;
             }
-            if (typeSource == 2) { *pxx = *pxx + v; *pyy = *pyy + v; d.Szz[c] = d.Szz[c] + v; }
-            else { *pxx = v; *pyy = v; d.Szz[c] = v; }
+            if (typeSource == 2) { if (pxx) { *pxx = *pxx + v; *pyy = *pyy + v; } d.Szz[c] = d.Szz[c] + v; }
+            else { if (pxx) { *pxx = v; *pyy = v; } d.Szz[c] = v; }
         } else {
             const float y = wy ? wy[s] : 1.0f, z = wz ? wz[s] : 1.0f;
             if (typeSource == 0) { d.Vx[c] = d.Vx[c] + val * x; d.Vy[c] = d.Vy[c] + val * y; d.Vz[c] = d.Vz[c] + val * z; }
@@ -372,12 +378,12 @@ __global__ void inject_sources_at(bfd_dev d, int typeSource, const uint32_t *__r
         if (typeSource >= 2) {
             const float v = val * x;
             float *pxx = d.Sxx + c, *pyy = d.Syy + c;
-            if (d.cssRow) {         // compact solid state: a listed cell's Sxx, Syy live in the list; elsewhere nobody reads them (fluid cells keep Szz only)
-                const long e = css_index(d, c);
-                if (e >= 0) { pxx = d.cSxx + e; pyy = d.cSyy + e; }
+            if (d.cssRow) {         // compact solid state: a listed cell's Sxx, Syy live in the list; elsewhere nobody reads them (fluid cells keep Szz only) and
+                const long e = css_index(d, c);      // the full-volume arrays are not to be written: they may host the compact ones
+                pxx = e >= 0 ? d.cSxx + e : nullptr; pyy = e >= 0 ? d.cSyy + e : nullptr;
             }
-            if (typeSource == 2) { *pxx = *pxx + v; *pyy = *pyy + v; d.Szz[c] = d.Szz[c] + v; }
-            else { *pxx = v; *pyy = v; d.Szz[c] = v; }
+            if (typeSource == 2) { if (pxx) { *pxx = *pxx + v; *pyy = *pyy + v; } d.Szz[c] = d.Szz[c] + v; }
+            else { if (pxx) { *pxx = v; *pyy = v; } d.Szz[c] = v; }
         } else {
             const float y = wy ? wy[s] : 1.0f, z = wz ? wz[s] : 1.0f;
             if (typeSource == 0) { d.Vx[c] = d.Vx[c] + val * x; d.Vy[c] = d.Vy[c] + val * y; d.Vz[c] = d.Vz[c] + val * z; }
@@ -980,6 +986,17 @@ int bfd_set_sensor_map(bfd_sim *s, const uint32_t *map, int64_t s1, int64_t s2, 
 #ifndef BFD_SOLID_MERGED_DEFAULT
 #define BFD_SOLID_MERGED_DEFAULT 0
 #endif
+// where the ten compact arrays live (bfd_tiles::cssHosted); called when the list is built and again whenever the state buffers change hands
+// (choose_placement exchanges them at step 0, when everything is still zero)
+static void bind_compact_views(bfd_sim *s)
+{
+    bfd_dev &d = s->d;
+    if (!d.cssRow) return;
+    float **cp[10] = {&d.cSxx, &d.cSyy, &d.cSxy, &d.cSxz, &d.cSyz, &d.cRxx, &d.cRyy, &d.cRxy, &d.cRxz, &d.cRyz};
+    static const int host[10] = {3, 4, 6, 7, 8, 9, 10, 12, 13, 14};      // Sxx Syy Sxy Sxz Syz Rxx Ryy Rxy Rxz Ryz among the 15 state arrays
+    for (int a = 0; a < 10; a++)
+        *cp[a] = s->tiles.cssHosted ? s->stateBase[host[a]] + 3 * (size_t)d.plane : s->tiles.css + (size_t)a * s->tiles.cssCap;
+}
 static int build_tile_lists(bfd_sim *s)
 {
     int tx, ty, nsub; bfd_tile_grid(s->d, &tx, &ty, &nsub);
@@ -989,11 +1006,19 @@ static int build_tile_lists(bfd_sim *s)
     const bool carryShearMemory = s->step > 0 && s->tilesReady == false && s->tiles.shearR && s->tiles.nShear > 0;
     const bool hadList = s->tiles.shearCells != nullptr, hadListR = s->tiles.shearR != nullptr, wasMerged = s->tiles.merged;
     if (carryShearMemory) { bfd_launch_scatter_shear_memory(s->d, s->stream, &s->tiles); BFD_HIP(hipStreamSynchronize(s->stream)); }
-    // the same for a compact solid state: back into the full-volume arrays, from which the new list is filled again
+    // the same for a compact solid state: its ten arrays are set aside with their list (the full-volume buffers may host the compact arrays
+    // themselves) and re-entered into the new list through one full-volume temporary, array by array, once that list exists
     const bool carryCompact = s->step > 0 && s->d.cssRow && s->tiles.nShear > 0;
-    if (carryCompact) { bfd_launch_css_copy(s->d, s->stream, &s->tiles, 0x7Fu, true); BFD_HIP(hipStreamSynchronize(s->stream)); }
-    s->d.cssRow = nullptr; s->d.cSxx = s->d.cSyy = s->d.cSxy = s->d.cSxz = s->d.cSyz = s->d.cRxx = s->d.cRyy = nullptr;
-    dev_release(s, &s->tiles.cssRow); dev_release(s, &s->tiles.css); s->tiles.cssCap = 0;
+    unsigned *oldCells = nullptr; float *oldComp = nullptr; const long oldN = s->tiles.nShear;
+    if (carryCompact) {
+        float *src[10] = {s->d.cSxx, s->d.cSyy, s->d.cSxy, s->d.cSxz, s->d.cSyz, s->d.cRxx, s->d.cRyy, s->d.cRxy, s->d.cRxz, s->d.cRyz};
+        BFD_HIP(hipMalloc((void **)&oldComp, 10 * (size_t)oldN * sizeof(float)));
+        for (int a = 0; a < 10; a++) BFD_HIP(hipMemcpyAsync(oldComp + (size_t)a * oldN, src[a], (size_t)oldN * sizeof(float), hipMemcpyDeviceToDevice, s->stream));
+        BFD_HIP(hipStreamSynchronize(s->stream));
+        oldCells = s->tiles.shearCells; s->tiles.shearCells = nullptr;       // released below, after the new list has taken the values over
+    }
+    s->d.cssRow = nullptr; s->d.cSxx = s->d.cSyy = s->d.cSxy = s->d.cSxz = s->d.cSyz = s->d.cRxx = s->d.cRyy = s->d.cRxy = s->d.cRxz = s->d.cRyz = nullptr;
+    dev_release(s, &s->tiles.cssRow); dev_release(s, &s->tiles.css); s->tiles.cssCap = 0; s->tiles.cssHosted = false;
     dev_release(s, &s->tiles.runsAll); s->tiles.nAll = s->tiles.nAllB = 0;
     dev_release(s, &s->tiles.runs); dev_release(s, &s->tiles.xmap); dev_release(s, &s->tiles.shearCells); dev_release(s, &s->tiles.shearCoef); dev_release(s, &s->tiles.shearR);    // lists of an earlier build
     dev_release(s, &s->tiles.shearCodes); dev_release(s, &s->tiles.shearTab);
@@ -1301,10 +1326,16 @@ static int build_tile_lists(bfd_sim *s)
             if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
             if (k0) hipFree(k0); if (k1) hipFree(k1); if (v1) hipFree(v1); if (w2) hipFree(w2);
         }
+        // Compact solid state (bfd_dev::cssRow): Sxx, Syy, the shear stresses and the five memory variables Rxx, Ryy, Rxy, Rxz, Ryz of the listed cells in
+        // list order. Needs the row-contiguous list order (mode 2) and the two-kernel form. In a Z-slab the ghost planes of Sxz / Syz stay in the
+        // full-volume arrays (the sparse kernel keeps full-volume copies of the planes a neighbour reads, the velocity kernel takes ghost planes from
+        // there): the halo exchange is unchanged. BFD_COMPACT_SOLID=0 keeps the full-volume arrays.
+        bool compact = count > 0 && orderMode == 2 && !T.merged && s->d.N1 <= 4095 && bfd_css_supported();
+        if (const char *ev = getenv("BFD_COMPACT_SOLID")) compact = compact && atoi(ev) != 0;
         if (e == hipSuccess) {
             rc = dev_alloc(s, &s->tiles.shearCells, (size_t)std::max(count, 1), false);
             if (!rc) rc = dev_alloc(s, &s->tiles.shearCoef, 6 * (size_t)std::max(count, 1), false);
-            if (!rc && !T.merged) rc = dev_alloc(s, &s->tiles.shearR, 3 * (size_t)std::max(count, 1), true);      // lists are built at step 0: the memory variables start at zero (merged form: they live in the full-volume arrays)
+            if (!rc && !T.merged && !compact) rc = dev_alloc(s, &s->tiles.shearR, 3 * (size_t)std::max(count, 1), true);      // lists are built at step 0: the memory variables start at zero (merged form: they live in the full-volume arrays; compact form: with the other compact arrays)
             if (!rc && count) e = hipMemcpyAsync(s->tiles.shearCells, sel, (size_t)count * sizeof(unsigned), hipMemcpyDeviceToDevice, s->stream);
             if (!rc) rc = dev_alloc(s, &s->tiles.shearCodes, (size_t)std::max(count, 1), false);
             if (!rc) rc = dev_alloc(s, &s->tiles.shearTab, 2 * (size_t)s->cfg.nMat, false);
@@ -1316,24 +1347,19 @@ static int build_tile_lists(bfd_sim *s)
         if (rc) return rc;
         s->tiles.nShear = count;
         if (s->step > 0 && s->tiles.shearR) { bfd_launch_gather_shear_memory(s->d, s->stream, &s->tiles); BFD_HIP(hipStreamSynchronize(s->stream)); }
-        // Compact solid state (bfd_dev::cssRow): Sxx, Syy, the shear stresses, Rxx, Ryy of the listed cells in list order. Needs the row-contiguous
-        // list order (mode 2) and the two-kernel form. In a Z-slab the ghost planes of Sxz / Syz stay in the full-volume arrays (the sparse kernel
-        // keeps full-volume copies of the planes a neighbour reads, the velocity kernel takes ghost planes from there): the halo exchange is
-        // unchanged. BFD_COMPACT_SOLID=0 keeps the full-volume arrays.
-        bool compact = count > 0 && orderMode == 2 && !T.merged && s->d.N1 <= 4095 && bfd_css_supported();
-        if (const char *ev = getenv("BFD_COMPACT_SOLID")) compact = compact && atoi(ev) != 0;
         if (compact) {
             const int stride = tx + 1;
             rc = dev_alloc(s, &s->tiles.cssRow, (size_t)(s->d.nk + 4) * s->d.N2 * stride, false);
-            if (!rc) rc = dev_alloc(s, &s->tiles.css, 7 * (size_t)count, true);
+            // the compact arrays live inside the full-volume buffers of their fields when the listed cells fit between the planes a Z-neighbour
+            // exchanges (allocation planes 3 .. nk); BFD_COMPACT_HOSTED=0 or too many solid cells: one block of their own
+            bool hosted = (size_t)count <= (size_t)std::max(s->d.nk - 3, 0) * s->d.plane;
+            if (const char *ev = getenv("BFD_COMPACT_HOSTED")) hosted = hosted && atoi(ev) != 0;
+            if (!rc && !hosted) rc = dev_alloc(s, &s->tiles.css, 10 * (size_t)count, true);
             if (rc) return rc;
-            s->tiles.cssCap = count;
+            s->tiles.cssCap = count; s->tiles.cssHosted = hosted;
             bfd_launch_css_row_table(s->d, s->stream, s->tiles.shearCells, count, s->tiles.cssRow, stride, lowPlanes, hiStart);
-            float *c = s->tiles.css;
             s->d.cssRow = s->tiles.cssRow; s->d.cssStride = stride;
-            s->d.cSxx = c; s->d.cSyy = c + (size_t)count; s->d.cSxy = c + 2 * (size_t)count; s->d.cSxz = c + 3 * (size_t)count; s->d.cSyz = c + 4 * (size_t)count;
-            s->d.cRxx = c + 5 * (size_t)count; s->d.cRyy = c + 6 * (size_t)count;
-            if (s->step > 0) bfd_launch_css_copy(s->d, s->stream, &s->tiles, 0x7Fu, false);
+            bind_compact_views(s);
             BFD_HIP(hipStreamSynchronize(s->stream));
             std::vector<int4> ra(listsAll[0]);
             ra.insert(ra.end(), listsAll[1].begin(), listsAll[1].end());
@@ -1341,6 +1367,24 @@ static int build_tile_lists(bfd_sim *s)
             if (rc) return rc;
             BFD_HIP(hipMemcpy(s->tiles.runsAll, ra.data(), ra.size() * sizeof(int4), hipMemcpyHostToDevice));
             s->tiles.nAllB = (int)listsAll[0].size(); s->tiles.nAll = (int)ra.size();
+        }
+        if (carryCompact) {       // the values of the old list into the new one (or, should the new state not be compact, into the full-volume arrays)
+            float *tmp = nullptr;
+            const size_t g = 2 * (size_t)s->d.plane;
+            float *newComp[10] = {s->d.cSxx, s->d.cSyy, s->d.cSxy, s->d.cSxz, s->d.cSyz, s->d.cRxx, s->d.cRyy, s->d.cRxy, s->d.cRxz, s->d.cRyz};
+            float *full[10] = {s->d.Sxx, s->d.Syy, s->d.Sxy, s->d.Sxz, s->d.Syz, s->d.Rxx, s->d.Ryy, s->d.Rxy, s->d.Rxz, s->d.Ryz};
+            hipError_t e2 = s->d.cssRow ? hipMalloc((void **)&tmp, s->nalloc * sizeof(float)) : hipSuccess;
+            for (int a = 0; a < 10 && e2 == hipSuccess; a++) {
+                if (s->d.cssRow) {
+                    e2 = hipMemsetAsync(tmp, 0, s->nalloc * sizeof(float), s->stream);
+                    bfd_launch_css_scatter(s->stream, oldCells, oldN, oldComp + (size_t)a * oldN, tmp + g);
+                    bfd_launch_css_gather(s->stream, s->tiles.shearCells, count, tmp + g, newComp[a]);
+                } else bfd_launch_css_scatter(s->stream, oldCells, oldN, oldComp + (size_t)a * oldN, full[a]);
+            }
+            if (e2 == hipSuccess) e2 = hipStreamSynchronize(s->stream);
+            if (tmp) hipFree(tmp);
+            if (e2 != hipSuccess) BFD_FAIL(-10, std::string("compact solid state, list rebuilt in the middle of a run: ") + hipGetErrorString(e2));
+            if (!s->d.cssRow && s->tiles.shearR) { bfd_launch_gather_shear_memory(s->d, s->stream, &s->tiles); BFD_HIP(hipStreamSynchronize(s->stream)); }
         }
         s->tiles.shearLowEnd = std::lower_bound(hostCells.begin(), hostCells.end(), (unsigned)lowPlanes * (unsigned)s->d.plane) - hostCells.begin();
         s->tiles.shearHighBeg = std::lower_bound(hostCells.begin(), hostCells.end(), (unsigned)hiStart * (unsigned)s->d.plane) - hostCells.begin();
@@ -1422,6 +1466,8 @@ static int build_tile_lists(bfd_sim *s)
         }
         if (T.merged && T.nSolid && s->cfg.kernelVariant != 2) for (int a = 0; a < 2; a++) B[a][BFD_K_STRESS_SOLID] += 16.0 * (double)cnt[4];   // S and R of every active edge, read and written
     }
+    if (oldCells) dev_release(s, &oldCells);
+    if (oldComp) hipFree(oldComp);
     s->tilesReady = true;
     return 0;
 }
@@ -1764,7 +1810,13 @@ static int check_ready(bfd_sim *s)
         const int rc = build_tile_lists(s);
         if (rc) return rc;
     }
-    if (!s->placementDone) { s->placementDone = true; return choose_placement(s); }
+    if (!s->placementDone) {
+        s->placementDone = true;
+        const int rc = choose_placement(s);
+        if (rc) return rc;
+        bind_compact_views(s);        // the state buffers may have changed hands
+        return 0;
+    }
     return 0;
 }
 
@@ -2112,7 +2164,7 @@ int bfd_reset(bfd_sim *s)
         if (n) BFD_HIP(hipMemsetAsync(d.psi[a], 0, n * sizeof(float), s->stream));
     }
     if (s->tiles.shearR && s->tiles.nShear) BFD_HIP(hipMemsetAsync(s->tiles.shearR, 0, 3 * (size_t)s->tiles.nShear * sizeof(float), s->stream));
-    if (s->tiles.css && s->tiles.cssCap) BFD_HIP(hipMemsetAsync(s->tiles.css, 0, 7 * (size_t)s->tiles.cssCap * sizeof(float), s->stream));
+    if (s->tiles.css && s->tiles.cssCap) BFD_HIP(hipMemsetAsync(s->tiles.css, 0, 10 * (size_t)s->tiles.cssCap * sizeof(float), s->stream));      // hosted compact arrays were zeroed with their buffers
     if (s->acc) BFD_HIP(hipMemsetAsync(s->acc, 0, (size_t)s->nSelR * s->nloc * sizeof(float), s->stream));
     if (s->pk) BFD_HIP(hipMemsetAsync(s->pk, 0, (size_t)s->nSelR * s->nloc * sizeof(float), s->stream));
     if (s->sensOut) BFD_HIP(hipMemsetAsync(s->sensOut, 0, (size_t)s->nSelS * s->nTs * (size_t)s->nSensors * sizeof(float), s->stream));
@@ -2217,6 +2269,7 @@ int bfd_get_map(bfd_sim *s, int32_t kind, int32_t map, float *out, int64_t s1, i
 
 static void expand_if_collapsed(bfd_sim *s)
 {
+    if (s->d.cssRow) return;        // compact solid state: Sxx, Syy, Rxx, Ryy full-volume are not output scratch (they may host the compact arrays); bfd_get_field builds its outputs in a temporary
     if (s->classesReady)
         hipLaunchKernelGGL(expand_normal, dim3(grid_for((long)s->nloc)), dim3(256), 0, s->stream, s->d, (long)s->nloc);
 }
@@ -2226,12 +2279,24 @@ int bfd_get_field(bfd_sim *s, int32_t a, float *out, int64_t s1, int64_t s2, int
     if (!s || !out || a < 0 || a > 14) BFD_FAIL(-1, "bfd_get_field: bad argument");
     BFD_HIP(hipSetDevice(s->cfg.device));
     expand_if_collapsed(s);
-    if (a >= 12 && s->tilesReady && s->cfg.kernelVariant != 1) bfd_launch_scatter_shear_memory(s->d, s->stream, &s->tiles);   // Rxy, Rxz, Ryz live beside the sparse list
-    {   // so do Sxx, Syy, Sxy, Sxz, Syz, Rxx, Ryy of the listed cells when the solid state is compact: into the full-volume array asked for
-        static const int cssOf[15] = {-1, -1, -1, 0, 1, -1, 2, 3, 4, 5, 6, -1, -1, -1, -1};
-        if (cssOf[a] >= 0 && s->tilesReady) bfd_launch_css_copy(s->d, s->stream, &s->tiles, 1u << cssOf[a], true);
-    }
     const bfd_dev &d = s->d;
+    static const int cssOf[15] = {-1, -1, -1, 0, 1, -1, 2, 3, 4, 5, 6, -1, 7, 8, 9};
+    if (d.cssRow && s->tilesReady && cssOf[a] >= 0) {
+        // compact solid state: the field is assembled in a temporary -- zeros, the Szz / Rzz copy at the fluid cells (Sxx, Syy, Rxx, Ryy), the compact
+        // values at the listed cells
+        const float *comp[10] = {d.cSxx, d.cSyy, d.cSxy, d.cSxz, d.cSyz, d.cRxx, d.cRyy, d.cRxy, d.cRxz, d.cRyz};
+        float *tmp = nullptr;
+        BFD_HIP(hipMalloc((void **)&tmp, s->nloc * sizeof(float)));
+        hipError_t e = hipMemsetAsync(tmp, 0, s->nloc * sizeof(float), s->stream);
+        if (e == hipSuccess && (a == 3 || a == 4 || a == 9 || a == 10))
+            hipLaunchKernelGGL(copy_at_fluid_cells, dim3(grid_for((long)s->nloc)), dim3(256), 0, s->stream, d, a >= 9 ? (const float *)d.Rzz : (const float *)d.Szz, tmp, (long)s->nloc);
+        bfd_launch_css_scatter(s->stream, s->tiles.shearCells, s->tiles.nShear, comp[cssOf[a]], tmp);
+        const int rc = e == hipSuccess ? download_volume(s, tmp, out, s1, s2, s3) : -10;
+        hipFree(tmp);
+        if (e != hipSuccess) BFD_FAIL(-10, std::string("bfd_get_field: ") + hipGetErrorString(e));
+        return rc;
+    }
+    if (a >= 12 && s->tilesReady && s->cfg.kernelVariant != 1) bfd_launch_scatter_shear_memory(s->d, s->stream, &s->tiles);   // Rxy, Rxz, Ryz live beside the sparse list
     float *cur[15] = {d.Vx, d.Vy, d.Vz, d.Sxx, d.Syy, d.Szz, d.Sxy, d.Sxz, d.Syz, d.Rxx, d.Ryy, d.Rzz, d.Rxy, d.Rxz, d.Ryz};
     return download_volume(s, cur[a], out, s1, s2, s3);
 }

@@ -78,7 +78,7 @@ struct bfd_dev {
     // list is contiguous in x, so the entry of cell i is that base + the number of listed cells of the row in [64 bx, i).
     // 0xFFFFFFFF marks planes without compact values (ghost planes: every value there is 0).
     const unsigned *cssRow; int cssStride;
-    float *cSxx, *cSyy, *cSxy, *cSxz, *cSyz, *cRxx, *cRyy;
+    float *cSxx, *cSyy, *cSxy, *cSxz, *cSyz, *cRxx, *cRyy, *cRxy, *cRxz, *cRyz;
 };
 #define BFD_CSS_NONE 0xFFFFFFFFu
 // a cell has compact values ("listed") when its class byte says solid centre, no reflector
@@ -122,7 +122,11 @@ struct bfd_tiles { bfd_sim *ktimer; int nMat; bool merged /* solid runs: normal 
                    unsigned *shearCells; float *shearCoef; long nShear, shearLowEnd, shearHighBeg;   /* sparse shear list */
                    unsigned *shearCodes; float *shearTab; long nShearExplicit;   /* per listed cell a byte per edge: 0 inactive, 1 + m = one material around the edge (coefficients from shearTab[2 m ..]), 255 = explicit coefficients in shearCoef; number of explicit edges */
                    int4 *runsAll; int nAll, nAllB;   /* compact solid state: every run, fluid and solid, in list order [boundary | interior] -- the stress half-step's one launch of the fluid kernel */
-                   unsigned *cssRow; float *css; long cssCap;   /* compact solid state (bfd_dev::cssRow): row table, [7][cssCap] values Sxx Syy Sxy Sxz Syz Rxx Ryy in list order */
+                   /* compact solid state (bfd_dev::cssRow): the row table and where the ten compact arrays (Sxx Syy Sxy Sxz Syz Rxx Ryy Rxy Rxz Ryz, list order) live:
+                      cssHosted = inside the full-volume buffers of their own fields (unused otherwise in this mode; the placement has spread those over the memory
+                      regions, which the sparse kernel's ten streams need as much as the marching kernels' do: 0.253 against 0.266-0.29 ms), from allocation plane 3 on
+                      (the planes a Z-neighbour exchanges stay free); else css = one block [10][cssCap] (solid cells too many for that) */
+                   unsigned *cssRow; float *css; long cssCap; bool cssHosted;
                    float *shearR;   /* memory variables Rxy, Rxz, Ryz of the listed cells, [3][nShear] in list order: only the sparse kernel uses them, so they live beside the list (dense, coalesced) instead of in the full-volume arrays, which are filled from here on demand (bfd_get_field) */
                    int nFluid, nFluidB, nSolid, nSolidB, nSolidBP /* leading boundary runs that touch the absorbing layer */, nSolidIP /* trailing interior ones */, nFused /* runs of the fused kernel, after the solid runs */;
                    int nLossless, nLossy, nSolidSub, nUni, nPml, nLean, nFusedSub;
@@ -219,10 +223,12 @@ void bfd_launch_shear_coefficients(const bfd_dev &d, hipStream_t s, const unsign
 // copies the list-ordered shear memory variables into the full-volume arrays Rxy, Rxz, Ryz (outputs only)
 void bfd_launch_scatter_shear_memory(const bfd_dev &d, hipStream_t s, const bfd_tiles *t);
 void bfd_launch_gather_shear_memory(const bfd_dev &d, hipStream_t s, const bfd_tiles *t);
-// compact solid state: the row table of a list in order mode 2 (lowPlanes / hiStart as for bfd_launch_shear_order_keys); copies between the
-// compact arrays and the full-volume ones (mask: bit a = array a of Sxx Syy Sxy Sxz Syz Rxx Ryy; toFull = compact -> full volume)
+// compact solid state: the row table of a list in order mode 2 (lowPlanes / hiStart as for bfd_launch_shear_order_keys)
 void bfd_launch_css_row_table(const bfd_dev &d, hipStream_t s, const unsigned *cells, long n, unsigned *rowTable, int stride, int lowPlanes, int hiStart);
-void bfd_launch_css_copy(const bfd_dev &d, hipStream_t s, const bfd_tiles *t, unsigned mask, bool toFull);
+// dstFull (pointer to local plane 0 of a full-volume buffer) [cell] = compact array a [entry], a = 0..9 in the order Sxx Syy Sxy Sxz Syz Rxx Ryy Rxy Rxz Ryz;
+// the reverse into dstCompact from a full-volume source. cells / n: the list the entries belong to.
+void bfd_launch_css_scatter(hipStream_t s, const unsigned *cells, long n, const float *compact, float *dstFull);
+void bfd_launch_css_gather(hipStream_t s, const unsigned *cells, long n, const float *srcFull, float *dstCompact);
 void bfd_launch_cell_classes(const bfd_dev &d, hipStream_t s, uint8_t *clsBase, long nalloc);
 // counts over the cells of the solid runs: [0] fluid no-memory, [1] fluid with memory, [2] solid no-memory, [3] solid with memory,
 // [4] active shear edges, [5] reflector cells

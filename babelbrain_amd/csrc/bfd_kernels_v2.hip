@@ -1960,7 +1960,8 @@ __global__ __launch_bounds__(256, SPARSE_WAVES_PER_SIMD) void stress_shear_spars
                                                            const float *__restrict__ tab, const float *__restrict__ coef,
                                                            float *__restrict__ Rc, long nTotal, long n, FastDiv divN1, FastDiv divPlane,
                                                            float *__restrict__ cSxy, float *__restrict__ cSxz, float *__restrict__ cSyz,
-                                                           float *__restrict__ cSxx, float *__restrict__ cSyy, float *__restrict__ cRxx, float *__restrict__ cRyy)
+                                                           float *__restrict__ cSxx, float *__restrict__ cSyy, float *__restrict__ cRxx, float *__restrict__ cRyy,
+                                                           float *__restrict__ cRxy, float *__restrict__ cRxz, float *__restrict__ cRyz)
 {
     // XCD e works through the e-th contiguous eighth of the list (order: shear_order_keys): the V values a cell gathers from its
     // row / plane neighbours were fetched by blocks just before it on the SAME XCD (its own L2)
@@ -1974,7 +1975,7 @@ __global__ __launch_bounds__(256, SPARSE_WAVES_PER_SIMD) void stress_shear_spars
     if (NORMAL && SPARSE_HOIST) {
         oSxx = LDNT(cSxx + t); oSyy = LDNT(cSyy + t); oRxx = LDNT(cRxx + t); oRyy = LDNT(cRyy + t);
         oSxy = LDNT(cSxy + t); oSxz = LDNT(cSxz + t); oSyz = LDNT(cSyz + t);
-        oRxy = LDNT(Rc + t); oRxz = LDNT(Rc + nTotal + t); oRyz = LDNT(Rc + 2 * nTotal + t);
+        oRxy = LDNT(cRxy + t); oRxz = LDNT(cRxz + t); oRyz = LDNT(cRyz + t);
     }
     const unsigned ukl = fdiv(c, divPlane), rem = c - ukl * (unsigned)d.plane, uj = fdiv(rem, divN1);
     const int i = (int)(rem - uj * (unsigned)N1), j = (int)uj, kl = (int)ukl;
@@ -2059,7 +2060,7 @@ __global__ __launch_bounds__(256, SPARSE_WAVES_PER_SIMD) void stress_shear_spars
     }
     // memory variables: beside the list (Rc, list order) or, when the list only holds the cells the merged solid kernel leaves
     // out (Rc == null), in the full-volume arrays
-    float *pRxy = Rc ? Rc + t : d.Rxy + c, *pRxz = Rc ? Rc + nTotal + t : d.Rxz + c, *pRyz = Rc ? Rc + 2 * nTotal + t : d.Ryz + c;
+    float *pRxy = NORMAL ? cRxy + t : (Rc ? Rc + t : d.Rxy + c), *pRxz = NORMAL ? cRxz + t : (Rc ? Rc + nTotal + t : d.Rxz + c), *pRyz = NORMAL ? cRyz + t : (Rc ? Rc + 2 * nTotal + t : d.Ryz + c);
     // shear stresses: in list order too when the solid state is compact (cSxy .. = the entries of this launch's part of the list)
     float *pSxy = cSxy ? cSxy + t : d.Sxy + c, *pSxz = cSxz ? cSxz + t : d.Sxz + c, *pSyz = cSyz ? cSyz + t : d.Syz + c;
     if (Axy != 0.f) {
@@ -2392,21 +2393,22 @@ void bfd_launch_css_row_table(const bfd_dev &d, hipStream_t s, const unsigned *c
     const long total = (long)(d.nk + 4) * d.N2 * stride;
     hipLaunchKernelGGL(css_row_table, dim3((unsigned)std::min<long>((total + 255) / 256, 65536)), dim3(256), 0, s, d, cells, n, rowTable, stride, lowPlanes, hiStart);
 }
-// compact arrays <-> full-volume arrays at the listed cells (outputs; a list rebuilt in the middle of a run)
-__global__ void css_copy(bfd_dev d, const unsigned *__restrict__ cells, long n, unsigned mask, int toFull)
+// one compact array <-> a full-volume buffer at the listed cells (outputs; a list rebuilt in the middle of a run)
+__global__ void css_scatter(const unsigned *__restrict__ cells, long n, const float *__restrict__ compact, float *__restrict__ dstFull)
 {
-    float *full[7] = {d.Sxx, d.Syy, d.Sxy, d.Sxz, d.Syz, d.Rxx, d.Ryy};
-    float *comp[7] = {d.cSxx, d.cSyy, d.cSxy, d.cSxz, d.cSyz, d.cRxx, d.cRyy};
-    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x) {
-        const unsigned c = cells[t];
-        for (int a = 0; a < 7; a++)
-            if (mask & (1u << a)) { if (toFull) full[a][c] = comp[a][t]; else comp[a][t] = full[a][c]; }
-    }
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x) dstFull[cells[t]] = compact[t];
 }
-void bfd_launch_css_copy(const bfd_dev &d, hipStream_t s, const bfd_tiles *t, unsigned mask, bool toFull)
+__global__ void css_gather(const unsigned *__restrict__ cells, long n, const float *__restrict__ srcFull, float *__restrict__ dstCompact)
 {
-    if (d.cssRow && t->shearCells && t->nShear && mask)
-        hipLaunchKernelGGL(css_copy, dim3((unsigned)std::min<long>((t->nShear + 255) / 256, 8192)), dim3(256), 0, s, d, t->shearCells, t->nShear, mask, toFull ? 1 : 0);
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x) dstCompact[t] = srcFull[cells[t]];
+}
+void bfd_launch_css_scatter(hipStream_t s, const unsigned *cells, long n, const float *compact, float *dstFull)
+{
+    if (n > 0) hipLaunchKernelGGL(css_scatter, dim3((unsigned)std::min<long>((n + 255) / 256, 8192)), dim3(256), 0, s, cells, n, compact, dstFull);
+}
+void bfd_launch_css_gather(hipStream_t s, const unsigned *cells, long n, const float *srcFull, float *dstCompact)
+{
+    if (n > 0) hipLaunchKernelGGL(css_gather, dim3((unsigned)std::min<long>((n + 255) / 256, 8192)), dim3(256), 0, s, cells, n, srcFull, dstCompact);
 }
 
 void bfd_launch_shear_order_keys(const bfd_dev &d, hipStream_t s, const unsigned *cells, unsigned long long *keys, long n, int lowPlanes, int hiStart, int mode)
@@ -2499,10 +2501,10 @@ void bfd_launch_stress_v2(const bfd_dev &d, hipStream_t s0, const bfd_tiles *t, 
         auto sparse = [&](long b, long e, float *R) {
             if (e <= b) return;
             const dim3 g((unsigned)((e - b + 255) / 256));
-            if (d.cssRow) hipLaunchKernelGGL(stress_shear_sparse<true>, g, dim3(256), 0, s, d, t->shearCells + b, t->shearCodes + b, t->shearTab, t->shearCoef + 6 * b, R, t->nShear, e - b, dN1, dPl,
-                                             d.cSxy + b, d.cSxz + b, d.cSyz + b, d.cSxx + b, d.cSyy + b, d.cRxx + b, d.cRyy + b);
+            if (d.cssRow) hipLaunchKernelGGL(stress_shear_sparse<true>, g, dim3(256), 0, s, d, t->shearCells + b, t->shearCodes + b, t->shearTab, t->shearCoef + 6 * b, (float *)nullptr, t->nShear, e - b, dN1, dPl,
+                                             d.cSxy + b, d.cSxz + b, d.cSyz + b, d.cSxx + b, d.cSyy + b, d.cRxx + b, d.cRyy + b, d.cRxy + b, d.cRxz + b, d.cRyz + b);
             else hipLaunchKernelGGL(stress_shear_sparse<false>, g, dim3(256), 0, s, d, t->shearCells + b, t->shearCodes + b, t->shearTab, t->shearCoef + 6 * b, R, t->nShear, e - b, dN1, dPl,
-                                    (float *)nullptr, (float *)nullptr, (float *)nullptr, (float *)nullptr, (float *)nullptr, (float *)nullptr, (float *)nullptr);
+                                    (float *)nullptr, (float *)nullptr, (float *)nullptr, (float *)nullptr, (float *)nullptr, (float *)nullptr, (float *)nullptr, (float *)nullptr, (float *)nullptr, (float *)nullptr);
         };
         sparse(b0, e0, R0); sparse(b1, e1, R1);
         BFD_KT(BFD_K_STRESS_SHEAR, 1);

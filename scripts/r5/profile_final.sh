@@ -13,7 +13,7 @@ for w in ${@:-c3 c2 c4 c5}; do
   esac
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktrace_$w -o k -- python3 bench.py $COMMON $A > $O/bench_${w}_under_rocprof.json 2>$O/bench_${w}.err
   cp $O/ktrace_$w/k_kernel_stats.csv $O/kernel_stats_$w.csv 2>/dev/null
-  i=0
+  mkdir -p $O/pmc_$w; i=0
   for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
     i=$((i+1))
     timeout 600 rocprofv3 --pmc $grp --output-format csv -d $O/pmc_$w/p$i -- python3 bench.py --steps 4 --warmup 2 --windows 1 --no-kernel-pass --no-steady-warmup $COMMON $A > $O/pmc_$w/p$i.log 2>&1

@@ -184,8 +184,9 @@ def test_compact_solid_state_equals_full_volume_arrays(seed, monkeypatch):
     mm, ml, f, smap, pulse, h, T, sensor = a
     nt = int(round(T / k['DT']))
 
-    def fields(env):
+    def fields(env, hosted='1', again=False):
         monkeypatch.setenv('BFD_COMPACT_SOLID', env)
+        monkeypatch.setenv('BFD_COMPACT_HOSTED', hosted)
         eng = _engine.Engine(*mm.shape, len(ml), h, k['DT'], f, nt, NDelta=k['NDelta'], typeSource=k['TypeSource'], sensorSub=k['SensorSubSampling'],
                              sensorStart=k['SensorStart'], selMapsRMS=['Pressure'], selMapsSensors=['Pressure', 'Sigmaxx', 'Sigmaxz'], selRMSorPeak=1)
         eng.set_materials(ml, k['QCorrection'])
@@ -199,6 +200,8 @@ def test_compact_solid_state_equals_full_volume_arrays(seed, monkeypatch):
             eng.run(nt // 2)
             out.append({n: eng.get_field(n).copy() for n in _engine.FIELD_NAMES})
             out[-1]['sensors'] = eng.sensors().copy()
+            if again:                         # inputs set again in the middle of a run: the lists are rebuilt, the compact values must move into the new list
+                eng.set_sources(*compact_sources(smap, k['Ox'], k['Oy'], k['Oz']), pulse)
             eng.run(nt - nt // 2)             # get_field in the middle of a run must not disturb it
             out.append({n: eng.get_field(n).copy() for n in _engine.FIELD_NAMES})
             eng.reset()
@@ -206,8 +209,10 @@ def test_compact_solid_state_equals_full_volume_arrays(seed, monkeypatch):
         return out
 
     sens_map = sensor
-    full, comp = fields('0'), fields('1')
+    full = fields('0')
     assert any(np.abs(full[1][n]).max() > 0 for n in ('Sxy', 'Sxz', 'Syz', 'Rxx', 'Rxy'))
-    for q, (x, y) in enumerate(zip(full, comp)):
-        for n in x:
-            assert np.array_equal(x[n], y[n]), (q, n)
+    # the compact arrays inside the full-volume buffers of their fields (default), in a block of their own, and with the lists rebuilt mid-run
+    for comp in (fields('1'), fields('1', hosted='0'), fields('1', again=True), fields('1', hosted='0', again=True)):
+        for q, (x, y) in enumerate(zip(full, comp)):
+            for n in x:
+                assert np.array_equal(x[n], y[n]), (q, n)
