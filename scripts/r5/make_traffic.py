@@ -32,7 +32,7 @@ for w, (key, name) in KEYS.items():
         shutil.copy(b, os.path.join(P, 'bench_%s_under_rocprof.json' % name))
     tr['_profile'] = {'pmc': 'profiles/r5/pmc_summary_%s.txt' % name, 'kernel_stats': 'profiles/r5/kernel_stats_%s.csv' % name, 'kernel_avg_us': avg,
                       'note': 'per class and time step (a class may take several launches per step); round 5, final binary (scripts/r5/profile_final.sh)'}
-    if key in t:
+    if key in t and 'r4_' + key not in t:
         t['r4_' + key] = t[key]
     t[key] = tr
     print(key, {c: round(v / 1e9, 3) for c, v in tr.items() if not c.startswith('_')}, avg)
