@@ -995,7 +995,7 @@ static void bind_compact_views(bfd_sim *s)
     float **cp[10] = {&d.cSxx, &d.cSyy, &d.cSxy, &d.cSxz, &d.cSyz, &d.cRxx, &d.cRyy, &d.cRxy, &d.cRxz, &d.cRyz};
     static const int host[10] = {3, 4, 6, 7, 8, 9, 10, 12, 13, 14};      // Sxx Syy Sxy Sxz Syz Rxx Ryy Rxy Rxz Ryz among the 15 state arrays
     for (int a = 0; a < 10; a++)
-        *cp[a] = s->tiles.cssHosted ? s->stateBase[host[a]] + 3 * (size_t)d.plane : s->tiles.css + (size_t)a * s->tiles.cssCap;
+        *cp[a] = s->tiles.cssHosted ? s->stateBase[host[a]] + 4 * (size_t)d.plane : s->tiles.css + (size_t)a * s->tiles.cssCap;
 }
 static int build_tile_lists(bfd_sim *s)
 {
@@ -1351,8 +1351,9 @@ static int build_tile_lists(bfd_sim *s)
             const int stride = tx + 1;
             rc = dev_alloc(s, &s->tiles.cssRow, (size_t)(s->d.nk + 4) * s->d.N2 * stride, false);
             // the compact arrays live inside the full-volume buffers of their fields when the listed cells fit between the planes a Z-neighbour
-            // exchanges (allocation planes 3 .. nk); BFD_COMPACT_HOSTED=0 or too many solid cells: one block of their own
-            bool hosted = (size_t)count <= (size_t)std::max(s->d.nk - 3, 0) * s->d.plane;
+            // exchanges (local planes 0, 1 and nk-2, nk-1 of Sxz / Syz travel: allocation planes 4 .. nk-1 are free); BFD_COMPACT_HOSTED=0 or
+            // too many solid cells: one block of their own
+            bool hosted = (size_t)count <= (size_t)std::max(s->d.nk - 4, 0) * s->d.plane;
             if (const char *ev = getenv("BFD_COMPACT_HOSTED")) hosted = hosted && atoi(ev) != 0;
             if (!rc && !hosted) rc = dev_alloc(s, &s->tiles.css, 10 * (size_t)count, true);
             if (rc) return rc;
@@ -1656,21 +1657,24 @@ static int choose_placement(bfd_sim *s)
     int nFresh = 0;
     bool probeTells = tSame >= 0.05f;                                          // ms; shorter probes are launch overhead, not memory time
     // How much throw-away memory the search for another region may hold at a time (candidates that missed + spacers, all freed
-    // before this function returns). A region is up to ~96 GiB wide and a fresh process may start at the beginning of one (one
-    // box needed 142 GiB of candidates), but a solver call must not take the device away from whoever shares it: by default
-    // at most 64 GiB and at most half of what was free on entry, and NOTHING when other allocations than this engine's are
-    // present on the device (another process, the other slabs of a group, a GUI's bio-heat volumes): the buffers are then only
-    // exchanged among themselves. bfd_set_placement(sim, mode, limitBytes) / BFD_PLACEMENT_SEARCH_MB set the limit explicitly
-    // (then the shared-device rule is off: the caller has decided).
+    // before this function returns). A region is up to ~96 GiB wide and a fresh process may start at the beginning of one (boxes
+    // needed 92-160 GiB of candidates), but a solver call must not take the device away from whoever shares it: NOTHING is searched
+    // when other allocations than this engine's are present on the device (another process, the other slabs of a group, a GUI's
+    // bio-heat volumes): the buffers are then only exchanged among themselves. On a device the engine has to itself the search may
+    // hold up to 192 GiB while always leaving 48 GiB of what was free on entry untouched (round 4 had capped it at 64 GiB, which
+    // gives up on about one box in three -- C3 85 instead of 91 Gvoxel-steps/s; since round 5 a successful search is paid once per
+    // process: its buffers are kept for the next engine, placement_cache_*). bfd_set_placement(sim, mode, limitBytes) /
+    // BFD_PLACEMENT_SEARCH_MB set the limit explicitly (then the shared-device rule is off: the caller has decided);
+    // BABELFDTD_PLACEMENT_SEARCH_GIB replaces the 192 GiB.
     size_t free0 = 0, total0 = 0;
     if (hipMemGetInfo(&free0, &total0) != hipSuccess) { free0 = total0 = 0; (void)hipGetLastError(); }
     const size_t others = total0 > free0 + (size_t)s->devBytes ? total0 - free0 - (size_t)s->devBytes : 0;
-    size_t heldCap = std::min((size_t)64 << 30, free0 / 2);
+    size_t heldCap = free0 > ((size_t)48 << 30) ? std::min((size_t)192 << 30, free0 - ((size_t)48 << 30)) : 0;
     std::string capNote;
     if (others > ((size_t)6 << 30)) { heldCap = 0; char q[96]; snprintf(q, sizeof q, "; device shared (%.0f GiB of other allocations): no search beyond the own buffers", others / 1073741824.0); capNote = q; }
     if (const char *ev = getenv("BABELFDTD_PLACEMENT_SEARCH_GIB")) {           // the owner of the device raises (or lowers) the default bound without code
         const double gib = atof(ev);
-        if (gib >= 0 && others <= ((size_t)6 << 30)) heldCap = std::min((size_t)(gib * 1073741824.0), free0 > (free0 / 8) ? free0 - free0 / 8 : 0);
+        if (gib >= 0 && others <= ((size_t)6 << 30)) heldCap = std::min((size_t)(gib * 1073741824.0), free0 > ((size_t)48 << 30) ? free0 - ((size_t)48 << 30) : 0);
     }
     if (s->placementLimit >= 0) { heldCap = (size_t)s->placementLimit; capNote.clear(); }
     if (const char *ev = getenv("BFD_PLACEMENT_SEARCH_MB")) { probeTells = true; heldCap = (size_t)atol(ev) << 20; capNote.clear(); }   // tests: walk a little on any grid

@@ -124,7 +124,7 @@ struct bfd_tiles { bfd_sim *ktimer; int nMat; bool merged /* solid runs: normal 
                    int4 *runsAll; int nAll, nAllB;   /* compact solid state: every run, fluid and solid, in list order [boundary | interior] -- the stress half-step's one launch of the fluid kernel */
                    /* compact solid state (bfd_dev::cssRow): the row table and where the ten compact arrays (Sxx Syy Sxy Sxz Syz Rxx Ryy Rxy Rxz Ryz, list order) live:
                       cssHosted = inside the full-volume buffers of their own fields (unused otherwise in this mode; the placement has spread those over the memory
-                      regions, which the sparse kernel's ten streams need as much as the marching kernels' do: 0.253 against 0.266-0.29 ms), from allocation plane 3 on
+                      regions, which the sparse kernel's ten streams need as much as the marching kernels' do: 0.253 against 0.266-0.29 ms), from allocation plane 4 on
                       (the planes a Z-neighbour exchanges stay free); else css = one block [10][cssCap] (solid cells too many for that) */
                    unsigned *cssRow; float *css; long cssCap; bool cssHosted;
                    float *shearR;   /* memory variables Rxy, Rxz, Ryz of the listed cells, [3][nShear] in list order: only the sparse kernel uses them, so they live beside the list (dense, coalesced) instead of in the full-volume arrays, which are filled from here on demand (bfd_get_field) */

@@ -70,9 +70,9 @@ def parse():
     ap.add_argument('--lean-host', action='store_true', help='build the inputs slab-style (size-1 Ox/Oy/Oz) also at N=1')
     ap.add_argument('--cpu-sample', type=int, nargs=4, default=None, help='N1 N2 N3 steps of the oracle sample (default: the grid of the config itself, 56 steps, when the host has the memory; else 384 384 256 224)')
     ap.add_argument('--group-child', nargs=4, default=None, metavar=('CONFIG', 'N1', 'N2', 'N3'), help='internal: run ONE volume through bfd_group over --gpus devices and print its block (the parent bench starts this as a child process with a timeout)')
-    ap.add_argument('--placement-search-gib', type=float, default=-1.0, help='throw-away device memory the placement of the arrays may hold while it looks for a buffer in another memory region; < 0 (default) = the library\'s own rule, i.e. what a PropagationModel() call gets: 64 GiB / half of the free memory / nothing on a shared device')
-    ap.add_argument('--wide-placement-gib', type=float, default=190.0, help='N=1: search bound of the extra block `wide_placement_search` (the headline uses the library default)')
-    ap.add_argument('--no-wide-placement', action='store_true', help='N=1: skip the extra block that times the headline workload again under the wide search bound')
+    ap.add_argument('--placement-search-gib', type=float, default=-1.0, help='throw-away device memory the placement of the arrays may hold while it looks for a buffer in another memory region; < 0 (default) = the library\'s own rule, i.e. what a PropagationModel() call gets: nothing on a shared device, up to 192 GiB (48 GiB left free) on a device of its own')
+    ap.add_argument('--wide-placement-gib', type=float, default=64.0, help='N=1: search bound of the extra block `bounded_placement_search` (the headline uses the library default)')
+    ap.add_argument('--no-wide-placement', action='store_true', help='N=1: skip the extra block that times the headline workload again under the 64 GiB bound the library had in round 4')
     ap.add_argument('--no-strong-c5', action='store_true', help='skip the block that times ONE C5 volume (1024^3) through the one-process path (N=1: the anchor of the 1/2/4/8 curve)')
     ap.add_argument('--strong-c5-steps', type=int, default=30, help='timed steps of the strong_c5 block (14 ms each on one device)')
     ap.add_argument('--no-group', action='store_true', help='skip the one-process bfd_group figures (group_one_slab at N=1, group_strong_c3 under torchrun)')
@@ -579,7 +579,7 @@ def main_group(args):
 
 
 def placement_rule(args):
-    return ('library default (what a PropagationModel() call gets: at most 64 GiB and half of the free memory held while searching, nothing on a shared device)'
+    return ('library default (what a PropagationModel() call gets: no search on a shared device; on a device of its own up to 192 GiB held while searching, 48 GiB always left free; paid once per process)'
             if args.placement_search_gib < 0 else 'explicit bound of %g GiB (--placement-search-gib)' % args.placement_search_gib)
 
 
@@ -757,18 +757,18 @@ def main():
         if have_cpu_group:
             dist.barrier(group=cpu_group)
     if world == 1 and not args.no_wide_placement and args.placement_search_gib < 0 and args.config == 'C3' and not args.size:
-        # the same workload, same engine, with the wide search bound the bench used as its default until round 4: what the library's
-        # bound costs on THIS box (on most boxes nothing: exchanging the buffers suffices)
+        # the same workload, same engine, under the 64 GiB bound the library had as its default in round 4: what that bound cost on THIS box
+        # (on two boxes in three nothing: exchanging the buffers, or a short walk, suffices)
         try:
             wargs = argparse.Namespace(**dict(vars(args), placement_search_gib=args.wide_placement_gib, windows=1))
             ww = Workload(wargs, args.config, dims, args.scaling, 0, 1, local_rank, None, dt_fn, args.steps, args.warmup, args.variant)
             wall, _ = ww.timed()
-            line['wide_placement_search'] = {'search_gib': args.wide_placement_gib, 'value': ww.total_vox * ww.steps / wall / 1e6, 'unit': 'Mvoxel-steps/s',
+            line['bounded_placement_search'] = {'search_gib': args.wide_placement_gib, 'value': ww.total_vox * ww.steps / wall / 1e6, 'unit': 'Mvoxel-steps/s',
                                              'ms_per_step': wall / ww.steps * 1e3, 'array_placement': ww.eng.placement_note(),
                                              'note': 'one window; `value` of the line is measured under the library default rule (config.placement_rule)'}
             ww.close()
         except Exception as e:
-            line['wide_placement_search'] = {'value': None, 'error': repr(e)}
+            line['bounded_placement_search'] = {'value': None, 'error': repr(e)}
     if world == 1 and not args.no_strong_c5 and not args.no_group and args.config == 'C3' and not args.size:
         try:       # the first point of the 1024^3 strong-scaling curve, in the line the driver records at N = 1
             line['strong_c5'] = strong_c5(args, 1, dt_fn, args.variant)

@@ -162,12 +162,13 @@ int bfd_prepare(bfd_sim *sim);
 const char *bfd_placement_note(bfd_sim *sim);
 /* Placement policy, before the first step / bfd_prepare. mode 0 = leave the arrays where hipMalloc put them. searchLimitBytes =
  * how much throw-away device memory the search for a buffer in another region may hold at a time (all of it is released
- * before bfd_prepare returns); < 0 = the default rule: at most 64 GiB and half of the free memory, and nothing at all when the
- * device carries other allocations than this engine's (another process, the other slabs of a group): the engine's own buffers
- * are then only exchanged among themselves. bfd_prepare never fails for lack of memory where mode 0 succeeds. */
+ * before bfd_prepare returns); < 0 = the default rule: nothing at all when the device carries other allocations than this
+ * engine's (another process, the other slabs of a group): the engine's own buffers are then only exchanged among themselves;
+ * on a device the engine has to itself up to 192 GiB, always leaving 48 GiB of what was free untouched.
+ * bfd_prepare never fails for lack of memory where mode 0 succeeds. */
 int bfd_set_placement(bfd_sim *sim, int32_t mode, int64_t searchLimitBytes);
-/* The default rule can be moved without code by whoever owns the device: BABELFDTD_PLACEMENT_SEARCH_GIB=<GiB> replaces the 64 GiB of the
- * default rule (the shared-device rule stays). Buffers a search found in another region are kept when their engine is destroyed and
+/* The default rule can be moved without code by whoever owns the device: BABELFDTD_PLACEMENT_SEARCH_GIB=<GiB> replaces the 192 GiB
+ * (the shared-device rule stays). Buffers a search found in another region are kept when their engine is destroyed and
  * offered to the next engine of this process with arrays of the same size on the same device, so that the two or three solver calls of
  * one RUN_SIMULATION (BabelIntegrationBASE.py:2338, 2374, 2401) pay the search once; at most BABELFDTD_PLACEMENT_CACHE_GIB (default
  * 48, 0 = keep nothing) are held between calls. bfd_placement_cache_release frees them now and returns the bytes freed. */

@@ -1,7 +1,7 @@
 """The placement of the per-voxel arrays by memory region (bfd_prepare) must never cost a caller the
-device: its search for a buffer in another region holds throw-away allocations, so it is bounded (64 GiB / half of the free
-memory), switched off on a device that carries other allocations, and it gives up quietly -- bfd_prepare succeeds wherever it
-would with the placement off, and the results do not depend on it."""
+device: its search for a buffer in another region holds throw-away allocations, so it is switched off on a device that carries
+other allocations, bounded on a device of its own (192 GiB, 48 GiB of the free memory always left; any explicit limit), and it
+gives up quietly -- bfd_prepare succeeds wherever it would with the placement off, and the results do not depend on it."""
 import subprocess
 import sys
 import threading
@@ -78,11 +78,11 @@ def test_placement_under_memory_pressure():
 
 @pytest.mark.timeout(600)
 def test_explicit_limit_and_default_bound():
-    """bfd_set_placement: an explicit limit of 0 bytes exchanges buffers only; the default on a free device may search but holds
-    at most 64 GiB at a time (the note reports what was released)."""
+    """bfd_set_placement: an explicit limit of 0 bytes exchanges buffers only, one of 64 GiB holds no more than that; the default on
+    a free device may search but holds at most 192 GiB at a time (the note reports what was released)."""
     a, k, info = H.make_problem('C3', steps=140, stable_dt_fn=_hip_dt, full_sensors=False)
     outs = []
-    for limit in (0, -1):
+    for limit in (0, 64 << 30, -1):
         eng = _engine_for(a, k, info)
         eng.set_placement(1, limit)
         eng.prepare()
@@ -93,13 +93,13 @@ def test_explicit_limit_and_default_bound():
             assert ' 0 fresh' in note and '0 candidates' in note
         else:
             gib = float(note.split('spacers (')[1].split(' GiB')[0])
-            assert gib <= 64.0 + 1e-6
+            assert gib <= (64.0 if limit > 0 else 192.0) + 1e-6
         with pytest.raises(_engine.EngineError):
             eng.set_placement(0)                        # too late: the arrays are placed
         eng.run(140)
         outs.append(eng.get_map(_engine.KIND_RMS, 'Pressure'))
         eng.close()
-    assert np.array_equal(outs[0], outs[1]) and outs[0].max() > 0
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2]) and outs[0].max() > 0
 
 
 @pytest.mark.timeout(600)
