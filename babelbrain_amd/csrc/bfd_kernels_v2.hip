@@ -21,12 +21,6 @@
 
 namespace {
 
-#ifdef BFD_EXP_ALL_FLUID_CLASSES
-// experiment build (wrong results): the solid-run kernels see every cell as a fluid cell -- what they cost without their solid-only streams
-#define EXPCL(x) (((x) | BFD_CLS_FLUID) & ~(BFD_CLS_EXY | BFD_CLS_EXZ | BFD_CLS_EYZ | BFD_CLS_REFL | BFD_CLS_MIXED))
-#else
-#define EXPCL(x) (x)
-#endif
 constexpr int TX = BFD_TILE_X;
 constexpr int TY = BFD_TILE_Y;
 constexpr int LW = TX + 4;          // LDS row length (floats)
@@ -812,7 +806,7 @@ __device__ __forceinline__ void stress_solid_body(const bfd_dev &d, const int4 &
     unsigned mraw = 0, cl = BFD_CLS_FLUID | BFD_CLS_NOMEM, cl1 = BFD_CLS_FLUID | BFD_CLS_NOMEM;
     if (valid) {
         const float *bVz = d.Vz + kbeg * pl;
-        cl = EXPCL(U1((d.cls + kbeg * pl), cij)); cl1 = EXPCL(U1((d.cls + kbeg * pl + pl), cij));
+        cl = U1((d.cls + kbeg * pl), cij); cl1 = U1((d.cls + kbeg * pl + pl), cij);
         vx0 = F4((d.Vx + kbeg * pl), cij * 4u); vy0 = F4((d.Vy + kbeg * pl), cij * 4u);
         vzm2 = F4((bVz - 2 * pl), cij * 4u); vzm1 = F4((bVz - pl), cij * 4u); vz0 = F4(bVz, cij * 4u); vzp1 = F4((bVz + pl), cij * 4u);
         mraw = U2((d.mat + kbeg * pl), cij * 2u);
@@ -835,7 +829,7 @@ __device__ __forceinline__ void stress_solid_body(const bfd_dev &d, const int4 &
         float nvx = 0, nvy = 0, nvz = 0, nh = 0, nsxx = 0, nsyy = 0, nszz = 0, nrxx = 0, nryy = 0, nrzz = 0, npx = 0, npy = 0, npz = 0;
         unsigned nmraw = 0, ncl2 = BFD_CLS_FLUID | BFD_CLS_NOMEM;
         auto prefetch_next = [&]() {
-        if (valid) ncl2 = EXPCL(U1((d.cls + ko + 2 * pl), cij));           // ghost planes make kl+2 addressable
+        if (valid) ncl2 = U1((d.cls + ko + 2 * pl), cij);           // ghost planes make kl+2 addressable
             if (kl + 1 < kend) {
                 if (valid) {
                     const bool nfl = cl1 & BFD_CLS_FLUID, nmem = !(cl1 & BFD_CLS_NOMEM) || !nfl;
@@ -1626,7 +1620,7 @@ __device__ __forceinline__ void velocity_solid_body_g(const bfd_dev &d, const in
         const float *bzz = d.Szz + kbeg * pl, *bxz = d.Sxz + kbeg * pl, *byz = d.Syz + kbeg * pl;
         const uint8_t *bc = d.cls + kbeg * pl;
         unsigned cm2 = BFD_CLS_FLUID, cm1 = BFD_CLS_FLUID, c0 = BFD_CLS_FLUID;
-        if (valid) { cm2 = EXPCL(gl1(bc - 2 * pl, cij)); cm1 = EXPCL(gl1(bc - pl, cij)); c0 = EXPCL(gl1(bc, cij)); cB = EXPCL(gl1(bc + pl, cij)); cC = EXPCL(gl1(bc + 2 * pl, cij)); }
+        if (valid) { cm2 = gl1(bc - 2 * pl, cij); cm1 = gl1(bc - pl, cij); c0 = gl1(bc, cij); cB = gl1(bc + pl, cij); cC = gl1(bc + 2 * pl, cij); }
         zzm1 = glp(bzz - pl, c4, valid); zz0 = glp(bzz, c4, valid); zzp1 = glp(bzz + pl, c4, valid); zzp2 = glp(bzz + 2 * pl, c4, valid);
         const bool fl0 = (c0 & BFD_CLS_FLUID) != 0;
         float sxx, syy, sxy;
@@ -1666,8 +1660,8 @@ __device__ __forceinline__ void velocity_solid_body_g(const bfd_dev &d, const in
     unsigned hcA = 0, hcB = 0;
     {
         unsigned h0A = 0, h0B = 0;
-        if (ta.ok) { h0A = EXPCL(gl1(d.cls + kbeg * pl, offA)); hcA = EXPCL(gl1(d.cls + kbeg * pl + pl, offA)); }
-        if (tb.ok) { h0B = EXPCL(gl1(d.cls + kbeg * pl, offB)); hcB = EXPCL(gl1(d.cls + kbeg * pl + pl, offB)); }
+        if (ta.ok) { h0A = gl1(d.cls + kbeg * pl, offA); hcA = gl1(d.cls + kbeg * pl + pl, offA); }
+        if (tb.ok) { h0B = gl1(d.cls + kbeg * pl, offB); hcB = gl1(d.cls + kbeg * pl + pl, offB); }
         float ha, hb;
         if (CSS) {
             const unsigned ra0 = rowbase(rowpA, kbeg);
@@ -1707,7 +1701,7 @@ __device__ __forceinline__ void velocity_solid_body_g(const bfd_dev &d, const in
         // here and the staging waits for them.
         const bool more = kl + 1 < kend;                // uniform
         const unsigned nm2 = gl2(d.mat + ko + 2 * pl, c2);                       // ghost planes make kl+2 addressable
-        const unsigned nc3raw = EXPCL(gl1(d.cls + ko + (kl + 2 < kend ? 3 : 2) * pl, cij));
+        const unsigned nc3raw = gl1(d.cls + ko + (kl + 2 < kend ? 3 : 2) * pl, cij);
         const bool bfl = (cB & BFD_CLS_FLUID) != 0;
         const long kn = more ? pl : 0;                  // the last iteration reads its own plane again (addressable, unused)
         const float nzzR = gl4(d.Szz + ko + 2 * pl + kn, c4);
@@ -1749,7 +1743,7 @@ __device__ __forceinline__ void velocity_solid_body_g(const bfd_dev &d, const in
             nhbR = *(BFD_GA const float *)(((substB && (hcB & BFD_CLS_FLUID)) ? paA : pbB) + (takeB ? offB * 4u : 0u));
         }
         const unsigned nmx = gl2(d.mat + ko + kn, cx2), nmy = gl2(d.mat + ko + kn, cy2);
-        const unsigned nhcA = EXPCL(gl1(d.cls + ko + pl + kn, offA)), nhcB = EXPCL(gl1(d.cls + ko + pl + kn, offB));
+        const unsigned nhcA = gl1(d.cls + ko + pl + kn, offA), nhcB = gl1(d.cls + ko + pl + kn, offB);
 
         float *wVx = d.VxW + ko, *wVy = d.VyW + ko, *wVz = d.VzW + ko;
         if (valid) {
