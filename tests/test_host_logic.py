@@ -186,3 +186,35 @@ def test_peer_status_words_decode():
     assert not d[2]['direct'] and d[2]['path'].startswith('STAGED') and d[2]['can_access'] == [True, False] and d[2]['enabled'] == [True, False]
     assert not d[3]['direct'] and d[3]['can_access'] == [False, False]
     assert decode_peer_status([]) == []
+
+
+def test_bench_strong_c5_block_anchors_itself(monkeypatch):
+    """bench.py's `strong_c5` block (the 1024^3 curve north_star names) carries its own one-device anchor and scaling_efficiency =
+    value / (distinct devices x anchor); at N = 1 the block is the anchor; a failing anchor or headline still yields a block."""
+    import argparse
+    import bench
+    calls = []
+
+    def fake_group_run(args, config, N, ndev, dt_fn, steps, warmup, windows, variant, label):
+        calls.append((config, tuple(N), ndev))
+        if ndev == 1 and fail.get('anchor'):
+            raise RuntimeError('no memory')
+        if ndev > 1 and fail.get('head'):
+            raise RuntimeError('peer access')
+        return {'value': 70000.0 * ndev * (0.9 if ndev > 1 else 1.0), 'ms_per_step': 15.0 / ndev, 'distinct_devices': ndev, 'emulated': False,
+                'array_placement_slab0': 'note'}
+    monkeypatch.setattr(bench, 'group_run', fake_group_run)
+    args = argparse.Namespace(strong_c5_steps=30, warmup=50)
+    fail = {}
+    b1 = bench.strong_c5(args, 1, None, 0)
+    assert calls == [('C5', (1024, 1024, 1024), 1)] and b1['scaling_efficiency'] == 1.0 and b1['one_device_same_volume']['value'] == b1['value']
+    calls.clear()
+    b4 = bench.strong_c5(args, 4, None, 0)
+    assert [c[2] for c in calls] == [1, 4] and b4['scaling'] == 'strong'
+    assert abs(b4['scaling_efficiency'] - 0.9) < 1e-12 and b4['one_device_same_volume']['value'] == 70000.0
+    fail = {'anchor': True}
+    b = bench.strong_c5(args, 4, None, 0)
+    assert b['value'] > 0 and b['scaling_efficiency'] is None and 'no memory' in b['one_device_same_volume']['error']
+    fail = {'head': True}
+    b = bench.strong_c5(args, 4, None, 0)
+    assert b['value'] is None and 'peer access' in b['error'] and b['one_device_same_volume']['value'] == 70000.0
