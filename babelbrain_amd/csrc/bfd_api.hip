@@ -1662,7 +1662,7 @@ static int choose_placement(bfd_sim *s)
     // when other allocations than this engine's are present on the device (another process, the other slabs of a group, a GUI's
     // bio-heat volumes): the buffers are then only exchanged among themselves. On a device the engine has to itself the search may
     // hold up to 192 GiB while always leaving 48 GiB of what was free on entry untouched (round 4 had capped it at 64 GiB, which
-    // gives up on about one box in three -- C3 85 instead of 91 Gvoxel-steps/s; since round 5 a successful search is paid once per
+    // gives up on some boxes -- C3 85 instead of 91 Gvoxel-steps/s there; since round 5 a successful search is paid once per
     // process: its buffers are kept for the next engine, placement_cache_*). bfd_set_placement(sim, mode, limitBytes) /
     // BFD_PLACEMENT_SEARCH_MB set the limit explicitly (then the shared-device rule is off: the caller has decided);
     // BABELFDTD_PLACEMENT_SEARCH_GIB replaces the 192 GiB.

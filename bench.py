@@ -758,7 +758,7 @@ def main():
             dist.barrier(group=cpu_group)
     if world == 1 and not args.no_wide_placement and args.placement_search_gib < 0 and args.config == 'C3' and not args.size:
         # the same workload, same engine, under the 64 GiB bound the library had as its default in round 4: what that bound cost on THIS box
-        # (on two boxes in three nothing: exchanging the buffers, or a short walk, suffices)
+        # (on most boxes nothing: exchanging the buffers, or a short walk, suffices)
         try:
             wargs = argparse.Namespace(**dict(vars(args), placement_search_gib=args.wide_placement_gib, windows=1))
             ww = Workload(wargs, args.config, dims, args.scaling, 0, 1, local_rank, None, dt_fn, args.steps, args.warmup, args.variant)

@@ -131,3 +131,27 @@ def test_engines_prepared_at_the_same_time_on_one_device():
     many = PropagationModel(devices=[0, 0, 0, 0]).StaggeredFDTD_3D_with_relaxation(*a, SILENT=True, **k)
     assert np.array_equal(one[2]['Pressure'], many[2]['Pressure']) and one[2]['Pressure'].max() > 0
     assert len(many[-1]['placement']) == 4 and isinstance(one[-1]['placement'], str)
+
+
+def test_placement_buffers_kept_between_engines_and_released(monkeypatch):
+    """Buffers a placement search found in another region are kept when their engine is destroyed and offered to the next engine of the
+    process (the solver calls of one RUN_SIMULATION pay a search once); bfd_placement_cache_release frees them. Forced on a small grid
+    (short search): whatever the search finds, a second engine built the same way gives the same results, the cache never holds more
+    than its bound, and after a release it is empty."""
+    monkeypatch.setenv('BFD_PLACEMENT_MIN_VOXELS', '0')
+    monkeypatch.setenv('BFD_PLACEMENT_SEARCH_MB', '64')
+    monkeypatch.setenv('BABELFDTD_PLACEMENT_CACHE_GIB', '1')
+    _engine.placement_cache_release()
+    a, k, info = H.make_problem('C2', N=(96, 80, 72), steps=60, stable_dt_fn=_hip_dt, full_sensors=False)
+    outs, notes = [], []
+    for _ in range(3):
+        eng = _engine_for(a, k, info)
+        eng.run(60)
+        outs.append(eng.get_map(_engine.KIND_RMS, 'Pressure'))
+        notes.append(eng.placement_note())
+        eng.close()
+    print(notes)
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2]) and outs[0].max() > 0
+    freed = _engine.placement_cache_release()
+    assert 0 <= freed <= 1 << 30
+    assert _engine.placement_cache_release() == 0
