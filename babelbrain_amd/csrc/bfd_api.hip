@@ -1010,6 +1010,7 @@ static int build_tile_lists(bfd_sim *s)
     // themselves) and re-entered into the new list through one full-volume temporary, array by array, once that list exists
     const bool carryCompact = s->step > 0 && s->d.cssRow && s->tiles.nShear > 0;
     unsigned *oldCells = nullptr; float *oldComp = nullptr; const long oldN = s->tiles.nShear;
+    struct FreeOnExit { float **p; ~FreeOnExit() { if (*p) hipFree(*p); } } freeOldComp{&oldComp};       // also on the error returns below
     if (carryCompact) {
         float *src[10] = {s->d.cSxx, s->d.cSyy, s->d.cSxy, s->d.cSxz, s->d.cSyz, s->d.cRxx, s->d.cRyy, s->d.cRxy, s->d.cRxz, s->d.cRyz};
         BFD_HIP(hipMalloc((void **)&oldComp, 10 * (size_t)oldN * sizeof(float)));
@@ -1468,7 +1469,6 @@ static int build_tile_lists(bfd_sim *s)
         if (T.merged && T.nSolid && s->cfg.kernelVariant != 2) for (int a = 0; a < 2; a++) B[a][BFD_K_STRESS_SOLID] += 16.0 * (double)cnt[4];   // S and R of every active edge, read and written
     }
     if (oldCells) dev_release(s, &oldCells);
-    if (oldComp) hipFree(oldComp);
     s->tilesReady = true;
     return 0;
 }
@@ -1504,6 +1504,13 @@ static size_t placement_cache_cap()
     double gib = 48.0;
     if (const char *ev = getenv("BABELFDTD_PLACEMENT_CACHE_GIB")) gib = atof(ev);
     return gib > 0 ? (size_t)(gib * 1073741824.0) : 0;
+}
+static size_t placement_cache_bytes(int device)
+{
+    std::lock_guard<std::mutex> lk(g_cacheMutex);
+    size_t held = 0;
+    for (const CachedBuf &c : g_cache) if (c.device == device) held += c.bytes;
+    return held;
 }
 static std::vector<void *> placement_cache_take(int device, size_t bytes)
 {
@@ -1668,7 +1675,9 @@ static int choose_placement(bfd_sim *s)
     // BABELFDTD_PLACEMENT_SEARCH_GIB replaces the 192 GiB.
     size_t free0 = 0, total0 = 0;
     if (hipMemGetInfo(&free0, &total0) != hipSuccess) { free0 = total0 = 0; (void)hipGetLastError(); }
-    const size_t others = total0 > free0 + (size_t)s->devBytes ? total0 - free0 - (size_t)s->devBytes : 0;
+    // what this process keeps from an earlier engine's search (placement_cache_*) is the engine's to take, not somebody else's memory
+    const size_t mine = (size_t)s->devBytes + placement_cache_bytes(s->cfg.device);
+    const size_t others = total0 > free0 + mine ? total0 - free0 - mine : 0;
     size_t heldCap = free0 > ((size_t)48 << 30) ? std::min((size_t)192 << 30, free0 - ((size_t)48 << 30)) : 0;
     std::string capNote;
     if (others > ((size_t)6 << 30)) { heldCap = 0; char q[96]; snprintf(q, sizeof q, "; device shared (%.0f GiB of other allocations): no search beyond the own buffers", others / 1073741824.0); capNote = q; }
