@@ -1462,8 +1462,10 @@ static int build_tile_lists(bfd_sim *s)
             hipFree(dc);
             if (e != hipSuccess) BFD_FAIL(-10, std::string("shear edge count: ") + hipGetErrorString(e));
             s->tiles.nShearExplicit = (long)hc[1];
-            // per listed cell: index 4 + edge codes 4 + V 12; per edge with explicit coefficients 8; per active edge S and R r/w 16
-            for (int a = 0; a < 2; a++) B[a][BFD_K_STRESS_SHEAR] = (s->d.cssRow ? 54.0 : 20.0) * (double)s->tiles.nShear + 8.0 * (double)hc[1] + 16.0 * (double)hc[0];
+            // per listed cell: index 4 + edge codes 4 + V 12; per edge with explicit coefficients 8; per active edge S and R r/w 16; compact solid
+            // state: + Sxx, Syy, Rxx, Ryy r/w 32 (+ the cell's id 2 when it does not fit the code word's fourth byte)
+            const double perCell = s->d.cssRow ? (s->cfg.nMat <= 255 ? 52.0 : 54.0) : 20.0;
+            for (int a = 0; a < 2; a++) B[a][BFD_K_STRESS_SHEAR] = perCell * (double)s->tiles.nShear + 8.0 * (double)hc[1] + 16.0 * (double)hc[0];
             if (T.merged) for (int a = 0; a < 2; a++) B[a][BFD_K_STRESS_SOLID] -= 16.0 * (double)hc[0];      // those edges are the sparse kernel's
         }
         if (T.merged && T.nSolid && s->cfg.kernelVariant != 2) for (int a = 0; a < 2; a++) B[a][BFD_K_STRESS_SOLID] += 16.0 * (double)cnt[4];   // S and R of every active edge, read and written

@@ -1978,6 +1978,12 @@ __global__ __launch_bounds__(256, SPARSE_WAVES_PER_SIMD) void stress_shear_spars
     // edge coefficients: from the per-material table where the four cells of the edge hold one material (most of a bone's
     // interior), explicit otherwise (24 B per cell less to stream)
     const unsigned cw = LDNT(codes + t);
+    float AP = 0.f, BP = 0.f, AS2 = 0.f, BS2 = 0.f;
+    if (NORMAL) {       // material of the cell: from the code word (its fourth byte), else from the id array
+        const unsigned mb = cw >> 24;
+        const int m = mb ? (int)mb - 1 : (int)(d.mat[c] & BFD_MAT_MASK);
+        AP = d.AP[m]; BP = d.BP[m]; AS2 = d.AS2[m]; BS2 = d.BS2[m];
+    }
     float Axy = 0.f, Bxy = 0.f, Axz = 0.f, Bxz = 0.f, Ayz = 0.f, Byz = 0.f;
     {
         const unsigned q = cw & 255u;
@@ -2041,8 +2047,6 @@ __global__ __launch_bounds__(256, SPARSE_WAVES_PER_SIMD) void stress_shear_spars
     }
     const float c1 = d.c1;
     if (NORMAL) {       // Sxx, Syy of the cell: the canonical expressions of stress_v2 / stress_solid
-        const int m = d.mat[c] & BFD_MAT_MASK;
-        const float AP = d.AP[m], BP = d.BP[m], AS2 = d.AS2[m], BS2 = d.BS2[m];
         const float sXY = dxVx + dyVy;
         const float div = sXY + dzVz;
         const float sYZ = dyVy + dzVz, sXZ = dxVx + dzVz;
@@ -2110,7 +2114,9 @@ __global__ void mark_solid_cells(bfd_dev d, unsigned char *__restrict__ flag, lo
 }
 // codes (may be null): one word per listed cell, a byte per edge (xy, xz, yz): 0 = the edge is never updated, 1 + m = its four
 // cells hold material m < 254 (coefficients from the per-material table shear_material_table builds with the very same
-// expression), 255 = mixed materials: the explicit coefficients in coef are read
+// expression), 255 = mixed materials: the explicit coefficients in coef are read; the fourth byte: 1 + material of the cell itself (0 when
+// it does not fit: the kernel reads the id array then) -- the sparse kernel's Sxx / Syy coefficients start from this word, which arrives
+// with the cell index, instead of from the id behind the index (one dependent memory round trip less)
 __global__ void shear_coefficients(bfd_dev d, const unsigned *__restrict__ cells, float *__restrict__ coef, unsigned *__restrict__ codes, long n)
 {
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2155,7 +2161,7 @@ __global__ void shear_coefficients(bfd_dev d, const unsigned *__restrict__ cells
     for (int q = 0; q < 6; q++) coef[6 * t + q] = o[q];
     if (codes) {
         auto code = [&](float A, int ma, int mb, int mc) { return A == 0.f ? 0u : ((m == ma && m == mb && m == mc && m < 254) ? (unsigned)(1 + m) : 255u); };
-        codes[t] = code(o[0], mx, my, mxy) | (code(o[2], mx, mz, mxz) << 8) | (code(o[4], my, mz, myz) << 16);
+        codes[t] = code(o[0], mx, my, mxy) | (code(o[2], mx, mz, mxz) << 8) | (code(o[4], my, mz, myz) << 16) | (m < 255 ? (unsigned)(1 + m) << 24 : 0u);
     }
 }
 // A, B of an edge whose four cells hold material m: tab[2 m], tab[2 m + 1]
