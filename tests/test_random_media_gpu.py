@@ -216,3 +216,28 @@ def test_compact_solid_state_equals_full_volume_arrays(seed, monkeypatch):
         for q, (x, y) in enumerate(zip(full, comp)):
             for n in x:
                 assert np.array_equal(x[n], y[n]), (q, n)
+
+
+@pytest.mark.parametrize('seed', [2, 7])
+def test_random_media_with_more_than_255_materials(seed):
+    """The sparse list's code word carries 1 + material of the cell in its fourth byte, the per-material edge codes stop at 253: a material
+    table of 306 rows (51 copies of the six rows, ids spread by position) sends cells through the id-array read and the explicit edge
+    coefficients instead. Copies are the same material: every output equals the six-row run bit for bit, and the oracle within the suite's bound."""
+    from babelbrain_amd import PropagationModel
+    a, k = random_case(seed)
+    mm, ml = a[0], a[1]
+    n = ml.shape[0]
+    copies = 51
+    ii, jj, kk = np.meshgrid(*[np.arange(s) for s in mm.shape], indexing='ij')
+    which = ((ii // 3 + 2 * (jj // 2) + 5 * kk) % copies).astype(np.uint32)
+    mm2 = (mm + n * which).astype(np.uint32)
+    ml2 = np.tile(ml, (copies, 1))
+    if not np.isscalar(k['QCorrection']):
+        k = dict(k, QCorrection=list(k['QCorrection']) * copies)       # per material
+    assert ml2.shape[0] > 255 and mm2.max() >= 255 and np.isin(mm2[mm2 >= 255] % n, [1, 3, 4]).any()
+    ref = PropagationModel().StaggeredFDTD_3D_with_relaxation(*a, SILENT=True, **random_case(seed)[1])
+    a2 = (mm2, ml2) + tuple(a[2:])
+    out = PropagationModel().StaggeredFDTD_3D_with_relaxation(*a2, SILENT=True, **k)
+    compare_runs(out, ref, 0.0, both=(k['SelRMSorPeak'] == 3))
+    orf = O.StaggeredFDTD_3D_with_relaxation(*a2, **k)
+    compare_runs(out, orf, 1e-5, both=(k['SelRMSorPeak'] == 3))
