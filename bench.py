@@ -475,13 +475,33 @@ def group_equals_single(args, ndev, dt_fn, variant):
             'wave_reached_last_slab': bool(one[:, :, -64:].max() > 0)}
 
 
+_LINE_OUT = None
+
+
+def claim_stdout():
+    """stdout carries exactly ONE JSON line. Libraries write to file descriptor 1 as well (gloo: "[Gloo] Rank 0 is connected to 1 peer
+    ranks", seen in front of the line of a 2-rank run): descriptor 1 is pointed at stderr for the life of the process and the line goes
+    to a duplicate of the original stdout (emit_line)."""
+    global _LINE_OUT
+    if _LINE_OUT is None:
+        sys.stdout.flush()
+        _LINE_OUT = os.fdopen(os.dup(1), 'w')
+        os.dup2(2, 1)
+
+
+def emit_line(line):
+    out = _LINE_OUT or sys.stdout
+    out.write(json.dumps(line) + '\n')
+    out.flush()
+
+
 def group_child(args):
     """`--group-child`: one group_run, its block as the only line on stdout."""
     from babelbrain_amd import _engine
     cfg, n1, n2, n3 = args.group_child
     out = group_run(args, cfg, (int(n1), int(n2), int(n3)), args.gpus, lambda ml, f, h, c: _engine.stable_dt(ml, f, True, h, c),
                     args.steps, args.warmup, max(args.windows, 1), args.variant, 'child process of the bench')
-    print(json.dumps(out))
+    emit_line(out)
 
 
 def group_in_child(args, config, N, ndev, steps, warmup, timeout=900):
@@ -575,7 +595,7 @@ def main_group(args):
         line['group_check'] = {'equals_single_domain': None, 'error': repr(e)}
     if not args.no_strong_c5 and not args.no_extra_strong:
         line['strong_c5'] = strong_c5(args, ndev, dt_fn, args.variant)
-    print(json.dumps(line))
+    emit_line(line)
 
 
 def placement_rule(args):
@@ -615,6 +635,7 @@ def measure(w, args, traffic):
 
 def main():
     args = parse()
+    claim_stdout()
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
@@ -838,7 +859,7 @@ def main():
         except Exception as e:   # the baseline is a reported extra; never lose the GPU line over it
             line['cpu_baseline'] = {'value': None, 'unit': 'Mvoxel-steps/s', 'cores': 0, 'kind': 'port', 'sample': 'failed: %r' % (e,)}
     if rank == 0:
-        print(json.dumps(line))
+        emit_line(line)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -218,3 +218,16 @@ def test_bench_strong_c5_block_anchors_itself(monkeypatch):
     fail = {'head': True}
     b = bench.strong_c5(args, 4, None, 0)
     assert b['value'] is None and 'peer access' in b['error'] and b['one_device_same_volume']['value'] == 70000.0
+
+
+def test_bench_stdout_carries_only_the_line(tmp_path):
+    """Libraries write to file descriptor 1 (gloo announces its connections there): after claim_stdout() such output lands on stderr and the
+    JSON line is the only thing on the process's stdout."""
+    import subprocess, sys, os, json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import os, sys; sys.path.insert(0, %r); import bench; bench.claim_stdout(); os.write(1, b'[Gloo] Rank 0 is connected\\n'); "
+            "print('chatter'); bench.emit_line({'metric': 'm', 'value': 1.0})" % root)
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert json.loads(r.stdout) == {'metric': 'm', 'value': 1.0}
+    assert '[Gloo] Rank 0 is connected' in r.stderr and 'chatter' in r.stderr
