@@ -1543,7 +1543,12 @@ __device__ __forceinline__ void stress_solid_body_g(const bfd_dev &d, const int4
 // CSS: Sxx, Syy and the three shear stresses of listed cells come from the compact arrays (bfd_dev::cssRow). Entry of a cell = base of its
 // row (per plane; own row and halo row: one scalar each, the halo columns: one table word per lane) + the listed cells before it in the row;
 // the bases a plane needs are fetched one iteration ahead, so the prefetch still issues without waiting for anything.
-template <bool ACC, bool PML, bool CSS>
+// WHOLE (compact form only): the engine holds a whole domain and updates V in place -- the stores share the plane bases of the loads and a
+// ghost plane's Sxz / Syz are the zeros nobody ever wrote, so the full-volume fallback and its two array bases go: ten scalar registers
+// fewer in a kernel that spilled twelve (each spilled one comes back through a v_readlane in every plane, and scalar address arithmetic
+// that no longer fits turns into vector instructions + readfirstlane). 0.400 -> 0.384 ms at the shear medium 512^3; a further flavour without
+// the peak accumulator (six spilled registers less) changed nothing measurable and was not kept. profiles/r5/velocity_solid_scalar_registers.txt
+template <bool ACC, bool PML, bool CSS, bool WHOLE = false>
 __device__ __forceinline__ void velocity_solid_body_g(const bfd_dev &d, const int4 &run, int tilesX, float (*sS)[5][LH * LW],
                                                       float *__restrict__ accP, float *__restrict__ pkP)
 {
@@ -1632,10 +1637,17 @@ __device__ __forceinline__ void velocity_solid_body_g(const bfd_dev &d, const in
             // a ghost plane (row base BFD_CSS_NONE) has no compact values: its Sxz / Syz come out of the full-volume arrays, where a Z-neighbour's
             // planes arrive (the sparse kernel keeps full-volume copies of the planes a neighbour reads); zeros at the ends of the domain
             const bool gm2 = rm2 != BFD_CSS_NONE, gm1 = rm1 != BFD_CSS_NONE, g1 = rbB != BFD_CSS_NONE;
+            if (WHOLE) {        // a ghost plane of a whole domain: zeros
+                xzm2 = glp(d.cSxz, em2, gm2 && (cm2 & BFD_CLS_EXZ) != 0); xzm1 = glp(d.cSxz, em1, gm1 && (cm1 & BFD_CLS_EXZ) != 0);
+                xz0 = glp(d.cSxz, e0, (c0 & BFD_CLS_EXZ) != 0); xzp1 = glp(d.cSxz, e1, g1 && (cB & BFD_CLS_EXZ) != 0);
+                yzm2 = glp(d.cSyz, em2, gm2 && (cm2 & BFD_CLS_EYZ) != 0); yzm1 = glp(d.cSyz, em1, gm1 && (cm1 & BFD_CLS_EYZ) != 0);
+                yz0 = glp(d.cSyz, e0, (c0 & BFD_CLS_EYZ) != 0); yzp1 = glp(d.cSyz, e1, g1 && (cB & BFD_CLS_EYZ) != 0);
+            } else {
             xzm2 = glp(gm2 ? d.cSxz : bxz - 2 * pl, gm2 ? em2 : c4, (cm2 & BFD_CLS_EXZ) != 0); xzm1 = glp(gm1 ? d.cSxz : bxz - pl, gm1 ? em1 : c4, (cm1 & BFD_CLS_EXZ) != 0);
             xz0 = glp(d.cSxz, e0, (c0 & BFD_CLS_EXZ) != 0); xzp1 = glp(g1 ? d.cSxz : bxz + pl, g1 ? e1 : c4, (cB & BFD_CLS_EXZ) != 0);
             yzm2 = glp(gm2 ? d.cSyz : byz - 2 * pl, gm2 ? em2 : c4, (cm2 & BFD_CLS_EYZ) != 0); yzm1 = glp(gm1 ? d.cSyz : byz - pl, gm1 ? em1 : c4, (cm1 & BFD_CLS_EYZ) != 0);
             yz0 = glp(d.cSyz, e0, (c0 & BFD_CLS_EYZ) != 0); yzp1 = glp(g1 ? d.cSyz : byz + pl, g1 ? e1 : c4, (cB & BFD_CLS_EYZ) != 0);
+            }
             sxx = glp(d.cSxx, e0, css_listed(c0)); syy = glp(d.cSyy, e0, css_listed(c0));
             sxy = glp(d.cSxy, e0, (c0 & BFD_CLS_EXY) != 0);
         } else {
@@ -1716,10 +1728,11 @@ __device__ __forceinline__ void velocity_solid_body_g(const bfd_dev &d, const in
             nrbA = rowbase(rowpA, kl + (more ? 2 : 1));
             nrbx = *(BFD_GA const unsigned *)((BFD_GA const char *)gbase(d.cssRow + (kl + (more ? 2 : 1)) * rs) + gpin(rtOfs));
             const bool gC = rbC != BFD_CSS_NONE;        // plane kl+2 may be the ghost plane nk: full-volume arrays there (uniform choice)
-            pXZ = more && (cC & BFD_CLS_EXZ); pYZ = more && (cC & BFD_CLS_EYZ);
+            pXZ = more && (cC & BFD_CLS_EXZ) && (!WHOLE || gC); pYZ = more && (cC & BFD_CLS_EYZ) && (!WHOLE || gC);
             pNN = more && lB; pXY = more && (cB & BFD_CLS_EXY);
-            const unsigned eZ = gC ? eC : c4;
-            nxzR = gl4(gC ? d.cSxz : d.Sxz + ko + pl + kn, pXZ ? eZ : 0u); nyzR = gl4(gC ? d.cSyz : d.Syz + ko + pl + kn, pYZ ? eZ : 0u);
+            const unsigned eZ = (WHOLE || gC) ? eC : c4;
+            if (WHOLE) { nxzR = gl4(d.cSxz, pXZ ? eZ : 0u); nyzR = gl4(d.cSyz, pYZ ? eZ : 0u); }
+            else { nxzR = gl4(gC ? d.cSxz : d.Sxz + ko + pl + kn, pXZ ? eZ : 0u); nyzR = gl4(gC ? d.cSyz : d.Syz + ko + pl + kn, pYZ ? eZ : 0u); }
             nxxR = gl4(d.cSxx, pNN ? eB : 0u); nyyR = gl4(d.cSyy, pNN ? eB : 0u); nxyR = gl4(d.cSxy, pXY ? eB : 0u);
             const unsigned eA = (rbA + css_rank(ta.ok && css_listed(hcA))) * 4u, eH = entryB(rbA, rbx, hcB) * 4u;
             const bool flA = substA && (hcA & BFD_CLS_FLUID), flB = substB && (hcB & BFD_CLS_FLUID);
@@ -1745,7 +1758,7 @@ __device__ __forceinline__ void velocity_solid_body_g(const bfd_dev &d, const in
         const unsigned nmx = gl2(d.mat + ko + kn, cx2), nmy = gl2(d.mat + ko + kn, cy2);
         const unsigned nhcA = gl1(d.cls + ko + pl + kn, offA), nhcB = gl1(d.cls + ko + pl + kn, offB);
 
-        float *wVx = d.VxW + ko, *wVy = d.VyW + ko, *wVz = d.VzW + ko;
+        float *wVx = (WHOLE ? d.Vx : d.VxW) + ko, *wVy = (WHOLE ? d.Vy : d.VyW) + ko, *wVz = (WHOLE ? d.Vz : d.VzW) + ko;
         if (valid) {
             const float sxx = sS[b][0][own], syy = sS[b][1][own], sxy = sS[b][2][own];
             if (ACC) {
@@ -1832,7 +1845,7 @@ __global__ __launch_bounds__(NTHREADS, SOLID_STRESS_WAVES_PER_SIMD) void stress_
 #ifndef SOLID_VELOCITY_WAVES_PER_SIMD
 #define SOLID_VELOCITY_WAVES_PER_SIMD 4      // lower bound of the plain flavour (78-80 VGPRs since round 4: 6 waves); the absorbing-layer flavour needs 105 registers and gets 4
 #endif
-template <bool ACC, bool PML, bool CSS>
+template <bool ACC, bool PML, bool CSS, bool WHOLE = false>
 __global__ __launch_bounds__(NTHREADS, PML ? 4 : SOLID_VELOCITY_WAVES_PER_SIMD) void velocity_solid(bfd_dev d, int tilesX, int nblocks, const int *__restrict__ xmap,
                                                         float *__restrict__ accP, float *__restrict__ pkP,
                                                         const int4 *__restrict__ runs)
@@ -1846,7 +1859,7 @@ __global__ __launch_bounds__(NTHREADS, PML ? 4 : SOLID_VELOCITY_WAVES_PER_SIMD) 
     if (ri < 0) return;
     const int4 run = runs[ri];
 #ifndef BFD_VELOCITY_SOLID_FLAT      // default since round 4: GLOBAL loads, prefetch without branches (0.405 -> 0.378 ms at the shear medium 512^3)
-    velocity_solid_body_g<ACC, PML, CSS>(d, run, tilesX, sS, accP, pkP);
+    velocity_solid_body_g<ACC, PML, CSS, WHOLE>(d, run, tilesX, sS, accP, pkP);
 #else
     static_assert(!CSS, "the FLAT body has no compact form");
     velocity_solid_body<ACC, PML>(d, run, tilesX, sS, accP, pkP);
@@ -2541,6 +2554,11 @@ void bfd_launch_velocity_v2(const bfd_dev &d, hipStream_t s0, float *accP, float
                 const int cnt = a1 - a0;
                 if (cnt <= 0) return;
 #ifndef BFD_VELOCITY_SOLID_FLAT
+                if (d.cssRow && d.VxW == d.Vx && d.VyW == d.Vy && d.VzW == d.Vz && d.k0 == 0 && d.nk == d.N3) {       // a whole domain, V in place
+                    if (pml) { if (acc) BFD_LAUNCH_X((velocity_solid<true, true, true, true>), cnt, m, accP, pkP, base + a0); else BFD_LAUNCH_X((velocity_solid<false, true, true, true>), cnt, m, accP, pkP, base + a0); }
+                    else { if (acc) BFD_LAUNCH_X((velocity_solid<true, false, true, true>), cnt, m, accP, pkP, base + a0); else BFD_LAUNCH_X((velocity_solid<false, false, true, true>), cnt, m, accP, pkP, base + a0); }
+                    return;
+                }
                 if (d.cssRow) {
                     if (pml) { if (acc) BFD_LAUNCH_X((velocity_solid<true, true, true>), cnt, m, accP, pkP, base + a0); else BFD_LAUNCH_X((velocity_solid<false, true, true>), cnt, m, accP, pkP, base + a0); }
                     else { if (acc) BFD_LAUNCH_X((velocity_solid<true, false, true>), cnt, m, accP, pkP, base + a0); else BFD_LAUNCH_X((velocity_solid<false, false, true>), cnt, m, accP, pkP, base + a0); }
