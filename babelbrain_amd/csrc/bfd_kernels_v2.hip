@@ -2554,7 +2554,8 @@ void bfd_launch_velocity_v2(const bfd_dev &d, hipStream_t s0, float *accP, float
                 const int cnt = a1 - a0;
                 if (cnt <= 0) return;
 #ifndef BFD_VELOCITY_SOLID_FLAT
-                if (d.cssRow && d.VxW == d.Vx && d.VyW == d.Vy && d.VzW == d.Vz && d.k0 == 0 && d.nk == d.N3) {       // a whole domain, V in place
+                // a whole domain, or the interior runs of a Z-slab (part 2 of a split half-step: they reach no ghost plane), V in place
+                if (d.cssRow && d.VxW == d.Vx && d.VyW == d.Vy && d.VzW == d.Vz && ((d.k0 == 0 && d.nk == d.N3) || part == 2)) {
                     if (pml) { if (acc) BFD_LAUNCH_X((velocity_solid<true, true, true, true>), cnt, m, accP, pkP, base + a0); else BFD_LAUNCH_X((velocity_solid<false, true, true, true>), cnt, m, accP, pkP, base + a0); }
                     else { if (acc) BFD_LAUNCH_X((velocity_solid<true, false, true, true>), cnt, m, accP, pkP, base + a0); else BFD_LAUNCH_X((velocity_solid<false, false, true, true>), cnt, m, accP, pkP, base + a0); }
                     return;
