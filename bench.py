@@ -807,7 +807,7 @@ def main():
             rs = measure(ws, args, profile_traffic('C2', dims[0], dims[1], dims[2], args.variant))
             line['shear_workload'] = {'workload': 'C2 medium (3 materials: water, cortical bone cS=%g m/s, brain) on %dx%dx%d, single source, same K/W' % (ws.a[1][1][2], *dims),
                                       'value': rs['value'], 'unit': 'Mvoxel-steps/s', 'ms_per_step': rs['ms_per_step'], 'device_ms_per_step': rs['device_ms_per_step'],
-                                      'half_steps_ms': rs['half_steps'], 'tiles': ws.eng.tile_counts(), 'roofline_step': rs.get('roofline_step'),
+                                      'half_steps_ms': rs['half_steps'], 'tiles': ws.eng.tile_counts(), 'array_placement': ws.eng.placement_note(), 'roofline_step': rs.get('roofline_step'),
                                       'roofline_kernels': rs.get('roofline_kernels')}
             ws.close()
         except Exception as e:
