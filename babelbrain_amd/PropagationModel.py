@@ -88,12 +88,20 @@ def _device_list(spec):
 
 
 class PropagationModel:
-    def __init__(self, device=None, kernelVariant=0, devices=None):
+    def __init__(self, device=None, kernelVariant=0, devices=None, keepPlacementCache=None):
         """device: HIP ordinal of a single-device run. devices: list of ordinals (or 'all'): ONE call is then split into
         Z-slabs over those devices inside the library (bfd_group_*), the return values are the whole-domain ones. The
         environment variable BABELFDTD_DEVICES ('all' or '0,1,2,3') does the same for a caller that cannot pass arguments
-        (the reference builds its module-global PModel without any, BASE:43)."""
+        (the reference builds its module-global PModel without any, BASE:43).
+        keepPlacementCache: the library keeps the device buffers a placement search found (bfd_placement_cache_*) for the next
+        engine of the process. By default a solver call gives them back when it returns, so that nothing idle of this library
+        sits on the device beside whatever the process does next (a thermal step, another library); True (or
+        BABELFDTD_PLACEMENT_CACHE_KEEP=1) keeps them between calls -- what the two or three back-to-back calls of one
+        RUN_SIMULATION (BASE:2338, 2374, 2401) want; release them with _engine.placement_cache_release()."""
         import os
+        if keepPlacementCache is None:
+            keepPlacementCache = os.environ.get('BABELFDTD_PLACEMENT_CACHE_KEEP', '0') not in ('', '0')
+        self._keepPlacementCache = bool(keepPlacementCache)
         self._device = device
         self._devices = _device_list(devices if devices is not None else os.environ.get('BABELFDTD_DEVICES'))
         self._kernelVariant = kernelVariant
@@ -199,6 +207,8 @@ class PropagationModel:
             out.append(InputParam)
         finally:
             eng.close()
+            if not self._keepPlacementCache:
+                _engine.placement_cache_release()
         if not SILENT and self.last_timing['total_ms'] > 0:
             print('HIP FDTD: %d steps, %.1f Mvoxel-steps/s' % (
                 nt, self.last_timing['voxel_steps'] / self.last_timing['total_ms'] / 1e3))
@@ -251,6 +261,8 @@ class PropagationModel:
             out.append(InputParam)
         finally:
             grp.close()
+            if not self._keepPlacementCache:
+                _engine.placement_cache_release()
         if not SILENT and self.last_timing['total_ms'] > 0:
             print('HIP FDTD: %d steps on %d slabs, %.1f Mvoxel-steps/s' % (
                 nt, len(devices), self.last_timing['voxel_steps'] / self.last_timing['total_ms'] / 1e3))

@@ -16,6 +16,7 @@
 #include <thread>
 #include <hipcub/hipcub.hpp>
 
+extern "C" int64_t bfd_placement_cache_release(void);
 static thread_local std::string g_err;
 void bfd_set_error(const std::string &s) { g_err = s; }
 #define BFD_FAIL(code, msg) do { bfd_set_error(msg); return (code); } while (0)
@@ -177,36 +178,57 @@ __device__ __forceinline__ bool normal_collapsed(const bfd_dev &d, long c)
 }
 
 // a value that exists only at solid cells: from the compact arrays when the solid state is compact (0 where the cell is not listed:
-// a reflector, or a fluid cell asked for a shear stress), else from the full-volume array
-__device__ __forceinline__ float solid_value(const bfd_dev &d, const float *full, const float *comp, long c)
+// a reflector, or a fluid cell asked for a shear stress), else from the full-volume array. KNOWN: the caller has the cell's list entry
+// already (e, -1 = not listed) -- the sensor kernels take it from a per-sensor table, accumulate_maps from the row table and a ballot --
+// otherwise css_index walks the class bytes of the row
+template <bool KNOWN>
+__device__ __forceinline__ float solid_value(const bfd_dev &d, const float *full, const float *comp, long c, long e)
 {
     if (!d.cssRow) return full[c];
-    const long e = css_index(d, c);
+    if (!KNOWN) e = css_index(d, c);
     return e >= 0 ? comp[e] : 0.0f;
 }
-__device__ __forceinline__ float map_value(const bfd_dev &d, int sel, long c)
+template <bool KNOWN>
+__device__ __forceinline__ float map_value_t(const bfd_dev &d, int sel, long c, long e)
 {
     switch (sel) {
     case BFD_MAP_VX: return d.Vx[c];
     case BFD_MAP_VY: return d.Vy[c];
     case BFD_MAP_VZ: return d.Vz[c];
-    case BFD_MAP_SIGMAXX: return normal_collapsed(d, c) ? d.Szz[c] : solid_value(d, d.Sxx, d.cSxx, c);     // a fluid cell keeps one copy of its normal stresses
-    case BFD_MAP_SIGMAYY: return normal_collapsed(d, c) ? d.Szz[c] : solid_value(d, d.Syy, d.cSyy, c);
+    case BFD_MAP_SIGMAXX: return normal_collapsed(d, c) ? d.Szz[c] : solid_value<KNOWN>(d, d.Sxx, d.cSxx, c, e);     // a fluid cell keeps one copy of its normal stresses
+    case BFD_MAP_SIGMAYY: return normal_collapsed(d, c) ? d.Szz[c] : solid_value<KNOWN>(d, d.Syy, d.cSyy, c, e);
     case BFD_MAP_SIGMAZZ: return d.Szz[c];
-    case BFD_MAP_SIGMAXY: return solid_value(d, d.Sxy, d.cSxy, c);
-    case BFD_MAP_SIGMAXZ: return solid_value(d, d.Sxz, d.cSxz, c);
-    case BFD_MAP_SIGMAYZ: return solid_value(d, d.Syz, d.cSyz, c);
+    case BFD_MAP_SIGMAXY: return solid_value<KNOWN>(d, d.Sxy, d.cSxy, c, e);
+    case BFD_MAP_SIGMAXZ: return solid_value<KNOWN>(d, d.Sxz, d.cSxz, c, e);
+    case BFD_MAP_SIGMAYZ: return solid_value<KNOWN>(d, d.Syz, d.cSyz, c, e);
     case BFD_MAP_PRESSURE: {
         const float zz = d.Szz[c];
         if (normal_collapsed(d, c)) return -((zz + zz) + zz) * (1.0f / 3.0f);
         float xx, yy;
-        if (d.cssRow) { const long e = css_index(d, c); xx = e >= 0 ? d.cSxx[e] : 0.0f; yy = e >= 0 ? d.cSyy[e] : 0.0f; }
+        if (d.cssRow) { if (!KNOWN) e = css_index(d, c); xx = e >= 0 ? d.cSxx[e] : 0.0f; yy = e >= 0 ? d.cSyy[e] : 0.0f; }
         else { xx = d.Sxx[c]; yy = d.Syy[c]; }
         const float s = (xx + yy) + zz;
         return -s * (1.0f / 3.0f);
     }
     default: return 0.0f;
     }
+}
+__device__ __forceinline__ float map_value(const bfd_dev &d, int sel, long c) { return map_value_t<false>(d, sel, c, -1); }
+// value of map `sel` as the outputs define it (ALLV = |V|) with the cell's list entry known
+__device__ __forceinline__ float output_value(const bfd_dev &d, int sel, long c, long e)
+{
+    if (sel == BFD_MAP_ALLV) { const float x = d.Vx[c], y = d.Vy[c], z = d.Vz[c]; return sqrtf((x * x + y * y) + z * z); }
+    return map_value_t<true>(d, sel, c, e);
+}
+__device__ __forceinline__ bool map_needs_entry(int sel)
+{
+    return sel == BFD_MAP_SIGMAXX || sel == BFD_MAP_SIGMAYY || sel == BFD_MAP_SIGMAXY || sel == BFD_MAP_SIGMAXZ || sel == BFD_MAP_SIGMAYZ || sel == BFD_MAP_PRESSURE;
+}
+// list entries of the sensor voxels (compact solid state), resolved once per list: a capture is a plain gather again
+__global__ void sensor_entries(bfd_dev d, const uint32_t *__restrict__ lin, long nSens, int *__restrict__ out)
+{
+    for (long s = (long)blockIdx.x * blockDim.x + threadIdx.x; s < nSens; s += (long)gridDim.x * blockDim.x)
+        out[s] = (int)css_index(d, (long)lin[s]);
 }
 // fluid cells keep only Szz/Rzz of their identical normal stresses: restore the other copies
 __global__ void expand_normal(bfd_dev d, long n)
@@ -235,21 +257,35 @@ __device__ __forceinline__ float map_sq(const bfd_dev &d, int sel, long c)
 
 struct SelList { int n; int sel[BFD_MAP_COUNT]; int skip[BFD_MAP_COUNT]; };
 
-// RMS / peak accumulation outside the absorbing layer (generic path, any map selection)
+// RMS / peak accumulation outside the absorbing layer (generic path, any map selection). A wave = 64 consecutive x cells of one row: with a
+// compact solid state the cell's list entry is the row-table base of this x tile + the listed lanes below (one ballot), once for all selections
 __global__ __launch_bounds__(256) void accumulate_maps(bfd_dev d, SelList L, float *__restrict__ acc, float *__restrict__ pk, long nloc)
 {
     const int i = blockIdx.x * 64 + threadIdx.x;
     const int j = blockIdx.y * 4 + threadIdx.y;
     const int kl = blockIdx.z;
     const int k = d.k0 + kl;
-    if (i < d.ND || i >= d.N1 - d.ND || j < d.ND || j >= d.N2 - d.ND || k < d.ND || k >= d.N3 - d.ND) return;
+    const bool inDomain = i < d.N1 && j < d.N2;
     const long c = (long)kl * d.plane + (long)j * d.N1 + i;
+    long e = -1;
+    if (d.cssRow) {
+        bool need = false;
+        for (int q = 0; q < L.n; q++) need = need || (!L.skip[q] && map_needs_entry(L.sel[q]));
+        if (need) {                                                      // block-uniform
+            const bool listed = inDomain && css_listed(d.cls[c]);
+            const unsigned rank = css_rank(listed);
+            const unsigned rb = j < d.N2 ? d.cssRow[((long)(kl + 2) * d.N2 + j) * d.cssStride + blockIdx.x] : BFD_CSS_NONE;
+            if (listed && rb != BFD_CSS_NONE) e = (long)rb + rank;
+        }
+    }
+    if (i < d.ND || i >= d.N1 - d.ND || j < d.ND || j >= d.N2 - d.ND || k < d.ND || k >= d.N3 - d.ND) return;
     for (int q = 0; q < L.n; q++) {
         if (L.skip[q]) continue;    // accumulated inside the velocity kernel
-        if (acc) acc[q * nloc + c] = acc[q * nloc + c] + map_sq(d, L.sel[q], c);
+        const float v = output_value(d, L.sel[q], c, e);
+        if (acc) acc[q * nloc + c] = acc[q * nloc + c] + (L.sel[q] == BFD_MAP_ALLV ? map_sq(d, BFD_MAP_ALLV, c) : v * v);
         if (pk) {
-            const float v = (L.sel[q] == BFD_MAP_ALLV) ? sqrtf(map_sq(d, BFD_MAP_ALLV, c)) : fabsf(map_value(d, L.sel[q], c));
-            if (v > pk[q * nloc + c]) pk[q * nloc + c] = v;
+            const float a = fabsf(v);
+            if (a > pk[q * nloc + c]) pk[q * nloc + c] = a;
         }
     }
 }
@@ -264,30 +300,30 @@ __global__ void last_map(bfd_dev d, int sel, float *__restrict__ out, long n)
         out[v] = (sel == BFD_MAP_ALLV) ? sqrtf(map_sq(d, BFD_MAP_ALLV, v)) : map_value(d, sel, v);
 }
 
-// sensors: out[q][col][s]
-__global__ void record_sensors(bfd_dev d, SelList L, const uint32_t *__restrict__ lin, long nSens, float *__restrict__ out,
-                               int col, int nTs)
+// sensors: out[q][col][s]; ent = the sensors' list entries (compact solid state) or null
+__global__ void record_sensors(bfd_dev d, SelList L, const uint32_t *__restrict__ lin, const int *__restrict__ ent, long nSens,
+                               float *__restrict__ out, int col, int nTs)
 {
     for (long s = (long)blockIdx.x * blockDim.x + threadIdx.x; s < nSens; s += (long)gridDim.x * blockDim.x) {
         const long c = lin[s];
-        for (int q = 0; q < L.n; q++) {
-            const float v = (L.sel[q] == BFD_MAP_ALLV) ? sqrtf(map_sq(d, BFD_MAP_ALLV, c)) : map_value(d, L.sel[q], c);
-            out[((long)q * nTs + col) * nSens + s] = v;
-        }
+        const long e = (ent && !normal_collapsed(d, c)) ? (long)ent[s] : -1;
+        for (int q = 0; q < L.n; q++)
+            out[((long)q * nTs + col) * nSens + s] = output_value(d, L.sel[q], c, e);
     }
 }
 // sensorMode 1: the sample of this step goes straight into the running single-bin DFT sums and peaks of its sensor
 // (same arithmetic, sample by sample, as dft_series applies to a stored series)
-__global__ void accumulate_sensor_dft(bfd_dev d, SelList L, const uint32_t *__restrict__ lin, long nSens, double *__restrict__ acc,
-                                      float *__restrict__ pk, int col, int nTs, int bin)
+__global__ void accumulate_sensor_dft(bfd_dev d, SelList L, const uint32_t *__restrict__ lin, const int *__restrict__ ent, long nSens,
+                                      double *__restrict__ acc, float *__restrict__ pk, int col, int nTs, int bin)
 {
     const int r = (int)(((long)bin * col) % nTs);                 // exact phase index
     double sn, cs;
     sincospi(2.0 * (double)r / (double)nTs, &sn, &cs);
     for (long s = (long)blockIdx.x * blockDim.x + threadIdx.x; s < nSens; s += (long)gridDim.x * blockDim.x) {
         const long c = lin[s];
+        const long e = (ent && !normal_collapsed(d, c)) ? (long)ent[s] : -1;
         for (int q = 0; q < L.n; q++) {
-            const float x = (L.sel[q] == BFD_MAP_ALLV) ? sqrtf(map_sq(d, BFD_MAP_ALLV, c)) : map_value(d, L.sel[q], c);
+            const float x = output_value(d, L.sel[q], c, e);
             double *a = acc + 2 * ((long)q * nSens + s);
             a[0] += (double)x * cs; a[1] -= (double)x * sn;
             float *p = pk + (long)q * nSens + s;
@@ -404,12 +440,23 @@ static void drop_step_graph(bfd_sim *s)
     s->stepDevValid = false;
 }
 
+// hipMalloc that gives idle buffers of the placement cache (placement_cache_*) back to the device before it reports that memory ran out
+static hipError_t malloc_or_release_cache(void **q, size_t bytes)
+{
+    hipError_t e = hipMalloc(q, bytes);
+    if (e == hipErrorOutOfMemory || e == hipErrorMemoryAllocation) {
+        (void)hipGetLastError();
+        if (bfd_placement_cache_release() > 0) e = hipMalloc(q, bytes);
+    }
+    return e;
+}
+
 template <typename T>
 int dev_alloc(bfd_sim *s, T **p, size_t count, bool zero = true)
 {
     void *q = nullptr;
     const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
-    BFD_HIP(hipMalloc(&q, bytes));
+    BFD_HIP(malloc_or_release_cache(&q, bytes));
     if (zero) BFD_HIP(hipMemsetAsync(q, 0, bytes, s->stream));
     s->allocs.push_back(q);
     s->devBytes += (int64_t)bytes;
@@ -613,6 +660,8 @@ int bfd_material_tables(int32_t nMat, const double *matlist, const double *qcorr
     return 0;
 }
 
+static bool placement_cache_put(int device, size_t bytes, void *p);
+static void placement_cache_evict_other_sizes(int device, size_t bytes);
 int bfd_create(const bfd_config *cfg, bfd_sim **out)
 {
     if (!cfg || !out) BFD_FAIL(-1, "bfd_create: null argument");
@@ -644,6 +693,7 @@ int bfd_create(const bfd_config *cfg, bfd_sim **out)
     s->nSources = s->lengthSource = 0;
     s->pulseHost = nullptr; s->tileSteps = s->nTiles = 0;
     for (int b = 0; b < 2; b++) { s->tileDev[b] = s->tilePinned[b] = nullptr; s->tileLoaded[b] = s->tilePacked[b] = -1; s->evTile[b] = nullptr; s->evTileUsed[b] = false; for (int q = 0; q < 2; q++) { s->evRead[b][q] = nullptr; s->evReadUsed[b][q] = false; } }
+    s->sensEnt = nullptr; s->sensEntValid = false;
     s->nSensors = 0; s->sensLin = nullptr; s->sensOut = nullptr; s->dftAcc = nullptr; s->dftPk = nullptr; s->dftBin = 0;
     s->acc = s->pk = nullptr; s->timing = s->perKernel = false;
     s->tables = nullptr; s->profiles = nullptr; s->cmax = 0;
@@ -665,6 +715,7 @@ int bfd_create(const bfd_config *cfg, bfd_sim **out)
     d.ND = cfg->NDelta; d.P = P; d.plane = cfg->N1 * cfg->N2;
     s->nloc = (size_t)d.plane * d.nk;
     s->nalloc = (size_t)d.plane * (d.nk + 4);
+    placement_cache_evict_other_sizes(cfg->device, s->nalloc * sizeof(float));
 
     int rc = 0;
     float **fp[15] = {&d.Vx, &d.Vy, &d.Vz, &d.Sxx, &d.Syy, &d.Szz, &d.Sxy, &d.Sxz, &d.Syz,
@@ -715,7 +766,6 @@ int bfd_create(const bfd_config *cfg, bfd_sim **out)
     return 0;
 }
 
-static bool placement_cache_put(int device, size_t bytes, void *p);
 void bfd_destroy(bfd_sim *s)
 {
     if (!s) return;
@@ -960,6 +1010,7 @@ int bfd_set_sensor_map(bfd_sim *s, const uint32_t *map, int64_t s1, int64_t s2, 
     if (e == hipSuccess) {
         s->nSensors = count;
         dev_release(s, &s->sensLin); dev_release(s, &s->sensOut); dev_release(s, &s->dftAcc); dev_release(s, &s->dftPk);
+        dev_release(s, &s->sensEnt); s->sensEntValid = false;
         rc = dev_alloc(s, &s->sensLin, (size_t)count, false);
         if (!rc && count) e = hipMemcpyAsync(s->sensLin, sel, (size_t)count * sizeof(uint32_t), hipMemcpyDeviceToDevice, s->stream);
         if (!rc && s->nSelS && s->nTs > 0) {
@@ -1018,6 +1069,7 @@ static int build_tile_lists(bfd_sim *s)
         BFD_HIP(hipStreamSynchronize(s->stream));
         oldCells = s->tiles.shearCells; s->tiles.shearCells = nullptr;       // released below, after the new list has taken the values over
     }
+    s->sensEntValid = false;
     s->d.cssRow = nullptr; s->d.cSxx = s->d.cSyy = s->d.cSxy = s->d.cSxz = s->d.cSyz = s->d.cRxx = s->d.cRyy = s->d.cRxy = s->d.cRxz = s->d.cRyz = nullptr;
     dev_release(s, &s->tiles.cssRow); dev_release(s, &s->tiles.css); s->tiles.cssCap = 0; s->tiles.cssHosted = false;
     dev_release(s, &s->tiles.runsAll); s->tiles.nAll = s->tiles.nAllB = 0;
@@ -1375,7 +1427,10 @@ static int build_tile_lists(bfd_sim *s)
             const size_t g = 2 * (size_t)s->d.plane;
             float *newComp[10] = {s->d.cSxx, s->d.cSyy, s->d.cSxy, s->d.cSxz, s->d.cSyz, s->d.cRxx, s->d.cRyy, s->d.cRxy, s->d.cRxz, s->d.cRyz};
             float *full[10] = {s->d.Sxx, s->d.Syy, s->d.Sxy, s->d.Sxz, s->d.Syz, s->d.Rxx, s->d.Ryy, s->d.Rxy, s->d.Rxz, s->d.Ryz};
-            hipError_t e2 = s->d.cssRow ? hipMalloc((void **)&tmp, s->nalloc * sizeof(float)) : hipSuccess;
+            hipError_t e2 = s->d.cssRow ? malloc_or_release_cache((void **)&tmp, s->nalloc * sizeof(float)) : hipSuccess;
+            // the new state is not compact (no solid cell left, or the form was switched off): the full-volume arrays take over, and the owned planes
+            // of buffers that hosted compact arrays hold list-ordered values, not fields: cleared before the old values are scattered into them
+            for (int a = 0; a < 10 && e2 == hipSuccess && !s->d.cssRow; a++) e2 = hipMemsetAsync(full[a], 0, s->nloc * sizeof(float), s->stream);
             for (int a = 0; a < 10 && e2 == hipSuccess; a++) {
                 if (s->d.cssRow) {
                     e2 = hipMemsetAsync(tmp, 0, s->nalloc * sizeof(float), s->stream);
@@ -1501,11 +1556,27 @@ static int build_tile_lists(bfd_sim *s)
 struct CachedBuf { int device; size_t bytes; void *p; };
 static std::mutex g_cacheMutex;
 static std::vector<CachedBuf> g_cache;
+// at most BABELFDTD_PLACEMENT_CACHE_GIB (default 48) and never more than an eighth of the device's memory
 static size_t placement_cache_cap()
 {
     double gib = 48.0;
     if (const char *ev = getenv("BABELFDTD_PLACEMENT_CACHE_GIB")) gib = atof(ev);
-    return gib > 0 ? (size_t)(gib * 1073741824.0) : 0;
+    size_t cap = gib > 0 ? (size_t)(gib * 1073741824.0) : 0;
+    size_t freeB = 0, totalB = 0;
+    if (cap && hipMemGetInfo(&freeB, &totalB) == hipSuccess && totalB) cap = std::min(cap, totalB / 8);
+    else (void)hipGetLastError();
+    return cap;
+}
+// a new engine on `device` whose state arrays have `bytes` each: cached buffers of any other size are of no use to it and go back to the device
+// before it allocates (they used to wait for the next bfd_destroy)
+static void placement_cache_evict_other_sizes(int device, size_t bytes)
+{
+    std::lock_guard<std::mutex> lk(g_cacheMutex);
+    for (size_t q = 0; q < g_cache.size();) {
+        if (g_cache[q].device == device && g_cache[q].bytes != bytes) { hipFree(g_cache[q].p); g_cache.erase(g_cache.begin() + q); }
+        else q++;
+    }
+    (void)hipGetLastError();
 }
 static size_t placement_cache_bytes(int device)
 {
@@ -1528,6 +1599,7 @@ static std::vector<void *> placement_cache_take(int device, size_t bytes)
 static bool placement_cache_put(int device, size_t bytes, void *p)
 {
     std::lock_guard<std::mutex> lk(g_cacheMutex);
+    hipSetDevice(device);
     const size_t cap = placement_cache_cap();
     // buffers of another size on this device are of no use to the caller that is coming: they make room first
     for (size_t q = 0; q < g_cache.size();) {
@@ -1680,17 +1752,27 @@ static int choose_placement(bfd_sim *s)
     // what this process keeps from an earlier engine's search (placement_cache_*) is the engine's to take, not somebody else's memory
     const size_t mine = (size_t)s->devBytes + placement_cache_bytes(s->cfg.device);
     const size_t others = total0 > free0 + mine ? total0 - free0 - mine : 0;
-    size_t heldCap = free0 > ((size_t)48 << 30) ? std::min((size_t)192 << 30, free0 - ((size_t)48 << 30)) : 0;
+    // default bound: 192 GiB, never more than two thirds of what was free on entry (an empty 288 GB device keeps 90 GiB for whoever comes), always
+    // leaving 48 GiB; while it walks the search watches the device's free memory: allocations that are neither this engine's nor the search's
+    // own (another process that started at the same moment) end it at once and everything held goes back
+    size_t heldCap = free0 > ((size_t)48 << 30) ? std::min(std::min((size_t)192 << 30, free0 / 3 * 2), free0 - ((size_t)48 << 30)) : 0;
+    bool defaultRule = true;
     std::string capNote;
     if (others > ((size_t)6 << 30)) { heldCap = 0; char q[96]; snprintf(q, sizeof q, "; device shared (%.0f GiB of other allocations): no search beyond the own buffers", others / 1073741824.0); capNote = q; }
     if (const char *ev = getenv("BABELFDTD_PLACEMENT_SEARCH_GIB")) {           // the owner of the device raises (or lowers) the default bound without code
         const double gib = atof(ev);
         if (gib >= 0 && others <= ((size_t)6 << 30)) heldCap = std::min((size_t)(gib * 1073741824.0), free0 > ((size_t)48 << 30) ? free0 - ((size_t)48 << 30) : 0);
     }
-    if (s->placementLimit >= 0) { heldCap = (size_t)s->placementLimit; capNote.clear(); }
-    if (const char *ev = getenv("BFD_PLACEMENT_SEARCH_MB")) { probeTells = true; heldCap = (size_t)atol(ev) << 20; capNote.clear(); }   // tests: walk a little on any grid
+    if (s->placementLimit >= 0) { heldCap = (size_t)s->placementLimit; capNote.clear(); defaultRule = false; }
+    if (const char *ev = getenv("BFD_PLACEMENT_SEARCH_MB")) { probeTells = true; heldCap = (size_t)atol(ev) << 20; capNote.clear(); defaultRule = false; }   // tests: walk a little on any grid
     if (heldCap == 0) probeTells = false;
     int nCached = 0;
+    // whatever leaves this function early gives back what the search holds: the misses, the spacers and the fresh buffers no array has taken
+    struct GiveBack {
+        std::vector<void *> *held; std::vector<Buf> *pool; bool armed;
+        ~GiveBack() { if (!armed) return; for (void *h : *held) hipFree(h); for (const Buf &b : *pool) if (b.fresh) hipFree(b.base); (void)hipGetLastError(); }
+    } giveBack{&held, &pool, true};
+    size_t ownFreshBytes = 0;                                                  // fresh buffers drawn below (the cached ones are part of `mine`)
     if ((need[0] > 0 || need[1] > 0) && tSame >= 0.05f) {                      // first what an earlier engine of this process found
         for (void *cp : placement_cache_take(s->cfg.device, bytes)) {
             float *c = (float *)cp;
@@ -1703,13 +1785,17 @@ static int choose_placement(bfd_sim *s)
     while ((need[0] > 0 || need[1] > 0) && !gaveUp && probeTells) {            // draw candidates until both sides have enough
         size_t freeB = 0, totalB = 0;
         if (hipMemGetInfo(&freeB, &totalB) != hipSuccess || freeB < 2 * bytes + totalB / 8 || heldBytes + bytes > heldCap) { gaveUp = true; break; }
+        if (defaultRule) {
+            const size_t known = mine + heldBytes + ownFreshBytes + others;
+            if (totalB > freeB + known && totalB - freeB - known > ((size_t)6 << 30)) { gaveUp = true; capNote += "; somebody else began to allocate on the device: search ended"; break; }
+        }
         float *c = nullptr;
         if (hipMalloc((void **)&c, bytes) != hipSuccess) { (void)hipGetLastError(); gaveUp = true; break; }
         if (hipMemsetAsync(c, 0, bytes, s->stream) != hipSuccess) { hipFree(c); gaveUp = true; break; }
         const float t = pair(repOf[M], c + g);
         if (t <= 0) { hipFree(c); gaveUp = true; break; }
         const int side = t >= thr ? 0 : 1;
-        if (need[side] > 0) { pool.push_back({c, side == 0 ? M : 100 + nFresh, true}); need[side]--; nFresh++; continue; }
+        if (need[side] > 0) { pool.push_back({c, side == 0 ? M : 100 + nFresh, true}); need[side]--; nFresh++; ownFreshBytes += bytes; continue; }
         held.push_back(c); heldBytes += bytes;
         // a region is ~90 GiB wide: walk on in growing strides (an unprobed throw-away block as large as everything held so
         // far, 4 GiB at most: hipMalloc of 4 GiB takes 0.3 ms, of 16 GiB 650 ms -- scripts/r3/malloc_cost.hip) instead of one
@@ -1742,6 +1828,8 @@ static int choose_placement(bfd_sim *s)
         taken[p] = 1; slotBuf[a] = p;
     }
     BFD_HIP(hipStreamSynchronize(s->stream));
+    giveBack.armed = false;                                                   // from here on every buffer has an owner again
+    struct FreeHeld { std::vector<void *> *held; ~FreeHeld() { for (void *h : *held) hipFree(h); held->clear(); } } freeHeld{&held};
     for (size_t q = 0; q < pool.size(); q++) {
         if (taken[q]) { if (pool[q].fresh) { s->allocs.push_back(pool[q].base); s->searched.push_back(pool[q].base); } continue; }
         if (!pool[q].fresh) {                                                 // an original buffer displaced by a fresh one
@@ -1796,13 +1884,15 @@ static int choose_placement(bfd_sim *s)
         prevRep = cur + (size_t)qP * s->nloc;
     }
     BFD_HIP(hipStreamSynchronize(s->stream));
+    const size_t nHeld = held.size();
     for (void *h : held) hipFree(h);
+    held.clear();
     std::string after;
     for (int a : order) { const Buf &b = pool[slotBuf[a]]; after += b.fresh ? (b.cls == M ? 'm' : 'n') : (char)('0' + std::min(b.cls, 9)); }
     char buf[1024];
     snprintf(buf, sizeof buf, "arrays placed by memory region (pair probe on the zero state: %d probes, within-region %.3f ms, threshold %.3f ms, gap between the levels %.0f %%; %zu regions seen): "
              "regions of %s %s -> %s (m / n = fresh allocation in / outside the most populated region),%s %d fresh, %zu candidates / spacers (%.1f GiB) released%s; %.2f s", nProbes, tSame, thr, 100.0 * widest, repOf.size(),
-             (std::string("Vx Vy Vz Szz Rzz") + (s->pingpong ? " + their second copies" : "") + (solids ? " Sxx Rxx Syy Ryy Sxy Rxy Sxz Rxz Syz Ryz" : "")).c_str(), before.c_str(), after.c_str(), accNote.c_str(), nFresh, held.size(), heldBytes / 1073741824.0,
+             (std::string("Vx Vy Vz Szz Rzz") + (s->pingpong ? " + their second copies" : "") + (solids ? " Sxx Rxx Syy Ryy Sxy Rxy Sxz Rxz Syz Ryz" : "")).c_str(), before.c_str(), after.c_str(), accNote.c_str(), nFresh, nHeld, heldBytes / 1073741824.0,
              (std::string(gaveUp ? "; search for another region given up (limit / memory)" : "") + capNote + (nCached ? "; " + std::to_string(nCached) + " of the fresh buffers came from an earlier search of this process" : "")).c_str(), std::chrono::duration<double>(std::chrono::steady_clock::now() - tStart).count());
     s->placementNote = buf;
     if (verbose) fprintf(stderr, "placement: %s\nplacement: probe times, array:ms against Vx, array/class:ms against the other representatives:%s\n", buf, times.c_str());
@@ -1930,11 +2020,22 @@ static int velocity_part(bfd_sim *s, int part, hipStream_t st)
         const int col = n / s->cfg.sensorSub - s->cfg.sensorStart;
         if (col < s->nTs) {
             SelList L; L.n = s->nSelS; memcpy(L.sel, s->selS, sizeof L.sel); memset(L.skip, 0, sizeof L.skip);
+            // compact solid state: the sensors' list entries, resolved when first needed after a list was built (round 6; every capture used to
+            // walk the class bytes of the row for each solid sensor: 1.08 ms per capture on the shear medium at 512^3 against 0.42 ms at C3)
+            const int *ent = nullptr;
+            if (d.cssRow) {
+                if (!s->sensEntValid) {
+                    if (!s->sensEnt) { rc = dev_alloc(s, &s->sensEnt, (size_t)s->nSensors, false); if (rc) return rc; }
+                    hipLaunchKernelGGL(sensor_entries, dim3(grid_for(s->nSensors)), dim3(256), 0, st, d, s->sensLin, (long)s->nSensors, s->sensEnt);
+                    s->sensEntValid = true;
+                }
+                ent = s->sensEnt;
+            }
             if (s->sensOut)
-                hipLaunchKernelGGL(record_sensors, dim3(grid_for(s->nSensors)), dim3(256), 0, st, d, L, s->sensLin,
+                hipLaunchKernelGGL(record_sensors, dim3(grid_for(s->nSensors)), dim3(256), 0, st, d, L, s->sensLin, ent,
                                    (long)s->nSensors, s->sensOut, col, s->nTs);
             else
-                hipLaunchKernelGGL(accumulate_sensor_dft, dim3(grid_for(s->nSensors)), dim3(256), 0, st, d, L, s->sensLin,
+                hipLaunchKernelGGL(accumulate_sensor_dft, dim3(grid_for(s->nSensors)), dim3(256), 0, st, d, L, s->sensLin, ent,
                                    (long)s->nSensors, s->dftAcc, s->dftPk, col, s->nTs, s->dftBin);
         }
     }
@@ -2296,12 +2397,12 @@ int bfd_get_field(bfd_sim *s, int32_t a, float *out, int64_t s1, int64_t s2, int
     expand_if_collapsed(s);
     const bfd_dev &d = s->d;
     static const int cssOf[15] = {-1, -1, -1, 0, 1, -1, 2, 3, 4, 5, 6, -1, 7, 8, 9};
-    if (d.cssRow && s->tilesReady && cssOf[a] >= 0) {
+    if (d.cssRow && cssOf[a] >= 0) {       // not on tilesReady: a setter at step > 0 clears that flag, but list, row table and compact arrays stay as they are until the next step rebuilds them
         // compact solid state: the field is assembled in a temporary -- zeros, the Szz / Rzz copy at the fluid cells (Sxx, Syy, Rxx, Ryy), the compact
         // values at the listed cells
         const float *comp[10] = {d.cSxx, d.cSyy, d.cSxy, d.cSxz, d.cSyz, d.cRxx, d.cRyy, d.cRxy, d.cRxz, d.cRyz};
         float *tmp = nullptr;
-        BFD_HIP(hipMalloc((void **)&tmp, s->nloc * sizeof(float)));
+        BFD_HIP(malloc_or_release_cache((void **)&tmp, s->nloc * sizeof(float)));
         hipError_t e = hipMemsetAsync(tmp, 0, s->nloc * sizeof(float), s->stream);
         if (e == hipSuccess && (a == 3 || a == 4 || a == 9 || a == 10))
             hipLaunchKernelGGL(copy_at_fluid_cells, dim3(grid_for((long)s->nloc)), dim3(256), 0, s->stream, d, a >= 9 ? (const float *)d.Rzz : (const float *)d.Szz, tmp, (long)s->nloc);

@@ -173,6 +173,7 @@ struct bfd_sim {
     hipEvent_t evRead[2][2]; bool evReadUsed[2][2];      // [buffer][0 = engine stream, 1 = a side stream]: behind the last kernels that read the tile the buffer holds
     std::future<void> packJob[2];
     // sensors
+    int *sensEnt; bool sensEntValid;   // compact solid state: list entry of every sensor voxel (-1 = none), valid for the current list
     int64_t nSensors; uint32_t *sensLin; float *sensOut; int nTs; int nSelS; int selS[BFD_MAP_COUNT];
     double *dftAcc; float *dftPk; int dftBin;      // sensorMode 1: [nSelS][nSensors][2] running DFT sums, [nSelS][nSensors] running peaks
     // accumulators

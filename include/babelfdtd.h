@@ -164,14 +164,18 @@ const char *bfd_placement_note(bfd_sim *sim);
  * how much throw-away device memory the search for a buffer in another region may hold at a time (all of it is released
  * before bfd_prepare returns); < 0 = the default rule: nothing at all when the device carries other allocations than this
  * engine's (another process, the other slabs of a group): the engine's own buffers are then only exchanged among themselves;
- * on a device the engine has to itself up to 192 GiB, always leaving 48 GiB of what was free untouched.
+ * on a device the engine has to itself up to 192 GiB, at most two thirds of what was free on entry and always leaving 48 GiB of it
+ * untouched; the search ends at once when allocations that are neither the engine's nor its own appear on the device while it walks.
  * bfd_prepare never fails for lack of memory where mode 0 succeeds. */
 int bfd_set_placement(bfd_sim *sim, int32_t mode, int64_t searchLimitBytes);
 /* The default rule can be moved without code by whoever owns the device: BABELFDTD_PLACEMENT_SEARCH_GIB=<GiB> replaces the 192 GiB
  * (the shared-device rule stays). Buffers a search found in another region are kept when their engine is destroyed and
  * offered to the next engine of this process with arrays of the same size on the same device, so that the two or three solver calls of
  * one RUN_SIMULATION (BabelIntegrationBASE.py:2338, 2374, 2401) pay the search once; at most BABELFDTD_PLACEMENT_CACHE_GIB (default
- * 48, 0 = keep nothing) are held between calls. bfd_placement_cache_release frees them now and returns the bytes freed. */
+ * 48, never more than an eighth of the device's memory, 0 = keep nothing) are held between engines; bfd_create evicts buffers of another
+ * array size, and any allocation of the library that runs out of memory frees the cache and tries once more.
+ * bfd_placement_cache_release frees them now and returns the bytes freed (the Python drop-in calls it when a solver call returns,
+ * unless it was built with keepPlacementCache=True / BABELFDTD_PLACEMENT_CACHE_KEEP=1). */
 int64_t bfd_placement_cache_release(void);
 
 /* device pointer/bytes of a halo region: field f (0..2 within the group), side 0 = low-k face,

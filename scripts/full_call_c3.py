@@ -9,7 +9,7 @@ t0 = time.time()
 a, k, info = H.make_problem('C3', stable_dt_fn=lambda ml, f, h, c: _engine.stable_dt(ml, f, True, h, c), forward=RayleighAndBHTE.ForwardSimple)
 t1 = time.time()
 print('inputs built in %.1f s: nt=%d ppp=%d sub=%d start=%d PulseSource %.1f GB' % (t1 - t0, info['nt'], info['ppp'], k['SensorSubSampling'], k['SensorStart'], a[4].nbytes / 1e9), flush=True)
-pm = PropagationModel()
+pm = PropagationModel(keepPlacementCache=True)      # the calls of one RUN_SIMULATION, back to back
 N = 512 ** 3
 for series in (True, False):      # the reference's return values; then without the sensor series (DFT accumulated in the loop)
     t2 = time.time()

@@ -3,8 +3,9 @@
   C1 128^3 water, SingleTx 500 kHz, 500 steps        -> against the oracle, full size
   C2 256^3 skull+brain (3 materials), 2000 steps     -> against the oracle, full size
   C3 512^3 CT-like skull, CTX-500, 140 steps         -> against the oracle, full size (+ tests/test_fullsize_gpu.py)
-  C4 512x512x1024, H317 phased array, 700 kHz        -> size-independent properties (below)
-  C5 1024^3, 1 MHz                                   -> size-independent properties (below)
+  C4 512x512x1024, H317 phased array, 700 kHz        -> against the oracle at 128x128x256 (600 steps) and at FULL size
+                                                        for 80 steps; size-independent properties at full size
+  C5 1024^3, 1 MHz                                   -> against the oracle at 192^3 (600 steps); properties at full size
 
 The oracle cannot finish C4 / C5 in seconds, so those are held through properties that the small-grid parity tests tie
 to the oracle: the independent device implementations (dense LDS-tiled variant 2, class-specialised variant 3) agree
@@ -75,6 +76,60 @@ def test_c3_full_size_against_oracle():
         worst = compare_runs(out_h, out_o, tol=1e-5)
         print('C3 512^3 x 140 steps, variant %d: worst rel L2 vs oracle %.3e (oracle step loop %.1f s)' % (variant, worst, out_o[-1]['stepLoopSeconds']))
         del out_h
+
+
+def _reduced_against_oracle(config, N, steps):
+    """A BASELINE configuration's own material rows (MatFreq[f], BASE:140-167), transducer source plane, spatial step and
+    time plan (PPP rule at that frequency) on a reduced grid, default kernels against the oracle on every output. The
+    shell's top lies 6 cells below the source plane, so the wave is inside bone (with shear) for most of the run."""
+    from babelbrain_amd import PropagationModel, RayleighAndBHTE
+    from oracle import oracle as O
+    a, k, info = H.make_problem(config, N=N, steps=steps, stable_dt_fn=oracle_dt, forward=RayleighAndBHTE.ForwardSimple)
+    assert a[0].shape == N and info['nt'] == steps and info['freq'] == H.CONFIGS[config]['freq']
+    assert np.array_equal(a[1], np.array([H.MATERIALS[info['freq']][m] for m in ('Water', 'Cortical', 'Brain')]))
+    out_o = O.StaggeredFDTD_3D_with_relaxation(*a, **k)
+    rms, last = out_o[2]['Pressure'], out_o[1]['Pressure']
+    bone, brain = a[0] == 1, a[0] == 2
+    assert bone.sum() > 1e4 and rms[bone].max() > 0 and rms[brain].max() > 0, 'the wave should have gone through bone'
+    for variant in (0, 2):
+        out_h = PropagationModel(kernelVariant=variant).StaggeredFDTD_3D_with_relaxation(*a, SILENT=True, **k)
+        worst = compare_runs(out_h, out_o, tol=1e-5)
+        print('%s at %s x %d steps, variant %d: worst rel L2 vs oracle %.3e' % (config, N, steps, variant, worst))
+    return info, out_o
+
+
+def test_c4_reduced_against_oracle():
+    """BASELINE configs[3] at 128x128x256: the 700 kHz rows, the H317 source plane (128 elements on an F = 135 mm cap,
+    H317.py:19,56-125; the plane the phased-array caller builds, CONCAVE_PHASEDARRAY:296-320) and the 700 kHz time plan."""
+    info, _ = _reduced_against_oracle('C4', (128, 128, 256), 600)
+    assert info['tx'] == 'h317' and info['freq'] == 700e3 and info['n_sources'] > 1000
+
+
+def test_c5_reduced_against_oracle():
+    """BASELINE configs[4] at 192^3: the 1 MHz rows (cS 1716 m/s, alphaS 329 Np/m in cortical bone) and time plan."""
+    info, _ = _reduced_against_oracle('C5', (192, 192, 192), 600)
+    assert info['freq'] == 1000e3
+
+
+@pytest.mark.timeout(900)
+def test_c4_full_size_first_steps_against_oracle():
+    """BASELINE configs[3] at its FULL size (512x512x1024) for the first 80 steps against the oracle, Pressure RMS over all
+    of them + last map + two sensor lines. The dense oracle holds 26 arrays of 1 GiB: needs 45 GB of free host memory
+    (skipped below that) and about 0.3 s per step on 16 threads."""
+    psutil = pytest.importorskip('psutil')
+    if psutil.virtual_memory().available < 45 * 2 ** 30:
+        pytest.skip('less than 45 GB of host memory available for the dense oracle at 512x512x1024')
+    from babelbrain_amd import PropagationModel, RayleighAndBHTE
+    from oracle import oracle as O
+    a, k, info = H.make_problem('C4', steps=80, stable_dt_fn=oracle_dt, full_sensors=False, accumulate_all_steps=True,
+                                forward=RayleighAndBHTE.ForwardSimple)
+    assert a[0].shape == (512, 512, 1024) and info['tx'] == 'h317' and info['n_sources'] > 1e5
+    out_h = PropagationModel().StaggeredFDTD_3D_with_relaxation(*a, SILENT=True, **k)
+    out_o = O.StaggeredFDTD_3D_with_relaxation(*a, **k)
+    worst = compare_runs(out_h, out_o, tol=1e-5)
+    rms = out_o[2]['Pressure']
+    assert rms[a[0] == 1].max() > 0 and np.count_nonzero(out_o[1]['Pressure']) > 1e6
+    print('C4 512x512x1024 x 80 steps: worst rel L2 vs oracle %.3e (oracle step loop %.1f s)' % (worst, out_o[-1]['stepLoopSeconds']))
 
 
 def _exchange(slabs, group):

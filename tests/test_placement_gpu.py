@@ -1,6 +1,6 @@
 """The placement of the per-voxel arrays by memory region (bfd_prepare) must never cost a caller the
 device: its search for a buffer in another region holds throw-away allocations, so it is switched off on a device that carries
-other allocations, bounded on a device of its own (192 GiB, 48 GiB of the free memory always left; any explicit limit), and it
+other allocations, bounded on a device of its own (192 GiB, at most two thirds of the free memory, 48 GiB always left; any explicit limit), and it
 gives up quietly -- bfd_prepare succeeds wherever it would with the placement off, and the results do not depend on it."""
 import subprocess
 import sys
@@ -155,3 +155,29 @@ def test_placement_buffers_kept_between_engines_and_released(monkeypatch):
     freed = _engine.placement_cache_release()
     assert 0 <= freed <= 1 << 30
     assert _engine.placement_cache_release() == 0
+
+
+def test_drop_in_call_leaves_no_idle_buffers_by_default(monkeypatch):
+    """A solver call through the drop-in gives the placement cache back when it returns (a process that goes on to something else on the device
+    finds nothing idle of this library there); keepPlacementCache=True keeps it for the next call, within the cache's bound. A new engine of
+    another array size evicts what the cache holds for the old size when it is created."""
+    monkeypatch.setenv('BFD_PLACEMENT_MIN_VOXELS', '0')
+    monkeypatch.setenv('BFD_PLACEMENT_SEARCH_MB', '64')
+    monkeypatch.setenv('BABELFDTD_PLACEMENT_CACHE_GIB', '1')
+    from babelbrain_amd import PropagationModel
+    _engine.placement_cache_release()
+    a, k, info = H.make_problem('C2', N=(96, 80, 72), steps=40, stable_dt_fn=_hip_dt, full_sensors=False)
+    ref = PropagationModel().StaggeredFDTD_3D_with_relaxation(*a, SILENT=True, **k)
+    assert _engine.placement_cache_release() == 0
+    pm = PropagationModel(keepPlacementCache=True)
+    out = pm.StaggeredFDTD_3D_with_relaxation(*a, SILENT=True, **k)
+    out2 = pm.StaggeredFDTD_3D_with_relaxation(*a, SILENT=True, **k)
+    assert np.array_equal(out[2]['Pressure'], ref[2]['Pressure']) and np.array_equal(out2[2]['Pressure'], ref[2]['Pressure'])
+    # an engine with arrays of another size: what the cache kept for the old size goes at bfd_create
+    b, kb, infob = H.make_problem('C2', N=(80, 80, 64), steps=10, stable_dt_fn=_hip_dt, full_sensors=False)
+    eng = _engine_for(b, kb, infob)
+    held_other_size = _engine.placement_cache_release()
+    eng.run(10)
+    eng.close()
+    assert held_other_size == 0
+    assert 0 <= _engine.placement_cache_release() <= 1 << 30

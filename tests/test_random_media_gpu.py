@@ -202,6 +202,10 @@ def test_compact_solid_state_equals_full_volume_arrays(seed, monkeypatch):
             out[-1]['sensors'] = eng.sensors().copy()
             if again:                         # inputs set again in the middle of a run: the lists are rebuilt, the compact values must move into the new list
                 eng.set_sources(*compact_sources(smap, k['Ox'], k['Oy'], k['Oz']), pulse)
+                # between a setter and the next step the old list is still the one the compact arrays are ordered by: a field read in that
+                # window must be the same field (round 5 handed out the hosting buffers' raw content here)
+                for n in _engine.FIELD_NAMES:
+                    assert np.array_equal(eng.get_field(n), out[-1][n]), ('get_field between a setter and the next step', n)
             eng.run(nt - nt // 2)             # get_field in the middle of a run must not disturb it
             out.append({n: eng.get_field(n).copy() for n in _engine.FIELD_NAMES})
             eng.reset()
