@@ -231,3 +231,33 @@ def test_bench_stdout_carries_only_the_line(tmp_path):
     assert r.returncode == 0, r.stderr
     assert json.loads(r.stdout) == {'metric': 'm', 'value': 1.0}
     assert '[Gloo] Rank 0 is connected' in r.stderr and 'chatter' in r.stderr
+
+
+def test_bench_line_fits_the_drivers_record_and_roofline_carries_the_rounds_numbers():
+    """The driver's record keeps `roofline`, `config` and `cpu_baseline` of the line whole and only a 2000-byte tail of the rest: the numbers a
+    reader needs to recompute the shear step and the 1024^3 anchor are flat scalars inside `roofline` (bench.roofline_summary), and the line
+    on stdout stays under 8 KB (bench.compact_line; the full text goes to stderr) without losing a headline number."""
+    import json, os
+    import bench
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    full = json.load(open(os.path.join(root, 'profiles', 'r5', 'bench_default_n1.json')))      # a real line of this bench (13 KB)
+    line = json.loads(json.dumps(full))
+    bench.roofline_summary(line)
+    r = line['roofline']
+    sh = full['shear_workload']
+    assert r['shear512_value'] == sh['value'] and r['shear512_step_frac'] == sh['roofline_step']['frac']
+    for c, row in sh['roofline_kernels'].items():
+        assert r['shear512_%s_frac' % c] == row['frac'] and r['shear512_%s_ms' % c] == row['avg_launch_ms']
+        assert abs(r['shear512_%s_moved_over_alg' % c] - row['traffic_from_profile'] / row['algorithmic_bytes_per_launch']) < 1e-12
+    assert r['step_frac'] == full['roofline_step']['frac'] and r['c5_value'] == full['strong_c5']['value'] and r['c5_one_device_value'] == r['c5_value']
+    assert all(not isinstance(v, (dict, list)) for k, v in r.items() if k != 'profile_ref')
+    short = bench.compact_line(line)
+    assert len(json.dumps(line)) > 8192 > len(json.dumps(short))
+    assert set(short) == set(line)
+    for k in ('metric', 'unit', 'n_gpus', 'steps', 'warmup', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data'):
+        assert short[k] == line[k]
+    assert abs(short['value'] / line['value'] - 1) < 1e-5 and abs(short['roofline']['frac'] / line['roofline']['frac'] - 1) < 1e-5
+    assert short['config']['workload'] == line['config']['workload'] and short['cpu_baseline']['kind'] == 'port'
+    assert abs(short['roofline']['shear512_velocity_solid_frac'] / r['shear512_velocity_solid_frac'] - 1) < 1e-5
+    # a line already short is not touched
+    assert bench.compact_line({'metric': 'm', 'value': 1.0}) == {'metric': 'm', 'value': 1.0}
