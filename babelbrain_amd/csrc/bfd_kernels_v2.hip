@@ -1698,10 +1698,14 @@ __device__ __forceinline__ void velocity_solid_body_g(const bfd_dev &d, const in
         const long ko = (long)__builtin_amdgcn_readfirstlane(kl) * pl;
         const int k = d.k0 + kl;
         const int bn = (b ^ 1) * bufStride;     // buffer of plane kl+1
-#ifdef BFD_VS_RELOAD
-        // experiment (round 6): the array bases are re-read from the kernel argument segment (d is the kernel's first argument) at three points of
-        // every plane instead of being held in scalar registers across the loop (~19 pairs + ~10 lane masks do not fit: 17 spilled, address
-        // arithmetic moved into vector registers)
+#ifndef BFD_VS_HOLD_BASES
+        // Round 6: the array bases are re-read from the kernel argument segment (d is the kernel's first argument; scalar loads, in the scalar cache
+        // after the first plane) at three points of every plane instead of being held in scalar registers across the loop: ~19 pairs + ~10 lane
+        // masks did not fit (17 scalars spilled to vector lanes, scalar address arithmetic done in vector registers). Spills 17 -> 8 (accumulating
+        // flavour) / 27 -> 0 (Z-slab flavour) / 96 -> 34 (absorbing layer), 92 -> 80-82 vector registers: with the bound of 6 waves per SIMD every
+        // flavour outside the layer fits 80 registers WITHOUT scratch (the round-5 build spilled 6-7 registers to scratch there and lost 12 %), so
+        // three workgroups share a CU instead of two: 0.386 -> 0.362 ms at the shear medium 512^3 (the reload alone, at 5 waves: 0.386).
+        // -DBFD_VS_HOLD_BASES restores the round-5 form. profiles/r6/velocity_solid_bases_reloaded.txt
         const __attribute__((address_space(4))) bfd_dev *kd = (const __attribute__((address_space(4))) bfd_dev *)__builtin_amdgcn_kernarg_segment_ptr();
         asm volatile("" : "+s"(kd));
 #define DD (*kd)
@@ -1720,7 +1724,7 @@ __device__ __forceinline__ void velocity_solid_body_g(const bfd_dev &d, const in
             ry = DD.invRho[my & BFD_MAT_MASK];
         }
         __syncthreads();
-#ifdef BFD_VS_RELOAD
+#ifndef BFD_VS_HOLD_BASES
         asm volatile("" : "+s"(kd));
 #endif
 
@@ -1773,7 +1777,7 @@ __device__ __forceinline__ void velocity_solid_body_g(const bfd_dev &d, const in
         const unsigned nmx = gl2(DD.mat + ko + kn, cx2), nmy = gl2(DD.mat + ko + kn, cy2);
         const unsigned nhcA = gl1(DD.cls + ko + pl + kn, offA), nhcB = gl1(DD.cls + ko + pl + kn, offB);
 
-#ifdef BFD_VS_RELOAD
+#ifndef BFD_VS_HOLD_BASES
         asm volatile("" : "+s"(kd));
 #endif
         float *wVx = (WHOLE ? DD.Vx : DD.VxW) + ko, *wVy = (WHOLE ? DD.Vy : DD.VyW) + ko, *wVz = (WHOLE ? DD.Vz : DD.VzW) + ko;
@@ -1862,7 +1866,7 @@ __global__ __launch_bounds__(NTHREADS, SOLID_STRESS_WAVES_PER_SIMD) void stress_
 // two kernels (the absorbing-layer flavour needs ~18 registers more and would spill inside a common one); the solid run
 // list keeps the runs that touch the layer at its two ends (bfd_tiles::nSolidBP / nSolidIP)
 #ifndef SOLID_VELOCITY_WAVES_PER_SIMD
-#define SOLID_VELOCITY_WAVES_PER_SIMD 4      // lower bound of the plain flavour (78-80 VGPRs since round 4: 6 waves); the absorbing-layer flavour needs 105 registers and gets 4
+#define SOLID_VELOCITY_WAVES_PER_SIMD 6      // 80 registers = three workgroups per CU; no scratch since the bases are re-read per plane (round 6). The absorbing-layer flavour needs 106 registers and gets 4
 #endif
 template <bool ACC, bool PML, bool CSS, bool WHOLE = false>
 __global__ __launch_bounds__(NTHREADS, PML ? 4 : SOLID_VELOCITY_WAVES_PER_SIMD) void velocity_solid(bfd_dev d, int tilesX, int nblocks, const int *__restrict__ xmap,
@@ -1981,37 +1985,27 @@ __device__ __forceinline__ unsigned fdiv(unsigned x, FastDiv f) { return __umulh
 // NORMAL (compact solid state): the kernel also updates Sxx, Syy and their memory variables of its cell (compact arrays, entry t of this launch's
 // part of the list) -- Szz / Rzz of the cell were written by the fluid stress kernel, which ran before and has advanced the absorbing-layer
 // memory variables of dxVx, dyVy, dzVz: they are read here, not advanced.
-// PART (compact solid state only; round 6): 0 = everything of the cell in one thread (the round-5 form: 84-90 registers, 5 waves per SIMD, parked on
-// memory for three quarters of its wave cycles); 1 = Sxx, Syy, Rxx, Ryy from the 12 velocities of dxVx, dyVy, dzVz; 2 = the three shear
-// entries from their 21. SPARSE_SPLIT = 1 launches 1 and 2 one after the other over the same list, 2 puts both into one launch (the two
-// halves of a pair of workgroups that follow each other on one XCD: the second finds index and code word of its cells in that L2).
-// Same expressions on the same values: bit-identical.
-#ifndef SPARSE_SPLIT
-#define SPARSE_SPLIT 0
-#endif
-#ifndef SPARSE_SPLIT_WAVES
-#define SPARSE_SPLIT_WAVES 8
-#endif
-template <bool NORMAL, int PART>
-__device__ __forceinline__ void stress_shear_sparse_body(const bfd_dev &d, const long t, const unsigned *__restrict__ cells, const unsigned *__restrict__ codes,
+template <bool NORMAL>
+__global__ __launch_bounds__(256, SPARSE_WAVES_PER_SIMD) void stress_shear_sparse(bfd_dev d, const unsigned *__restrict__ cells, const unsigned *__restrict__ codes,
                                                            const float *__restrict__ tab, const float *__restrict__ coef,
-                                                           float *__restrict__ Rc, long nTotal, FastDiv divN1, FastDiv divPlane,
+                                                           float *__restrict__ Rc, long nTotal, long n, FastDiv divN1, FastDiv divPlane,
                                                            float *__restrict__ cSxy, float *__restrict__ cSxz, float *__restrict__ cSyz,
                                                            float *__restrict__ cSxx, float *__restrict__ cSyy, float *__restrict__ cRxx, float *__restrict__ cRyy,
                                                            float *__restrict__ cRxy, float *__restrict__ cRxz, float *__restrict__ cRyz)
 {
-    constexpr bool DO_N = NORMAL && PART != 2, DO_S = PART != 1;
+    // XCD e works through the e-th contiguous eighth of the list (order: shear_order_keys): the V values a cell gathers from its
+    // row / plane neighbours were fetched by blocks just before it on the SAME XCD (its own L2)
+    const long t = (long)remap_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
+    if (t >= n) return;
     const int N1 = d.N1, N2 = d.N2, P = d.P;
     const long pl = d.plane;
     const unsigned c = LDNT(cells + t);
     // compact solid state: the ten values of the cell are dense streams in list order and depend on nothing -- in flight before the gathers start
     float oSxx = 0.f, oSyy = 0.f, oRxx = 0.f, oRyy = 0.f, oSxy = 0.f, oSxz = 0.f, oSyz = 0.f, oRxy = 0.f, oRxz = 0.f, oRyz = 0.f;
     if (NORMAL && SPARSE_HOIST) {
-        if (DO_N) { oSxx = LDNT(cSxx + t); oSyy = LDNT(cSyy + t); oRxx = LDNT(cRxx + t); oRyy = LDNT(cRyy + t); }
-        if (DO_S) {
-            oSxy = LDNT(cSxy + t); oSxz = LDNT(cSxz + t); oSyz = LDNT(cSyz + t);
-            oRxy = LDNT(cRxy + t); oRxz = LDNT(cRxz + t); oRyz = LDNT(cRyz + t);
-        }
+        oSxx = LDNT(cSxx + t); oSyy = LDNT(cSyy + t); oRxx = LDNT(cRxx + t); oRyy = LDNT(cRyy + t);
+        oSxy = LDNT(cSxy + t); oSxz = LDNT(cSxz + t); oSyz = LDNT(cSyz + t);
+        oRxy = LDNT(cRxy + t); oRxz = LDNT(cRxz + t); oRyz = LDNT(cRyz + t);
     }
     const unsigned ukl = fdiv(c, divPlane), rem = c - ukl * (unsigned)d.plane, uj = fdiv(rem, divN1);
     const int i = (int)(rem - uj * (unsigned)N1), j = (int)uj, kl = (int)ukl;
@@ -2021,87 +2015,74 @@ __device__ __forceinline__ void stress_shear_sparse_body(const bfd_dev &d, const
     // interior), explicit otherwise (24 B per cell less to stream)
     const unsigned cw = LDNT(codes + t);
     float AP = 0.f, BP = 0.f, AS2 = 0.f, BS2 = 0.f;
-    if (DO_N) {       // material of the cell: from the code word (its fourth byte), else from the id array
+    if (NORMAL) {       // material of the cell: from the code word (its fourth byte), else from the id array
         const unsigned mb = cw >> 24;
         const int m = mb ? (int)mb - 1 : (int)(d.mat[c] & BFD_MAT_MASK);
         AP = d.AP[m]; BP = d.BP[m]; AS2 = d.AS2[m]; BS2 = d.BS2[m];
     }
     float Axy = 0.f, Bxy = 0.f, Axz = 0.f, Bxz = 0.f, Ayz = 0.f, Byz = 0.f;
-    if (DO_S) {
-        {
-            const unsigned q = cw & 255u;
-            if (q == 255u) { Axy = LDNT(coef + 6 * t); Bxy = LDNT(coef + 6 * t + 1); } else if (q) { Axy = tab[2 * (q - 1)]; Bxy = tab[2 * (q - 1) + 1]; }
-        }
-        {
-            const unsigned q = (cw >> 8) & 255u;
-            if (q == 255u) { Axz = LDNT(coef + 6 * t + 2); Bxz = LDNT(coef + 6 * t + 3); } else if (q) { Axz = tab[2 * (q - 1)]; Bxz = tab[2 * (q - 1) + 1]; }
-        }
-        {
-            const unsigned q = (cw >> 16) & 255u;
-            if (q == 255u) { Ayz = LDNT(coef + 6 * t + 4); Byz = LDNT(coef + 6 * t + 5); } else if (q) { Ayz = tab[2 * (q - 1)]; Byz = tab[2 * (q - 1) + 1]; }
-        }
+    {
+        const unsigned q = cw & 255u;
+        if (q == 255u) { Axy = LDNT(coef + 6 * t); Bxy = LDNT(coef + 6 * t + 1); } else if (q) { Axy = tab[2 * (q - 1)]; Bxy = tab[2 * (q - 1) + 1]; }
+    }
+    {
+        const unsigned q = (cw >> 8) & 255u;
+        if (q == 255u) { Axz = LDNT(coef + 6 * t + 2); Bxz = LDNT(coef + 6 * t + 3); } else if (q) { Axz = tab[2 * (q - 1)]; Bxz = tab[2 * (q - 1) + 1]; }
+    }
+    {
+        const unsigned q = (cw >> 16) & 255u;
+        if (q == 255u) { Ayz = LDNT(coef + 6 * t + 4); Byz = LDNT(coef + 6 * t + 5); } else if (q) { Ayz = tab[2 * (q - 1)]; Byz = tab[2 * (q - 1) + 1]; }
     }
     // the 21 velocities: wave-uniform bases + one 32-bit byte offset (c < 2^30); a cell whose stencil stays inside the domain in x and y
     // (all but the cells on the outermost two rows / columns) takes them without a test per value
     const unsigned c4 = c * 4u, r4 = (unsigned)N1 * 4u;
-    float vx0 = 0.f, vy0 = 0.f, vz0 = 0.f;
-    float dyVx = 0.f, dxVy = 0.f, dxVz = 0.f, dyVz = 0.f, dxVx = 0.f, dyVy = 0.f, dzVz = 0.f, dzVx = 0.f, dzVy = 0.f;
+    float vx0, vy0, vz0;
+    float dyVx, dxVy, dxVz, dyVz, dxVx = 0.f, dyVy = 0.f, dzVz = 0.f;
     const bool inside = i >= 2 && i + 2 < N1 && j >= 2 && j + 2 < N2;
-    vx0 = F4(d.Vx, c4); vy0 = F4(d.Vy, c4); vz0 = F4(d.Vz, c4);
     if (inside) {
-        if (DO_S) {
-            dyVx = dplus4(F4(d.Vx, c4 - r4), vx0, F4(d.Vx, c4 + r4), F4(d.Vx, c4 + 2 * r4));
-            dxVy = dplus4(F4(d.Vy, c4 - 4u), vy0, F4(d.Vy, c4 + 4u), F4(d.Vy, c4 + 8u));
-            dxVz = dplus4(F4(d.Vz, c4 - 4u), vz0, F4(d.Vz, c4 + 4u), F4(d.Vz, c4 + 8u));
-            dyVz = dplus4(F4(d.Vz, c4 - r4), vz0, F4(d.Vz, c4 + r4), F4(d.Vz, c4 + 2 * r4));
-        }
-        if (DO_N) { dxVx = dminus4(F4(d.Vx, c4 - 8u), F4(d.Vx, c4 - 4u), vx0, F4(d.Vx, c4 + 4u)); dyVy = dminus4(F4(d.Vy, c4 - 2 * r4), F4(d.Vy, c4 - r4), vy0, F4(d.Vy, c4 + r4)); }
+        vx0 = F4(d.Vx, c4); vy0 = F4(d.Vy, c4); vz0 = F4(d.Vz, c4);
+        dyVx = dplus4(F4(d.Vx, c4 - r4), vx0, F4(d.Vx, c4 + r4), F4(d.Vx, c4 + 2 * r4));
+        dxVy = dplus4(F4(d.Vy, c4 - 4u), vy0, F4(d.Vy, c4 + 4u), F4(d.Vy, c4 + 8u));
+        dxVz = dplus4(F4(d.Vz, c4 - 4u), vz0, F4(d.Vz, c4 + 4u), F4(d.Vz, c4 + 8u));
+        dyVz = dplus4(F4(d.Vz, c4 - r4), vz0, F4(d.Vz, c4 + r4), F4(d.Vz, c4 + 2 * r4));
+        if (NORMAL) { dxVx = dminus4(F4(d.Vx, c4 - 8u), F4(d.Vx, c4 - 4u), vx0, F4(d.Vx, c4 + 4u)); dyVy = dminus4(F4(d.Vy, c4 - 2 * r4), F4(d.Vy, c4 - r4), vy0, F4(d.Vy, c4 + r4)); }
     } else {
-        if (DO_S) {
-            dyVx = dplus4(ldv(d.Vx, N1, N2, i, j - 1, ko), vx0, ldv(d.Vx, N1, N2, i, j + 1, ko), ldv(d.Vx, N1, N2, i, j + 2, ko));
-            dxVy = dplus4(ldv(d.Vy, N1, N2, i - 1, j, ko), vy0, ldv(d.Vy, N1, N2, i + 1, j, ko), ldv(d.Vy, N1, N2, i + 2, j, ko));
-            dxVz = dplus4(ldv(d.Vz, N1, N2, i - 1, j, ko), vz0, ldv(d.Vz, N1, N2, i + 1, j, ko), ldv(d.Vz, N1, N2, i + 2, j, ko));
-            dyVz = dplus4(ldv(d.Vz, N1, N2, i, j - 1, ko), vz0, ldv(d.Vz, N1, N2, i, j + 1, ko), ldv(d.Vz, N1, N2, i, j + 2, ko));
-        }
-        if (DO_N) {
+        vx0 = F4(d.Vx, c4); vy0 = F4(d.Vy, c4); vz0 = F4(d.Vz, c4);
+        dyVx = dplus4(ldv(d.Vx, N1, N2, i, j - 1, ko), vx0, ldv(d.Vx, N1, N2, i, j + 1, ko), ldv(d.Vx, N1, N2, i, j + 2, ko));
+        dxVy = dplus4(ldv(d.Vy, N1, N2, i - 1, j, ko), vy0, ldv(d.Vy, N1, N2, i + 1, j, ko), ldv(d.Vy, N1, N2, i + 2, j, ko));
+        dxVz = dplus4(ldv(d.Vz, N1, N2, i - 1, j, ko), vz0, ldv(d.Vz, N1, N2, i + 1, j, ko), ldv(d.Vz, N1, N2, i + 2, j, ko));
+        dyVz = dplus4(ldv(d.Vz, N1, N2, i, j - 1, ko), vz0, ldv(d.Vz, N1, N2, i, j + 1, ko), ldv(d.Vz, N1, N2, i, j + 2, ko));
+        if (NORMAL) {
             dxVx = dminus4(ldv(d.Vx, N1, N2, i - 2, j, ko), ldv(d.Vx, N1, N2, i - 1, j, ko), vx0, ldv(d.Vx, N1, N2, i + 1, j, ko));
             dyVy = dminus4(ldv(d.Vy, N1, N2, i, j - 2, ko), ldv(d.Vy, N1, N2, i, j - 1, ko), vy0, ldv(d.Vy, N1, N2, i, j + 1, ko));
         }
     }
-    if (DO_S) {
-        dzVx = dplus4(F4(d.Vx - pl, c4), vx0, F4(d.Vx + pl, c4), F4(d.Vx + 2 * pl, c4));
-        dzVy = dplus4(F4(d.Vy - pl, c4), vy0, F4(d.Vy + pl, c4), F4(d.Vy + 2 * pl, c4));
-    }
-    if (DO_N) dzVz = dminus4(F4(d.Vz - 2 * pl, c4), F4(d.Vz - pl, c4), vz0, F4(d.Vz + pl, c4));
+    float dzVx = dplus4(F4(d.Vx - pl, c4), vx0, F4(d.Vx + pl, c4), F4(d.Vx + 2 * pl, c4));
+    float dzVy = dplus4(F4(d.Vy - pl, c4), vy0, F4(d.Vy + pl, c4), F4(d.Vy + 2 * pl, c4));
+    if (NORMAL) dzVz = dminus4(F4(d.Vz - 2 * pl, c4), F4(d.Vz - pl, c4), vz0, F4(d.Vz + pl, c4));
     if (i < P || i >= N1 - P) {
         const int xi = i < P ? i : i - (N1 - 2 * P);
         const unsigned q = (unsigned)((kl * N2 + j) * (2 * P) + xi);
-        if (DO_S) {
-            dxVy = cpml(d.psi[4], q, d.axH[i], d.bxH[i], dxVy);
-            dxVz = cpml(d.psi[6], q, d.axH[i], d.bxH[i], dxVz);
-        }
-        if (DO_N) dxVx = dxVx + d.psi[0][q];          // advanced by the fluid stress kernel in this half-step
+        dxVy = cpml(d.psi[4], q, d.axH[i], d.bxH[i], dxVy);
+        dxVz = cpml(d.psi[6], q, d.axH[i], d.bxH[i], dxVz);
+        if (NORMAL) dxVx = dxVx + d.psi[0][q];          // advanced by the fluid stress kernel in this half-step
     }
     if (j < P || j >= N2 - P) {
         const int yj = j < P ? j : j - (N2 - 2 * P);
         const unsigned q = (unsigned)((kl * (2 * P) + yj) * N1 + i);
-        if (DO_S) {
-            dyVx = cpml(d.psi[3], q, d.ayH[j], d.byH[j], dyVx);
-            dyVz = cpml(d.psi[8], q, d.ayH[j], d.byH[j], dyVz);
-        }
-        if (DO_N) dyVy = dyVy + d.psi[1][q];
+        dyVx = cpml(d.psi[3], q, d.ayH[j], d.byH[j], dyVx);
+        dyVz = cpml(d.psi[8], q, d.ayH[j], d.byH[j], dyVz);
+        if (NORMAL) dyVy = dyVy + d.psi[1][q];
     }
     if (k < P || k >= d.N3 - P) {
         const int zk = k < P ? k : k - (d.N3 - 2 * P);
         const unsigned q = (unsigned)(zk * d.plane) + (unsigned)(j * N1 + i);
-        if (DO_S) {
-            dzVx = cpml(d.psi[5], q, d.azH[k], d.bzH[k], dzVx);
-            dzVy = cpml(d.psi[7], q, d.azH[k], d.bzH[k], dzVy);
-        }
-        if (DO_N) dzVz = dzVz + d.psi[2][q];
+        dzVx = cpml(d.psi[5], q, d.azH[k], d.bzH[k], dzVx);
+        dzVy = cpml(d.psi[7], q, d.azH[k], d.bzH[k], dzVy);
+        if (NORMAL) dzVz = dzVz + d.psi[2][q];
     }
     const float c1 = d.c1;
-    if (DO_N) {       // Sxx, Syy of the cell: the canonical expressions of stress_v2 / stress_solid
+    if (NORMAL) {       // Sxx, Syy of the cell: the canonical expressions of stress_v2 / stress_solid
         const float sXY = dxVx + dyVy;
         const float div = sXY + dzVz;
         const float sYZ = dyVy + dzVz, sXZ = dxVx + dzVz;
@@ -2111,7 +2092,6 @@ __device__ __forceinline__ void stress_shear_sparse_body(const bfd_dev &d, const
         rn = c1 * oRyy - (BP * div - BS2 * sXZ);
         __builtin_nontemporal_store(oSyy + ((AP * div - AS2 * sXZ) + 0.5f * (oRyy + rn)), cSyy + t); __builtin_nontemporal_store(rn, cRyy + t);
     }
-    if (!DO_S) return;
     // memory variables: beside the list (Rc, list order) or, when the list only holds the cells the merged solid kernel leaves
     // out (Rc == null), in the full-volume arrays
     float *pRxy = NORMAL ? cRxy + t : (Rc ? Rc + t : d.Rxy + c), *pRxz = NORMAL ? cRxz + t : (Rc ? Rc + nTotal + t : d.Rxz + c), *pRyz = NORMAL ? cRyz + t : (Rc ? Rc + 2 * nTotal + t : d.Ryz + c);
@@ -2139,45 +2119,6 @@ __device__ __forceinline__ void stress_shear_sparse_body(const bfd_dev &d, const
         *pSyz = v; *pRyz = rn;
         if (shared) d.Syz[c] = v;
     }
-}
-
-#define SPARSE_ARGS const unsigned *__restrict__ cells, const unsigned *__restrict__ codes, const float *__restrict__ tab, const float *__restrict__ coef, \
-                    float *__restrict__ Rc, long nTotal, long n, FastDiv divN1, FastDiv divPlane, float *__restrict__ cSxy, float *__restrict__ cSxz, \
-                    float *__restrict__ cSyz, float *__restrict__ cSxx, float *__restrict__ cSyy, float *__restrict__ cRxx, float *__restrict__ cRyy, \
-                    float *__restrict__ cRxy, float *__restrict__ cRxz, float *__restrict__ cRyz
-#define SPARSE_PASS cells, codes, tab, coef, Rc, nTotal, divN1, divPlane, cSxy, cSxz, cSyz, cSxx, cSyy, cRxx, cRyy, cRxy, cRxz, cRyz
-template <bool NORMAL>
-__global__ __launch_bounds__(256, SPARSE_WAVES_PER_SIMD) void stress_shear_sparse(bfd_dev d, SPARSE_ARGS)
-{
-    // XCD e works through the e-th contiguous eighth of the list (order: shear_order_keys): the V values a cell gathers from its
-    // row / plane neighbours were fetched by blocks just before it on the SAME XCD (its own L2)
-    const long t = (long)remap_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
-    if (t >= n) return;
-    stress_shear_sparse_body<NORMAL, 0>(d, t, SPARSE_PASS);
-}
-// one of the two parts over the whole list (SPARSE_SPLIT = 1)
-template <int PART>
-__global__ __launch_bounds__(256, SPARSE_SPLIT_WAVES) void stress_shear_sparse_part(bfd_dev d, SPARSE_ARGS)
-{
-    const long t = (long)remap_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
-    if (t >= n) return;
-    stress_shear_sparse_body<true, PART>(d, t, SPARSE_PASS);
-}
-// both parts in one launch of 2 x ceil(n / 256) workgroups (SPARSE_SPLIT = 2): workgroup b runs on XCD b & 7 as the (b >> 3)-th of that XCD;
-// the two workgroups of a chunk of 256 cells are consecutive there
-__global__ __launch_bounds__(256, SPARSE_SPLIT_WAVES) void stress_shear_sparse_pair(bfd_dev d, SPARSE_ARGS)
-{
-    const unsigned nchunks = (unsigned)((n + 255) >> 8);      // the launch has 16 * ceil(nchunks / 8) workgroups
-    const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
-    const unsigned part = slot & 1u, local = slot >> 1;       // local-th chunk of this XCD
-    // chunk ids as remap_block hands them out: XCD e takes the e-th contiguous eighth
-    const unsigned per = (nchunks + 7u) >> 3;
-    const unsigned chunk = xcd * per + local;
-    if (local >= per || chunk >= nchunks) return;
-    const long t = (long)chunk * 256 + threadIdx.x;
-    if (t >= n) return;
-    if (part == 0) stress_shear_sparse_body<true, 1>(d, t, SPARSE_PASS);
-    else stress_shear_sparse_body<true, 2>(d, t, SPARSE_PASS);
 }
 
 // outputs: the list-ordered memory variables of the shear stresses into the full-volume arrays
@@ -2596,21 +2537,8 @@ void bfd_launch_stress_v2(const bfd_dev &d, hipStream_t s0, const bfd_tiles *t, 
         auto sparse = [&](long b, long e, float *R) {
             if (e <= b) return;
             const dim3 g((unsigned)((e - b + 255) / 256));
-            if (d.cssRow) {
-#if SPARSE_SPLIT == 1
-                hipLaunchKernelGGL(stress_shear_sparse_part<1>, g, dim3(256), 0, s, d, t->shearCells + b, t->shearCodes + b, t->shearTab, t->shearCoef + 6 * b, (float *)nullptr, t->nShear, e - b, dN1, dPl,
-                                   d.cSxy + b, d.cSxz + b, d.cSyz + b, d.cSxx + b, d.cSyy + b, d.cRxx + b, d.cRyy + b, d.cRxy + b, d.cRxz + b, d.cRyz + b);
-                hipLaunchKernelGGL(stress_shear_sparse_part<2>, g, dim3(256), 0, s, d, t->shearCells + b, t->shearCodes + b, t->shearTab, t->shearCoef + 6 * b, (float *)nullptr, t->nShear, e - b, dN1, dPl,
-                                   d.cSxy + b, d.cSxz + b, d.cSyz + b, d.cSxx + b, d.cSyy + b, d.cRxx + b, d.cRyy + b, d.cRxy + b, d.cRxz + b, d.cRyz + b);
-#elif SPARSE_SPLIT == 2
-                const unsigned nch = (unsigned)((e - b + 255) / 256), per = (nch + 7u) / 8u;
-                hipLaunchKernelGGL(stress_shear_sparse_pair, dim3(16u * per), dim3(256), 0, s, d, t->shearCells + b, t->shearCodes + b, t->shearTab, t->shearCoef + 6 * b, (float *)nullptr, t->nShear, e - b, dN1, dPl,
-                                   d.cSxy + b, d.cSxz + b, d.cSyz + b, d.cSxx + b, d.cSyy + b, d.cRxx + b, d.cRyy + b, d.cRxy + b, d.cRxz + b, d.cRyz + b);
-#else
-                hipLaunchKernelGGL(stress_shear_sparse<true>, g, dim3(256), 0, s, d, t->shearCells + b, t->shearCodes + b, t->shearTab, t->shearCoef + 6 * b, (float *)nullptr, t->nShear, e - b, dN1, dPl,
+            if (d.cssRow) hipLaunchKernelGGL(stress_shear_sparse<true>, g, dim3(256), 0, s, d, t->shearCells + b, t->shearCodes + b, t->shearTab, t->shearCoef + 6 * b, (float *)nullptr, t->nShear, e - b, dN1, dPl,
                                              d.cSxy + b, d.cSxz + b, d.cSyz + b, d.cSxx + b, d.cSyy + b, d.cRxx + b, d.cRyy + b, d.cRxy + b, d.cRxz + b, d.cRyz + b);
-#endif
-            }
             else hipLaunchKernelGGL(stress_shear_sparse<false>, g, dim3(256), 0, s, d, t->shearCells + b, t->shearCodes + b, t->shearTab, t->shearCoef + 6 * b, R, t->nShear, e - b, dN1, dPl,
                                     (float *)nullptr, (float *)nullptr, (float *)nullptr, (float *)nullptr, (float *)nullptr, (float *)nullptr, (float *)nullptr, (float *)nullptr, (float *)nullptr, (float *)nullptr);
         };
