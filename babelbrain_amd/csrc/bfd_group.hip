@@ -98,7 +98,18 @@ template <typename F> int for_slabs(int n, F fn)
 int group_prepare(bfd_group *g)
 {
     if (g->prepared) return 0;
-    for (int r = 0; r < g->n; r++) {            // one after the other: several slabs may share a device (placement is transient memory)
+    // Slabs that share a device prepare one after the other (the placement holds transient memory, and a slab that sees its siblings' arrays on
+    // the device does not search at all). One slab per device -- the real multi-GPU case -- is every device's only tenant: each slab runs the same
+    // bounded search a single-device call runs (choose_placement prices `others` per device), and the slabs prepare SIDE BY SIDE on their host
+    // threads, so that eight searches cost the time of one (round 6; BFD_GROUP_PARALLEL_PREPARE=0 / 1 forces either order).
+    bool distinct = true;
+    for (int r = 0; r < g->n; r++) for (int q = 0; q < r; q++) if (g->dev[r] == g->dev[q]) distinct = false;
+    bool side = distinct && g->n > 1;
+    if (const char *ev = getenv("BFD_GROUP_PARALLEL_PREPARE")) side = g->n > 1 && atoi(ev) != 0;
+    if (side) {
+        const int rc = for_slabs(g->n, [&](int r) { return bfd_prepare(g->sim[r]); });
+        if (rc) return rc;
+    } else for (int r = 0; r < g->n; r++) {
         const int rc = bfd_prepare(g->sim[r]);
         if (rc) return rc;
     }

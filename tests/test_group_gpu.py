@@ -142,3 +142,16 @@ def test_group_reports_how_halo_planes_travel():
     peer = out[-1]['timing']['peer']
     assert [p['interface'] for p in peer] == [0, 1] and all(p['path'].startswith('same device') and p['direct'] for p in peer), peer
     assert all(p['devices'] == [0, 0] for p in peer)
+
+
+def test_group_slabs_prepared_side_by_side(monkeypatch):
+    """One slab per device prepares all slabs at once on their host threads (each device's only tenant runs the placement search a single-device
+    call runs; eight searches then cost the time of one). On the 1-GPU box BFD_GROUP_PARALLEL_PREPARE=1 sends slabs that share the device
+    through the same threads -- with the placement probe forced onto this small grid -- and the call must equal the single-device one."""
+    monkeypatch.setenv('BFD_GROUP_PARALLEL_PREPARE', '1')
+    monkeypatch.setenv('BFD_PLACEMENT_MIN_VOXELS', '0')
+    a, k, info = _problem('C2', (64, 56, 128), 300)
+    ref = PropagationModel(device=0).StaggeredFDTD_3D_with_relaxation(*a, SILENT=True, **k)
+    out = PropagationModel(devices=[0, 0, 0, 0]).StaggeredFDTD_3D_with_relaxation(*a, SILENT=True, **k)
+    _same(out, ref)
+    assert len(out[-1]['placement']) == 4 and ref[2]['Pressure'].max() > 0
