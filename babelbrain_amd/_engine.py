@@ -27,7 +27,7 @@ ABI_SYMBOLS = [
     'bfd_set_material_map', 'bfd_set_reflector', 'bfd_set_sources', 'bfd_set_sensor_map', 'bfd_run',
     'bfd_half_step_stress', 'bfd_half_step_velocity', 'bfd_half_step_stress_part', 'bfd_half_step_velocity_part', 'bfd_half_step_stress_part_on', 'bfd_half_step_velocity_part_on', 'bfd_sync', 'bfd_current_step', 'bfd_prepare', 'bfd_halo_region',
     'bfd_timing_begin', 'bfd_timing_end', 'bfd_timing_kernels', 'bfd_algorithmic_bytes', 'bfd_reset', 'bfd_num_sensors', 'bfd_num_sensor_steps', 'bfd_get_sensor_index',
-    'bfd_get_sensors', 'bfd_get_map', 'bfd_get_field', 'bfd_tile_counts', 'bfd_tile_count_lean', 'bfd_tile_count_fused', 'bfd_device_bytes', 'bfd_rayleigh_forward', 'bfd_get_sensor_dft', 'bfd_dft_series', 'bfd_bhte_run', 'bfd_bhte_run_fields', 'bfd_bhte_run_volumes',
+    'bfd_get_sensors', 'bfd_get_map', 'bfd_get_field', 'bfd_tile_counts', 'bfd_tile_count_lean', 'bfd_tile_count_fused', 'bfd_activity_counts', 'bfd_device_bytes', 'bfd_rayleigh_forward', 'bfd_get_sensor_dft', 'bfd_dft_series', 'bfd_bhte_run', 'bfd_bhte_run_fields', 'bfd_bhte_run_volumes',
     'bfd_halo_fields', 'bfd_placement_note', 'bfd_set_placement', 'bfd_group_set_placement',
     'bfd_group_create', 'bfd_group_destroy', 'bfd_group_size', 'bfd_group_slab', 'bfd_group_set_materials', 'bfd_group_set_material_map',
     'bfd_group_set_reflector', 'bfd_group_set_sources', 'bfd_group_set_sensor_map', 'bfd_group_prepare', 'bfd_group_run', 'bfd_group_sync',
@@ -131,6 +131,7 @@ def load_library():
     lib.bfd_tile_counts.argtypes = [C.c_void_p] + [C.POINTER(C.c_int32)] * 5
     lib.bfd_tile_count_lean.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
     lib.bfd_tile_count_fused.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+    lib.bfd_activity_counts.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.bfd_device_bytes.restype = C.c_int64
     lib.bfd_device_name.argtypes = [C.c_int, C.c_char_p, C.c_int]
     lib.bfd_bhte_run.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -178,7 +179,7 @@ def load_library():
     lib.bfd_group_peer_status.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
     lib.bfd_placement_cache_release.argtypes = []
     lib.bfd_placement_cache_release.restype = C.c_int64
-    if lib.bfd_abi_version() != 6:
+    if lib.bfd_abi_version() != 7:
         raise EngineError('libbabelfdtd_hip.so ABI version mismatch')
     _lib = lib
     return lib
@@ -474,6 +475,12 @@ class Engine:
         _check(self.lib.bfd_tile_count_fused(self.h, C.byref(fused)), 'bfd_tile_count_fused')
         return {'lossless_fluid': n[0].value, 'lossy_fluid': n[1].value, 'solid': n[2].value,
                 'uniform_fluid': n[3].value, 'pml_fluid': n[4].value, 'lean_fluid': lean.value, 'fused_fluid': fused.value}
+
+    def activity_counts(self):
+        """(active, total) sub-tiles of the quiet-run map; (0, 0) when the engine works on every tile in every half-step."""
+        a, t = C.c_int64(), C.c_int64()
+        _check(self.lib.bfd_activity_counts(self.h, C.byref(a), C.byref(t)), 'bfd_activity_counts')
+        return a.value, t.value
 
     @property
     def device_bytes(self):

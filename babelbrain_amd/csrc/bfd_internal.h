@@ -79,6 +79,10 @@ struct bfd_dev {
     // 0xFFFFFFFF marks planes without compact values (ghost planes: every value there is 0).
     const unsigned *cssRow; int cssStride;
     float *cSxx, *cSyy, *cSxy, *cSxz, *cSyz, *cRxx, *cRyy, *cRxy, *cRxz, *cRyz;
+    // Activity map (round 6; null = every run works in every half-step): one byte per 64 x 8 x BFD_SUBZ sub-tile, 1 = a non-zero V or S value has
+    // been written there. Padded by one sub-tile on every side: sub-tile (bx, by, q) at ((q + 1) * actY + by + 1) * actX + bx + 1. A run whose
+    // sub-tiles and all their neighbours are clear returns at entry (bfd_kernels_v2.hip, "QUIET runs"). Whole domains in production calls only.
+    unsigned char *act; int actX, actY;
 };
 #define BFD_CSS_NONE 0xFFFFFFFFu
 // a cell has compact values ("listed") when its class byte says solid centre, no reflector
@@ -173,6 +177,7 @@ struct bfd_sim {
     hipEvent_t evRead[2][2]; bool evReadUsed[2][2];      // [buffer][0 = engine stream, 1 = a side stream]: behind the last kernels that read the tile the buffer holds
     std::future<void> packJob[2];
     // sensors
+    unsigned char *actBase; size_t actBytes; bool actReady;   // storage of bfd_dev::act; actReady = the map matches the state (cleared by setters and bfd_reset)
     int *sensEnt; bool sensEntValid;   // compact solid state: list entry of every sensor voxel (-1 = none), valid for the current list
     int64_t nSensors; uint32_t *sensLin; float *sensOut; int nTs; int nSelS; int selS[BFD_MAP_COUNT];
     double *dftAcc; float *dftPk; int dftBin;      // sensorMode 1: [nSelS][nSensors][2] running DFT sums, [nSelS][nSensors] running peaks
@@ -217,6 +222,7 @@ int bfd_fused_max_materials(void);
 int bfd_tile_subz(void);
 bool bfd_css_supported(void);     // false in the experiment builds whose solid-run kernels have no compact form
 void bfd_launch_classify(const bfd_dev &d, hipStream_t s, int *flagsDev, int *tileMatDev);
+void bfd_launch_mark_source_subtiles(const bfd_dev &d, hipStream_t s, const uint32_t *lin, long n);
 // flags the cells of the sparse shear list: solid, non-reflector centre; mixedOnly: only those with BFD_CLS_MIXED (merged solid stress kernel)
 void bfd_launch_mark_solid(const bfd_dev &d, hipStream_t s, unsigned char *flag, long n, bool mixedOnly);
 void bfd_launch_shear_order_keys(const bfd_dev &d, hipStream_t s, const unsigned *cells, unsigned long long *keys, long n, int lowPlanes, int hiStart, int mode);

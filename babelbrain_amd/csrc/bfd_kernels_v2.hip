@@ -471,6 +471,39 @@ __global__ __launch_bounds__(NTHREADS, VELOCITY_WAVES_PER_SIMD) void velocity_v2
 
 
 // ------------------------------------------------------------------------------------------------
+// QUIET runs (round 6, production calls only: bfd_dev::act != null). Ahead of the wave front every field is EXACTLY zero (float32 with
+// denormals flushed: the numerical precursors of the front die out some 25 cells ahead of it), and a half-step maps an all-zero
+// neighbourhood onto itself. bfd_dev::act holds one byte per 64 x 8 x SUBZ sub-tile (padded by one sub-tile on every side, border 0):
+// 1 = a kernel has written a non-zero V or S value into the sub-tile at some time (set-only; the sub-tiles that hold source voxels carry
+// it from the start). A run whose own sub-tiles and all their 26 neighbours are clear returns at entry: everything it would read is zero,
+// everything it would write is the zero that is there already (memory variables and absorbing-layer variables included: they are driven
+// by the same values). A run that does work ORs the bits of what it stores and sets the byte of its sub-tiles if anything was non-zero.
+// Flags only ever get set, so reading a neighbour's byte while that neighbour sets it in the same launch errs on the side of working.
+// The sparse kernel has no part in this: a non-zero it writes lies within 2 cells of a non-zero V, whose sub-tile is flagged, and every run
+// within reach of that cell is a neighbour of that sub-tile. Bit-identical to running every run (the -0 a skipped update might have
+// produced compares equal to the +0 that stays).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool run_all_quiet(const bfd_dev &d, int bx, int by, int kbeg, int kend)
+{
+    const int q0 = kbeg / SUBZ, q1 = (kend - 1) / SUBZ;
+    const int nq = q1 - q0 + 3;                             // the run's sub-tiles, one more below and one above
+    if (9 * nq > 64) return false;
+    const int l = threadIdx.x;                              // lane: a wave is one tile row
+    const int dq = l / 9, r = l - 9 * dq, dy = r / 3, dx = r - 3 * dy;
+    // padded coordinates: sub-tile (bx, by, q) sits at (bx + 1, by + 1, q + 1), so its lower neighbour is at (bx, by, q)
+    const unsigned idx = (unsigned)(((q0 + dq) * d.actY + (by + dy)) * d.actX + (bx + dx));
+    const unsigned f = (l < 9 * nq) ? (unsigned)d.act[idx] : 0u;
+    return __ballot(f != 0u) == 0ull;
+}
+__device__ __forceinline__ void run_mark_active(const bfd_dev &d, int bx, int by, int kbeg, int kend, unsigned nzbits)
+{
+    if (__ballot((nzbits & 0x7fffffffu) != 0u) == 0ull) return;
+    if (threadIdx.x == 0)
+        for (int q = kbeg / SUBZ; q <= (kend - 1) / SUBZ; q++) d.act[((q + 1) * d.actY + by + 1) * d.actX + bx + 1] = 1;
+}
+__device__ __forceinline__ unsigned fbits(float v) { return __float_as_uint(v); }
+
+// ------------------------------------------------------------------------------------------------
 // FLUID tiles: no solid cell within the tile grown by 2 cells in every direction. There
 //   * shear stresses and their memory variables are never updated (a shear update needs the 4
 //     cells around an edge to be solid), so they stay exactly 0 and need not be read;
@@ -491,10 +524,11 @@ __global__ __launch_bounds__(NTHREADS, VELOCITY_WAVES_PER_SIMD) void velocity_v2
 // a fluid: the same expression serves every lane, equal to the fluid one up to the sign of an exact zero); everything else a solid cell has --
 // Sxx, Syy, the shear stresses and their memory variables -- is the sparse kernel's (stress_shear_sparse, which runs after this one and reads
 // the absorbing-layer memory variables this kernel has just advanced).
-template <bool LOSSY, bool COLLAPSED, bool UNI, bool PML, bool SOLID = false>
+template <bool LOSSY, bool COLLAPSED, bool UNI, bool PML, bool SOLID = false, bool QUIET = false>
 __device__ __forceinline__ void stress_fluid_body(const bfd_dev &d, int bx, int by, int kbeg, int kend, int tm,
                                                   float (*sV)[2][LH * LW])
 {
+    unsigned nzb = 0u;          // QUIET: bits of everything stored
     // The three normal stresses are identical in a FLUID tile; Szz is the one that is read (it is
     // also the one whose ghost planes the Z-neighbour exchange carries), all three are written.
     const int N1 = d.N1, N2 = d.N2;
@@ -605,6 +639,7 @@ __device__ __forceinline__ void stress_fluid_body(const bfd_dev &d, int bx, int 
             // COLLAPSED (no solid tile in the slab, no per-component stress output selected): nobody
             // reads Sxx/Syy/Rxx/Ryy, so only the Szz/Rzz copy is kept (expanded on demand, bfd_api.hip)
             ST4((d.SzzW + ko), cij * 4u, val);
+            if (QUIET) nzb |= fbits(val) | fbits(rn);
             if (!COLLAPSED) { F4((d.Sxx + ko), cij * 4u) = val; F4((d.Syy + ko), cij * 4u) = val; }
             if (LOSSY) {
                 ST4((d.RzzW + ko), cij * 4u, rn);
@@ -616,9 +651,10 @@ __device__ __forceinline__ void stress_fluid_body(const bfd_dev &d, int bx, int 
         hv = nh; szz = nszz; rzz = nrzz; mraw = nmraw;
         px = npx; py = npy; pz = npz; qx += dqx; qy += dqy;
     }
+    if (QUIET) run_mark_active(d, bx, by, kbeg, kend, nzb);
 }
 
-template <bool ACC, bool UNI, bool PML>
+template <bool ACC, bool UNI, bool PML, bool QUIET = false>
 __device__ __forceinline__ void velocity_fluid_body(const bfd_dev &d, int bx, int by, int kbeg, int kend, int tm,
                                                     float (*sS)[LH * LW], float *__restrict__ accP, float *__restrict__ pkP)
 {
@@ -645,6 +681,7 @@ __device__ __forceinline__ void velocity_fluid_body(const bfd_dev &d, int bx, in
 
     const bool inner = valid && i >= d.ND && i < N1 - d.ND && j >= d.ND && j < N2 - d.ND;
     const bool accA = ACC && accP != nullptr, accK = ACC && pkP != nullptr;
+    unsigned nzb = 0u;          // QUIET: bits of everything stored
     float ru = 0.f;
     if (UNI) ru = d.invRho[tm];                       // 0.5*(r+r) == r exactly: every face of a UNI tile sees one 1/rho
 
@@ -735,9 +772,15 @@ __device__ __forceinline__ void velocity_fluid_body(const bfd_dev &d, int bx, in
                         dz = dz + pn;
                     }
                 }
-                ST4((d.VxW + ko), cij * 4u, vx + (0.5f * (r0 + rx)) * dx);
-                ST4((d.VyW + ko), cij * 4u, vy + (0.5f * (r0 + ry)) * dy);
-                ST4((d.VzW + ko), cij * 4u, vz + (0.5f * (r0 + r1)) * dz);
+                if (!QUIET) {
+                    ST4((d.VxW + ko), cij * 4u, vx + (0.5f * (r0 + rx)) * dx);
+                    ST4((d.VyW + ko), cij * 4u, vy + (0.5f * (r0 + ry)) * dy);
+                    ST4((d.VzW + ko), cij * 4u, vz + (0.5f * (r0 + r1)) * dz);
+                } else {
+                    { const float w = vx + (0.5f * (r0 + rx)) * dx; ST4((d.VxW + ko), cij * 4u, w); nzb |= fbits(w); }
+                    { const float w = vy + (0.5f * (r0 + ry)) * dy; ST4((d.VyW + ko), cij * 4u, w); nzb |= fbits(w); }
+                    { const float w = vz + (0.5f * (r0 + r1)) * dz; ST4((d.VzW + ko), cij * 4u, w); nzb |= fbits(w); }
+                }
             }
         }
         sm1 = s0; s0 = sp1; sp1 = sp2; sp2 = ns;
@@ -745,6 +788,7 @@ __device__ __forceinline__ void velocity_fluid_body(const bfd_dev &d, int bx, in
         r0 = r1; mraw = mraw1; mraw1 = nm2; mx = nmx; my = nmy;
         px = npx; py = npy; pz = npz; qx += dqx; qy += dqy;
     }
+    if (QUIET) run_mark_active(d, bx, by, kbeg, kend, nzb);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1550,10 +1594,11 @@ __device__ __forceinline__ void stress_solid_body_g(const bfd_dev &d, const int4
 // fewer in a kernel that spilled twelve (each spilled one comes back through a v_readlane in every plane, and scalar address arithmetic
 // that no longer fits turns into vector instructions + readfirstlane). 0.400 -> 0.384 ms at the shear medium 512^3; a further flavour without
 // the peak accumulator (six spilled registers less) changed nothing measurable and was not kept. profiles/r5/velocity_solid_scalar_registers.txt
-template <bool ACC, bool PML, bool CSS, bool WHOLE = false>
+template <bool ACC, bool PML, bool CSS, bool WHOLE = false, bool QUIET = false>
 __device__ __forceinline__ void velocity_solid_body_g(const bfd_dev &d, const int4 &run, int tilesX, float (*sS)[5][LH * LW],
                                                       float *__restrict__ accP, float *__restrict__ pkP)
 {
+    unsigned nzb = 0u;          // QUIET: bits of everything stored
     const int N1 = d.N1, N2 = d.N2;
     const int bx = run.x % tilesX, by = run.x / tilesX;
     const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * TX + tx;
@@ -1827,9 +1872,9 @@ __device__ __forceinline__ void velocity_solid_body_g(const bfd_dev &d, const in
                     dzSzz = cpml(d.psi[17], q, d.azH[k], d.bzH[k], dzSzz);
                 }
                 const float bxv = 0.5f * (r0 + rx), byv = 0.5f * (r0 + ry), bzv = 0.5f * (r0 + r1);
-                gs4nt(wVx, c4, vx + bxv * ((dxSxx + dySxy) + dzSxz));
-                gs4nt(wVy, c4, vy + byv * ((dxSxy + dySyy) + dzSyz));
-                gs4nt(wVz, c4, vz + bzv * ((dxSxz + dySyz) + dzSzz));
+                { const float w = vx + bxv * ((dxSxx + dySxy) + dzSxz); gs4nt(wVx, c4, w); if (QUIET) nzb |= fbits(w); }
+                { const float w = vy + byv * ((dxSxy + dySyy) + dzSyz); gs4nt(wVy, c4, w); if (QUIET) nzb |= fbits(w); }
+                { const float w = vz + bzv * ((dxSxz + dySyz) + dzSzz); gs4nt(wVz, c4, w); if (QUIET) nzb |= fbits(w); }
             }
         }
         // masks of the prefetched values, queues, staging of plane kl+1
@@ -1848,6 +1893,7 @@ __device__ __forceinline__ void velocity_solid_body_g(const bfd_dev &d, const in
         cB = cC; cC = nc3;
         if (CSS) { rbB = rbC; rbC = nrb; rbA = nrbA; rbx = nrbx; }
     }
+    if (QUIET) run_mark_active(d, run.x % tilesX, run.x / tilesX, run.y & 0xFFFF, run.y >> 16, nzb);
 }
 #undef DD
 
@@ -1868,7 +1914,7 @@ __global__ __launch_bounds__(NTHREADS, SOLID_STRESS_WAVES_PER_SIMD) void stress_
 #ifndef SOLID_VELOCITY_WAVES_PER_SIMD
 #define SOLID_VELOCITY_WAVES_PER_SIMD 6      // 80 registers = three workgroups per CU; no scratch since the bases are re-read per plane (round 6). The absorbing-layer flavour needs 106 registers and gets 4
 #endif
-template <bool ACC, bool PML, bool CSS, bool WHOLE = false>
+template <bool ACC, bool PML, bool CSS, bool WHOLE = false, bool QUIET = false>
 __global__ __launch_bounds__(NTHREADS, PML ? 4 : SOLID_VELOCITY_WAVES_PER_SIMD) void velocity_solid(bfd_dev d, int tilesX, int nblocks, const int *__restrict__ xmap,
                                                         float *__restrict__ accP, float *__restrict__ pkP,
                                                         const int4 *__restrict__ runs)
@@ -1881,8 +1927,9 @@ __global__ __launch_bounds__(NTHREADS, PML ? 4 : SOLID_VELOCITY_WAVES_PER_SIMD) 
     const int ri = run_index(nblocks, xmap);
     if (ri < 0) return;
     const int4 run = runs[ri];
+    if (QUIET && run_all_quiet(d, run.x % tilesX, run.x / tilesX, run.y & 0xFFFF, run.y >> 16)) return;
 #ifndef BFD_VELOCITY_SOLID_FLAT      // default since round 4: GLOBAL loads, prefetch without branches (0.405 -> 0.378 ms at the shear medium 512^3)
-    velocity_solid_body_g<ACC, PML, CSS, WHOLE>(d, run, tilesX, sS, accP, pkP);
+    velocity_solid_body_g<ACC, PML, CSS, WHOLE, QUIET>(d, run, tilesX, sS, accP, pkP);
 #else
     static_assert(!CSS, "the FLAT body has no compact form");
     velocity_solid_body<ACC, PML>(d, run, tilesX, sS, accP, pkP);
@@ -2218,24 +2265,25 @@ __global__ void shear_material_table(bfd_dev d, float *__restrict__ tab, int nMa
 // ---- dispatchers: one launch for all fluid runs; block-uniform switch on the run's flags ----
 // run = (x: bx + tilesX*by, y: kbeg | kend<<16, z: flags, w: material id of UNI runs)
 // flags: bit0 solid, bit1 lossy, bit2 UNI, bit3 PML, bit4 LEAN
-template <bool COLLAPSED>
+template <bool COLLAPSED, bool QUIET = false>
 __device__ __forceinline__ void stress_fluid_switch(const bfd_dev &d, const int4 &run, int tilesX, float (*sV)[2][LH * LW])
 {
     const int bx = run.x % tilesX, by = run.x / tilesX, kbeg = run.y & 0xFFFF, kend = run.y >> 16, tm = run.w;
+    if (QUIET && run_all_quiet(d, bx, by, kbeg, kend)) return;
     if (run.z & 1) {          // a solid run in the fluid launch (compact solid state): memory variables, several materials
-        if (run.z & 8) stress_fluid_body<true, true, false, true, true>(d, bx, by, kbeg, kend, tm, sV);
-        else stress_fluid_body<true, true, false, false, true>(d, bx, by, kbeg, kend, tm, sV);
+        if (run.z & 8) stress_fluid_body<true, true, false, true, true, QUIET>(d, bx, by, kbeg, kend, tm, sV);
+        else stress_fluid_body<true, true, false, false, true, QUIET>(d, bx, by, kbeg, kend, tm, sV);
         return;
     }
     switch ((run.z >> 1) & 7) {
-    case 0: stress_fluid_body<false, COLLAPSED, false, false>(d, bx, by, kbeg, kend, tm, sV); break;
-    case 1: stress_fluid_body<true, COLLAPSED, false, false>(d, bx, by, kbeg, kend, tm, sV); break;
-    case 2: stress_fluid_body<false, COLLAPSED, true, false>(d, bx, by, kbeg, kend, tm, sV); break;
-    case 3: stress_fluid_body<true, COLLAPSED, true, false>(d, bx, by, kbeg, kend, tm, sV); break;
-    case 4: stress_fluid_body<false, COLLAPSED, false, true>(d, bx, by, kbeg, kend, tm, sV); break;
-    case 5: stress_fluid_body<true, COLLAPSED, false, true>(d, bx, by, kbeg, kend, tm, sV); break;
-    case 6: stress_fluid_body<false, COLLAPSED, true, true>(d, bx, by, kbeg, kend, tm, sV); break;
-    default: stress_fluid_body<true, COLLAPSED, true, true>(d, bx, by, kbeg, kend, tm, sV); break;
+    case 0: stress_fluid_body<false, COLLAPSED, false, false, false, QUIET>(d, bx, by, kbeg, kend, tm, sV); break;
+    case 1: stress_fluid_body<true, COLLAPSED, false, false, false, QUIET>(d, bx, by, kbeg, kend, tm, sV); break;
+    case 2: stress_fluid_body<false, COLLAPSED, true, false, false, QUIET>(d, bx, by, kbeg, kend, tm, sV); break;
+    case 3: stress_fluid_body<true, COLLAPSED, true, false, false, QUIET>(d, bx, by, kbeg, kend, tm, sV); break;
+    case 4: stress_fluid_body<false, COLLAPSED, false, true, false, QUIET>(d, bx, by, kbeg, kend, tm, sV); break;
+    case 5: stress_fluid_body<true, COLLAPSED, false, true, false, QUIET>(d, bx, by, kbeg, kend, tm, sV); break;
+    case 6: stress_fluid_body<false, COLLAPSED, true, true, false, QUIET>(d, bx, by, kbeg, kend, tm, sV); break;
+    default: stress_fluid_body<true, COLLAPSED, true, true, false, QUIET>(d, bx, by, kbeg, kend, tm, sV); break;
     }
 }
 
@@ -2262,7 +2310,7 @@ __device__ __forceinline__ void xcd_clock_end(int) {}
 
 // COLLAPSED = true: all-fluid slab, every run keeps only Szz/Rzz. false: slab with solid tiles; runs flagged LEAN
 // (bit4) still take the collapsed bodies, the others write all three normal stresses.
-template <bool COLLAPSED>
+template <bool COLLAPSED, bool QUIET = false>
 __global__ __launch_bounds__(NTHREADS, FLUID_WAVES_PER_SIMD) void stress_fluid(bfd_dev d, int tilesX, int nblocks, const int *__restrict__ xmap,
                                                                                const int4 *__restrict__ runs)
 {
@@ -2271,12 +2319,12 @@ __global__ __launch_bounds__(NTHREADS, FLUID_WAVES_PER_SIMD) void stress_fluid(b
     if (ri < 0) return;
     const int4 run = runs[ri];
     xcd_clock_begin(0);
-    if (COLLAPSED || (run.z & 16)) stress_fluid_switch<true>(d, run, tilesX, sV);
-    else stress_fluid_switch<false>(d, run, tilesX, sV);
+    if (COLLAPSED || (run.z & 16)) stress_fluid_switch<true, QUIET>(d, run, tilesX, sV);
+    else stress_fluid_switch<false, QUIET>(d, run, tilesX, sV);
     xcd_clock_end(0);
 }
 
-template <bool ACC>
+template <bool ACC, bool QUIET = false>
 __global__ __launch_bounds__(NTHREADS, VELOCITY_FLUID_WAVES_PER_SIMD) void velocity_fluid(bfd_dev d, int tilesX, int nblocks, const int *__restrict__ xmap,
                                                                                  const int4 *__restrict__ runs,
                                                                                  float *__restrict__ accP, float *__restrict__ pkP)
@@ -2287,11 +2335,12 @@ __global__ __launch_bounds__(NTHREADS, VELOCITY_FLUID_WAVES_PER_SIMD) void veloc
     const int4 run = runs[ri];
     const int bx = run.x % tilesX, by = run.x / tilesX, kbeg = run.y & 0xFFFF, kend = run.y >> 16, tm = run.w;
     xcd_clock_begin(1);
+    if (QUIET && run_all_quiet(d, bx, by, kbeg, kend)) return;
     switch ((run.z >> 2) & 3) {
-    case 0: velocity_fluid_body<ACC, false, false>(d, bx, by, kbeg, kend, tm, sS, accP, pkP); break;
-    case 1: velocity_fluid_body<ACC, true, false>(d, bx, by, kbeg, kend, tm, sS, accP, pkP); break;
-    case 2: velocity_fluid_body<ACC, false, true>(d, bx, by, kbeg, kend, tm, sS, accP, pkP); break;
-    default: velocity_fluid_body<ACC, true, true>(d, bx, by, kbeg, kend, tm, sS, accP, pkP); break;
+    case 0: velocity_fluid_body<ACC, false, false, QUIET>(d, bx, by, kbeg, kend, tm, sS, accP, pkP); break;
+    case 1: velocity_fluid_body<ACC, true, false, QUIET>(d, bx, by, kbeg, kend, tm, sS, accP, pkP); break;
+    case 2: velocity_fluid_body<ACC, false, true, QUIET>(d, bx, by, kbeg, kend, tm, sS, accP, pkP); break;
+    default: velocity_fluid_body<ACC, true, true, QUIET>(d, bx, by, kbeg, kend, tm, sS, accP, pkP); break;
     }
     xcd_clock_end(1);
 }
@@ -2472,6 +2521,20 @@ void bfd_launch_shear_coefficients(const bfd_dev &d, hipStream_t s, const unsign
     if (tab) hipLaunchKernelGGL(shear_material_table, dim3((unsigned)((nMat + 255) / 256)), dim3(256), 0, s, d, tab, nMat);
 }
 
+// activity map (bfd_dev::act): the sub-tiles that hold source voxels are active from the start
+__global__ void mark_source_subtiles(bfd_dev d, const uint32_t *__restrict__ lin, long n)
+{
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const unsigned c = lin[t];
+    const int kl = (int)(c / (unsigned)d.plane), r = (int)(c - (unsigned)kl * (unsigned)d.plane), j = r / d.N1, i = r - j * d.N1;
+    d.act[((kl / SUBZ + 1) * d.actY + j / TY + 1) * d.actX + i / TX + 1] = 1;
+}
+void bfd_launch_mark_source_subtiles(const bfd_dev &d, hipStream_t s, const uint32_t *lin, long n)
+{
+    if (n > 0) hipLaunchKernelGGL(mark_source_subtiles, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d, lin, n);
+}
+
 void bfd_launch_classify(const bfd_dev &d, hipStream_t s, int *flagsDev, int *tileMatDev)
 {
     int tx, ty, tz; bfd_tile_grid(d, &tx, &ty, &tz);
@@ -2510,7 +2573,8 @@ void bfd_launch_stress_v2(const bfd_dev &d, hipStream_t s0, const bfd_tiles *t, 
         part_range(t->nAll, t->nAllB, part, &offA, &nA);
         if (nA) {
             BFD_KT(BFD_K_STRESS_FLUID, 0);
-            BFD_LAUNCH((stress_fluid<true>), nA, (const int *)nullptr, t->runsAll + offA);
+            if (d.act) BFD_LAUNCH((stress_fluid<true, true>), nA, (const int *)nullptr, t->runsAll + offA);
+            else BFD_LAUNCH((stress_fluid<true>), nA, (const int *)nullptr, t->runsAll + offA);
             BFD_KT(BFD_K_STRESS_FLUID, 1);
         }
         n = 0; nS = 0;
@@ -2548,7 +2612,8 @@ void bfd_launch_stress_v2(const bfd_dev &d, hipStream_t s0, const bfd_tiles *t, 
     s = s0;
     if (n) {
         BFD_KT(BFD_K_STRESS_FLUID, 0);
-        BFD_LAUNCH_X((stress_fluid<true>), n, BFD_XM_SF + part, t->runs + off);      // fluid cells keep one copy of their normal stresses (bfd_dev::cls)
+        if (d.act) BFD_LAUNCH_X((stress_fluid<true, true>), n, BFD_XM_SF + part, t->runs + off);
+        else BFD_LAUNCH_X((stress_fluid<true>), n, BFD_XM_SF + part, t->runs + off);      // fluid cells keep one copy of their normal stresses (bfd_dev::cls)
         BFD_KT(BFD_K_STRESS_FLUID, 1);
     }
     if (conc) for (int q = 0; q < 2; q++) { hipEventRecord(t->sideJoin[q], t->sideStream[q]); hipStreamWaitEvent(s0, t->sideJoin[q], 0); }
@@ -2578,6 +2643,11 @@ void bfd_launch_velocity_v2(const bfd_dev &d, hipStream_t s0, float *accP, float
                 if (cnt <= 0) return;
 #ifndef BFD_VELOCITY_SOLID_FLAT
                 // a whole domain, or the interior runs of a Z-slab (part 2 of a split half-step: they reach no ghost plane), V in place
+                if (d.act && d.cssRow && d.VxW == d.Vx && d.VyW == d.Vy && d.VzW == d.Vz && d.k0 == 0 && d.nk == d.N3) {       // quiet runs return at entry (production calls)
+                    if (pml) { if (acc) BFD_LAUNCH_X((velocity_solid<true, true, true, true, true>), cnt, m, accP, pkP, base + a0); else BFD_LAUNCH_X((velocity_solid<false, true, true, true, true>), cnt, m, accP, pkP, base + a0); }
+                    else { if (acc) BFD_LAUNCH_X((velocity_solid<true, false, true, true, true>), cnt, m, accP, pkP, base + a0); else BFD_LAUNCH_X((velocity_solid<false, false, true, true, true>), cnt, m, accP, pkP, base + a0); }
+                    return;
+                }
                 if (d.cssRow && d.VxW == d.Vx && d.VyW == d.Vy && d.VzW == d.Vz && ((d.k0 == 0 && d.nk == d.N3) || part == 2)) {
                     if (pml) { if (acc) BFD_LAUNCH_X((velocity_solid<true, true, true, true>), cnt, m, accP, pkP, base + a0); else BFD_LAUNCH_X((velocity_solid<false, true, true, true>), cnt, m, accP, pkP, base + a0); }
                     else { if (acc) BFD_LAUNCH_X((velocity_solid<true, false, true, true>), cnt, m, accP, pkP, base + a0); else BFD_LAUNCH_X((velocity_solid<false, false, true, true>), cnt, m, accP, pkP, base + a0); }
@@ -2602,7 +2672,10 @@ void bfd_launch_velocity_v2(const bfd_dev &d, hipStream_t s0, float *accP, float
     s = s0;
     if (nF) {
         BFD_KT(BFD_K_VELOCITY_FLUID, 0);
-        if (acc) BFD_LAUNCH_X((velocity_fluid<true>), nF, BFD_XM_VF + part, t->runs + offF, accP, pkP);
+        if (d.act) {
+            if (acc) BFD_LAUNCH_X((velocity_fluid<true, true>), nF, BFD_XM_VF + part, t->runs + offF, accP, pkP);
+            else BFD_LAUNCH_X((velocity_fluid<false, true>), nF, BFD_XM_VF + part, t->runs + offF, accP, pkP);
+        } else if (acc) BFD_LAUNCH_X((velocity_fluid<true>), nF, BFD_XM_VF + part, t->runs + offF, accP, pkP);
         else BFD_LAUNCH_X((velocity_fluid<false>), nF, BFD_XM_VF + part, t->runs + offF, accP, pkP);
         BFD_KT(BFD_K_VELOCITY_FLUID, 1);
     }

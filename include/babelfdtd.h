@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define BFD_ABI_VERSION 6
+#define BFD_ABI_VERSION 7
 
 enum {
     BFD_MAP_VX = 0, BFD_MAP_VY = 1, BFD_MAP_VZ = 2,
@@ -237,6 +237,14 @@ int bfd_tile_counts(bfd_sim *sim, int32_t *nLossless, int32_t *nLossy, int32_t *
 int bfd_tile_count_lean(bfd_sim *sim, int32_t *nLean);
 /* fluid sub-tiles advanced by the fused time-step kernel (kernelVariant 4 on a whole domain; 0 otherwise) */
 int bfd_tile_count_fused(bfd_sim *sim, int32_t *nFused);
+/* Quiet runs (ABI 7). A production call of a whole domain -- the caller's own accumulation window (rmsFirstStep = 0), class-specialised
+ * kernels, solid-only values compact; BFD_SKIP_ZERO=0 switches it off -- keeps one activity byte per 64x8x8-voxel sub-tile: set once a kernel
+ * has written a non-zero velocity or stress there (the sub-tiles of the source voxels from the start). Ahead of the wave front every field
+ * is exactly zero (float32, denormals flushed), and a tile run whose sub-tiles and all their neighbours are clear returns at entry: results
+ * are bit-identical, the steps before the front has crossed the domain cost less (the time plan BabelIntegrationBASE.py:2082-2109 gives a
+ * call about 1.8 transits of the domain's diagonal). *active = sub-tiles marked so far, *total = sub-tiles of the domain; both 0 when the
+ * engine runs every tile in every half-step (Z-slabs, bench.py's timed windows, the other kernel variants). */
+int bfd_activity_counts(bfd_sim *sim, int64_t *active, int64_t *total);
 /* device memory this sim holds, bytes */
 int64_t bfd_device_bytes(bfd_sim *sim);
 

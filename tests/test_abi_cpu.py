@@ -27,7 +27,7 @@ def test_header_symbols_exported(lib):
     assert declared == sorted(_engine.ABI_SYMBOLS)
     for s in declared:
         assert hasattr(lib, s), s
-    assert lib.bfd_abi_version() == 6
+    assert lib.bfd_abi_version() == 7
 
 
 def test_struct_layout_matches_header():

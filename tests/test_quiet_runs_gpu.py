@@ -1,0 +1,131 @@
+"""Quiet runs (bfd_dev::act, ABI 7): in a production call of a whole domain the tile runs ahead of the wave front -- every field there is exactly
+zero -- return at entry. The results must not know: every test here compares bit for bit with the same engine under BFD_SKIP_ZERO=0 (every run
+works in every half-step), on grids several tiles wide so that runs really are skipped, and checks through bfd_activity_counts that they were."""
+import numpy as np
+import pytest
+
+from babelbrain_amd import _engine, harness as H
+from babelbrain_amd.PropagationModel import compact_sources
+from tests.util import compare_runs, oracle_dt
+
+pytestmark = pytest.mark.gpu
+
+
+def _hip_dt(ml, f, h, c):
+    return _engine.stable_dt(ml, f, True, h, c)
+
+
+def _engine_for(a, k, nt, maps=('Pressure',), **kw):
+    mm, ml, f, smap, pulse, h, T, sensor = a
+    eng = _engine.Engine(*mm.shape, len(ml), h, k['DT'], f, nt, NDelta=k['NDelta'], typeSource=k['TypeSource'], sensorSub=k['SensorSubSampling'],
+                         sensorStart=k['SensorStart'], selMapsRMS=list(maps), selMapsSensors=['Pressure'], selRMSorPeak=1, **kw)
+    eng.set_materials(ml, k['QCorrection'])
+    eng.set_material_map(mm, 0, 0)
+    if k.get('ReflectorMask') is not None:
+        eng.set_reflector(k['ReflectorMask'])
+    eng.set_sources(*compact_sources(smap, k['Ox'], k['Oy'], k['Oz']), pulse)
+    eng.set_sensor_map(sensor)
+    return eng
+
+
+def _staged(a, k, stages, skip, monkeypatch, again_at=None, **kw):
+    """Runs the stages one after the other; after each: all 15 state arrays, the RMS map, the sensors and the activity counts."""
+    monkeypatch.setenv('BFD_SKIP_ZERO', '1' if skip else '0')
+    nt = sum(stages)
+    eng = _engine_for(a, k, nt, **kw)
+    out = []
+    for q, n in enumerate(stages):
+        if again_at is not None and q == again_at:         # inputs set again in the middle of a run: from here on every sub-tile counts as active
+            mm, ml, f, smap, pulse, h, T, sensor = a
+            eng.set_sources(*compact_sources(smap, k['Ox'], k['Oy'], k['Oz']), pulse)
+        eng.run(n)
+        o = {n_: eng.get_field(n_).copy() for n_ in _engine.FIELD_NAMES}
+        o['rms'] = eng.get_map(_engine.KIND_RMS, 'Pressure').copy()
+        o['sensors'] = eng.sensors().copy()
+        o['activity'] = eng.activity_counts()
+        out.append(o)
+    eng.reset()
+    eng.run(stages[0])                                     # after a reset the map starts over
+    o = {n_: eng.get_field(n_).copy() for n_ in _engine.FIELD_NAMES}
+    o['activity'] = eng.activity_counts()
+    out.append(o)
+    eng.close()
+    return out
+
+
+def _same(on, off):
+    for q, (x, y) in enumerate(zip(on, off)):
+        for n in x:
+            if n != 'activity':
+                assert np.array_equal(x[n], y[n]), (q, n)
+
+
+@pytest.mark.parametrize('config,N', [('C1', (192, 96, 160)), ('C2', (192, 96, 160)), ('C3', (160, 128, 144))])
+def test_quiet_runs_do_not_change_a_bit(config, N, monkeypatch):
+    """Water, skull with shear (compact solid state, the sparse kernel beside the marching ones) and the CT medium: stages of 60 + 200 + 400 steps,
+    then a reset. While the front is on its way some sub-tiles are still clear (runs were skipped), later all of the interior is active."""
+    a, k, info = H.make_problem(config, N=N, steps=660, stable_dt_fn=_hip_dt)
+    on = _staged(a, k, (60, 200, 400), True, monkeypatch)
+    off = _staged(a, k, (60, 200, 400), False, monkeypatch)
+    _same(on, off)
+    assert all(o['activity'] == (0, 0) for o in off)
+    act = [o['activity'] for o in on]
+    total = act[0][1]
+    assert total == -(-N[0] // 64) * -(-N[1] // 8) * -(-N[2] // 8)
+    assert 0 < act[0][0] < act[1][0] < act[2][0] <= total and act[0][0] < 0.5 * total, act
+    assert act[3] == act[0]                                # the same stage after a reset marks the same sub-tiles
+    assert on[2]['rms'].max() > 0 and np.abs(on[0]['Vz']).max() > 0
+
+
+def test_quiet_runs_with_a_stress_source_a_reflector_and_every_map(monkeypatch):
+    """The back-propagation call's shape (a stress point source, TypeSource 2), a reflector mask, all map selections accumulated outside the kernels."""
+    from tests.util import ALL_MAPS
+    a, k, info = H.make_problem('C2', N=(192, 96, 160), steps=420, stable_dt_fn=_hip_dt)
+    mm, ml, f, smap, pulse, h, T, sensor = a
+    smap2, pulse2 = H.punctual_source_map(*mm.shape, (120, 47, 100)), H.punctual_source(f, k['DT'], T, ramp_length=1)
+    refl = np.zeros(mm.shape, np.uint32); refl[60:70, 30:60, 60:64] = 1
+    k2 = dict(k, TypeSource=2, ReflectorMask=refl, Ox=np.array([1.0]), Oy=np.array([1.0]), Oz=np.array([1.0]))
+    a2 = (mm, ml, f, smap2.astype(np.uint32), pulse2, h, T, sensor)
+    on = _staged(a2, k2, (80, 340), True, monkeypatch, maps=ALL_MAPS)
+    off = _staged(a2, k2, (80, 340), False, monkeypatch, maps=ALL_MAPS)
+    _same(on, off)
+    assert 0 < on[0]['activity'][0] < on[1]['activity'][0] and np.abs(on[1]['Sxy']).max() > 0
+
+
+def test_inputs_set_again_in_the_middle_of_a_run(monkeypatch):
+    a, k, info = H.make_problem('C2', N=(192, 96, 160), steps=400, stable_dt_fn=_hip_dt)
+    on = _staged(a, k, (100, 300), True, monkeypatch, again_at=1)
+    off = _staged(a, k, (100, 300), False, monkeypatch, again_at=1)
+    _same(on, off)
+    assert on[0]['activity'][0] < on[0]['activity'][1] and on[1]['activity'][0] == on[1]['activity'][1]
+
+
+def test_drop_in_call_with_quiet_runs_against_the_oracle(monkeypatch):
+    """The drop-in call (which is a production call: quiet runs on) against the oracle, and against itself with every run working, on a grid the front
+    has not crossed when the run ends."""
+    from babelbrain_amd import PropagationModel
+    from oracle import oracle as O
+    a, k, info = H.make_problem('C2', N=(192, 96, 160), steps=300, stable_dt_fn=oracle_dt)
+    monkeypatch.setenv('BFD_SKIP_ZERO', '1')
+    out_on = PropagationModel().StaggeredFDTD_3D_with_relaxation(*a, SILENT=True, **k)
+    monkeypatch.setenv('BFD_SKIP_ZERO', '0')
+    out_off = PropagationModel().StaggeredFDTD_3D_with_relaxation(*a, SILENT=True, **k)
+    assert compare_runs(out_on, out_off, tol=0.0) == 0.0
+    out_o = O.StaggeredFDTD_3D_with_relaxation(*a, **k)
+    compare_runs(out_on, out_o, tol=1e-5)
+    assert out_o[1]['Pressure'][:, :, -40:].max() == 0 and out_o[1]['Pressure'].max() > 0      # the far end is still untouched
+
+
+def test_bench_windows_and_slabs_work_on_every_run(monkeypatch):
+    """rmsFirstStep > 0 (bench.py's timed windows) and Z-slabs keep every run working: no map at all."""
+    monkeypatch.setenv('BFD_SKIP_ZERO', '1')
+    a, k, info = H.make_problem('C1', N=(128, 64, 96), steps=40, stable_dt_fn=_hip_dt)
+    eng = _engine_for(a, k, 40, rmsFirstStep=1)
+    eng.run(40)
+    assert eng.activity_counts() == (0, 0)
+    eng.close()
+    from babelbrain_amd import slab
+    s, info2 = slab.create_hip_slab(a, k, 0, 2, 0)
+    s.half_step_stress(0); s.half_step_velocity(0)
+    assert s.eng.activity_counts() == (0, 0)
+    s.close()
