@@ -478,7 +478,8 @@ __global__ __launch_bounds__(NTHREADS, VELOCITY_WAVES_PER_SIMD) void velocity_v2
 // it from the start). A run whose own sub-tiles and all their 26 neighbours are clear returns at entry: everything it would read is zero,
 // everything it would write is the zero that is there already (memory variables and absorbing-layer variables included: they are driven
 // by the same values). A run that does work ORs the bits of what it stores and sets the byte of its sub-tiles if anything was non-zero.
-// Flags only ever get set, so reading a neighbour's byte while that neighbour sets it in the same launch errs on the side of working.
+// Flags only ever get set, so reading a neighbour's byte while that neighbour sets it in the same launch errs on the side of working (the
+// decision is taken once per workgroup: run_all_quiet).
 // The sparse kernel has no part in this: a non-zero it writes lies within 2 cells of a non-zero V, whose sub-tile is flagged, and every run
 // within reach of that cell is a neighbour of that sub-tile. Bit-identical to running every run (the -0 a skipped update might have
 // produced compares equal to the +0 that stays).
@@ -493,7 +494,9 @@ __device__ __forceinline__ bool run_all_quiet(const bfd_dev &d, int bx, int by, 
     // padded coordinates: sub-tile (bx, by, q) sits at (bx + 1, by + 1, q + 1), so its lower neighbour is at (bx, by, q)
     const unsigned idx = (unsigned)(((q0 + dq) * d.actY + (by + dy)) * d.actX + (bx + dx));
     const unsigned f = (l < 9 * nq) ? (unsigned)d.act[idx] : 0u;
-    return __ballot(f != 0u) == 0ull;
+    // ONE answer per workgroup: every wave reads the bytes for itself, and a neighbour may set its byte between two of those reads -- a wave that
+    // left while its siblings stayed would leave their LDS tile with rows nobody filled. If any wave saw a set byte, all of them work.
+    return __syncthreads_or(f != 0u) == 0;
 }
 __device__ __forceinline__ void run_mark_active(const bfd_dev &d, int bx, int by, int kbeg, int kend, unsigned nzbits)
 {

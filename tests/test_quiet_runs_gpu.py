@@ -129,3 +129,25 @@ def test_bench_windows_and_slabs_work_on_every_run(monkeypatch):
     s.half_step_stress(0); s.half_step_velocity(0)
     assert s.eng.activity_counts() == (0, 0)
     s.close()
+
+
+@pytest.mark.timeout(900)
+def test_production_length_call_at_c3_with_and_without_quiet_runs(monkeypatch):
+    """The metric's own configuration over a whole production call (512^3, nt = 6760 from the caller's time plan): Pressure RMS, last map and
+    the sensor lines of a call whose runs ahead of the front return at entry equal those of a call in which every run works, bit for bit.
+    (What small grids cannot show: 2 x 10^8 workgroups take the decision while neighbours set their bytes in the same launch.)"""
+    psutil = pytest.importorskip('psutil')
+    if psutil.virtual_memory().available < 40 * 2 ** 30:
+        pytest.skip('less than 40 GB of host memory for the 12.9 GB source table and the outputs of two calls')
+    from babelbrain_amd import PropagationModel, RayleighAndBHTE
+    a, k, info = H.make_problem('C3', stable_dt_fn=_hip_dt, forward=RayleighAndBHTE.ForwardSimple, full_sensors=False)
+    assert a[0].shape == (512, 512, 512) and info['nt'] > 6000
+    outs = []
+    for mode in ('1', '0'):
+        monkeypatch.setenv('BFD_SKIP_ZERO', mode)
+        outs.append(PropagationModel().StaggeredFDTD_3D_with_relaxation(*a, SILENT=True, **k))
+    assert compare_runs(outs[0], outs[1], tol=0.0) == 0.0
+    assert outs[0][2]['Pressure'].max() > 0
+    t_on, t_off = outs[0][-1]['timing']['total_ms'], outs[1][-1]['timing']['total_ms']
+    print('C3 production call, step loop: %.2f s with quiet runs, %.2f s with every run working' % (t_on / 1e3, t_off / 1e3))
+    assert t_on < t_off
