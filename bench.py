@@ -47,6 +47,9 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E, /opt/skills/guides/MI355X_MICROAR
 BYTES_STEP_DENSE = 172.0       # every array of every voxel, full viscoelastic everywhere (secondary figure)
 STEADY_SECONDS = 0.35          # GPU load before the timed window (clocks settle; short bursts read a few % high)
 METRIC = 'Mvoxel-steps/sec, 512^3 skull FDTD per device (achieved HBM GB/s in roofline)'      # the same quantity on every launch path and at every N
+# rayleigh_forward<4, false>: SIMD cycles per source-point pair and lane from the instruction mix of its innermost loop (scripts/r6/rayleigh_isa_counts.sh)
+RAYLEIGH_SIMD_CYCLES_PER_PAIR = 864.0 / 8 / 64
+RAYLEIGH_PEAK_GPAIRS = 1024 * 2.4 / RAYLEIGH_SIMD_CYCLES_PER_PAIR        # 1024 SIMDs x 2.4 GHz
 PROFILE_STALE_TOL = 0.03       # a committed PMC profile describes the running binary while its kernel's live launch average stays within 3 % of the profiled one
 
 
@@ -100,7 +103,13 @@ def next_rows(device):
     R.ForwardSimple(2 * np.pi * f / c, cen, ds, u0, rf[:1000])
     R.ForwardSimple(2 * np.pi * f / c, cen, ds, u0, rf)
     pairs = float(len(ds)) * len(rf)
-    out = {'rayleigh_forward': {'value': pairs / R.last_kernel_ms / 1e6, 'unit': 'Gpairs/s', 'sources': len(ds), 'points': len(rf), 'kernel_ms': R.last_kernel_ms}}
+    rate = pairs / R.last_kernel_ms / 1e6
+    out = {'rayleigh_forward': {'value': rate, 'unit': 'Gpairs/s', 'sources': len(ds), 'points': len(rf), 'kernel_ms': R.last_kernel_ms,
+                                'bound': 'valu', 'valu_cycles_per_pair': RAYLEIGH_SIMD_CYCLES_PER_PAIR, 'valu_peak_gpairs': RAYLEIGH_PEAK_GPAIRS,
+                                'valu_frac': rate / RAYLEIGH_PEAK_GPAIRS,
+                                'note': 'vector-ALU roofline of its own kind: the innermost loop of rayleigh_forward<4, false> issues 194 vector instructions per 8 pairs '
+                                        'and lane (104 float64 at 4 cycles per wave64, 38 conversions at 4, 24 packed float32 at 4, 24 quarter-rate sin / cos / rsq at 8, '
+                                        '4 moves at 2: 864 SIMD cycles per 512 pairs; profiles/r6/rayleigh_isa_counts.txt), peak = 1024 SIMDs x 2.4 GHz / that'}}
     N = (320, 320, 320)
     rng = np.random.default_rng(0)
     mm = np.zeros(N, np.uint8); mm[:, :, 100:140] = 1; mm[:, :, 140:] = 2
@@ -114,7 +123,11 @@ def next_rows(device):
     bpv = (21.0 * on + 17.0 * (steps - on)) / 2 / steps
     out['bhte'] = {'value': vox / R.last_kernel_ms / 1e6, 'unit': 'Gvoxel-steps/s', 'grid': list(N), 'steps': steps, 'steps_heating': on, 'steps_per_launch': 2,
                    'kernel': 'bhte_step2g', 'kernel_ms': R.last_kernel_ms, 'call_s': wall, 'bytes_per_voxel_step': bpv,
-                   'frac_of_8TBps': bpv * vox / R.last_kernel_ms / 1e6 / 8000,
+                   'frac_of_8TBps': bpv * vox / R.last_kernel_ms / 1e6 / 8000, 'bound': 'hbm',
+                   'roof_note': 'HBM is the right roof at this size: one launch streams T in / out, the dose in / out, the heat source and the ids -- %.0f MB at %d^3 -- '
+                                'which exceeds the 256 MiB Infinity Cache, and a line stays resident there only while everything touched between two of its uses fits '
+                                '(MI355X_MICROARCH.md, Infinity Cache); the kernel moves 1.18-1.29 x its algorithmic bytes at 4.4-4.7 TB/s '
+                                '(profiles/r4/pmc_summary_bhte_step2g_384.txt)' % ((21.0 * float(np.prod(N))) / 1e6, N[0]),
                    'note': 'a launch takes TWO steps and moves T in / out, dose in / out and the id once for both: 17 B per voxel, 21 B with the heat source '
                            '(the first %d steps): %.1f B per voxel-step over this schedule' % (on, bpv)}
     return out
