@@ -15,6 +15,10 @@
 #include <math.h>
 #include <vector>
 
+#ifndef BFD_BHTE_STEPS_DEFAULT
+#define BFD_BHTE_STEPS_DEFAULT 4
+#endif
+
 namespace {
 
 // (wave-uniform plane base) + (32-bit byte offset in a VGPR): see bfd_kernels_v2.hip, uni() / F4()
@@ -340,6 +344,198 @@ __global__ __launch_bounds__(G2_T, G2_WAVES) void bhte_step2g(B2_ARGS)
     }
     bhte_step2g_body<REV, QM>(b, Tin, Tout, dose, qa, qb, mat, cd, cp, nMat, N1, N2, N3, Tcore, dtMin, zrun, tilesX, tilesY, nBlocks, xcdOrder);
 }
+// ---- round 6: S = 3 or 4 steps per pass (bhte_stepNg) ----
+// Two steps per pass move T in / out, the dose in / out, the heat source and the ids once for two steps (10.5 B per voxel-step while heating); S steps
+// move them once for S. Same machinery as bhte_step2g, one more level of it per step: a workgroup marches a z-run over a region of (64 + 2 S) x 28
+// cells (outputs 64 x (28 - 2 S)); thread = one column position, four cells 7 rows apart; level k = T(n + k) lives in per-thread z-queues of three
+// planes (compile-time slots, plane loop unrolled by three) and, for the in-plane neighbours, in a double-buffered LDS plane per level (one barrier
+// per plane). In iteration p level 1 is computed for plane p, level 2 for plane p - 1, ..., the output level S for plane p - S + 1; a level-k value
+// is computed where the cell lies k cells inside the region (ring cells copy the level below: never used by a cell that counts), face cells keep
+// their temperature. The dose takes its S increments in step order: (((d + r(T1)) + r(T2)) + ...) -- T1 of the output plane has left its queue
+// when S = 4 and is taken from the slot the new plane is about to overwrite. Heat source of the last S planes and their ids ride in small
+// rotating queues (the ids as bytes of one register). QM: 0 no heating in any of the S steps, 1 the same field in all of them; mixed stretches
+// take the two-step kernel. Same expressions in the same order: bit-identical to S launches of bhte_step.
+template <int S> struct GN { static constexpr int W = 64 + 2 * S, H = 28, TY = H - 2 * S, T = 512, NC = 4, ROWS = 7, ACT = ROWS * W, CELLS = W * H; };
+template <bool REV, int QM, int S>
+__device__ __forceinline__ void bhte_stepNg_body(int b, B2_ARGS)
+{
+    using G = GN<S>;
+    static_assert(G::ACT <= G::T && S >= 3 && S <= 4, "region / thread mapping");
+    __shared__ float L[S][2][G::CELLS + 2 * G::W];
+    __shared__ float2 sC[256];
+    for (int m = threadIdx.x; m < nMat; m += G::T) sC[m] = make_float2(cd[m], cp[m]);
+    const bool mirror = threadIdx.x >= G::ACT;
+    const int tid = mirror ? threadIdx.x - G::ACT : threadIdx.x;
+    const int bx = b % tilesX, by = (b / tilesX) % tilesY, bz = b / (tilesX * tilesY);
+    const int x0 = bx * 64 - S, y0 = by * G::TY - S, z0 = bz * zrun, z1 = min(z0 + zrun, N3);
+    const long pl = (long)N1 * N2;
+    const int r = tid / G::W, rx = tid - r * G::W, e0 = tid + G::W;
+    unsigned g[G::NC];
+    int dist[G::NC];
+    bool fIn[G::NC], fFace[G::NC], fOut[G::NC];
+    #pragma unroll
+    for (int n = 0; n < G::NC; n++) {
+        const int ry = r + G::ROWS * n, gi = x0 + rx, gj = y0 + ry;
+        g[n] = 4u * (unsigned)(ry * N1 + rx);
+        const bool in = gi >= 0 && gi < N1 && gj >= 0 && gj < N2;
+        const bool face = gi == 0 || gi == N1 - 1 || gj == 0 || gj == N2 - 1;
+        dist[n] = min(min(rx, G::W - 1 - rx), min(ry, G::H - 1 - ry));
+        fIn[n] = in && !face;
+        fFace[n] = in && face;
+        fOut[n] = in && !mirror && dist[n] >= S;
+    }
+    const int corner = __builtin_amdgcn_readfirstlane(y0 * N1 + x0);
+    auto clampz = [&](int k) { return (long)__builtin_amdgcn_readfirstlane(min(max(k, 0), N3 - 1)) * pl + corner; };
+    const bool heat = QM == 1;
+    const float *qE = heat ? qa : Tin;
+
+    float t[S][G::NC][3];                 // level k (T(n + k)), planes by slot (plane - p0) mod 3
+    float q[G::NC][S], qn[G::NC];         // heat source of planes p, p - 1, ..., p - S + 1; of plane p + 1 on its way
+    unsigned mi[G::NC], mn[G::NC];        // ids of planes p .. p - 3 as bytes; of plane p + 1 on its way
+    const int p0 = z0 - (S - 1);
+    #pragma unroll
+    for (int n = 0; n < G::NC; n++) {
+        asm volatile("" : "+v"(g[n]));
+        const unsigned gp = g[n];
+        t[0][n][2] = gl4(Tin + clampz(p0 - 1), gp);
+        t[0][n][0] = gl4(Tin + clampz(p0), gp);
+        t[0][n][1] = gl4(Tin + clampz(p0 + 1), gp);
+        mi[n] = gl1(mat + clampz(p0), gp >> 2);
+        q[n][0] = QM ? gl4(qE + clampz(p0), gp) : 0.0f;
+        #pragma unroll
+        for (int k = 1; k < S; k++) { t[k][n][0] = t[k][n][1] = t[k][n][2] = 0.0f; q[n][k] = 0.0f; }
+        qn[n] = 0.0f; mn[n] = 0u;
+    }
+    __syncthreads();
+
+    auto plane = [&](auto PH, const int p) {
+        constexpr int c = decltype(PH)::v;
+        const int par = p & 1;
+        const int o = p - S + 1;                                                    // the plane of this iteration's outputs
+        const bool outs = o >= z0 && o < z1;
+        const long kO = clampz(o);
+        float dz[G::NC], t1old[G::NC];
+        #pragma unroll
+        for (int n = 0; n < G::NC; n++) asm volatile("" : "+v"(g[n]));
+        #pragma unroll
+        for (int n = 0; n < G::NC; n++) {
+            dz[n] = gl4(dose + kO, g[n]);
+            L[0][par][e0 + n * G::ACT] = t[0][n][c];
+            t1old[n] = t[1][n][c];                                                  // S = 4: T(n + 1) of plane p - 3, about to be overwritten
+        }
+        __syncthreads();
+        #pragma unroll
+        for (int k = 1; k <= S; k++) {
+            // level k of plane pk = p - k + 1 from level k - 1: planes pk - 1, pk, pk + 1 in the queue, plane pk in LDS
+            constexpr int dummy = 0; (void)dummy;
+            const int pk = p - k + 1;
+            const bool innerz = pk > 0 && pk < N3 - 1;
+            const float *Lp = k == 1 ? L[0][par] : L[k - 1][par ^ 1];
+            #pragma unroll
+            for (int n = 0; n < G::NC; n++) {
+                const int e = e0 + n * G::ACT;
+                const int sc = ((c - k + 1) % 3 + 3) % 3, sm = ((c - k) % 3 + 3) % 3, sp = ((c - k + 2) % 3 + 3) % 3;
+                const float tc = t[k - 1][n][sc];
+                const float2 cc = sC[(mi[n] >> (8 * (k - 1))) & 255u];
+                float U = bhte_update<REV>(tc, Lp[e - 1], Lp[e + 1], Lp[e - G::W], Lp[e + G::W], t[k - 1][n][sm], t[k - 1][n][sp], cc.x, cc.y, Tcore, heat, q[n][k - 1]);
+                asm volatile("" : "+v"(U));                                         // computed by every lane, selected below
+                const float val = (innerz && fIn[n] && dist[n] >= k) ? U : tc;
+                if (k < S) {
+                    t[k][n][sc] = val;
+                    L[k][par][e] = val;
+                } else if (outs && fOut[n]) {
+                    // dose: the increments of the S steps in step order
+                    float dsum = dz[n];
+                    #pragma unroll
+                    for (int j = 1; j < S; j++) {
+                        const int so = ((c - S + 1) % 3 + 3) % 3;                    // slot of plane o
+                        const float Tj = (S == 4 && j == 1) ? t1old[n] : t[j][n][so];
+                        dsum = __fadd_rn(dsum, bhte_dose_rate(Tj, dtMin));
+                    }
+                    gs4(Tout + kO, g[n], val);
+                    gs4(dose + kO, g[n], __fadd_rn(dsum, bhte_dose_rate(val, dtMin)));
+                }
+            }
+            if (k == 1) {
+                // what the next iteration's level 1 needs: T(n) of plane p + 2 replaces plane p - 1, id and heat source of plane p + 1
+                const long kN = clampz(p + 1), kNN = clampz(p + 2);
+                #pragma unroll
+                for (int n = 0; n < G::NC; n++) {
+                    mn[n] = gl1(mat + kN, g[n] >> 2);
+                    if (QM) qn[n] = gl4(qE + kN, g[n]);
+                    t[0][n][(c + 2) % 3] = gl4(Tin + kNN, g[n]);
+                }
+            }
+        }
+        #pragma unroll
+        for (int n = 0; n < G::NC; n++) {
+            mi[n] = (mi[n] << 8) | mn[n];
+            #pragma unroll
+            for (int k = S - 1; k >= 1; k--) q[n][k] = q[n][k - 1];
+            q[n][0] = qn[n];
+        }
+    };
+    const int pend = z1 + S - 2;
+    int p = p0;
+    for (; p + 2 <= pend; p += 3) { plane(Ph3<0>(), p); plane(Ph3<1>(), p + 1); plane(Ph3<2>(), p + 2); }
+    if (p <= pend) plane(Ph3<0>(), p);
+    if (p + 1 <= pend) plane(Ph3<1>(), p + 1);
+}
+
+#ifndef GN_WAVES
+#define GN_WAVES 4           // 128 registers: two workgroups of 8 waves per CU
+#endif
+template <bool REV, int QM, int S>
+__global__ __launch_bounds__(512, GN_WAVES) void bhte_stepNg(B2_ARGS)
+{
+    int b = blockIdx.x;
+    if (xcdOrder) {
+        const int per = nBlocks >> 3, rem = nBlocks & 7, x = b & 7, slot = b >> 3;
+        b = x * per + (x < rem ? x : rem) + slot;
+    }
+    bhte_stepNg_body<REV, QM, S>(b, Tin, Tout, dose, qa, qb, mat, cd, cp, nMat, N1, N2, N3, Tcore, dtMin, zrun, tilesX, tilesY, nBlocks, xcdOrder);
+}
+
+// Monitor points of the intermediate steps of an S-step pass: T(n + depth) at the listed voxels from T(n), depth 1 .. 3 -- the cube of side
+// 2 depth + 1 around the voxel advanced level by level in LDS (one workgroup per point; the caller monitors 1 - 4 points,
+// CalculateTemperatureEffects.py:1003-1023). The same cell update as everywhere: equal to the value a one-step run would hold.
+template <bool REV>
+__global__ __launch_bounds__(64) void cone_points(const float *__restrict__ Tin, const float *__restrict__ q, const unsigned char *__restrict__ mat,
+                                                  const float *__restrict__ cd, const float *__restrict__ cp, int N1, int N2, int N3, float Tcore,
+                                                  const unsigned *__restrict__ idx, float *__restrict__ out, long stride, long col, int depth)
+{
+    __shared__ float A[2][343];
+    const int side = 2 * depth + 1, ncell = side * side * side;
+    const unsigned c0 = idx[blockIdx.x];
+    const int ci = (int)(c0 % (unsigned)N1), cj = (int)((c0 / (unsigned)N1) % (unsigned)N2), ck = (int)(c0 / ((unsigned)N1 * (unsigned)N2));
+    const long pl = (long)N1 * N2;
+    for (int v = threadIdx.x; v < ncell; v += 64) {
+        const int li = v % side, lj = (v / side) % side, lk = v / (side * side);
+        const int i = min(max(ci - depth + li, 0), N1 - 1), j = min(max(cj - depth + lj, 0), N2 - 1), k = min(max(ck - depth + lk, 0), N3 - 1);
+        A[0][v] = Tin[(long)k * pl + (long)j * N1 + i];
+    }
+    __syncthreads();
+    for (int lev = 1; lev <= depth; lev++) {
+        const float *src = A[(lev - 1) & 1]; float *dst = A[lev & 1];
+        for (int v = threadIdx.x; v < ncell; v += 64) {
+            const int li = v % side, lj = (v / side) % side, lk = v / (side * side);
+            float val = src[v];
+            if (li >= lev && li < side - lev && lj >= lev && lj < side - lev && lk >= lev && lk < side - lev) {
+                const int i = ci - depth + li, j = cj - depth + lj, k = ck - depth + lk;
+                if (i > 0 && i < N1 - 1 && j > 0 && j < N2 - 1 && k > 0 && k < N3 - 1) {       // inside the volume and off its faces: all six neighbours exist
+                    const long c = (long)k * pl + (long)j * N1 + i;
+                    const int m = mat[c];
+                    val = bhte_update<REV>(src[v], src[v - 1], src[v + 1], src[v - side], src[v + side], src[v - side * side], src[v + side * side], cd[m], cp[m], Tcore,
+                                           q != nullptr, q ? q[c] : 0.0f);
+                }
+            }
+            dst[v] = val;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[(long)blockIdx.x * stride + col] = A[depth & 1][(depth * side + depth) * side + depth];
+}
+
 // Monitors of the first of two fused steps: T(n+1) at the listed voxels / on the monitored plane, computed from T(n)
 template <bool REV>
 __global__ void step_points(const float *__restrict__ Tin, const float *__restrict__ q, const unsigned char *__restrict__ mat,
@@ -425,7 +621,7 @@ static int bhte_run_core(int32_t device, int32_t F, int32_t M, int32_t S, int32_
     std::vector<void *> allocs;
     auto A = [&](void **p, size_t bytes) { hipError_t e = hipMalloc(p, bytes ? bytes : 1); if (e == hipSuccess) allocs.push_back(*p); return e; };
     // the volumes carry pads (elements): bhte_step2g addresses every cell of its 68 x 28 regions, also those that hang over the faces
-    const size_t padF = (((size_t)2 * N1 + 64 + 255) / 256) * 256, padB = (size_t)49 * N1 + 256;
+    const size_t padF = (((size_t)4 * N1 + 64 + 255) / 256) * 256, padB = (size_t)49 * N1 + 256;       // bhte_stepNg: 72 x 28 regions, 4 rows / cells in front
     auto AP = [&](void **p, size_t elems, size_t elemBytes) {
         void *raw = nullptr; const hipError_t e = A(&raw, (padF + elems + padB) * elemBytes);
         if (e == hipSuccess) *p = (char *)raw + padF * elemBytes;
@@ -502,7 +698,46 @@ static int bhte_run_core(int32_t device, int32_t F, int32_t M, int32_t S, int32_
             if (dPts) hipLaunchKernelGGL(gather_points, dim3((unsigned)((nPoints + 255) / 256)), dim3(256), 0, 0, dT[cur], dIdx, dPts, (long)nPoints, (long)nSteps, (long)s);
             if (dSlice && s % fm == 0) hipLaunchKernelGGL(gather_slice<REV>, dim3(256), dim3(256), 0, 0, dT[cur], dSlice, N1, N2, N3, sliceJ, (long)(s / fm), nSamples);
         };
+        // S steps per pass (round 6; BFD_BHTE_STEPS=2 keeps two): where the next S steps carry the same heat field (or none) and no sample of the
+        // monitored plane falls on a step strictly inside the pass (the first step's sample is recomputed from T(n), the last one's is read off the
+        // result; one in between would need a cone per cell of the plane). The monitor points of the steps inside are recomputed by cone_points.
+        ev = getenv("BFD_BHTE_STEPS");
+        int stepsN = (ev && atoi(ev) >= 2 && atoi(ev) <= 4) ? atoi(ev) : BFD_BHTE_STEPS_DEFAULT;
+        if (!gform || !fuse) stepsN = 2;
+        const int tileYN = stepsN >= 3 ? 28 - 2 * stepsN : tileY, tilesYN = (N2 + tileYN - 1) / tileYN;
+        int zrunN = 0;
+        if (stepsN >= 3) {
+            ev = getenv("BFD_BHTE_ZRUN");
+            zrunN = (ev && atoi(ev) > 0) ? atoi(ev) : 0;
+            if (!zrunN) {
+                long best = -1;
+                for (int z = 8; z <= 96; z++) {
+                    const long w = (long)tilesX * tilesYN * ((N3 + z - 1) / z), cost = ((w + 255) / 256) * (z + 2 * stepsN - 2);
+                    if (best < 0 || cost <= best) { best = cost; zrunN = z; }
+                }
+            }
+        }
+        const long nBlocksN = stepsN >= 3 ? (long)tilesX * tilesYN * ((N3 + zrunN - 1) / zrunN) : 0;
         for (int s = 0; s < nSteps;) {
+            bool passN = stepsN >= 3 && s + stepsN <= nSteps && nBlocksN < 0x7fffffffL;
+            for (int j = 1; j < stepsN && passN; j++) passN = fieldOfStep[s + j] == fieldOfStep[s];
+            for (int j = 1; j + 1 < stepsN && passN && dSlice; j++) passN = (s + j) % fm != 0;
+            if (passN) {
+                const float *qa = Q(fieldOfStep[s]);
+                if (dPts) {
+                    hipLaunchKernelGGL(cone_points<REV>, dim3((unsigned)nPoints), dim3(64), 0, 0, dT[cur], qa, dmat, dcd, dcp, N1, N2, N3, Tcore, dIdx, dPts, (long)nSteps, (long)s, 1);
+                    for (int j = 2; j < stepsN; j++)
+                        hipLaunchKernelGGL(cone_points<REV>, dim3((unsigned)nPoints), dim3(64), 0, 0, dT[cur], qa, dmat, dcd, dcp, N1, N2, N3, Tcore, dIdx, dPts, (long)nSteps, (long)(s + j - 1), j);
+                }
+                if (dSlice && s % fm == 0) hipLaunchKernelGGL(step_slice<REV>, dim3(256), dim3(256), 0, 0, dT[cur], qa, dmat, dcd, dcp, N1, N2, N3, Tcore, dSlice, sliceJ, (long)(s / fm), nSamples);
+#define BNG_LAUNCH(QM, SS) hipLaunchKernelGGL((bhte_stepNg<REV, QM, SS>), dim3((unsigned)nBlocksN), dim3(512), 0, 0, dT[cur], dT[1 - cur], dDose, qa, qa, dmat, dcd, dcp, nMat, N1, N2, N3, \
+                                              Tcore, dtMin, zrunN, tilesX, tilesYN, (int)nBlocksN, xcdOrder)
+                if (stepsN == 4) { if (qa) BNG_LAUNCH(1, 4); else BNG_LAUNCH(0, 4); }
+                else { if (qa) BNG_LAUNCH(1, 3); else BNG_LAUNCH(0, 3); }
+                cur = 1 - cur; s += stepsN;
+                monitors(s - 1);
+                continue;
+            }
             if (fuse && s + 1 < nSteps && nBlocks2 < 0x7fffffffL) {
                 const float *qa = Q(fieldOfStep[s]), *qb = Q(fieldOfStep[s + 1]);
                 if (dPts) hipLaunchKernelGGL(step_points<REV>, dim3((unsigned)((nPoints + 255) / 256)), dim3(256), 0, 0, dT[cur], qa, dmat, dcd, dcp, N1, N2, N3, Tcore, dIdx, dPts, (long)nPoints, (long)nSteps, (long)s);
