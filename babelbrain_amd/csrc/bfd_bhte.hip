@@ -9,14 +9,18 @@
 //   T' = T + cd[m] * (((((Txm+Txp)+Tym)+Typ)+Tzm)+Tzp - 6 T) + cp[m] * (Tcore - T) + (n < nStepsOn ? q : 0)
 //   cd = dt k/(rho c dx^2),  cp = dt rho_b c_b w / (6e7 c)  (w in mL/min/kg),  q = dt * duty * a_abs p^2/(rho c_s) / (rho c)
 //   dose += dt/60 * R^(43 - T'),  R = 0.5 for T' >= 43 else 0.25 (evaluated as exp2).   Faces of the volume keep their temperature.
-// Bound: HBM. One step moves T read + write, q read, dose RMW, uint8 ids: ~21 B per voxel; the default path takes TWO steps per
-// launch (bhte_step2g; bhte_step2 is its round-3 form) and moves those 21 B once for both. x-fastest layout.
+// Bound: HBM. One step moves T read + write, q read, dose RMW, uint8 ids: ~21 B per voxel; the default path takes THREE steps per
+// launch (round 6: bhte_stepNg; stretches it cannot take go to the two-step kernel bhte_step2g and the one-step kernel) and moves those 21 B
+// once for all three. x-fastest layout.
 #include "bfd_internal.h"
 #include <math.h>
 #include <vector>
 
+// steps per pass of the default path (bhte_stepNg): 3. Measured (scripts/r6/bhte_ab.sh, Gvoxel-steps/s, 200 steps of which 100 heat): 320^3 2 / 3 / 4 steps
+// 388 / 505 / 501, 384^3 417 / 526 / 519, 512^3 423 / 604 / 512 -- four steps need 128 registers and still spill 18 to scratch (three: 114, none)
+// and 71 KB of LDS. profiles/r6/bhte_steps_per_pass.txt
 #ifndef BFD_BHTE_STEPS_DEFAULT
-#define BFD_BHTE_STEPS_DEFAULT 4
+#define BFD_BHTE_STEPS_DEFAULT 3
 #endif
 
 namespace {

@@ -166,6 +166,46 @@ def test_two_steps_per_launch_equal_one_step_per_launch(monkeypatch):
     assert np.array_equal(T, To) and rel_l2(D, Do) < 1e-6
 
 
+@pytest.mark.parametrize('steps', ['3', '4'])
+def test_three_and_four_steps_per_pass_equal_one_step_per_launch(steps, monkeypatch):
+    """Round 6: bhte_stepNg takes S = 3 (default) or 4 steps per pass over regions of (64 + 2 S) x 28 cells wherever the next S steps carry the same heat
+    field (or none) and no sample of the monitored plane falls strictly inside; the monitor points of the steps inside a pass come from cone_points
+    (the cube around the point advanced level by level). Temperature, dose, monitored plane, heat source and point series must have the bits of one
+    step per launch: long and short on / off stretches, several fields, plane samples every 1 .. 10 steps, points on faces and edges, grids at the
+    tile edges (y tiles of 22 / 20 rows), run lengths from 1 plane up, and against the oracle."""
+    from babelbrain_amd import RayleighAndBHTE as R
+    rng = np.random.default_rng(23)
+    ml = _materials()
+    monkeypatch.delenv('BFD_BHTE_KERNEL', raising=False)
+    cases = (((150, 61, 37), 40, [[9, 7], [5, 3]], None, 3, 30), ((64, 22, 16), 16, [[4, 4]], None, 1, 10), ((65, 23, 9), 13, [[7, 6]], '1', 4, 11),
+             ((70, 41, 35), 27, [[12, 6], [3, 0]], '5', 10, -1), ((3, 3, 3), 9, [[4, 2]], None, 2, 1), ((131, 45, 20), 30, [[6, 4], [0, 5], [8, 2]], '32', 5, 22),
+             ((129, 20, 50), 25, [[13, 12]], '64', 7, 0))
+    for N, nS, onoff, zrun, fm, sl in cases:
+        mm = rng.integers(0, 5, N).astype(np.uint8)
+        fields = (3.0e6 * rng.random((len(onoff),) + N)).astype(np.float32)
+        mpm = np.zeros(N, np.uint32); mpm[1, 1, 1] = 1; mpm[N[0] // 2, N[1] // 2, N[2] // 2] = 2; mpm[N[0] - 1, N[1] - 2, 0] = 3; mpm[0, N[1] - 1, N[2] - 1] = 4
+        T0 = (37.0 + 8.0 * rng.random(N)).astype(np.float32)
+        out = {}
+        for name, env in (('S', dict(BFD_BHTE_STEPS=steps)), ('one', dict(BFD_BHTE_FUSE='0'))):
+            for k in ('BFD_BHTE_FUSE', 'BFD_BHTE_STEPS'): monkeypatch.delenv(k, raising=False)
+            for k, v in env.items(): monkeypatch.setenv(k, v)
+            if zrun: monkeypatch.setenv('BFD_BHTE_ZRUN', zrun)
+            else: monkeypatch.delenv('BFD_BHTE_ZRUN', raising=False)
+            out[name] = R.BHTEMultiplePressureFields(fields, mm, ml, 4e-4, nS, onoff, sl, nFactorMonitoring=fm, dt=0.02, initT0=T0, MonitoringPointsMap=mpm)
+        for q, (a, b) in enumerate(zip(out['S'], out['one'])):
+            assert np.array_equal(a, b), (N, nS, onoff, zrun, fm, q)
+        assert out['S'][0].max() > 44.0 and out['S'][1].max() > 0 and out['S'][4].shape == (4, nS)
+    for k in ('BFD_BHTE_FUSE', 'BFD_BHTE_ZRUN'): monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv('BFD_BHTE_STEPS', steps)
+    N = (70, 30, 35)
+    mm = rng.integers(0, 5, N).astype(np.uint8)
+    p = (3.0e6 * rng.random(N)).astype(np.float32)
+    T, D, _, Q = R.BHTE(p, mm, ml, 4e-4, 23, 13, -1, dt=0.02)
+    cd, cp, qf = R.bhte_coefficients(ml, 4e-4, 0.02, 1.0)
+    To, Do = BO.bhte(np.full(N, 37.0, np.float32), np.zeros(N, np.float32), Q, mm, cd, cp, 37.0, 0.02, 23, 13)
+    assert np.array_equal(T, To) and rel_l2(D, Do) < 1e-6
+
+
 def test_x_fastest_entry_points_of_the_c_abi():
     """bfd_bhte_run / bfd_bhte_run_fields keep their x-fastest contract (volumes [k][j][i], heat source precomputed); the
     drop-in goes through bfd_bhte_run_volumes (caller's C order). Same run both ways: equal up to the order in which the six
