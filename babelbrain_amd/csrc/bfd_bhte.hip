@@ -10,17 +10,18 @@
 //   cd = dt k/(rho c dx^2),  cp = dt rho_b c_b w / (6e7 c)  (w in mL/min/kg),  q = dt * duty * a_abs p^2/(rho c_s) / (rho c)
 //   dose += dt/60 * R^(43 - T'),  R = 0.5 for T' >= 43 else 0.25 (evaluated as exp2).   Faces of the volume keep their temperature.
 // Bound: HBM. One step moves T read + write, q read, dose RMW, uint8 ids: ~21 B per voxel; the default path takes THREE steps per
-// launch (round 6: bhte_stepNg; stretches it cannot take go to the two-step kernel bhte_step2g and the one-step kernel) and moves those 21 B
-// once for all three. x-fastest layout.
+// launch while a field heats and FOUR while nothing does (round 6: bhte_stepNg; stretches it cannot take go to the two-step kernel bhte_step2g
+// and the one-step kernel) and moves those bytes once for all of them. x-fastest layout.
 #include "bfd_internal.h"
 #include <math.h>
 #include <vector>
 
-// steps per pass of the default path (bhte_stepNg): 3. Measured (scripts/r6/bhte_ab.sh, Gvoxel-steps/s, 200 steps of which 100 heat): 320^3 2 / 3 / 4 steps
-// 388 / 505 / 501, 384^3 417 / 526 / 519, 512^3 423 / 604 / 512 -- four steps need 128 registers and still spill 18 to scratch (three: 114, none)
-// and 71 KB of LDS. profiles/r6/bhte_steps_per_pass.txt
-#ifndef BFD_BHTE_STEPS_DEFAULT
-#define BFD_BHTE_STEPS_DEFAULT 3
+// steps per pass of the default path (bhte_stepNg): four while nothing heats, three while a field heats (bhte_run_core says why)
+#ifndef BFD_BHTE_STEPS_HEATING
+#define BFD_BHTE_STEPS_HEATING 3
+#endif
+#ifndef BFD_BHTE_STEPS_COOLING
+#define BFD_BHTE_STEPS_COOLING 4
 #endif
 
 namespace {
@@ -705,25 +706,32 @@ static int bhte_run_core(int32_t device, int32_t F, int32_t M, int32_t S, int32_
         // S steps per pass (round 6; BFD_BHTE_STEPS=2 keeps two): where the next S steps carry the same heat field (or none) and no sample of the
         // monitored plane falls on a step strictly inside the pass (the first step's sample is recomputed from T(n), the last one's is read off the
         // result; one in between would need a cone per cell of the plane). The monitor points of the steps inside are recomputed by cone_points.
+        // BFD_BHTE_STEPS=2 / 3 / 4 forces one pass length; default: FOUR steps per pass while nothing heats (99 registers ... 128 with 2 spilled, 710 / 810
+        // Gvoxel-steps/s at 320^3 / 512^3 against 568 / 679 with three) and THREE while a field heats (114 registers, none spilled: 487 / 568; the four-step
+        // flavour with its heat-source queue spills 18 registers to scratch: 395 / 403) -- scripts/r6/bhte_phases.sh, profiles/r6/bhte_steps_per_pass.txt
         ev = getenv("BFD_BHTE_STEPS");
-        int stepsN = (ev && atoi(ev) >= 2 && atoi(ev) <= 4) ? atoi(ev) : BFD_BHTE_STEPS_DEFAULT;
-        if (!gform || !fuse) stepsN = 2;
-        const int tileYN = stepsN >= 3 ? 28 - 2 * stepsN : tileY, tilesYN = (N2 + tileYN - 1) / tileYN;
-        int zrunN = 0;
-        if (stepsN >= 3) {
+        const int forced = (ev && atoi(ev) >= 2 && atoi(ev) <= 4) ? atoi(ev) : 0;
+        int stepsHeat = forced ? forced : BFD_BHTE_STEPS_HEATING, stepsCool = forced ? forced : BFD_BHTE_STEPS_COOLING;
+        if (!gform || !fuse) stepsHeat = stepsCool = 2;
+        struct PassGeom { int tileY, tilesY, zrun; long nBlocks; } geom[5] = {};
+        for (int S = 3; S <= 4; S++) {
+            PassGeom &G = geom[S];
+            G.tileY = 28 - 2 * S; G.tilesY = (N2 + G.tileY - 1) / G.tileY;
             ev = getenv("BFD_BHTE_ZRUN");
-            zrunN = (ev && atoi(ev) > 0) ? atoi(ev) : 0;
-            if (!zrunN) {
+            G.zrun = (ev && atoi(ev) > 0) ? atoi(ev) : 0;
+            if (!G.zrun) {
                 long best = -1;
                 for (int z = 8; z <= 96; z++) {
-                    const long w = (long)tilesX * tilesYN * ((N3 + z - 1) / z), cost = ((w + 255) / 256) * (z + 2 * stepsN - 2);
-                    if (best < 0 || cost <= best) { best = cost; zrunN = z; }
+                    const long w = (long)tilesX * G.tilesY * ((N3 + z - 1) / z), cost = ((w + 255) / 256) * (z + 2 * S - 2);
+                    if (best < 0 || cost <= best) { best = cost; G.zrun = z; }
                 }
             }
+            G.nBlocks = (long)tilesX * G.tilesY * ((N3 + G.zrun - 1) / G.zrun);
         }
-        const long nBlocksN = stepsN >= 3 ? (long)tilesX * tilesYN * ((N3 + zrunN - 1) / zrunN) : 0;
         for (int s = 0; s < nSteps;) {
-            bool passN = stepsN >= 3 && s + stepsN <= nSteps && nBlocksN < 0x7fffffffL;
+            const int stepsN = fieldOfStep[s] >= 0 ? stepsHeat : stepsCool;
+            const PassGeom &G = geom[stepsN >= 3 ? stepsN : 3];
+            bool passN = stepsN >= 3 && s + stepsN <= nSteps && G.nBlocks < 0x7fffffffL;
             for (int j = 1; j < stepsN && passN; j++) passN = fieldOfStep[s + j] == fieldOfStep[s];
             for (int j = 1; j + 1 < stepsN && passN && dSlice; j++) passN = (s + j) % fm != 0;
             if (passN) {
@@ -734,8 +742,8 @@ static int bhte_run_core(int32_t device, int32_t F, int32_t M, int32_t S, int32_
                         hipLaunchKernelGGL(cone_points<REV>, dim3((unsigned)nPoints), dim3(64), 0, 0, dT[cur], qa, dmat, dcd, dcp, N1, N2, N3, Tcore, dIdx, dPts, (long)nSteps, (long)(s + j - 1), j);
                 }
                 if (dSlice && s % fm == 0) hipLaunchKernelGGL(step_slice<REV>, dim3(256), dim3(256), 0, 0, dT[cur], qa, dmat, dcd, dcp, N1, N2, N3, Tcore, dSlice, sliceJ, (long)(s / fm), nSamples);
-#define BNG_LAUNCH(QM, SS) hipLaunchKernelGGL((bhte_stepNg<REV, QM, SS>), dim3((unsigned)nBlocksN), dim3(512), 0, 0, dT[cur], dT[1 - cur], dDose, qa, qa, dmat, dcd, dcp, nMat, N1, N2, N3, \
-                                              Tcore, dtMin, zrunN, tilesX, tilesYN, (int)nBlocksN, xcdOrder)
+#define BNG_LAUNCH(QM, SS) hipLaunchKernelGGL((bhte_stepNg<REV, QM, SS>), dim3((unsigned)G.nBlocks), dim3(512), 0, 0, dT[cur], dT[1 - cur], dDose, qa, qa, dmat, dcd, dcp, nMat, N1, N2, N3, \
+                                              Tcore, dtMin, G.zrun, tilesX, G.tilesY, (int)G.nBlocks, xcdOrder)
                 if (stepsN == 4) { if (qa) BNG_LAUNCH(1, 4); else BNG_LAUNCH(0, 4); }
                 else { if (qa) BNG_LAUNCH(1, 3); else BNG_LAUNCH(0, 3); }
                 cur = 1 - cur; s += stepsN;

@@ -11,7 +11,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 ml = dict(Density=np.array([1000., 1896.5, 1041., 1100., 1850.]), SoS=np.array([1500., 2476., 1562., 1610., 2140.]), Attenuation=np.array([0., 81., 3.45, 20., 60.]),
           SpecificHeat=np.array([4178., 1313., 3630., 3391., 1793.]), Conductivity=np.array([0.6, 0.32, 0.51, 0.37, 0.31]), Perfusion=np.array([0., 10., 559., 106., 30.]),
           Absorption=np.array([0., 0.16, 0.85, 0.5, 0.2]), InitTemperature=np.array([37., 37., 37., 37., 37.]))
-VARIANTS = {'one step': dict(BFD_BHTE_FUSE='0'), 'S=4': dict(BFD_BHTE_STEPS='4'), 'S=3': dict(BFD_BHTE_STEPS='3'), 'two steps': dict(BFD_BHTE_STEPS='2'),
+VARIANTS = {'one step': dict(BFD_BHTE_FUSE='0'), 'default (3 heating / 4 cooling)': {}, 'S=4': dict(BFD_BHTE_STEPS='4'), 'S=3': dict(BFD_BHTE_STEPS='3'), 'two steps': dict(BFD_BHTE_STEPS='2'),
             'two steps, round 3': dict(BFD_BHTE_KERNEL='1')}
 bad = 0
 for c in range(cases):

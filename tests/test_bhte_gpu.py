@@ -166,9 +166,9 @@ def test_two_steps_per_launch_equal_one_step_per_launch(monkeypatch):
     assert np.array_equal(T, To) and rel_l2(D, Do) < 1e-6
 
 
-@pytest.mark.parametrize('steps', ['3', '4'])
+@pytest.mark.parametrize('steps', ['3', '4', 'default'])
 def test_three_and_four_steps_per_pass_equal_one_step_per_launch(steps, monkeypatch):
-    """Round 6: bhte_stepNg takes S = 3 (default) or 4 steps per pass over regions of (64 + 2 S) x 28 cells wherever the next S steps carry the same heat
+    """Round 6: bhte_stepNg takes S = 3 (default while a field heats) or 4 (default while nothing does) steps per pass over regions of (64 + 2 S) x 28 cells wherever the next S steps carry the same heat
     field (or none) and no sample of the monitored plane falls strictly inside; the monitor points of the steps inside a pass come from cone_points
     (the cube around the point advanced level by level). Temperature, dose, monitored plane, heat source and point series must have the bits of one
     step per launch: long and short on / off stretches, several fields, plane samples every 1 .. 10 steps, points on faces and edges, grids at the
@@ -186,7 +186,7 @@ def test_three_and_four_steps_per_pass_equal_one_step_per_launch(steps, monkeypa
         mpm = np.zeros(N, np.uint32); mpm[1, 1, 1] = 1; mpm[N[0] // 2, N[1] // 2, N[2] // 2] = 2; mpm[N[0] - 1, N[1] - 2, 0] = 3; mpm[0, N[1] - 1, N[2] - 1] = 4
         T0 = (37.0 + 8.0 * rng.random(N)).astype(np.float32)
         out = {}
-        for name, env in (('S', dict(BFD_BHTE_STEPS=steps)), ('one', dict(BFD_BHTE_FUSE='0'))):
+        for name, env in (('S', dict(BFD_BHTE_STEPS=steps) if steps != 'default' else {}), ('one', dict(BFD_BHTE_FUSE='0'))):
             for k in ('BFD_BHTE_FUSE', 'BFD_BHTE_STEPS'): monkeypatch.delenv(k, raising=False)
             for k, v in env.items(): monkeypatch.setenv(k, v)
             if zrun: monkeypatch.setenv('BFD_BHTE_ZRUN', zrun)
@@ -194,9 +194,10 @@ def test_three_and_four_steps_per_pass_equal_one_step_per_launch(steps, monkeypa
             out[name] = R.BHTEMultiplePressureFields(fields, mm, ml, 4e-4, nS, onoff, sl, nFactorMonitoring=fm, dt=0.02, initT0=T0, MonitoringPointsMap=mpm)
         for q, (a, b) in enumerate(zip(out['S'], out['one'])):
             assert np.array_equal(a, b), (N, nS, onoff, zrun, fm, q)
-        assert out['S'][0].max() > 44.0 and out['S'][1].max() > 0 and out['S'][4].shape == (4, nS)
+        assert out['S'][0].max() > 44.0 and out['S'][1].max() > 0 and out['S'][4].shape[1] == nS and out['S'][4].shape[0] in (3, 4)
     for k in ('BFD_BHTE_FUSE', 'BFD_BHTE_ZRUN'): monkeypatch.delenv(k, raising=False)
-    monkeypatch.setenv('BFD_BHTE_STEPS', steps)
+    if steps != 'default':
+        monkeypatch.setenv('BFD_BHTE_STEPS', steps)
     N = (70, 30, 35)
     mm = rng.integers(0, 5, N).astype(np.uint8)
     p = (3.0e6 * rng.random(N)).astype(np.float32)
