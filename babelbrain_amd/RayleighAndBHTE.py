@@ -8,7 +8,7 @@
 
 ForwardSimple runs on the MI355X through the C ABI (bfd_rayleigh_forward); there is no CPU fallback.
 BHTE / BHTEMultiplePressureFields (CalculateTemperatureEffects.py:365-456, 960-990) run on the device too
-(bfd_bhte_run_fields: two time steps per launch, csrc/bfd_bhte.hip).
+(bfd_bhte_run_fields: three / four time steps per pass, csrc/bfd_bhte.hip).
 """
 import ctypes as C
 import os
@@ -173,6 +173,24 @@ def field_schedule(nStepsOnOffList, TotalDurationSteps):
     cycle = np.concatenate([np.concatenate([np.full(on, n, np.int32), np.full(off, -1, np.int32)]) for n, (on, off) in enumerate(oo)])
     reps = -(-int(TotalDurationSteps) // len(cycle)) if TotalDurationSteps > 0 else 0
     return np.ascontiguousarray(np.tile(cycle, reps)[:int(TotalDurationSteps)], np.int32)
+
+
+def bhte_pass_plan(sched, nFactorMonitoring=1, monitored_plane=True, steps_heating=3, steps_cooling=4):
+    """The passes bfd_bhte_run_* cuts a schedule into (the rule of bhte_run_core, restated for byte accounting): S steps per pass -- 3 while a field
+    heats, 4 while none does -- wherever the next S steps carry the same field and no sample of the monitored plane (taken after every step whose
+    index is a multiple of nFactorMonitoring) falls strictly inside; else two steps, else one. Returns [(first step, length, heating)]."""
+    sched = [int(v) for v in sched]
+    fm = max(int(nFactorMonitoring), 1)
+    out, s, n = [], 0, len(sched)
+    while s < n:
+        S = steps_heating if sched[s] >= 0 else steps_cooling
+        ok = S >= 3 and s + S <= n and all(sched[s + j] == sched[s] for j in range(1, S))
+        if ok and monitored_plane:
+            ok = all((s + j) % fm != 0 for j in range(1, S - 1))
+        L = S if ok else (2 if s + 1 < n else 1)
+        out.append((s, L, sched[s] >= 0 or (L == 2 and sched[s + 1] >= 0)))
+        s += L
+    return out
 
 
 def _bhte_run(fields, sched, MaterialMap, MaterialList, dx, LocationMonitoring, nFactorMonitoring, dt, blood_rho, blood_ct,
