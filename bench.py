@@ -652,6 +652,7 @@ def main_group(args):
         line['group_check'] = {'equals_single_domain': None, 'error': repr(e)}
     if not args.no_strong_c5 and not args.no_extra_strong:
         line['strong_c5'] = strong_c5(args, ndev, dt_fn, args.variant)
+    roofline_summary(line)
     emit_line(line)
 
 
