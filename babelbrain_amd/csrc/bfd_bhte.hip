@@ -360,7 +360,10 @@ __global__ __launch_bounds__(G2_T, G2_WAVES) void bhte_step2g(B2_ARGS)
 // when S = 4 and is taken from the slot the new plane is about to overwrite. Heat source of the last S planes and their ids ride in small
 // rotating queues (the ids as bytes of one register). QM: 0 no heating in any of the S steps, 1 the same field in all of them; mixed stretches
 // take the two-step kernel. Same expressions in the same order: bit-identical to S launches of bhte_step.
-template <int S> struct GN { static constexpr int W = 64 + 2 * S, H = 28, TY = H - 2 * S, T = 512, NC = 4, ROWS = 7, ACT = ROWS * W, CELLS = W * H; };
+#ifndef GN_NC
+#define GN_NC 4              // cells per thread (experiment: 2 = 1024 threads per workgroup, rows 14 apart)
+#endif
+template <int S> struct GN { static constexpr int W = 64 + 2 * S, H = 28, TY = H - 2 * S, NC = GN_NC, T = 2048 / NC, ROWS = H / NC, ACT = ROWS * W, CELLS = W * H; };
 template <bool REV, int QM, int S>
 __device__ __forceinline__ void bhte_stepNg_body(int b, B2_ARGS)
 {
@@ -488,10 +491,10 @@ __device__ __forceinline__ void bhte_stepNg_body(int b, B2_ARGS)
 }
 
 #ifndef GN_WAVES
-#define GN_WAVES 4           // 128 registers: two workgroups of 8 waves per CU
+#define GN_WAVES (GN_NC == 4 ? 4 : 8)           // 128 registers: two workgroups of 8 waves per CU (four cells per thread)
 #endif
 template <bool REV, int QM, int S>
-__global__ __launch_bounds__(512, GN_WAVES) void bhte_stepNg(B2_ARGS)
+__global__ __launch_bounds__(GN<S>::T, GN_WAVES) void bhte_stepNg(B2_ARGS)
 {
     int b = blockIdx.x;
     if (xcdOrder) {
@@ -742,7 +745,7 @@ static int bhte_run_core(int32_t device, int32_t F, int32_t M, int32_t S, int32_
                         hipLaunchKernelGGL(cone_points<REV>, dim3((unsigned)nPoints), dim3(64), 0, 0, dT[cur], qa, dmat, dcd, dcp, N1, N2, N3, Tcore, dIdx, dPts, (long)nSteps, (long)(s + j - 1), j);
                 }
                 if (dSlice && s % fm == 0) hipLaunchKernelGGL(step_slice<REV>, dim3(256), dim3(256), 0, 0, dT[cur], qa, dmat, dcd, dcp, N1, N2, N3, Tcore, dSlice, sliceJ, (long)(s / fm), nSamples);
-#define BNG_LAUNCH(QM, SS) hipLaunchKernelGGL((bhte_stepNg<REV, QM, SS>), dim3((unsigned)G.nBlocks), dim3(512), 0, 0, dT[cur], dT[1 - cur], dDose, qa, qa, dmat, dcd, dcp, nMat, N1, N2, N3, \
+#define BNG_LAUNCH(QM, SS) hipLaunchKernelGGL((bhte_stepNg<REV, QM, SS>), dim3((unsigned)G.nBlocks), dim3(GN<SS>::T), 0, 0, dT[cur], dT[1 - cur], dDose, qa, qa, dmat, dcd, dcp, nMat, N1, N2, N3, \
                                               Tcore, dtMin, G.zrun, tilesX, G.tilesY, (int)G.nBlocks, xcdOrder)
                 if (stepsN == 4) { if (qa) BNG_LAUNCH(1, 4); else BNG_LAUNCH(0, 4); }
                 else { if (qa) BNG_LAUNCH(1, 3); else BNG_LAUNCH(0, 3); }
