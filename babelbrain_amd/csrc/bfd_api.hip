@@ -1930,6 +1930,7 @@ static int setup_activity_map(bfd_sim *s)
         // the border stays clear (it stands for what lies outside the domain); every sub-tile inside is taken as active
         std::vector<unsigned char> h(bytes, 0);
         for (int q = 1; q <= nsub; q++) for (int y = 1; y <= ty; y++) memset(&h[((size_t)q * (ty + 2) + y) * (tx + 2) + 1], 1, (size_t)tx);
+        BFD_HIP(hipStreamSynchronize(s->stream));                            // the engine's stream does not wait for the legacy stream this copy runs on
         BFD_HIP(hipMemcpy(s->actBase, h.data(), bytes, hipMemcpyHostToDevice));
     }
     BFD_HIP(hipGetLastError());
