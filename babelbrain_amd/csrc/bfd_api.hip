@@ -1392,7 +1392,7 @@ static int build_tile_lists(bfd_sim *s)
             if (!rc && !T.merged && !compact) rc = dev_alloc(s, &s->tiles.shearR, 3 * (size_t)std::max(count, 1), true);      // lists are built at step 0: the memory variables start at zero (merged form: they live in the full-volume arrays; compact form: with the other compact arrays)
             if (!rc && count) e = hipMemcpyAsync(s->tiles.shearCells, sel, (size_t)count * sizeof(unsigned), hipMemcpyDeviceToDevice, s->stream);
             if (!rc) rc = dev_alloc(s, &s->tiles.shearCodes, (size_t)std::max(count, 1), false);
-            if (!rc) rc = dev_alloc(s, &s->tiles.shearTab, 2 * (size_t)s->cfg.nMat, false);
+            if (!rc) rc = dev_alloc(s, &s->tiles.shearTab, 8 * (size_t)s->cfg.nMat, false);
             if (!rc && e == hipSuccess) bfd_launch_shear_coefficients(s->d, s->stream, s->tiles.shearCells, s->tiles.shearCoef, s->tiles.shearCodes, s->tiles.shearTab, s->cfg.nMat, count);
             if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
         }

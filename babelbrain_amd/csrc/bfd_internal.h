@@ -124,7 +124,7 @@ void bfd_kmark(bfd_sim *sim, int cls, int end, hipStream_t st);
 enum { BFD_XM_SF = 0, BFD_XM_VF = 3, BFD_XM_SS = 6, BFD_XM_VS = 9, BFD_XM_VSP_LO = 12, BFD_XM_VSP_HI = 13, BFD_XM_FUSED = 14, BFD_XMAP_COUNT = 15 };
 struct bfd_tiles { bfd_sim *ktimer; int nMat; bool merged /* solid runs: normal and shear stresses in one kernel, the sparse list holds the MIXED cells only */; int4 *runs;
                    unsigned *shearCells; float *shearCoef; long nShear, shearLowEnd, shearHighBeg;   /* sparse shear list */
-                   unsigned *shearCodes; float *shearTab; long nShearExplicit;   /* per listed cell a byte per edge: 0 inactive, 1 + m = one material around the edge (coefficients from shearTab[2 m ..]), 255 = explicit coefficients in shearCoef; number of explicit edges */
+                   unsigned *shearCodes; float *shearTab; long nShearExplicit;   /* per listed cell a byte per edge: 0 inactive, 1 + m = one material around the edge (coefficients from shearTab[8 m], [8 m + 1]; the cell's own AP, BP, AS2, BS2 at [8 m + 4 ..]), 255 = explicit coefficients in shearCoef; number of explicit edges */
                    int4 *runsAll; int nAll, nAllB;   /* compact solid state: every run, fluid and solid, in list order [boundary | interior] -- the stress half-step's one launch of the fluid kernel */
                    /* compact solid state (bfd_dev::cssRow): the row table and where the ten compact arrays (Sxx Syy Sxy Sxz Syz Rxx Ryy Rxy Rxz Ryz, list order) live:
                       cssHosted = inside the full-volume buffers of their own fields (unused otherwise in this mode; the placement has spread those over the memory

@@ -1091,7 +1091,7 @@ __device__ __forceinline__ void stress_solid_merged_body(const bfd_dev &d, const
         const int m = mraw & BFD_MAT_MASK;
         const bool fl = cl & BFD_CLS_FLUID, mem = !(cl & BFD_CLS_NOMEM) || !fl;
         float AP = 0, BP = 0, AS2 = 0, BS2 = 0, As = 0, Bs = 0;
-        if (valid) { AP = d.AP[m]; if (mem) BP = d.BP[m]; if (!fl) { AS2 = d.AS2[m]; BS2 = d.BS2[m]; } if (eXY || eXZ || eYZ) { As = shearTab[2 * m]; Bs = shearTab[2 * m + 1]; } }
+        if (valid) { AP = d.AP[m]; if (mem) BP = d.BP[m]; if (!fl) { AS2 = d.AS2[m]; BS2 = d.BS2[m]; } if (eXY || eXZ || eYZ) { As = shearTab[8 * m]; Bs = shearTab[8 * m + 1]; } }
         __syncthreads();
 
         prefetch_next();
@@ -2068,20 +2068,21 @@ __global__ __launch_bounds__(256, SPARSE_WAVES_PER_SIMD) void stress_shear_spars
     if (NORMAL) {       // material of the cell: from the code word (its fourth byte), else from the id array
         const unsigned mb = cw >> 24;
         const int m = mb ? (int)mb - 1 : (int)(d.mat[c] & BFD_MAT_MASK);
-        AP = d.AP[m]; BP = d.BP[m]; AS2 = d.AS2[m]; BS2 = d.BS2[m];
+        const float4 cm = *(const float4 *)(tab + 8 * m + 4);
+        AP = cm.x; BP = cm.y; AS2 = cm.z; BS2 = cm.w;
     }
     float Axy = 0.f, Bxy = 0.f, Axz = 0.f, Bxz = 0.f, Ayz = 0.f, Byz = 0.f;
     {
         const unsigned q = cw & 255u;
-        if (q == 255u) { Axy = LDNT(coef + 6 * t); Bxy = LDNT(coef + 6 * t + 1); } else if (q) { Axy = tab[2 * (q - 1)]; Bxy = tab[2 * (q - 1) + 1]; }
+        if (q == 255u) { Axy = LDNT(coef + 6 * t); Bxy = LDNT(coef + 6 * t + 1); } else if (q) { const float2 ab = *(const float2 *)(tab + 8 * (q - 1)); Axy = ab.x; Bxy = ab.y; }
     }
     {
         const unsigned q = (cw >> 8) & 255u;
-        if (q == 255u) { Axz = LDNT(coef + 6 * t + 2); Bxz = LDNT(coef + 6 * t + 3); } else if (q) { Axz = tab[2 * (q - 1)]; Bxz = tab[2 * (q - 1) + 1]; }
+        if (q == 255u) { Axz = LDNT(coef + 6 * t + 2); Bxz = LDNT(coef + 6 * t + 3); } else if (q) { const float2 ab = *(const float2 *)(tab + 8 * (q - 1)); Axz = ab.x; Bxz = ab.y; }
     }
     {
         const unsigned q = (cw >> 16) & 255u;
-        if (q == 255u) { Ayz = LDNT(coef + 6 * t + 4); Byz = LDNT(coef + 6 * t + 5); } else if (q) { Ayz = tab[2 * (q - 1)]; Byz = tab[2 * (q - 1) + 1]; }
+        if (q == 255u) { Ayz = LDNT(coef + 6 * t + 4); Byz = LDNT(coef + 6 * t + 5); } else if (q) { const float2 ab = *(const float2 *)(tab + 8 * (q - 1)); Ayz = ab.x; Byz = ab.y; }
     }
     // the 21 velocities: wave-uniform bases + one 32-bit byte offset (c < 2^30); a cell whose stencil stays inside the domain in x and y
     // (all but the cells on the outermost two rows / columns) takes them without a test per value
@@ -2090,12 +2091,25 @@ __global__ __launch_bounds__(256, SPARSE_WAVES_PER_SIMD) void stress_shear_spars
     float dyVx, dxVy, dxVz, dyVz, dxVx = 0.f, dyVy = 0.f, dzVz = 0.f;
     const bool inside = i >= 2 && i + 2 < N1 && j >= 2 && j + 2 < N2;
     if (inside) {
+#ifndef SPARSE_NO_X4  // round 6: the four x-taps of a component as ONE unaligned 16-byte load: 12 of the 30 gathers become 3 (0.245 -> 0.232 ms at the shear medium 512^3)
+        typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+        const f4u qx = *(const f4u *)((const char *)uni(d.Vx) + (c4 - 8u));        // Vx at i-2 .. i+1
+        const f4u qy = *(const f4u *)((const char *)uni(d.Vy) + (c4 - 4u));        // Vy at i-1 .. i+2
+        const f4u qz = *(const f4u *)((const char *)uni(d.Vz) + (c4 - 4u));        // Vz at i-1 .. i+2
+        vx0 = qx.z; vy0 = qy.y; vz0 = qz.y;
+        dyVx = dplus4(F4(d.Vx, c4 - r4), vx0, F4(d.Vx, c4 + r4), F4(d.Vx, c4 + 2 * r4));
+        dxVy = dplus4(qy.x, vy0, qy.z, qy.w);
+        dxVz = dplus4(qz.x, vz0, qz.z, qz.w);
+        dyVz = dplus4(F4(d.Vz, c4 - r4), vz0, F4(d.Vz, c4 + r4), F4(d.Vz, c4 + 2 * r4));
+        if (NORMAL) { dxVx = dminus4(qx.x, qx.y, vx0, qx.w); dyVy = dminus4(F4(d.Vy, c4 - 2 * r4), F4(d.Vy, c4 - r4), vy0, F4(d.Vy, c4 + r4)); }
+#else
         vx0 = F4(d.Vx, c4); vy0 = F4(d.Vy, c4); vz0 = F4(d.Vz, c4);
         dyVx = dplus4(F4(d.Vx, c4 - r4), vx0, F4(d.Vx, c4 + r4), F4(d.Vx, c4 + 2 * r4));
         dxVy = dplus4(F4(d.Vy, c4 - 4u), vy0, F4(d.Vy, c4 + 4u), F4(d.Vy, c4 + 8u));
         dxVz = dplus4(F4(d.Vz, c4 - 4u), vz0, F4(d.Vz, c4 + 4u), F4(d.Vz, c4 + 8u));
         dyVz = dplus4(F4(d.Vz, c4 - r4), vz0, F4(d.Vz, c4 + r4), F4(d.Vz, c4 + 2 * r4));
         if (NORMAL) { dxVx = dminus4(F4(d.Vx, c4 - 8u), F4(d.Vx, c4 - 4u), vx0, F4(d.Vx, c4 + 4u)); dyVy = dminus4(F4(d.Vy, c4 - 2 * r4), F4(d.Vy, c4 - r4), vy0, F4(d.Vy, c4 + r4)); }
+#endif
     } else {
         vx0 = F4(d.Vx, c4); vy0 = F4(d.Vy, c4); vz0 = F4(d.Vz, c4);
         dyVx = dplus4(ldv(d.Vx, N1, N2, i, j - 1, ko), vx0, ldv(d.Vx, N1, N2, i, j + 1, ko), ldv(d.Vx, N1, N2, i, j + 2, ko));
@@ -2262,7 +2276,10 @@ __global__ void shear_material_table(bfd_dev d, float *__restrict__ tab, int nMa
         const float tau = 0.25f * ((t0 + t0) + (t0 + t0));
         A = muH * (1.0f + tau); B = (muH * tau) * k2;
     }
-    tab[2 * m] = A; tab[2 * m + 1] = B;
+    // 32 bytes per material: (A, B) of a one-material edge as one 8-byte load, the cell's own AP, BP, AS2, BS2 as one 16-byte load (round 6: the sparse
+    // kernel takes its per-material coefficients with 1 + 3 loads instead of 4 + 6)
+    tab[8 * m] = A; tab[8 * m + 1] = B; tab[8 * m + 2] = 0.f; tab[8 * m + 3] = 0.f;
+    tab[8 * m + 4] = d.AP[m]; tab[8 * m + 5] = d.BP[m]; tab[8 * m + 6] = d.AS2[m]; tab[8 * m + 7] = d.BS2[m];
 }
 
 // ---- dispatchers: one launch for all fluid runs; block-uniform switch on the run's flags ----
