@@ -1758,6 +1758,8 @@ static int choose_placement(bfd_sim *s)
     // own (another process that started at the same moment) end it at once and everything held goes back
     size_t heldCap = free0 > ((size_t)48 << 30) ? std::min(std::min((size_t)192 << 30, free0 / 3 * 2), free0 - ((size_t)48 << 30)) : 0;
     bool defaultRule = true;
+    double searchSeconds = 2.0;                                                // BABELFDTD_PLACEMENT_SEARCH_SECONDS
+    if (const char *ev = getenv("BABELFDTD_PLACEMENT_SEARCH_SECONDS")) searchSeconds = atof(ev);
     std::string capNote;
     if (others > ((size_t)6 << 30)) { heldCap = 0; char q[96]; snprintf(q, sizeof q, "; device shared (%.0f GiB of other allocations): no search beyond the own buffers", others / 1073741824.0); capNote = q; }
     if (const char *ev = getenv("BABELFDTD_PLACEMENT_SEARCH_GIB")) {           // the owner of the device raises (or lowers) the default bound without code
@@ -1787,6 +1789,11 @@ static int choose_placement(bfd_sim *s)
         size_t freeB = 0, totalB = 0;
         if (hipMemGetInfo(&freeB, &totalB) != hipSuccess || freeB < 2 * bytes + totalB / 8 || heldBytes + bytes > heldCap) { gaveUp = true; break; }
         if (defaultRule) {
+            // ... and a clock: what the placement is worth to ONE solver call is a few per cent of its run time, so a search that has walked for longer than
+            // that (seen once: ~6 s in a process that had built and destroyed many engines before) stops and keeps what exchanging gives
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - tStart).count() > searchSeconds) {
+                gaveUp = true; capNote += "; search ended by its time bound"; break;
+            }
             const size_t known = mine + heldBytes + ownFreshBytes + others;
             if (totalB > freeB + known && totalB - freeB - known > ((size_t)6 << 30)) { gaveUp = true; capNote += "; somebody else began to allocate on the device: search ended"; break; }
         }

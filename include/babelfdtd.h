@@ -165,7 +165,8 @@ const char *bfd_placement_note(bfd_sim *sim);
  * before bfd_prepare returns); < 0 = the default rule: nothing at all when the device carries other allocations than this
  * engine's (another process, the other slabs of a group): the engine's own buffers are then only exchanged among themselves;
  * on a device the engine has to itself up to 192 GiB, at most two thirds of what was free on entry and always leaving 48 GiB of it
- * untouched; the search ends at once when allocations that are neither the engine's nor its own appear on the device while it walks.
+ * untouched; the search ends at once when allocations that are neither the engine's nor its own appear on the device while it walks, and
+ * after 2 s (BABELFDTD_PLACEMENT_SEARCH_SECONDS): the placement is worth a few per cent of one call's run time.
  * bfd_prepare never fails for lack of memory where mode 0 succeeds. */
 int bfd_set_placement(bfd_sim *sim, int32_t mode, int64_t searchLimitBytes);
 /* The default rule can be moved without code by whoever owns the device: BABELFDTD_PLACEMENT_SEARCH_GIB=<GiB> replaces the 192 GiB
