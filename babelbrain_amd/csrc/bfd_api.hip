@@ -300,12 +300,35 @@ __global__ void last_map(bfd_dev d, int sel, float *__restrict__ out, long n)
         out[v] = (sel == BFD_MAP_ALLV) ? sqrtf(map_sq(d, BFD_MAP_ALLV, v)) : map_value(d, sel, v);
 }
 
+// Sensor sets that are a dense box of voxels (what the caller's CreateSensorMap makes: everything inside the absorbing layer past the source plane,
+// BASE:2279-2290) need no index list: sensor s of the box is voxel (i0 + s % bx, j0 + (s / bx) % by, k0 + s / (bx by)) -- the order of the ascending
+// x-fastest linear index the list is in. lin == null selects that form (4 of the 13 bytes a captured sample moved were the index).
+struct SensorBox { unsigned bx, bxy, i0, j0, k0; };
+__device__ __forceinline__ long sensor_cell(const bfd_dev &d, const uint32_t *__restrict__ lin, const SensorBox &B, long s)
+{
+    if (lin) return (long)lin[s];
+    const unsigned u = (unsigned)s, kk = u / B.bxy, r = u - kk * B.bxy, jj = r / B.bx, ii = r - jj * B.bx;
+    return (long)(B.k0 + kk) * d.plane + (long)(B.j0 + jj) * d.N1 + (B.i0 + ii);
+}
+// bounding box of a sensor list (min / max of i, j, k): six atomics per workgroup
+__global__ __launch_bounds__(256) void sensor_bounds(bfd_dev d, const uint32_t *__restrict__ lin, long n, unsigned *__restrict__ mm)
+{
+    unsigned lo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hi[3] = {0u, 0u, 0u};
+    for (long s = (long)blockIdx.x * blockDim.x + threadIdx.x; s < n; s += (long)gridDim.x * blockDim.x) {
+        const unsigned c = lin[s], kl = c / (unsigned)d.plane, r = c - kl * (unsigned)d.plane, j = r / (unsigned)d.N1, i = r - j * (unsigned)d.N1;
+        lo[0] = min(lo[0], i); hi[0] = max(hi[0], i); lo[1] = min(lo[1], j); hi[1] = max(hi[1], j); lo[2] = min(lo[2], kl); hi[2] = max(hi[2], kl);
+    }
+    for (int a = 0; a < 3; a++) {
+        for (int o = 32; o > 0; o >>= 1) { lo[a] = min(lo[a], (unsigned)__shfl_down((int)lo[a], o)); hi[a] = max(hi[a], (unsigned)__shfl_down((int)hi[a], o)); }
+        if ((threadIdx.x & 63) == 0) { atomicMin(mm + a, lo[a]); atomicMax(mm + 3 + a, hi[a]); }
+    }
+}
 // sensors: out[q][col][s]; ent = the sensors' list entries (compact solid state) or null
-__global__ void record_sensors(bfd_dev d, SelList L, const uint32_t *__restrict__ lin, const int *__restrict__ ent, long nSens,
+__global__ void record_sensors(bfd_dev d, SelList L, const uint32_t *__restrict__ lin, SensorBox B, const int *__restrict__ ent, long nSens,
                                float *__restrict__ out, int col, int nTs)
 {
     for (long s = (long)blockIdx.x * blockDim.x + threadIdx.x; s < nSens; s += (long)gridDim.x * blockDim.x) {
-        const long c = lin[s];
+        const long c = sensor_cell(d, lin, B, s);
         const long e = (ent && !normal_collapsed(d, c)) ? (long)ent[s] : -1;
         for (int q = 0; q < L.n; q++)
             out[((long)q * nTs + col) * nSens + s] = output_value(d, L.sel[q], c, e);
@@ -313,14 +336,14 @@ __global__ void record_sensors(bfd_dev d, SelList L, const uint32_t *__restrict_
 }
 // sensorMode 1: the sample of this step goes straight into the running single-bin DFT sums and peaks of its sensor
 // (same arithmetic, sample by sample, as dft_series applies to a stored series)
-__global__ void accumulate_sensor_dft(bfd_dev d, SelList L, const uint32_t *__restrict__ lin, const int *__restrict__ ent, long nSens,
+__global__ void accumulate_sensor_dft(bfd_dev d, SelList L, const uint32_t *__restrict__ lin, SensorBox B, const int *__restrict__ ent, long nSens,
                                       double *__restrict__ acc, float *__restrict__ pk, int col, int nTs, int bin)
 {
     const int r = (int)(((long)bin * col) % nTs);                 // exact phase index
     double sn, cs;
     sincospi(2.0 * (double)r / (double)nTs, &sn, &cs);
     for (long s = (long)blockIdx.x * blockDim.x + threadIdx.x; s < nSens; s += (long)gridDim.x * blockDim.x) {
-        const long c = lin[s];
+        const long c = sensor_cell(d, lin, B, s);
         const long e = (ent && !normal_collapsed(d, c)) ? (long)ent[s] : -1;
         for (int q = 0; q < L.n; q++) {
             const float x = output_value(d, L.sel[q], c, e);
@@ -693,7 +716,7 @@ int bfd_create(const bfd_config *cfg, bfd_sim **out)
     s->nSources = s->lengthSource = 0;
     s->pulseHost = nullptr; s->tileSteps = s->nTiles = 0;
     for (int b = 0; b < 2; b++) { s->tileDev[b] = s->tilePinned[b] = nullptr; s->tileLoaded[b] = s->tilePacked[b] = -1; s->evTile[b] = nullptr; s->evTileUsed[b] = false; for (int q = 0; q < 2; q++) { s->evRead[b][q] = nullptr; s->evReadUsed[b][q] = false; } }
-    s->sensEnt = nullptr; s->sensEntValid = false;
+    s->sensEnt = nullptr; s->sensEntValid = false; s->sensIsBox = false; memset(s->sensBox, 0, sizeof s->sensBox);
     s->actBase = nullptr; s->actBytes = 0; s->actReady = false;
     s->nSensors = 0; s->sensLin = nullptr; s->sensOut = nullptr; s->dftAcc = nullptr; s->dftPk = nullptr; s->dftBin = 0;
     s->acc = s->pk = nullptr; s->timing = s->perKernel = false;
@@ -1021,6 +1044,31 @@ int bfd_set_sensor_map(bfd_sim *s, const uint32_t *map, int64_t s1, int64_t s2, 
                 if (!rc) rc = dev_alloc(s, &s->dftPk, (size_t)s->nSelS * (size_t)std::max(count, 1), false);
                 if (!rc && count > 0) hipLaunchKernelGGL(fill_float, dim3(grid_for((long)s->nSelS * count)), dim3(256), 0, s->stream, s->dftPk, (long)s->nSelS * count, -INFINITY);
                 s->dftBin = dft_bin(s->nTs, s->cfg.dt * s->cfg.sensorSub, s->cfg.freq);
+            }
+        }
+        // a dense box of voxels? (count == volume of the bounding box: every voxel of the box is a sensor); BFD_SENSOR_BOX=0 keeps the index list in use
+        s->sensIsBox = false;
+        bool tryBox = count > 0;
+        if (const char *ev = getenv("BFD_SENSOR_BOX")) tryBox = tryBox && atoi(ev) != 0;
+        if (!rc && e == hipSuccess && tryBox) {
+            unsigned init[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u}, mm[6];
+            unsigned *dmm = (unsigned *)dcount;          // reuse: 4 bytes are not enough
+            unsigned *dbox = nullptr;
+            e = hipMalloc((void **)&dbox, sizeof init);
+            if (e == hipSuccess) e = hipMemcpyAsync(dbox, init, sizeof init, hipMemcpyHostToDevice, s->stream);
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL(sensor_bounds, dim3(std::min(grid_for((long)count), 1024)), dim3(256), 0, s->stream, d, s->sensLin, (long)count, dbox);
+                e = hipMemcpyAsync(mm, dbox, sizeof mm, hipMemcpyDeviceToHost, s->stream);
+            }
+            if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+            if (dbox) hipFree(dbox);
+            (void)dmm;
+            if (e == hipSuccess) {
+                const long bx = (long)mm[3] - mm[0] + 1, by = (long)mm[4] - mm[1] + 1, bz = (long)mm[5] - mm[2] + 1;
+                if (bx * by * bz == (long)count) {
+                    s->sensIsBox = true;
+                    s->sensBox[0] = (int)bx; s->sensBox[1] = (int)by; s->sensBox[2] = (int)mm[0]; s->sensBox[3] = (int)mm[1]; s->sensBox[4] = (int)mm[2];
+                }
             }
         }
         if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
@@ -2077,11 +2125,13 @@ static int velocity_part(bfd_sim *s, int part, hipStream_t st)
                 }
                 ent = s->sensEnt;
             }
+            SensorBox B = {(unsigned)s->sensBox[0], (unsigned)s->sensBox[0] * (unsigned)s->sensBox[1], (unsigned)s->sensBox[2], (unsigned)s->sensBox[3], (unsigned)s->sensBox[4]};
+            const uint32_t *lin = s->sensIsBox ? nullptr : s->sensLin;
             if (s->sensOut)
-                hipLaunchKernelGGL(record_sensors, dim3(grid_for(s->nSensors)), dim3(256), 0, st, d, L, s->sensLin, ent,
+                hipLaunchKernelGGL(record_sensors, dim3(grid_for(s->nSensors)), dim3(256), 0, st, d, L, lin, B, ent,
                                    (long)s->nSensors, s->sensOut, col, s->nTs);
             else
-                hipLaunchKernelGGL(accumulate_sensor_dft, dim3(grid_for(s->nSensors)), dim3(256), 0, st, d, L, s->sensLin, ent,
+                hipLaunchKernelGGL(accumulate_sensor_dft, dim3(grid_for(s->nSensors)), dim3(256), 0, st, d, L, lin, B, ent,
                                    (long)s->nSensors, s->dftAcc, s->dftPk, col, s->nTs, s->dftBin);
         }
     }

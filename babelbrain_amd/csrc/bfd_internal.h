@@ -178,6 +178,7 @@ struct bfd_sim {
     std::future<void> packJob[2];
     // sensors
     unsigned char *actBase; size_t actBytes; bool actReady;   // storage of bfd_dev::act; actReady = the map matches the state (cleared by setters and bfd_reset)
+    bool sensIsBox; int sensBox[5];    // the sensor set is a dense box of voxels: extents in x, y and its first voxel (i0, j0, local k0); captures then need no index list
     int *sensEnt; bool sensEntValid;   // compact solid state: list entry of every sensor voxel (-1 = none), valid for the current list
     int64_t nSensors; uint32_t *sensLin; float *sensOut; int nTs; int nSelS; int selS[BFD_MAP_COUNT];
     double *dftAcc; float *dftPk; int dftBin;      // sensorMode 1: [nSelS][nSensors][2] running DFT sums, [nSelS][nSensors] running peaks
