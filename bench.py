@@ -79,6 +79,7 @@ def parse():
     ap.add_argument('--no-strong-c5', action='store_true', help='skip the block that times ONE C5 volume (1024^3) through the one-process path (N=1: the anchor of the 1/2/4/8 curve)')
     ap.add_argument('--strong-c5-steps', type=int, default=30, help='timed steps of the strong_c5 block (14 ms each on one device)')
     ap.add_argument('--no-group', action='store_true', help='skip the one-process bfd_group figures (group_one_slab at N=1, group_strong_c3 under torchrun)')
+    ap.add_argument('--production-call', action='store_true', help='N=1: also time ONE production-shaped drop-in call of the config (nt from the caller\'s time plan, RMS over the last 2 periods, full sensor block) with the tile runs ahead of the wave front returning at entry (library default) and with every run working (BFD_SKIP_ZERO=0); adds about a minute at C3')
     ap.add_argument('--no-next-rows', action='store_true', help='skip the Rayleigh / BHTE kernel rates (N=1, default workload only)')
     ap.add_argument('--no-extra-strong', action='store_true', help='N > 1: skip the extra block that splits ONE C5 volume (1024^3, 1 MHz) over the ranks')
     ap.add_argument('--extra-strong-steps', type=int, default=40, help='timed steps of the extra strong-scaling block')
@@ -135,6 +136,47 @@ def next_rows(device):
                                 'with three / four steps per pass the kernel needs %.1f B per voxel-step and is no longer held by the memory system alone '
                                 '(128 / 114 registers: two workgroups per CU)' % ((21.0 * float(np.prod(N))) / 1e6, N[0], bpv),
                    'note': 'a pass moves T in / out, dose in / out and the id once for all its steps: 17 B per voxel, 21 B with the heat source'}
+    return out
+
+
+def production_call(args, dt_fn, device):
+    """ONE production-shaped call through the drop-in (what BASE:2338 does): wall time of PropagationModel.StaggeredFDTD_3D_with_relaxation including upload, layout
+    conversion, the step loop and the download of maps and sensor block; with quiet runs (library default) and with every run working. Never `value`."""
+    from babelbrain_amd import harness as H, PropagationModel, RayleighAndBHTE
+    RayleighAndBHTE._device = device
+    t0 = time.time()
+    a, k, info = H.make_problem(args.config, N=tuple(args.size) if args.size else None, stable_dt_fn=dt_fn, forward=RayleighAndBHTE.ForwardSimple)
+    build = time.time() - t0
+    vox = float(np.prod(a[0].shape)) * info['nt']
+    out = {'workload': '%s %dx%dx%d, nt = %d (the caller\'s time plan), PulseSource %.1f GB, %d sensors' % (args.config, *a[0].shape, info['nt'], a[4].nbytes / 1e9, int((a[7] > 0).sum())),
+           'host_build_s': build, 'unit': 'Mvoxel-steps/s'}
+    ref = None
+    for name, env in (('quiet_runs', None), ('every_run_working', '0')):
+        old = os.environ.get('BFD_SKIP_ZERO')
+        if env is None:
+            os.environ.pop('BFD_SKIP_ZERO', None)
+        else:
+            os.environ['BFD_SKIP_ZERO'] = env
+        try:
+            pm = PropagationModel(device=device, keepPlacementCache=True)
+            t1 = time.time()
+            res = pm.StaggeredFDTD_3D_with_relaxation(*a, SILENT=True, **k)
+            wall = time.time() - t1
+            rms = res[2]['Pressure']
+            out[name] = {'production_call_wall_s': wall, 'step_loop_s': pm.last_timing['total_ms'] / 1e3, 'device_only': vox / pm.last_timing['total_ms'] / 1e3,
+                         'pcie_inclusive': vox / wall / 1e6}
+            if ref is None:
+                ref = rms
+            else:
+                out['results_equal'] = bool(np.array_equal(ref, rms))
+            del res
+        finally:
+            if old is None:
+                os.environ.pop('BFD_SKIP_ZERO', None)
+            else:
+                os.environ['BFD_SKIP_ZERO'] = old
+    from babelbrain_amd import _engine
+    _engine.placement_cache_release()
     return out
 
 
@@ -702,6 +744,11 @@ def roofline_summary(line):
         r['c5_step_frac'] = (c5.get('roofline_step') or {}).get('frac')
         r['c5_one_device_value'] = (c5.get('one_device_same_volume') or {}).get('value')
         r['c5_scaling_efficiency'] = c5.get('scaling_efficiency')
+    pc = line.get('production_call') or {}
+    for name in ('quiet_runs', 'every_run_working'):
+        if isinstance(pc.get(name), dict):
+            r['production_call_wall_s_%s' % name] = pc[name].get('production_call_wall_s')
+            r['production_call_device_only_%s' % name] = pc[name].get('device_only')
     pr = (line.get('production_schedule') or {}).get('whole_call_weighted') or {}
     if pr.get('value'):
         r['production_call_value'] = pr['value']
@@ -963,6 +1010,11 @@ def main():
             line['next_rows'] = next_rows(local_rank)
         except Exception as e:
             line['next_rows'] = {'error': repr(e)}
+    if world == 1 and args.production_call:
+        try:
+            line['production_call'] = production_call(args, dt_fn, local_rank)
+        except Exception as e:
+            line['production_call'] = {'error': repr(e)}
     if world == 1 and not args.no_cpu_baseline:
         try:
             line['cpu_baseline'] = cpu_baseline(args, dt_fn)
