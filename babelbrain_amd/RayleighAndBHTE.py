@@ -175,9 +175,8 @@ def field_schedule(nStepsOnOffList, TotalDurationSteps):
     return np.ascontiguousarray(np.tile(cycle, reps)[:int(TotalDurationSteps)], np.int32)
 
 
-def bhte_pass_plan(sched, nFactorMonitoring=1, monitored_plane=True, steps_heating=3, steps_cooling=4):
-    """The passes bfd_bhte_run_* cuts a schedule into (the rule of bhte_run_core, restated for byte accounting): S steps per pass -- 3 while a field
-    heats, 4 while none does -- wherever the next S steps carry the same field and no sample of the monitored plane (taken after every step whose
+def bhte_pass_plan(sched, nFactorMonitoring=1, monitored_plane=True, steps_heating=4, steps_cooling=4):
+    """The passes bfd_bhte_run_* cuts a schedule into (the rule of bhte_run_core, restated for byte accounting): S = 4 steps per pass wherever the next S steps carry the same field and no sample of the monitored plane (taken after every step whose
     index is a multiple of nFactorMonitoring) falls strictly inside; else two steps, else one. Returns [(first step, length, heating)]."""
     sched = [int(v) for v in sched]
     fm = max(int(nFactorMonitoring), 1)

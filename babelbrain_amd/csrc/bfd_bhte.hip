@@ -16,9 +16,9 @@
 #include <math.h>
 #include <vector>
 
-// steps per pass of the default path (bhte_stepNg): four while nothing heats, three while a field heats (bhte_run_core says why)
+// steps per pass of the default path (bhte_stepNg): four (bhte_run_core says how that was chosen)
 #ifndef BFD_BHTE_STEPS_HEATING
-#define BFD_BHTE_STEPS_HEATING 3
+#define BFD_BHTE_STEPS_HEATING 4
 #endif
 #ifndef BFD_BHTE_STEPS_COOLING
 #define BFD_BHTE_STEPS_COOLING 4
@@ -360,14 +360,16 @@ __global__ __launch_bounds__(G2_T, G2_WAVES) void bhte_step2g(B2_ARGS)
 // when S = 4 and is taken from the slot the new plane is about to overwrite. Heat source of the last S planes and their ids ride in small
 // rotating queues (the ids as bytes of one register). QM: 0 no heating in any of the S steps, 1 the same field in all of them; mixed stretches
 // take the two-step kernel. Same expressions in the same order: bit-identical to S launches of bhte_step.
-#ifndef GN_NC
-#define GN_NC 4              // cells per thread (experiment: 2 = 1024 threads per workgroup, rows 14 apart)
-#endif
-template <int S> struct GN { static constexpr int W = 64 + 2 * S, H = 28, TY = H - 2 * S, NC = GN_NC, T = 2048 / NC, ROWS = H / NC, ACT = ROWS * W, CELLS = W * H; };
+// Cells per thread: four (512 threads per workgroup, rows 7 apart), or two (1024 threads, rows 14 apart). Two workgroups of 8 waves and one of 16 are
+// the same 4 waves per SIMD and the same 128-register budget, but a thread with two cells carries half the queues: the four-step flavour WITH a heat
+// source fits 82 registers with two cells (with four it needs 128 and spills 18 to scratch: 382-397 against 564-642 Gvoxel-steps/s), while the
+// flavours that fit anyway are faster with four (cooling, S = 4: 728 / 805 against 651 / 734) -- so the heating flavour of S = 4 takes two, the rest four.
+template <int QM, int S> struct GNCells { static constexpr int v = (QM == 1 && S == 4) ? 2 : 4; };
+template <int S, int NCELLS> struct GN { static constexpr int W = 64 + 2 * S, H = 28, TY = H - 2 * S, NC = NCELLS, T = 2048 / NC, ROWS = H / NC, ACT = ROWS * W, CELLS = W * H; };
 template <bool REV, int QM, int S>
 __device__ __forceinline__ void bhte_stepNg_body(int b, B2_ARGS)
 {
-    using G = GN<S>;
+    using G = GN<S, GNCells<QM, S>::v>;
     static_assert(G::ACT <= G::T && S >= 3 && S <= 4, "region / thread mapping");
     __shared__ float L[S][2][G::CELLS + 2 * G::W];
     __shared__ float2 sC[256];
@@ -491,10 +493,10 @@ __device__ __forceinline__ void bhte_stepNg_body(int b, B2_ARGS)
 }
 
 #ifndef GN_WAVES
-#define GN_WAVES (GN_NC == 4 ? 4 : 8)           // 128 registers: two workgroups of 8 waves per CU (four cells per thread)
+#define GN_WAVES 4           // 128 registers: two workgroups of 8 waves per CU, or one of 16
 #endif
 template <bool REV, int QM, int S>
-__global__ __launch_bounds__(GN<S>::T, GN_WAVES) void bhte_stepNg(B2_ARGS)
+__global__ __launch_bounds__((GN<S, GNCells<QM, S>::v>::T), GN_WAVES) void bhte_stepNg(B2_ARGS)
 {
     int b = blockIdx.x;
     if (xcdOrder) {
@@ -709,9 +711,10 @@ static int bhte_run_core(int32_t device, int32_t F, int32_t M, int32_t S, int32_
         // S steps per pass (round 6; BFD_BHTE_STEPS=2 keeps two): where the next S steps carry the same heat field (or none) and no sample of the
         // monitored plane falls on a step strictly inside the pass (the first step's sample is recomputed from T(n), the last one's is read off the
         // result; one in between would need a cone per cell of the plane). The monitor points of the steps inside are recomputed by cone_points.
-        // BFD_BHTE_STEPS=2 / 3 / 4 forces one pass length; default: FOUR steps per pass while nothing heats (99 registers ... 128 with 2 spilled, 710 / 810
-        // Gvoxel-steps/s at 320^3 / 512^3 against 568 / 679 with three) and THREE while a field heats (114 registers, none spilled: 487 / 568; the four-step
-        // flavour with its heat-source queue spills 18 registers to scratch: 395 / 403) -- scripts/r6/bhte_phases.sh, profiles/r6/bhte_steps_per_pass.txt
+        // BFD_BHTE_STEPS=2 / 3 / 4 forces one pass length; default: FOUR steps per pass. Gvoxel-steps/s at 320^3 / 512^3 (scripts/r6/bhte_phases.sh, bhte_nc_ab.sh,
+        // profiles/r6/bhte_steps_per_pass.txt): nothing heats -- two steps 470 / 515, three 568 / 679, four 710-728 / 795-810 (four cells per thread: 99-128 registers,
+        // 2 spilled); a field heats -- two 374 / 395, three 487 / 568, four with four cells per thread 382-397 / 380-403 (its heat-source queue spills 18 registers
+        // to scratch), four with TWO cells per thread 564 / 642 (82 registers, none spilled: GNCells)
         ev = getenv("BFD_BHTE_STEPS");
         const int forced = (ev && atoi(ev) >= 2 && atoi(ev) <= 4) ? atoi(ev) : 0;
         int stepsHeat = forced ? forced : BFD_BHTE_STEPS_HEATING, stepsCool = forced ? forced : BFD_BHTE_STEPS_COOLING;
@@ -745,7 +748,7 @@ static int bhte_run_core(int32_t device, int32_t F, int32_t M, int32_t S, int32_
                         hipLaunchKernelGGL(cone_points<REV>, dim3((unsigned)nPoints), dim3(64), 0, 0, dT[cur], qa, dmat, dcd, dcp, N1, N2, N3, Tcore, dIdx, dPts, (long)nSteps, (long)(s + j - 1), j);
                 }
                 if (dSlice && s % fm == 0) hipLaunchKernelGGL(step_slice<REV>, dim3(256), dim3(256), 0, 0, dT[cur], qa, dmat, dcd, dcp, N1, N2, N3, Tcore, dSlice, sliceJ, (long)(s / fm), nSamples);
-#define BNG_LAUNCH(QM, SS) hipLaunchKernelGGL((bhte_stepNg<REV, QM, SS>), dim3((unsigned)G.nBlocks), dim3(GN<SS>::T), 0, 0, dT[cur], dT[1 - cur], dDose, qa, qa, dmat, dcd, dcp, nMat, N1, N2, N3, \
+#define BNG_LAUNCH(QM, SS) hipLaunchKernelGGL((bhte_stepNg<REV, QM, SS>), dim3((unsigned)G.nBlocks), dim3(GN<SS, GNCells<QM, SS>::v>::T), 0, 0, dT[cur], dT[1 - cur], dDose, qa, qa, dmat, dcd, dcp, nMat, N1, N2, N3, \
                                               Tcore, dtMin, G.zrun, tilesX, G.tilesY, (int)G.nBlocks, xcdOrder)
                 if (stepsN == 4) { if (qa) BNG_LAUNCH(1, 4); else BNG_LAUNCH(0, 4); }
                 else { if (qa) BNG_LAUNCH(1, 3); else BNG_LAUNCH(0, 3); }

@@ -126,15 +126,15 @@ def next_rows(device):
     bpv = sum(21.0 if heating else 17.0 for _, _, heating in plan) / steps           # one pass moves T in / out, dose in / out, ids (+ the heat source) once
     bpv2 = (21.0 * on + 17.0 * (steps - on)) / 2 / steps
     out['bhte'] = {'value': vox / R.last_kernel_ms / 1e6, 'unit': 'Gvoxel-steps/s', 'grid': list(N), 'steps': steps, 'steps_heating': on,
-                   'steps_per_launch': 'three while the field heats, four while nothing does (bhte_stepNg); two or one where a sample of the monitored plane or a change of field falls inside',
+                   'steps_per_launch': 'four (bhte_stepNg; four cells per thread while nothing heats, two while a field heats); two or one where a sample of the monitored plane or a change of field falls inside',
                    'passes': {str(L): sum(1 for _, l, _ in plan if l == L) for L in (1, 2, 3, 4)},
                    'kernel': 'bhte_stepNg', 'kernel_ms': R.last_kernel_ms, 'call_s': wall, 'bytes_per_voxel_step': bpv,
                    'frac_of_8TBps': bpv * vox / R.last_kernel_ms / 1e6 / 8000, 'bound': 'hbm',
                    'two_steps_per_launch_accounting': {'bytes_per_voxel_step': bpv2, 'frac_of_8TBps': bpv2 * vox / R.last_kernel_ms / 1e6 / 8000,
                                                        'note': 'what round 5 moved for this rate (bhte_step2g: 399 Gvoxel-steps/s = 0.47)'},
                    'roof_note': 'HBM is the roof a one- or two-step launch has at this size (it streams %.0f MB at %d^3, more than the 256 MiB Infinity Cache; MI355X_MICROARCH.md); '
-                                'with three / four steps per pass the kernel needs %.1f B per voxel-step and is no longer held by the memory system alone '
-                                '(128 / 114 registers: two workgroups per CU)' % ((21.0 * float(np.prod(N))) / 1e6, N[0], bpv),
+                                'with four steps per pass the kernel needs %.1f B per voxel-step and is no longer held by the memory system alone '
+                                '(82-128 registers: 4 waves per SIMD)' % ((21.0 * float(np.prod(N))) / 1e6, N[0], bpv),
                    'note': 'a pass moves T in / out, dose in / out and the id once for all its steps: 17 B per voxel, 21 B with the heat source'}
     return out
 
