@@ -8,7 +8,7 @@
 
 ForwardSimple runs on the MI355X through the C ABI (bfd_rayleigh_forward); there is no CPU fallback.
 BHTE / BHTEMultiplePressureFields (CalculateTemperatureEffects.py:365-456, 960-990) run on the device too
-(bfd_bhte_run_fields: three / four time steps per pass, csrc/bfd_bhte.hip).
+(bfd_bhte_run_fields: four time steps per pass, csrc/bfd_bhte.hip).
 """
 import ctypes as C
 import os

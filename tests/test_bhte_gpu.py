@@ -168,7 +168,7 @@ def test_two_steps_per_launch_equal_one_step_per_launch(monkeypatch):
 
 @pytest.mark.parametrize('steps', ['3', '4', 'default'])
 def test_three_and_four_steps_per_pass_equal_one_step_per_launch(steps, monkeypatch):
-    """Round 6: bhte_stepNg takes S = 3 (default while a field heats) or 4 (default while nothing does) steps per pass over regions of (64 + 2 S) x 28 cells wherever the next S steps carry the same heat
+    """Round 6: bhte_stepNg takes S = 4 (default; two cells per thread while a field heats, four while nothing does) or 3 steps per pass over regions of (64 + 2 S) x 28 cells wherever the next S steps carry the same heat
     field (or none) and no sample of the monitored plane falls strictly inside; the monitor points of the steps inside a pass come from cone_points
     (the cube around the point advanced level by level). Temperature, dose, monitored plane, heat source and point series must have the bits of one
     step per launch: long and short on / off stretches, several fields, plane samples every 1 .. 10 steps, points on faces and edges, grids at the
