@@ -9,9 +9,9 @@
 //   T' = T + cd[m] * (((((Txm+Txp)+Tym)+Typ)+Tzm)+Tzp - 6 T) + cp[m] * (Tcore - T) + (n < nStepsOn ? q : 0)
 //   cd = dt k/(rho c dx^2),  cp = dt rho_b c_b w / (6e7 c)  (w in mL/min/kg),  q = dt * duty * a_abs p^2/(rho c_s) / (rho c)
 //   dose += dt/60 * R^(43 - T'),  R = 0.5 for T' >= 43 else 0.25 (evaluated as exp2).   Faces of the volume keep their temperature.
-// Bound: HBM. One step moves T read + write, q read, dose RMW, uint8 ids: ~21 B per voxel; the default path takes THREE steps per
-// launch while a field heats and FOUR while nothing does (round 6: bhte_stepNg; stretches it cannot take go to the two-step kernel bhte_step2g
-// and the one-step kernel) and moves those bytes once for all of them. x-fastest layout.
+// Bound: HBM. One step moves T read + write, q read, dose RMW, uint8 ids: ~21 B per voxel; the default path takes FOUR steps per
+// launch (round 6: bhte_stepNg; stretches it cannot take go to the two-step kernel bhte_step2g and the one-step kernel) and moves those bytes
+// once for all of them. x-fastest layout.
 #include "bfd_internal.h"
 #include <math.h>
 #include <vector>
