@@ -352,7 +352,7 @@ __global__ __launch_bounds__(G2_T, G2_WAVES) void bhte_step2g(B2_ARGS)
 // ---- round 6: S = 3 or 4 steps per pass (bhte_stepNg) ----
 // Two steps per pass move T in / out, the dose in / out, the heat source and the ids once for two steps (10.5 B per voxel-step while heating); S steps
 // move them once for S. Same machinery as bhte_step2g, one more level of it per step: a workgroup marches a z-run over a region of (64 + 2 S) x 28
-// cells (outputs 64 x (28 - 2 S)); thread = one column position, four cells 7 rows apart; level k = T(n + k) lives in per-thread z-queues of three
+// cells (outputs 64 x (28 - 2 S)); thread = one column position, four cells 7 rows apart (or two, 14 apart: GNCells); level k = T(n + k) lives in per-thread z-queues of three
 // planes (compile-time slots, plane loop unrolled by three) and, for the in-plane neighbours, in a double-buffered LDS plane per level (one barrier
 // per plane). In iteration p level 1 is computed for plane p, level 2 for plane p - 1, ..., the output level S for plane p - S + 1; a level-k value
 // is computed where the cell lies k cells inside the region (ring cells copy the level below: never used by a cell that counts), face cells keep
