@@ -176,16 +176,13 @@ def field_schedule(nStepsOnOffList, TotalDurationSteps):
 
 
 def bhte_pass_plan(sched, nFactorMonitoring=1, monitored_plane=True, steps_heating=4, steps_cooling=4):
-    """The passes bfd_bhte_run_* cuts a schedule into (the rule of bhte_run_core, restated for byte accounting): S = 4 steps per pass wherever the next S steps carry the same field and no sample of the monitored plane (taken after every step whose
-    index is a multiple of nFactorMonitoring) falls strictly inside; else two steps, else one. Returns [(first step, length, heating)]."""
+    """The passes bfd_bhte_run_* cuts a schedule into (the rule of bhte_run_core, restated for byte accounting): S = 4 steps per pass wherever the next S steps carry the same field; else two steps, else one. Returns [(first step, length, heating)]."""
     sched = [int(v) for v in sched]
     fm = max(int(nFactorMonitoring), 1)
     out, s, n = [], 0, len(sched)
     while s < n:
         S = steps_heating if sched[s] >= 0 else steps_cooling
         ok = S >= 3 and s + S <= n and all(sched[s + j] == sched[s] for j in range(1, S))
-        if ok and monitored_plane:
-            ok = all((s + j) % fm != 0 for j in range(1, S - 1))
         L = S if ok else (2 if s + 1 < n else 1)
         out.append((s, L, sched[s] >= 0 or (L == 2 and sched[s + 1] >= 0)))
         s += L

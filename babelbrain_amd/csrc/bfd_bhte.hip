@@ -546,6 +546,48 @@ __global__ __launch_bounds__(64) void cone_points(const float *__restrict__ Tin,
     if (threadIdx.x == 0) out[(long)blockIdx.x * stride + col] = A[depth & 1][(depth * side + depth) * side + depth];
 }
 
+// The monitored plane at a step INSIDE a pass: T(n + depth) on the row j = jsel for a patch of 16 x 16 cells in (i, k), from T(n) -- the slab of
+// (16 + 2 depth) x (2 depth + 1) x (16 + 2 depth) cells around the patch advanced level by level in LDS, like cone_points does for a cube. One sample of
+// a 320 x 320 plane at depth 3 costs 400 workgroups x 3388 cells: a few per cent of one volume step, once per nFactorMonitoring steps.
+template <bool REV>
+__global__ __launch_bounds__(256) void cone_slice(const float *__restrict__ Tin, const float *__restrict__ q, const unsigned char *__restrict__ mat,
+                                                  const float *__restrict__ cd, const float *__restrict__ cp, int N1, int N2, int N3, float Tcore,
+                                                  float *__restrict__ out, int jsel, long sample, long nSamples, int depth)
+{
+    __shared__ float A[2][22 * 7 * 22];
+    const int sx = 16 + 2 * depth, sy = 2 * depth + 1, sz = 16 + 2 * depth, ncell = sx * sy * sz;
+    const int i0 = blockIdx.x * 16 - depth, j0 = jsel - depth, k0 = blockIdx.y * 16 - depth;
+    const long pl = (long)N1 * N2;
+    for (int v = threadIdx.x; v < ncell; v += 256) {
+        const int li = v % sx, lj = (v / sx) % sy, lk = v / (sx * sy);
+        const int i = min(max(i0 + li, 0), N1 - 1), j = min(max(j0 + lj, 0), N2 - 1), k = min(max(k0 + lk, 0), N3 - 1);
+        A[0][v] = Tin[(long)k * pl + (long)j * N1 + i];
+    }
+    __syncthreads();
+    for (int lev = 1; lev <= depth; lev++) {
+        const float *src = A[(lev - 1) & 1]; float *dst = A[lev & 1];
+        for (int v = threadIdx.x; v < ncell; v += 256) {
+            const int li = v % sx, lj = (v / sx) % sy, lk = v / (sx * sy);
+            float val = src[v];
+            if (li >= lev && li < sx - lev && lj >= lev && lj < sy - lev && lk >= lev && lk < sz - lev) {
+                const int i = i0 + li, j = j0 + lj, k = k0 + lk;
+                if (i > 0 && i < N1 - 1 && j > 0 && j < N2 - 1 && k > 0 && k < N3 - 1) {
+                    const long c = (long)k * pl + (long)j * N1 + i;
+                    const int m = mat[c];
+                    val = bhte_update<REV>(src[v], src[v - 1], src[v + 1], src[v - sx], src[v + sx], src[v - sx * sy], src[v + sx * sy], cd[m], cp[m], Tcore,
+                                           q != nullptr, q ? q[c] : 0.0f);
+                }
+            }
+            dst[v] = val;
+        }
+        __syncthreads();
+    }
+    const float *res = A[depth & 1];
+    const int li = depth + (int)(threadIdx.x & 15), lk = depth + (int)(threadIdx.x >> 4);
+    const int i = i0 + li, k = k0 + lk;
+    if (i < N1 && k < N3) out[(REV ? (long)k * N1 + i : (long)i * N3 + k) * nSamples + sample] = res[(lk * sy + depth) * sx + li];
+}
+
 // Monitors of the first of two fused steps: T(n+1) at the listed voxels / on the monitored plane, computed from T(n)
 template <bool REV>
 __global__ void step_points(const float *__restrict__ Tin, const float *__restrict__ q, const unsigned char *__restrict__ mat,
@@ -708,9 +750,9 @@ static int bhte_run_core(int32_t device, int32_t F, int32_t M, int32_t S, int32_
             if (dPts) hipLaunchKernelGGL(gather_points, dim3((unsigned)((nPoints + 255) / 256)), dim3(256), 0, 0, dT[cur], dIdx, dPts, (long)nPoints, (long)nSteps, (long)s);
             if (dSlice && s % fm == 0) hipLaunchKernelGGL(gather_slice<REV>, dim3(256), dim3(256), 0, 0, dT[cur], dSlice, N1, N2, N3, sliceJ, (long)(s / fm), nSamples);
         };
-        // S steps per pass (round 6; BFD_BHTE_STEPS=2 keeps two): where the next S steps carry the same heat field (or none) and no sample of the
-        // monitored plane falls on a step strictly inside the pass (the first step's sample is recomputed from T(n), the last one's is read off the
-        // result; one in between would need a cone per cell of the plane). The monitor points of the steps inside are recomputed by cone_points.
+        // S steps per pass (round 6; BFD_BHTE_STEPS=2 keeps two): where the next S steps carry the same heat field (or none). Monitors of the steps
+        // inside a pass are recomputed from the pass's input: the points by cone_points, a sample of the monitored plane by step_slice (first step) or
+        // cone_slice (steps in between); the last step's are read off the result.
         // BFD_BHTE_STEPS=2 / 3 / 4 forces one pass length; default: FOUR steps per pass. Gvoxel-steps/s at 320^3 / 512^3 (scripts/r6/bhte_phases.sh, bhte_nc_ab.sh,
         // profiles/r6/bhte_steps_per_pass.txt): nothing heats -- two steps 470 / 515, three 568 / 679, four 710-728 / 795-810 (four cells per thread: 99-128 registers,
         // 2 spilled); a field heats -- two 374 / 395, three 487 / 568, four with four cells per thread 382-397 / 380-403 (its heat-source queue spills 18 registers
@@ -739,7 +781,6 @@ static int bhte_run_core(int32_t device, int32_t F, int32_t M, int32_t S, int32_
             const PassGeom &G = geom[stepsN >= 3 ? stepsN : 3];
             bool passN = stepsN >= 3 && s + stepsN <= nSteps && G.nBlocks < 0x7fffffffL;
             for (int j = 1; j < stepsN && passN; j++) passN = fieldOfStep[s + j] == fieldOfStep[s];
-            for (int j = 1; j + 1 < stepsN && passN && dSlice; j++) passN = (s + j) % fm != 0;
             if (passN) {
                 const float *qa = Q(fieldOfStep[s]);
                 if (dPts) {
@@ -748,6 +789,10 @@ static int bhte_run_core(int32_t device, int32_t F, int32_t M, int32_t S, int32_
                         hipLaunchKernelGGL(cone_points<REV>, dim3((unsigned)nPoints), dim3(64), 0, 0, dT[cur], qa, dmat, dcd, dcp, N1, N2, N3, Tcore, dIdx, dPts, (long)nSteps, (long)(s + j - 1), j);
                 }
                 if (dSlice && s % fm == 0) hipLaunchKernelGGL(step_slice<REV>, dim3(256), dim3(256), 0, 0, dT[cur], qa, dmat, dcd, dcp, N1, N2, N3, Tcore, dSlice, sliceJ, (long)(s / fm), nSamples);
+                for (int j = 1; j + 1 < stepsN && dSlice; j++)           // samples of the monitored plane at the steps inside the pass
+                    if ((s + j) % fm == 0)
+                        hipLaunchKernelGGL(cone_slice<REV>, dim3((unsigned)((N1 + 15) / 16), (unsigned)((N3 + 15) / 16)), dim3(256), 0, 0, dT[cur], qa, dmat, dcd, dcp, N1, N2, N3, Tcore,
+                                           dSlice, sliceJ, (long)((s + j) / fm), nSamples, j + 1);
 #define BNG_LAUNCH(QM, SS) hipLaunchKernelGGL((bhte_stepNg<REV, QM, SS>), dim3((unsigned)G.nBlocks), dim3(GN<SS, GNCells<QM, SS>::v>::T), 0, 0, dT[cur], dT[1 - cur], dDose, qa, qa, dmat, dcd, dcp, nMat, N1, N2, N3, \
                                               Tcore, dtMin, G.zrun, tilesX, G.tilesY, (int)G.nBlocks, xcdOrder)
                 if (stepsN == 4) { if (qa) BNG_LAUNCH(1, 4); else BNG_LAUNCH(0, 4); }

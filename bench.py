@@ -126,7 +126,7 @@ def next_rows(device):
     bpv = sum(21.0 if heating else 17.0 for _, _, heating in plan) / steps           # one pass moves T in / out, dose in / out, ids (+ the heat source) once
     bpv2 = (21.0 * on + 17.0 * (steps - on)) / 2 / steps
     out['bhte'] = {'value': vox / R.last_kernel_ms / 1e6, 'unit': 'Gvoxel-steps/s', 'grid': list(N), 'steps': steps, 'steps_heating': on,
-                   'steps_per_launch': 'four (bhte_stepNg; four cells per thread while nothing heats, two while a field heats); two or one where a sample of the monitored plane or a change of field falls inside',
+                   'steps_per_launch': 'four (bhte_stepNg; four cells per thread while nothing heats, two while a field heats); two or one where a change of field falls inside or fewer than four steps are left',
                    'passes': {str(L): sum(1 for _, l, _ in plan if l == L) for L in (1, 2, 3, 4)},
                    'kernel': 'bhte_stepNg', 'kernel_ms': R.last_kernel_ms, 'call_s': wall, 'bytes_per_voxel_step': bpv,
                    'frac_of_8TBps': bpv * vox / R.last_kernel_ms / 1e6 / 8000, 'bound': 'hbm',
