@@ -37,6 +37,7 @@ for fuse in ('1', '0'):
     t0 = time.time(); out = R.BHTE(P, mm, ML, h, steps, on, N[1] // 2, nFactorMonitoring=10, dt=0.05); wall = time.time() - t0
     vox = float(np.prod(N)) * steps
     ms = R.last_kernel_ms
-    print('BHTE %dx%dx%d, %d steps (%d heating), %s: kernel %.1f ms -> %.0f Gvoxel-steps/s, %.0f GB/s on 21 B per voxel-step = %.2f of 8 TB/s (call %.1f s); Tmax %.3f'
-          % (N + (steps, on, 'two steps per launch (21 B per voxel per launch)' if fuse == '1' else 'one step per launch', ms, vox / ms / 1e6, 21 * vox / ms / 1e6,
-             21 * vox / ms / 1e6 / 8000, wall, float(out[0].max()))))
+    bpv = (sum(21.0 if heating else 17.0 for _, _, heating in R.bhte_pass_plan([0] * on + [-1] * (steps - on), 10, True)) / steps) if fuse == '1' else (21.0 * on + 17.0 * (steps - on)) / steps
+    print('BHTE %dx%dx%d, %d steps (%d heating), %s: kernel %.1f ms -> %.0f Gvoxel-steps/s, %.2f B per voxel-step = %.2f of 8 TB/s (call %.1f s); Tmax %.3f'
+          % (N + (steps, on, 'default path (four steps per pass)' if fuse == '1' else 'one step per launch', ms, vox / ms / 1e6, bpv,
+             bpv * vox / ms / 1e6 / 8000, wall, float(out[0].max()))))
