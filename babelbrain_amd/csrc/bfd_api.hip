@@ -1955,16 +1955,18 @@ static int choose_placement(bfd_sim *s)
     return 0;
 }
 
-// Quiet runs (bfd_dev::act; bfd_kernels_v2.hip): a production call of a whole domain lets the runs ahead of the wave front return at entry. On when the
-// engine holds a whole domain, accumulates its maps over the caller's own window (rmsFirstStep = 0: bench.py's timed windows, which accumulate from
+// Quiet runs (bfd_dev::act; bfd_kernels_v2.hip): a production call lets the runs ahead of the wave front return at entry. On when the
+// engine (a whole domain or a Z-slab of at least three sub-tiles: its boundary runs always work) accumulates its maps over the caller's own window (rmsFirstStep = 0: bench.py's timed windows, which accumulate from
 // step 1, never see it), runs the class-specialised kernels (variants 0 / 3, in-place update) and keeps solid-only values compact; BFD_SKIP_ZERO=0
 // switches it off. The map starts with the sub-tiles of the source voxels at step 0; when inputs are set again in the middle of a run every sub-tile
 // counts as active from then on.
 static int setup_activity_map(bfd_sim *s)
 {
     bfd_dev &d = s->d;
-    bool on = d.k0 == 0 && d.nk == d.N3 && s->cfg.rmsFirstStep == 0 && (s->cfg.kernelVariant == 0 || s->cfg.kernelVariant == 3) && !s->pingpong &&
-              s->tilesReady && (s->tiles.nSolid == 0 || d.cssRow != nullptr);
+    const bool whole = d.k0 == 0 && d.nk == d.N3;
+    bool on = s->cfg.rmsFirstStep == 0 && (s->cfg.kernelVariant == 0 || s->cfg.kernelVariant == 3) && !s->pingpong &&
+              s->tilesReady && (s->tiles.nSolid == 0 || d.cssRow != nullptr) && d.nk >= 3 * bfd_tile_subz();
+    if (const char *ev = getenv("BFD_SKIP_ZERO_SLABS")) on = on && (whole || atoi(ev) != 0);      // 0: whole domains only (the first form of the round)
     if (const char *ev = getenv("BFD_SKIP_ZERO")) on = on && atoi(ev) != 0;
     s->actReady = true;
     BFD_HIP(hipSetDevice(s->cfg.device));
@@ -1978,6 +1980,10 @@ static int setup_activity_map(bfd_sim *s)
         s->actBytes = bytes;
     }
     d.act = s->actBase; d.actX = tx + 2; d.actY = ty + 2;
+    {   // a Z-slab: the runs of the sub-tiles that hold the planes next to a neighbour (the "boundary" runs of a split half-step) always work
+        const int SUB = bfd_tile_subz(), lowPlanes = std::min(SUB, d.nk), hiStart = std::max(((d.nk - 2) / SUB) * SUB, lowPlanes);
+        d.actLo = whole ? 0 : lowPlanes; d.actHi = whole ? 0x7fffffff : hiStart;
+    }
     if (s->step == 0) {
         BFD_HIP(hipMemsetAsync(s->actBase, 0, bytes, s->stream));
         bfd_launch_mark_source_subtiles(d, s->stream, s->srcLin, (long)s->nSrcVox);
@@ -1989,6 +1995,7 @@ static int setup_activity_map(bfd_sim *s)
         BFD_HIP(hipMemcpy(s->actBase, h.data(), bytes, hipMemcpyHostToDevice));
     }
     BFD_HIP(hipGetLastError());
+    BFD_HIP(hipStreamSynchronize(s->stream));        // a slab's half-steps may be queued on other streams than the engine's
     drop_step_graph(s);
     return 0;
 }

@@ -81,8 +81,9 @@ struct bfd_dev {
     float *cSxx, *cSyy, *cSxy, *cSxz, *cSyz, *cRxx, *cRyy, *cRxy, *cRxz, *cRyz;
     // Activity map (round 6; null = every run works in every half-step): one byte per 64 x 8 x BFD_SUBZ sub-tile, 1 = a non-zero V or S value has
     // been written there. Padded by one sub-tile on every side: sub-tile (bx, by, q) at ((q + 1) * actY + by + 1) * actX + bx + 1. A run whose
-    // sub-tiles and all their neighbours are clear returns at entry (bfd_kernels_v2.hip, "QUIET runs"). Whole domains in production calls only.
+    // sub-tiles and all their neighbours are clear returns at entry (bfd_kernels_v2.hip, "QUIET runs"). Production calls only (whole domains and Z-slabs).
     unsigned char *act; int actX, actY;
+    int actLo, actHi;      // Z-slabs: runs that touch local planes below actLo or from actHi on (the sub-tiles a neighbour's planes reach) always work; whole domains: 0, INT_MAX
 };
 #define BFD_CSS_NONE 0xFFFFFFFFu
 // a cell has compact values ("listed") when its class byte says solid centre, no reflector

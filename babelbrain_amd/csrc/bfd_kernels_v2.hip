@@ -481,7 +481,7 @@ __global__ __launch_bounds__(NTHREADS, VELOCITY_WAVES_PER_SIMD) void velocity_v2
 // Flags only ever get set, so reading a neighbour's byte while that neighbour sets it in the same launch errs on the side of working (the
 // decision is taken once per workgroup: run_all_quiet).
 // The sparse kernel has no part in this: a non-zero it writes lies within 2 cells of a non-zero V, whose sub-tile is flagged, and every run
-// within reach of that cell is a neighbour of that sub-tile. Bit-identical to running every run (the -0 a skipped update might have
+// within reach of that cell is a neighbour of that sub-tile. In a Z-slab the runs next to a neighbour's planes always work (run_all_quiet). Bit-identical to running every run (the -0 a skipped update might have
 // produced compares equal to the +0 that stays).
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool run_all_quiet(const bfd_dev &d, int bx, int by, int kbeg, int kend)
@@ -489,6 +489,9 @@ __device__ __forceinline__ bool run_all_quiet(const bfd_dev &d, int bx, int by, 
     const int q0 = kbeg / SUBZ, q1 = (kend - 1) / SUBZ;
     const int nq = q1 - q0 + 3;                             // the run's sub-tiles, one more below and one above
     if (9 * nq > 64) return false;
+    // Z-slab: the runs of the first and the last sub-tile read the ghost planes a neighbour fills: nothing here knows when those turn non-zero, so these runs
+    // always work -- and set their bytes when they write a non-zero, which is how the rest of the slab learns that the wave has come in
+    if (kbeg < d.actLo || kend > d.actHi) return false;
     const int l = threadIdx.x;                              // lane: a wave is one tile row
     const int dq = l / 9, r = l - 9 * dq, dy = r / 3, dx = r - 3 * dy;
     // padded coordinates: sub-tile (bx, by, q) sits at (bx + 1, by + 1, q + 1), so its lower neighbour is at (bx, by, q)
@@ -2663,9 +2666,14 @@ void bfd_launch_velocity_v2(const bfd_dev &d, hipStream_t s0, float *accP, float
                 if (cnt <= 0) return;
 #ifndef BFD_VELOCITY_SOLID_FLAT
                 // a whole domain, or the interior runs of a Z-slab (part 2 of a split half-step: they reach no ghost plane), V in place
-                if (d.act && d.cssRow && d.VxW == d.Vx && d.VyW == d.Vy && d.VzW == d.Vz && d.k0 == 0 && d.nk == d.N3) {       // quiet runs return at entry (production calls)
-                    if (pml) { if (acc) BFD_LAUNCH_X((velocity_solid<true, true, true, true, true>), cnt, m, accP, pkP, base + a0); else BFD_LAUNCH_X((velocity_solid<false, true, true, true, true>), cnt, m, accP, pkP, base + a0); }
-                    else { if (acc) BFD_LAUNCH_X((velocity_solid<true, false, true, true, true>), cnt, m, accP, pkP, base + a0); else BFD_LAUNCH_X((velocity_solid<false, false, true, true, true>), cnt, m, accP, pkP, base + a0); }
+                if (d.act && d.cssRow && d.VxW == d.Vx && d.VyW == d.Vy && d.VzW == d.Vz) {       // quiet runs return at entry (production calls)
+                    if ((d.k0 == 0 && d.nk == d.N3) || part == 2) {
+                        if (pml) { if (acc) BFD_LAUNCH_X((velocity_solid<true, true, true, true, true>), cnt, m, accP, pkP, base + a0); else BFD_LAUNCH_X((velocity_solid<false, true, true, true, true>), cnt, m, accP, pkP, base + a0); }
+                        else { if (acc) BFD_LAUNCH_X((velocity_solid<true, false, true, true, true>), cnt, m, accP, pkP, base + a0); else BFD_LAUNCH_X((velocity_solid<false, false, true, true, true>), cnt, m, accP, pkP, base + a0); }
+                    } else {
+                        if (pml) { if (acc) BFD_LAUNCH_X((velocity_solid<true, true, true, false, true>), cnt, m, accP, pkP, base + a0); else BFD_LAUNCH_X((velocity_solid<false, true, true, false, true>), cnt, m, accP, pkP, base + a0); }
+                        else { if (acc) BFD_LAUNCH_X((velocity_solid<true, false, true, false, true>), cnt, m, accP, pkP, base + a0); else BFD_LAUNCH_X((velocity_solid<false, false, true, false, true>), cnt, m, accP, pkP, base + a0); }
+                    }
                     return;
                 }
                 if (d.cssRow && d.VxW == d.Vx && d.VyW == d.Vy && d.VzW == d.Vz && ((d.k0 == 0 && d.nk == d.N3) || part == 2)) {

@@ -116,19 +116,58 @@ def test_drop_in_call_with_quiet_runs_against_the_oracle(monkeypatch):
     assert out_o[1]['Pressure'][:, :, -40:].max() == 0 and out_o[1]['Pressure'].max() > 0      # the far end is still untouched
 
 
-def test_bench_windows_and_slabs_work_on_every_run(monkeypatch):
-    """rmsFirstStep > 0 (bench.py's timed windows) and Z-slabs keep every run working: no map at all."""
+def test_bench_windows_work_on_every_run(monkeypatch):
+    """rmsFirstStep > 0 (bench.py's timed windows) keeps every run working: no map at all."""
     monkeypatch.setenv('BFD_SKIP_ZERO', '1')
     a, k, info = H.make_problem('C1', N=(128, 64, 96), steps=40, stable_dt_fn=_hip_dt)
     eng = _engine_for(a, k, 40, rmsFirstStep=1)
     eng.run(40)
     assert eng.activity_counts() == (0, 0)
     eng.close()
-    from babelbrain_amd import slab
-    s, info2 = slab.create_hip_slab(a, k, 0, 2, 0)
-    s.half_step_stress(0); s.half_step_velocity(0)
-    assert s.eng.activity_counts() == (0, 0)
-    s.close()
+
+
+@pytest.mark.parametrize('config,split', [('C2', True), ('C2', False), ('C1', True)])
+def test_quiet_runs_in_z_slabs(config, split, monkeypatch):
+    """A production call cut into Z-slabs (the one-process group path and torchrun's slab.py drive the same engines): every slab keeps its own map, the
+    runs of its first and last sub-tile -- the ones a neighbour's planes reach -- always work and wake the rest when the wave comes in. Three slabs with
+    the halo planes exchanged by device copies, both step orders, against the single domain with every run working: bit for bit; and the slabs the wave has
+    not reached yet show clear sub-tiles."""
+    import torch
+    from babelbrain_amd import PropagationModel, slab
+    from babelbrain_amd._engine import HALO_STRESS, HALO_VELOCITY
+    from tests.test_slab_gpu import _exchange
+    N, steps, world = (128, 64, 288), 420, 3
+    a, k, info = H.make_problem(config, N=N, steps=steps, stable_dt_fn=_hip_dt)
+    monkeypatch.setenv('BFD_SKIP_ZERO', '0')
+    ref = PropagationModel().StaggeredFDTD_3D_with_relaxation(*a, SILENT=True, **k)
+    monkeypatch.setenv('BFD_SKIP_ZERO', '1')
+    slabs, infos = zip(*[slab.create_hip_slab(a, k, r, world, 0, kernelVariant=0) for r in range(world)])
+    seen = []
+    for n in range(steps):
+        if split:
+            for s in slabs: s.half_step_stress(1)
+            _exchange(slabs, HALO_STRESS)
+            for s in slabs: s.half_step_stress(2)
+            for s in slabs: s.half_step_velocity(1)
+            _exchange(slabs, HALO_VELOCITY)
+            for s in slabs: s.half_step_velocity(2)
+        else:
+            _exchange(slabs, HALO_VELOCITY)
+            for s in slabs: s.half_step_stress()
+            _exchange(slabs, HALO_STRESS)
+            for s in slabs: s.half_step_velocity()
+        if n in (60, steps - 1):
+            torch.cuda.synchronize()
+            seen.append([s.eng.activity_counts() for s in slabs])
+    torch.cuda.synchronize()
+    m = slab.merge_slab_outputs([slab.collect_slab_outputs(s.eng, k, i) for s, i in zip(slabs, infos)])
+    for s in slabs: s.close()
+    assert np.array_equal(m['RMS']['Pressure'], ref[2]['Pressure']) and np.array_equal(m['LastMap']['Pressure'], ref[1]['Pressure'])
+    assert np.array_equal(m['Sensor']['Pressure'], ref[0]['Pressure'])
+    early, late = seen
+    assert all(t > 0 for _, t in early) and early[0][0] > 0 and early[2][0] == 0, early       # the wave starts in slab 0; slab 2 is still asleep after 60 steps
+    assert late[0][0] > early[0][0] and late[1][0] > 0, (early, late)
+    assert ref[1]['Pressure'][:, :, 96:192].max() > 0                                              # it did cross the first interface
 
 
 @pytest.mark.timeout(900)
