@@ -2413,22 +2413,39 @@ int bfd_get_sensor_index(bfd_sim *s, uint32_t *index)
     return 0;
 }
 
-int bfd_get_sensors(bfd_sim *s, float *out)
+}  // extern "C"
+
+int bfd_sensors_into(bfd_sim *s, float *out, int64_t rowElems)
 {
+    // the series of selected map q go to out + q * rowElems (rowElems >= nSensors * nTs): a slab of a group
+    // writes straight into its columns of the caller's array
     if (!s) BFD_FAIL(-1, "null sim");
-    const size_t n = (size_t)s->nSelS * s->nTs * (size_t)s->nSensors;
+    const size_t row = (size_t)s->nTs * (size_t)s->nSensors, n = (size_t)s->nSelS * row;
     if (!n) return 0;
     if (s->cfg.sensorMode != 0) BFD_FAIL(-6, "bfd_get_sensors: the series are not stored with sensorMode 1 (use bfd_get_sensor_dft)");
     if (!out || !s->sensOut) BFD_FAIL(-1, "bfd_get_sensors: null argument");
+    if (rowElems < (int64_t)row) BFD_FAIL(-2, "bfd_get_sensors: row shorter than nSensors * nSteps");
     BFD_HIP(hipSetDevice(s->cfg.device));
     float *tmp = nullptr;
     BFD_HIP(hipMalloc((void **)&tmp, n * sizeof(float)));
     hipLaunchKernelGGL(transpose_sensors, dim3(grid_for((long)n)), dim3(256), 0, s->stream, s->sensOut, tmp, (long)s->nSensors, s->nTs, s->nSelS);
-    hipError_t e = hipMemcpyAsync(out, tmp, n * sizeof(float), hipMemcpyDeviceToHost, s->stream);
+    hipError_t e = hipSuccess;
+    if ((size_t)rowElems == row) e = hipMemcpyAsync(out, tmp, n * sizeof(float), hipMemcpyDeviceToHost, s->stream);
+    else
+        for (int q = 0; q < s->nSelS && e == hipSuccess; q++)
+            e = hipMemcpyAsync(out + (size_t)q * rowElems, tmp + (size_t)q * row, row * sizeof(float), hipMemcpyDeviceToHost, s->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
     hipFree(tmp);
     if (e != hipSuccess) BFD_FAIL(-10, std::string("bfd_get_sensors: ") + hipGetErrorString(e));
     return 0;
+}
+
+extern "C" {
+
+int bfd_get_sensors(bfd_sim *s, float *out)
+{
+    if (!s) BFD_FAIL(-1, "null sim");
+    return bfd_sensors_into(s, out, (int64_t)s->nTs * (int64_t)s->nSensors);
 }
 
 static int download_volume(bfd_sim *s, const float *devXfast, float *out, int64_t s1, int64_t s2, int64_t s3)

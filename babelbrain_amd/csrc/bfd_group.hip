@@ -523,19 +523,12 @@ int bfd_group_get_sensors(bfd_group *g, float *out)
     const int nTs = bfd_num_sensor_steps(g->sim[0]);
     if (total == 0 || nTs <= 0) return 0;
     if (!out) GRP_FAIL(-1, "bfd_group_get_sensors: null argument");
-    const int nSel = g->sim[0]->nSelS;
     std::vector<int64_t> off(g->n + 1, 0);
     for (int r = 0; r < g->n; r++) off[r + 1] = off[r] + bfd_num_sensors(g->sim[r]);
     return for_slabs(g->n, [&](int r) {
         const int64_t ns = off[r + 1] - off[r];
         if (!ns) return 0;
-        if (g->n == 1) return bfd_get_sensors(g->sim[r], out);
-        std::vector<float> tmp((size_t)nSel * ns * nTs);
-        const int rc = bfd_get_sensors(g->sim[r], tmp.data());
-        if (rc) return rc;
-        for (int q = 0; q < nSel; q++)
-            memcpy(out + ((size_t)q * total + off[r]) * nTs, tmp.data() + (size_t)q * ns * nTs, (size_t)ns * nTs * sizeof(float));
-        return 0;
+        return bfd_sensors_into(g->sim[r], out + (size_t)off[r] * nTs, total * (int64_t)nTs);   // straight into this slab's columns
     });
 }
 

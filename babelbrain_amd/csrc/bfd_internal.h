@@ -213,6 +213,8 @@ void bfd_set_error(const std::string &s);
         }                                                                                          \
     } while (0)
 
+// bfd_get_sensors with a row pitch: the series of selected map q at out + q * rowElems (bfd_group.hip: a slab writes into its columns)
+int bfd_sensors_into(bfd_sim *s, float *out, int64_t rowElems);
 // kernel launchers (bfd_kernels_*.hip)
 void bfd_launch_stress_v1(const bfd_dev &d, hipStream_t s);
 void bfd_launch_velocity_v1(const bfd_dev &d, hipStream_t s);
