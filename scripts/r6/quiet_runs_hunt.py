@@ -86,21 +86,26 @@ def run(a, k, mode):
     return out, act
 
 
-first, count = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (0, 40)
-bad, skipped_share, t0 = [], [], time.time()
-for seed in range(first, first + count):
-    try:
-        a, k = big_case(seed)
-        on, act = run(a, k, '1')
-        off, _ = run(a, k, '0')
-        diff = [n for n in on if not np.array_equal(on[n], off[n])]
-        if diff:
-            bad.append(seed); print('MISMATCH seed', seed, a[0].shape, diff[:6], flush=True)
-        if not any(np.abs(on[n]).max() > 0 for n in ('Vx', 'Vy', 'Vz')):
-            print('note: seed', seed, 'left the field at zero', flush=True)
-        skipped_share.append(1.0 - act[0][0] / max(act[0][1], 1))
-    except Exception as e:
-        bad.append(seed); print('ERROR seed', seed, repr(e)[:300], flush=True)
-print('quiet runs against every run working: %d seeds (%d..%d) in %.0f s, %d bad; sub-tiles still clear half way through: %.0f %% on average (min %.0f %%, max %.0f %%)'
-      % (count, first, first + count - 1, time.time() - t0, len(bad), 100 * np.mean(skipped_share), 100 * np.min(skipped_share), 100 * np.max(skipped_share)))
-sys.exit(1 if bad else 0)
+def main():
+    first, count = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (0, 40)
+    bad, skipped_share, t0 = [], [], time.time()
+    for seed in range(first, first + count):
+        try:
+            a, k = big_case(seed)
+            on, act = run(a, k, '1')
+            off, _ = run(a, k, '0')
+            diff = [n for n in on if not np.array_equal(on[n], off[n])]
+            if diff:
+                bad.append(seed); print('MISMATCH seed', seed, a[0].shape, diff[:6], flush=True)
+            if not any(np.abs(on[n]).max() > 0 for n in ('Vx', 'Vy', 'Vz')):
+                print('note: seed', seed, 'left the field at zero', flush=True)
+            skipped_share.append(1.0 - act[0][0] / max(act[0][1], 1))
+        except Exception as e:
+            bad.append(seed); print('ERROR seed', seed, repr(e)[:300], flush=True)
+    print('quiet runs against every run working: %d seeds (%d..%d) in %.0f s, %d bad; sub-tiles still clear half way through: %.0f %% on average (min %.0f %%, max %.0f %%)'
+          % (count, first, first + count - 1, time.time() - t0, len(bad), 100 * np.mean(skipped_share), 100 * np.min(skipped_share), 100 * np.max(skipped_share)))
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == '__main__':
+    main()
