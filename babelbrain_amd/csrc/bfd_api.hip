@@ -1129,7 +1129,9 @@ static int build_tile_lists(bfd_sim *s)
     // workgroups (measured: 256^3 49 -> 58, 128^3 29 -> 46 Gvoxel-steps/s). 32 was best at 512^3 while the z-chunks of
     // a column were consecutive in the list; under the banded order 16 is 2.5 % faster than 32 and 3 % faster than 8.
     const int t32 = tx * ty * ((s->d.nk + 31) / 32);
-    s->zchunk = t32 >= 1500 ? 16 : 8;
+    // round 6: the switch point moved from 1500 to 3000 columns (320^3: 8 planes +4 % in water, +7 % with bone -- velocity_solid wants the workgroups; 352^3: +1.5 %;
+    // 384^3: 16 planes +4 %; profiles/r6/pml_flavour_cost_and_run_length_mid_size.txt)
+    s->zchunk = t32 >= 3000 ? 16 : 8;
     if (const char *ev = getenv("BFD_ZRUN")) { const int z = atoi(ev); if (z >= SUB && z % SUB == 0) s->zchunk = z; }   // tuning experiments
     if (s->zchunk > bfd_tile_zchunk()) s->zchunk = bfd_tile_zchunk();
     const int perChunk = s->zchunk / SUB;
