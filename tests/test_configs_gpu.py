@@ -58,6 +58,22 @@ def test_c2_full_size_against_oracle():
     print('C2 256^3 x 2000 steps: worst rel L2 vs oracle %.3e (oracle step loop %.1f s)' % (worst, out_o[-1]['stepLoopSeconds']))
 
 
+@pytest.mark.timeout(600)
+def test_c2_medium_at_320_cubed_against_oracle():
+    """A mid-size grid of the kind BabelBrain users run (C2's skull + brain at 320^3, 2000 columns of 32 planes): since round 6
+    the run lists of this size are cut into 8-plane runs (16 from 3000 columns); 400 steps -- the wave is through the bone --
+    and, with the wave front half way, the quiet runs of a production call on the same grid."""
+    from babelbrain_amd import PropagationModel
+    from oracle import oracle as O
+    a, k, info = H.make_problem('C2', N=(320, 320, 320), steps=400, stable_dt_fn=oracle_dt, full_sensors=False)
+    assert a[0].shape == (320, 320, 320) and info['nt'] == 400
+    out_h = PropagationModel().StaggeredFDTD_3D_with_relaxation(*a, SILENT=True, **k)
+    out_o = O.StaggeredFDTD_3D_with_relaxation(*a, **k)
+    worst = compare_runs(out_h, out_o, tol=1e-5)
+    assert out_o[2]['Pressure'].max() > 0
+    print('C2 medium 320^3 x 400 steps: worst rel L2 vs oracle %.3e (oracle step loop %.1f s)' % (worst, out_o[-1]['stepLoopSeconds']))
+
+
 @pytest.mark.timeout(900)
 def test_c3_full_size_against_oracle():
     """BASELINE configs[2], the configuration the metric is quoted on: 512^3 CT-derived heterogeneous skull (515 materials,
