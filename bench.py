@@ -80,6 +80,7 @@ def parse():
     ap.add_argument('--strong-c5-steps', type=int, default=30, help='timed steps of the strong_c5 block (14 ms each on one device)')
     ap.add_argument('--no-group', action='store_true', help='skip the one-process bfd_group figures (group_one_slab at N=1, group_strong_c3 under torchrun)')
     ap.add_argument('--production-call', action='store_true', help='N=1: also time ONE production-shaped drop-in call of the config (nt from the caller\'s time plan, RMS over the last 2 periods, full sensor block) with the tile runs ahead of the wave front returning at entry (library default) and with every run working (BFD_SKIP_ZERO=0); adds about a minute at C3')
+    ap.add_argument('--watchdog-seconds', type=float, default=1200.0, help='rank 0 / the launcher-free process: after this long the line is printed with whatever blocks have finished (a headline that was measured must not be lost to a secondary block that hangs on hardware nobody has run it on); 0 = off')
     ap.add_argument('--no-next-rows', action='store_true', help='skip the Rayleigh / BHTE kernel rates (N=1, default workload only)')
     ap.add_argument('--no-extra-strong', action='store_true', help='N > 1: skip the extra block that splits ONE C5 volume (1024^3, 1 MHz) over the ranks')
     ap.add_argument('--extra-strong-steps', type=int, default=40, help='timed steps of the extra strong-scaling block')
@@ -583,6 +584,58 @@ def compact_line(line, limit=STDOUT_LINE_LIMIT):
     return out
 
 
+_PARTIAL = {'line': None, 'done': False, 'timer': None}
+
+
+def watch_line(line):
+    """The line as it stands becomes what the watchdog prints (the dict is filled in place by the blocks that follow)."""
+    _PARTIAL['line'] = line
+
+
+def start_watchdog(args, n_gpus):
+    """A timer thread on the process that prints the line. When it fires the line goes out as it is -- 'watchdog' says which blocks were cut off --
+    and the process ends (os._exit: a block stuck inside a collective or a runtime call cannot be unwound)."""
+    import threading
+    if args.watchdog_seconds <= 0:
+        return
+
+    def fire():
+        if _PARTIAL['done']:
+            return
+        _PARTIAL['done'] = True
+        line = _PARTIAL['line']
+        note = 'bench.py --watchdog-seconds %g expired: printed with the blocks finished so far' % args.watchdog_seconds
+        if line is None:
+            line = {'metric': METRIC, 'value': None, 'unit': 'Mvoxel-steps/s', 'n_gpus': n_gpus, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': None,
+                    'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+                    'config': {'workload': args.config}, 'error': 'no headline after %g s' % args.watchdog_seconds}
+        for _ in range(20):
+            try:
+                out = dict(line); out['watchdog'] = note
+                if out.get('value') is not None and 'roofline' in out:
+                    roofline_summary(out)
+                emit_line(out)
+                break
+            except RuntimeError:      # the main thread was adding a block to the dict
+                time.sleep(0.05)
+        os._exit(0 if line.get('value') else 3)
+
+    t = threading.Timer(args.watchdog_seconds, fire)
+    t.daemon = True
+    t.start()
+    _PARTIAL['timer'] = t
+
+
+def stop_watchdog():
+    """True if the caller may print the line (the watchdog has not)."""
+    if _PARTIAL['done']:
+        return False
+    _PARTIAL['done'] = True
+    if _PARTIAL['timer'] is not None:
+        _PARTIAL['timer'].cancel()
+    return True
+
+
 def emit_line(line):
     """stdout: ONE JSON line under 8 KB (compact_line); stderr: the full line."""
     full = json.dumps(line)
@@ -656,6 +709,7 @@ def main_group(args):
     def dt_fn(ml, f, h, acfl):
         return _engine.stable_dt(ml, f, True, h, acfl)
 
+    start_watchdog(args, ndev)
     cfgname = args.config
     c = tuple(args.size) if args.size else H.CONFIGS[cfgname]['N']
     dims = (c[0], c[1], c[2] * ndev) if args.scaling == 'weak' else c
@@ -665,6 +719,7 @@ def main_group(args):
             'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': '%s, %s: %dx%dx%d in %d Z-slabs, one process (bfd_group_*)' % (cfgname, what, dims[0], dims[1], dims[2], ndev),
                        'parallelism': 'z-slab x%d, one process' % ndev, 'kernel_variant': args.variant, 'launcher': 'none (bfd_group_*)'}}
+    watch_line(line)
     try:
         head = group_run(args, cfgname, dims, ndev, dt_fn, args.steps, args.warmup, args.windows, args.variant, what)
     except Exception as e:          # a first-ever failure on real hardware (peer access, memory) must still leave a line
@@ -694,8 +749,9 @@ def main_group(args):
         line['group_check'] = {'equals_single_domain': None, 'error': repr(e)}
     if not args.no_strong_c5 and not args.no_extra_strong:
         line['strong_c5'] = strong_c5(args, ndev, dt_fn, args.variant)
-    roofline_summary(line)
-    emit_line(line)
+    if stop_watchdog():
+        roofline_summary(line)
+        emit_line(line)
 
 
 def placement_rule(args):
@@ -802,6 +858,8 @@ def main():
         return main_group(args)          # no launcher: the one-process split behind the drop-in call
     if world != args.gpus:
         args.gpus = world
+    if rank == 0:
+        start_watchdog(args, world)
     import torch
     from babelbrain_amd import _engine, harness as H
     if not torch.cuda.is_available():
@@ -871,6 +929,8 @@ def main():
                                     traffic=None, note=note)
         if 'roofline_step' in res:
             line['roofline_step'] = res['roofline_step']
+    if rank == 0:
+        watch_line(line)
     w.close()
 
     if world > 1 and not args.no_extra_strong and not (args.config == 'C5' and args.scaling == 'strong'):
@@ -1020,7 +1080,7 @@ def main():
             line['cpu_baseline'] = cpu_baseline(args, dt_fn)
         except Exception as e:   # the baseline is a reported extra; never lose the GPU line over it
             line['cpu_baseline'] = {'value': None, 'unit': 'Mvoxel-steps/s', 'cores': 0, 'kind': 'port', 'sample': 'failed: %r' % (e,)}
-    if rank == 0:
+    if rank == 0 and stop_watchdog():
         roofline_summary(line)
         emit_line(line)
     if world > 1:

@@ -261,3 +261,24 @@ def test_bench_line_fits_the_drivers_record_and_roofline_carries_the_rounds_numb
     assert abs(short['roofline']['shear512_velocity_solid_frac'] / r['shear512_velocity_solid_frac'] - 1) < 1e-5
     # a line already short is not touched
     assert bench.compact_line({'metric': 'm', 'value': 1.0}) == {'metric': 'm', 'value': 1.0}
+
+
+def test_bench_watchdog_prints_the_line_it_has():
+    """bench.py --watchdog-seconds: a block that hangs after the headline was measured must not cost the line (rank 0 prints what it has and
+    ends the process); without a headline the line says so and the exit code is not 0."""
+    import json, subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    head = "import bench, time, argparse; a = argparse.Namespace(watchdog_seconds=0.3, steps=20, warmup=5, scaling='weak', config='C3'); bench.start_watchdog(a, 1); "
+    r = subprocess.run([sys.executable, '-c', head + "bench.watch_line({'metric': 'm', 'value': 5.0, 'n_gpus': 1}); time.sleep(20); print('not reached')"],
+                       cwd=root, capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and 'not reached' not in r.stdout
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line['value'] == 5.0 and 'expired' in line['watchdog']
+    r = subprocess.run([sys.executable, '-c', head + "time.sleep(20); print('not reached')"], cwd=root, capture_output=True, text=True, timeout=60)
+    assert r.returncode == 3 and 'not reached' not in r.stdout
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line['value'] is None and line['n_gpus'] == 1 and 'no headline' in line['error']
+    # a run that finishes first prints exactly one line
+    r = subprocess.run([sys.executable, '-c', head + "bench.watch_line({'value': 1.0}); ok = bench.stop_watchdog(); time.sleep(0.6); print('finished', ok)"],
+                       cwd=root, capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and r.stdout.strip().splitlines() == ['finished True']
