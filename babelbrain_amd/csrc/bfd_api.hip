@@ -3,6 +3,9 @@
 //
 // Mirrors what BabelIntegrationBASE.py:2338-2365 hands to the reference's solver
 // (package BabelViscoFDTD==1.2.4, absent from /root/reference).
+#include <functional>
+#include <cstring>
+#include <sys/mman.h>
 #include "bfd_internal.h"
 
 #include <math.h>
@@ -372,6 +375,18 @@ __global__ void transpose_sensors(const float *__restrict__ in, float *__restric
         const long s = (v / nTs) % nSens;
         const long q = v / ((long)nTs * nSens);
         out[v] = in[(q * nTs + t) * nSens + s];
+    }
+}
+
+// the same for elements [v0, v0 + cnt) of the transposed block only (out = a piece buffer): the sensor series leave the device piece by piece
+__global__ void transpose_sensors_range(const float *__restrict__ in, float *__restrict__ out, long nSens, int nTs, long v0, long cnt)
+{
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += (long)gridDim.x * blockDim.x) {
+        const long v = v0 + i;
+        const int t = (int)(v % nTs);
+        const long s = (v / nTs) % nSens;
+        const long q = v / ((long)nTs * nSens);
+        out[i] = in[(q * nTs + t) * nSens + s];
     }
 }
 
@@ -2409,6 +2424,7 @@ int bfd_get_sensor_index(bfd_sim *s, uint32_t *index)
     if ((long)s->d.N1 * s->d.N2 * s->d.N3 >= (1L << 32) - 1) BFD_FAIL(-2, "domain too large for 32-bit sensor indices");
     if (!s->nSensors) return 0;
     BFD_HIP(hipSetDevice(s->cfg.device));
+    bfd_advise_result_buffer(index, (size_t)s->nSensors * sizeof(uint32_t));
     BFD_HIP(hipMemcpy(index, s->sensLin, (size_t)s->nSensors * sizeof(uint32_t), hipMemcpyDeviceToHost));
     const uint32_t off = (uint32_t)((size_t)s->d.k0 * s->d.plane + 1);
     for (int64_t v = 0; v < s->nSensors; v++) index[v] += off;
@@ -2416,6 +2432,83 @@ int bfd_get_sensor_index(bfd_sim *s, uint32_t *index)
 }
 
 }  // extern "C"
+
+// A large result block lands in host memory the caller has just allocated and never touched (a fresh numpy array): the copy then runs at the rate the
+// kernel can fault 4 KB pages in. Transparent huge pages are in `madvise` mode on the ROCm images, so the range is advised first: one hipMemcpy of
+// 4.3 GiB into untouched memory 0.46 -> 0.22 s on the MI355X box (profiles/r6/d2h_into_untouched_memory.txt). Advice only: a mapping that cannot
+// take it (file-backed, already populated) is left as it is.
+void bfd_advise_result_buffer(void *p, size_t bytes)
+{
+    if (!p || bytes < ((size_t)8 << 20)) return;
+    const uintptr_t a = ((uintptr_t)p + 4095) & ~(uintptr_t)4095, b = ((uintptr_t)p + bytes) & ~(uintptr_t)4095;
+    if (b > a) (void)madvise((void *)a, (size_t)(b - a), MADV_HUGEPAGE);
+}
+
+// Device -> pageable host for the large result blocks (sensor series, maps): T host threads, each moving its slice in 16 MB pieces through two pinned
+// buffers of its own (the next piece in flight while the last one is copied out). One hipMemcpy is bound by the single thread that copies out of the
+// runtime's staging buffers: 4.3 GiB into untouched huge-page memory 0.22 s, this way 0.11 s (profiles/r6/d2h_into_untouched_memory.txt). `after`: the
+// stream whose work produces src (waited for here). Anything that fails on the way falls back to the plain copy.
+// produce (optional): fills a device piece buffer with bytes [o, o + len) of the block on the given stream -- the block then never exists as a whole
+// on the device (the sensor series: no 4.6 GB scratch allocation, which after a placement search had to wait 5 s for the driver to clear what the
+// search had released). Returns hipErrorNotSupported when it declines (small block, threads off) and a producer was given: the caller takes its old way.
+static hipError_t copy_out_large(int device, void *dst, const void *src, size_t bytes, hipStream_t after,
+                                 const std::function<void(float *, size_t, size_t, hipStream_t)> *produce = nullptr)
+{
+    int T = 4;
+    if (const char *ev = getenv("BFD_D2H_THREADS")) T = atoi(ev);
+    size_t PIECE = (size_t)16 << 20, least = (size_t)256 << 20;
+    if (const char *ev = getenv("BFD_D2H_PIECE_KB")) PIECE = std::max((size_t)4096, ((size_t)atol(ev) << 10) & ~(size_t)4095);      // tests: small grids through the same code
+    if (const char *ev = getenv("BFD_D2H_MIN_MB")) least = (size_t)atol(ev) << 20;
+    if (T < 2 || bytes < least || bytes < (size_t)T * 4096) {
+        if (produce) return hipErrorNotSupported;
+        const hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, after);
+        return e == hipSuccess ? hipStreamSynchronize(after) : e;
+    }
+    T = std::min(T, 16);
+    hipError_t e = hipStreamSynchronize(after);
+    if (e != hipSuccess) return e;
+    std::vector<char *> pin(2 * (size_t)T, nullptr);
+    bool ok = true;
+    for (auto &q : pin) if (ok && hipHostMalloc((void **)&q, PIECE, hipHostMallocDefault) != hipSuccess) { q = nullptr; ok = false; (void)hipGetLastError(); }
+    std::vector<float *> dpiece(produce ? 2 * (size_t)T : 0, nullptr);
+    for (auto &q : dpiece) if (ok && hipMalloc((void **)&q, PIECE) != hipSuccess) { q = nullptr; ok = false; (void)hipGetLastError(); }
+    std::vector<int> failed((size_t)T, 0);
+    if (ok) {
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; t++)
+            th.emplace_back([&, t] {
+                const size_t a = (bytes / T * t) & ~(size_t)4095, b = t + 1 == T ? bytes : (bytes / T * (t + 1)) & ~(size_t)4095;
+                hipStream_t st = nullptr;
+                hipEvent_t ev[2] = {nullptr, nullptr};
+                if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess ||
+                    hipEventCreateWithFlags(&ev[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ev[1], hipEventDisableTiming) != hipSuccess) failed[t] = 1;
+                const size_t np = (b - a + PIECE - 1) / PIECE;
+                auto issue = [&](size_t i) {
+                    const size_t o = a + i * PIECE, len = std::min(PIECE, b - o);
+                    const void *from = (const char *)src + o;
+                    if (produce) { (*produce)(dpiece[2 * t + (i & 1)], o, len, st); from = dpiece[2 * t + (i & 1)]; if (hipGetLastError() != hipSuccess) failed[t] = 1; }
+                    if (hipMemcpyAsync(pin[2 * t + (i & 1)], from, len, hipMemcpyDeviceToHost, st) != hipSuccess || hipEventRecord(ev[i & 1], st) != hipSuccess) failed[t] = 1;
+                };
+                if (!failed[t] && np) issue(0);
+                for (size_t i = 0; i < np && !failed[t]; i++) {
+                    if (i + 1 < np) issue(i + 1);
+                    if (failed[t] || hipEventSynchronize(ev[i & 1]) != hipSuccess) { failed[t] = 1; break; }
+                    const size_t o = a + i * PIECE, len = std::min(PIECE, b - o);
+                    memcpy((char *)dst + o, pin[2 * t + (i & 1)], len);
+                }
+                if (st) { hipStreamSynchronize(st); hipStreamDestroy(st); }
+                for (int q = 0; q < 2; q++) if (ev[q]) hipEventDestroy(ev[q]);
+            });
+        for (auto &x : th) x.join();
+        for (int t = 0; t < T; t++) if (failed[t]) ok = false;
+    }
+    for (auto &q : pin) if (q) hipHostFree(q);
+    for (auto &q : dpiece) if (q) hipFree(q);
+    if (ok) return hipSuccess;
+    (void)hipGetLastError();
+    if (produce) return hipErrorNotSupported;
+    return hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost);      // the plain way
+}
 
 int bfd_sensors_into(bfd_sim *s, float *out, int64_t rowElems)
 {
@@ -2428,16 +2521,40 @@ int bfd_sensors_into(bfd_sim *s, float *out, int64_t rowElems)
     if (!out || !s->sensOut) BFD_FAIL(-1, "bfd_get_sensors: null argument");
     if (rowElems < (int64_t)row) BFD_FAIL(-2, "bfd_get_sensors: row shorter than nSensors * nSteps");
     BFD_HIP(hipSetDevice(s->cfg.device));
+    {   // piece by piece through the host threads, no scratch block on the device
+        hipError_t e = hipSuccess;
+        for (int q = 0; q < s->nSelS; q++) bfd_advise_result_buffer(out + (size_t)q * rowElems, row * sizeof(float));
+        const bool oneBlock = (size_t)rowElems == row;
+        for (int q = 0; q < (oneBlock ? 1 : s->nSelS) && e == hipSuccess; q++) {
+            const long v00 = oneBlock ? 0 : (long)q * (long)row;
+            const std::function<void(float *, size_t, size_t, hipStream_t)> produce = [&, v00](float *piece, size_t o, size_t len, hipStream_t st) {
+                const long cnt = (long)(len / sizeof(float));
+                hipLaunchKernelGGL(transpose_sensors_range, dim3(grid_for(cnt)), dim3(256), 0, st, s->sensOut, piece, (long)s->nSensors, s->nTs, v00 + (long)(o / sizeof(float)), cnt);
+            };
+            e = copy_out_large(s->cfg.device, out + (size_t)q * rowElems, nullptr, (oneBlock ? n : row) * sizeof(float), s->stream, &produce);
+        }
+        if (e == hipSuccess) return 0;
+        (void)hipGetLastError();      // declined (small block, BFD_D2H_THREADS < 2) or failed on the way: the whole block through a scratch copy
+    }
     float *tmp = nullptr;
+    const bool trace = getenv("BFD_TRACE_SENSORS") != nullptr;
+    auto tnow = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double tt[5]; tt[0] = tnow();
     BFD_HIP(hipMalloc((void **)&tmp, n * sizeof(float)));
+    tt[1] = tnow();
     hipLaunchKernelGGL(transpose_sensors, dim3(grid_for((long)n)), dim3(256), 0, s->stream, s->sensOut, tmp, (long)s->nSensors, s->nTs, s->nSelS);
+    if (trace) hipStreamSynchronize(s->stream);
+    tt[2] = tnow();
     hipError_t e = hipSuccess;
-    if ((size_t)rowElems == row) e = hipMemcpyAsync(out, tmp, n * sizeof(float), hipMemcpyDeviceToHost, s->stream);
+    for (int q = 0; q < s->nSelS; q++) bfd_advise_result_buffer(out + (size_t)q * rowElems, row * sizeof(float));
+    if ((size_t)rowElems == row) e = copy_out_large(s->cfg.device, out, tmp, n * sizeof(float), s->stream);
     else
         for (int q = 0; q < s->nSelS && e == hipSuccess; q++)
-            e = hipMemcpyAsync(out + (size_t)q * rowElems, tmp + (size_t)q * row, row * sizeof(float), hipMemcpyDeviceToHost, s->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+            e = copy_out_large(s->cfg.device, out + (size_t)q * rowElems, tmp + (size_t)q * row, row * sizeof(float), s->stream);
+    tt[3] = tnow();
     hipFree(tmp);
+    tt[4] = tnow();
+    if (trace) fprintf(stderr, "bfd_get_sensors: %.2f GB: hipMalloc %.3f s, transpose %.3f s, copy %.3f s, hipFree %.3f s\n", n * 4e-9, tt[1] - tt[0], tt[2] - tt[1], tt[3] - tt[2], tt[4] - tt[3]);
     if (e != hipSuccess) BFD_FAIL(-10, std::string("bfd_get_sensors: ") + hipGetErrorString(e));
     return 0;
 }
@@ -2458,13 +2575,15 @@ static int download_volume(bfd_sim *s, const float *devXfast, float *out, int64_
     float *tmp = nullptr;
     BFD_HIP(hipMalloc((void **)&tmp, span * sizeof(float)));
     hipError_t e = hipSuccess;
+    bfd_advise_result_buffer(out, span * sizeof(float));
     if (span != s->nloc) {   // non-dense view: keep what the caller has in the gaps
         e = hipMemcpyAsync(tmp, out, span * sizeof(float), hipMemcpyHostToDevice, s->stream);
     }
     if (e == hipSuccess) {
         hipLaunchKernelGGL(scatter_from_xfast, dim3(grid_for((long)s->nloc)), dim3(256), 0, s->stream, devXfast, tmp,
                            (long)s1, (long)s2, (long)s3, d.N1, d.N2, d.nk);
-        e = hipMemcpyAsync(out, tmp, span * sizeof(float), hipMemcpyDeviceToHost, s->stream);
+        if (e == hipSuccess) e = hipGetLastError();
+        if (e == hipSuccess) e = copy_out_large(s->cfg.device, out, tmp, span * sizeof(float), s->stream);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
     hipFree(tmp);
@@ -2560,6 +2679,8 @@ int bfd_get_sensor_dft(bfd_sim *s, double freq, float *outReIm, float *outPeak)
     if (!outReIm || !(s->sensOut || s->dftAcc)) BFD_FAIL(-1, "bfd_get_sensor_dft: null argument");
     BFD_HIP(hipSetDevice(s->cfg.device));
     const int bin = dft_bin(s->nTs, s->cfg.dt * s->cfg.sensorSub, freq);
+    bfd_advise_result_buffer(outReIm, 2 * n * sizeof(float));
+    bfd_advise_result_buffer(outPeak, n * sizeof(float));
     if (s->dftAcc) {         // accumulated in the loop
         if (bin != s->dftBin) BFD_FAIL(-2, "bfd_get_sensor_dft: with sensorMode 1 the bin is the one of the sim's own frequency");
         float *dre = nullptr;

@@ -213,6 +213,8 @@ void bfd_set_error(const std::string &s);
         }                                                                                          \
     } while (0)
 
+// madvise(MADV_HUGEPAGE) on a result buffer of the caller before a large device-to-host copy (bfd_api.hip)
+void bfd_advise_result_buffer(void *p, size_t bytes);
 // bfd_get_sensors with a row pitch: the series of selected map q at out + q * rowElems (bfd_group.hip: a slab writes into its columns)
 int bfd_sensors_into(bfd_sim *s, float *out, int64_t rowElems);
 // kernel launchers (bfd_kernels_*.hip)

@@ -447,3 +447,26 @@ def test_cost_balanced_run_maps_do_not_change_results(monkeypatch):
         assert np.array_equal(merged['Peak'][n], ref[3][n]), n
     for s in slabs:
         s.eng.close()
+
+
+def test_large_result_blocks_through_threads_equal_the_plain_copy(monkeypatch):
+    """Sensor series and maps of 256 MB and more leave the device through several host threads with pinned pieces of their own
+    (copy_out_large, bfd_api.hip). Here the same code on a small grid (thresholds lowered): every output equal to the one-copy path,
+    for an even and an odd number of threads, single engine and two slabs (row pitch)."""
+    a, k, info = H.make_problem('C2', N=(192, 160, 160), steps=80, stable_dt_fn=oracle_dt)
+    k['SelMapsRMSPeakList'] = ['Pressure', 'Vz', 'Sigmaxy']
+    k['SelMapsSensorsList'] = ['Pressure', 'Vx', 'Sigmaxz']
+    k['SelRMSorPeak'] = 3
+    monkeypatch.setenv('BFD_D2H_THREADS', '0')
+    ref = hip_model().StaggeredFDTD_3D_with_relaxation(*a, SILENT=True, **k)
+    assert ref[0]['Vx'].nbytes > (8 << 20) and np.abs(ref[0]['Vx']).max() > 0
+    monkeypatch.setenv('BFD_D2H_MIN_MB', '1')
+    monkeypatch.setenv('BFD_D2H_PIECE_KB', '256')
+    from babelbrain_amd import PropagationModel
+    for threads, devices in (('4', None), ('3', None), ('4', [0, 0])):
+        monkeypatch.setenv('BFD_D2H_THREADS', threads)
+        pm = hip_model() if devices is None else PropagationModel(devices=devices)
+        out = pm.StaggeredFDTD_3D_with_relaxation(*a, SILENT=True, **k)
+        for idx in range(4):
+            for name in ref[idx]:
+                assert np.array_equal(ref[idx][name], out[idx][name]), (threads, devices, idx, name)
