@@ -1850,7 +1850,9 @@ static int choose_placement(bfd_sim *s)
             else { hipStreamSynchronize(s->stream); hipFree(c); }
         }
     }
-    while ((need[0] > 0 || need[1] > 0) && !gaveUp && probeTells) {            // draw candidates until both sides have enough
+    int forcedWalk = 0;                                                        // BFD_PLACEMENT_FORCE_WALK=n (experiments): n more candidates are drawn, held and released, as an unlucky search does
+    if (const char *ev = getenv("BFD_PLACEMENT_FORCE_WALK")) forcedWalk = atoi(ev);
+    while ((need[0] > 0 || need[1] > 0 || forcedWalk-- > 0) && !gaveUp && probeTells) {            // draw candidates until both sides have enough
         size_t freeB = 0, totalB = 0;
         if (hipMemGetInfo(&freeB, &totalB) != hipSuccess || freeB < 2 * bytes + totalB / 8 || heldBytes + bytes > heldCap) { gaveUp = true; break; }
         if (defaultRule) {
