@@ -21,6 +21,36 @@
 
 extern "C" int64_t bfd_placement_cache_release(void);
 static thread_local std::string g_err;
+// pinned 16 MB pieces of copy_out_large, kept from one readback of a call to the next (allocating and releasing eight of them costs 22 ms, as much as
+// moving a 512^3 map); given back to the system with the placement cache (bfd_placement_cache_release: the drop-in call does that at its end)
+static std::mutex g_pinMutex;
+static std::vector<char *> g_pinFree;
+static const size_t kPinPiece = (size_t)16 << 20;
+static char *pin_take(size_t bytes)
+{
+    if (bytes == kPinPiece) {
+        std::lock_guard<std::mutex> lk(g_pinMutex);
+        if (!g_pinFree.empty()) { char *p = g_pinFree.back(); g_pinFree.pop_back(); return p; }
+    }
+    char *p = nullptr;
+    if (hipHostMalloc((void **)&p, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+static void pin_give(char *p, size_t bytes)
+{
+    if (!p) return;
+    if (bytes == kPinPiece) {
+        std::lock_guard<std::mutex> lk(g_pinMutex);
+        if (g_pinFree.size() < 32) { g_pinFree.push_back(p); return; }
+    }
+    hipHostFree(p);
+}
+static void pin_release_all()
+{
+    std::lock_guard<std::mutex> lk(g_pinMutex);
+    for (char *p : g_pinFree) hipHostFree(p);
+    g_pinFree.clear();
+}
 void bfd_set_error(const std::string &s) { g_err = s; }
 #define BFD_FAIL(code, msg) do { bfd_set_error(msg); return (code); } while (0)
 
@@ -2292,6 +2322,7 @@ int64_t bfd_placement_cache_release(void)
     const bool haveCur = hipGetDevice(&cur) == hipSuccess;
     for (const CachedBuf &c : g_cache) { hipSetDevice(c.device); hipFree(c.p); freed += (int64_t)c.bytes; }
     g_cache.clear();
+    pin_release_all();          // host memory: not part of the count
     if (haveCur) hipSetDevice(cur);
     (void)hipGetLastError();
     return freed;
@@ -2469,12 +2500,15 @@ static hipError_t copy_out_large(int device, void *dst, const void *src, size_t 
     T = std::min(T, 16);
     hipError_t e = hipStreamSynchronize(after);
     if (e != hipSuccess) return e;
+    const bool traceCopy = getenv("BFD_TRACE_COPY") != nullptr;
+    const auto tc0 = std::chrono::steady_clock::now();
     std::vector<char *> pin(2 * (size_t)T, nullptr);
     bool ok = true;
-    for (auto &q : pin) if (ok && hipHostMalloc((void **)&q, PIECE, hipHostMallocDefault) != hipSuccess) { q = nullptr; ok = false; (void)hipGetLastError(); }
+    for (auto &q : pin) if (ok && !(q = pin_take(PIECE))) ok = false;
     std::vector<float *> dpiece(produce ? 2 * (size_t)T : 0, nullptr);
     for (auto &q : dpiece) if (ok && hipMalloc((void **)&q, PIECE) != hipSuccess) { q = nullptr; ok = false; (void)hipGetLastError(); }
     std::vector<int> failed((size_t)T, 0);
+    const auto tc1 = std::chrono::steady_clock::now();
     if (ok) {
         std::vector<std::thread> th;
         for (int t = 0; t < T; t++)
@@ -2504,8 +2538,11 @@ static hipError_t copy_out_large(int device, void *dst, const void *src, size_t 
         for (auto &x : th) x.join();
         for (int t = 0; t < T; t++) if (failed[t]) ok = false;
     }
-    for (auto &q : pin) if (q) hipHostFree(q);
+    const auto tc2 = std::chrono::steady_clock::now();
+    for (auto &q : pin) pin_give(q, PIECE);
     for (auto &q : dpiece) if (q) hipFree(q);
+    if (traceCopy) fprintf(stderr, "copy_out_large: %.2f GB, %d threads: buffers %.3f s, copy %.3f s, release %.3f s\n", bytes * 1e-9, T, std::chrono::duration<double>(tc1 - tc0).count(),
+                           std::chrono::duration<double>(tc2 - tc1).count(), std::chrono::duration<double>(std::chrono::steady_clock::now() - tc2).count());
     if (ok) return hipSuccess;
     (void)hipGetLastError();
     if (produce) return hipErrorNotSupported;
