@@ -176,7 +176,8 @@ int bfd_set_placement(bfd_sim *sim, int32_t mode, int64_t searchLimitBytes);
  * 48, never more than an eighth of the device's memory, 0 = keep nothing) are held between engines; bfd_create evicts buffers of another
  * array size, and any allocation of the library that runs out of memory frees the cache and tries once more.
  * bfd_placement_cache_release frees them now and returns the bytes freed (the Python drop-in calls it when a solver call returns,
- * unless it was built with keepPlacementCache=True / BABELFDTD_PLACEMENT_CACHE_KEEP=1). */
+ * unless it was built with keepPlacementCache=True / BABELFDTD_PLACEMENT_CACHE_KEEP=1). It also gives back the pinned host pieces
+ * (16 MB each, at most 32) the result readbacks keep between them; those are not part of the count. */
 int64_t bfd_placement_cache_release(void);
 
 /* device pointer/bytes of a halo region: field f (0..2 within the group), side 0 = low-k face,
@@ -212,7 +213,9 @@ int64_t bfd_num_sensors(bfd_sim *sim);
 int32_t bfd_num_sensor_steps(bfd_sim *sim);
 /* 1-based GLOBAL x-fastest linear index of every sensor of this slab, ascending (BASE:2369,2503) */
 int bfd_get_sensor_index(bfd_sim *sim, uint32_t *index);
-/* out[nSelSensors][nSensors][nTs] float32, maps in ascending BFD_MAP_* order (BASE:2507: FFT along axis 1) */
+/* out[nSelSensors][nSensors][nTs] float32, maps in ascending BFD_MAP_* order (BASE:2507: FFT along axis 1). Blocks of 256 MB and
+ * more (this one, the maps below) are carried by four host threads of the library through pinned pieces (BFD_D2H_THREADS; the
+ * call returns when all of it has arrived); the destination is advised to use huge pages. */
 int bfd_get_sensors(bfd_sim *sim, float *out);
 /* Single-frequency content of the recorded sensor series, computed on the device: replaces the host
  * FFT + bin pick of CalculatePhaseData (BASE:2498-2520) without moving the (nSensor x nTs) block.
