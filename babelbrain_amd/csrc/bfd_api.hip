@@ -2482,8 +2482,8 @@ void bfd_advise_result_buffer(void *p, size_t bytes)
 // runtime's staging buffers: 4.3 GiB into untouched huge-page memory 0.22 s, this way 0.11 s (profiles/r6/d2h_into_untouched_memory.txt). `after`: the
 // stream whose work produces src (waited for here). Anything that fails on the way falls back to the plain copy.
 // produce (optional): fills a device piece buffer with bytes [o, o + len) of the block on the given stream -- the block then never exists as a whole
-// on the device (the sensor series: no 4.6 GB scratch allocation, which after a placement search had to wait 5 s for the driver to clear what the
-// search had released). Returns hipErrorNotSupported when it declines (small block, threads off) and a producer was given: the caller takes its old way.
+// on the device (the sensor series: no 4.6 GB scratch allocation, which in a short call waited 5 s when a placement search had just released its
+// candidates -- the runtime gives them back in the background). Returns hipErrorNotSupported when it declines (small block, threads off) and a producer was given: the caller takes its old way.
 static hipError_t copy_out_large(int device, void *dst, const void *src, size_t bytes, hipStream_t after,
                                  const std::function<void(float *, size_t, size_t, hipStream_t)> *produce = nullptr)
 {
